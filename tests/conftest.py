@@ -1,0 +1,38 @@
+"""Shared fixtures.  `gpu` marks tests that need a real MI355X (run via gpurun)."""
+import json
+import os
+import sys
+
+import numpy as np
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+GOLDEN_DIR = os.path.join(ROOT, "tests", "golden")
+
+
+def pytest_configure(config):
+    config.addinivalue_line("markers", "gpu: needs a real MI355X (gfx950) device")
+
+
+@pytest.fixture(scope="session")
+def golden():
+    """Arrays the reference produced (tools/gen_golden.py), loaded without pickle."""
+    with np.load(os.path.join(GOLDEN_DIR, "reference_outputs.npz"), allow_pickle=False) as z:
+        return {k: z[k] for k in z.files}
+
+
+@pytest.fixture(scope="session")
+def golden_dicts():
+    with open(os.path.join(GOLDEN_DIR, "reference_dicts.json")) as fh:
+        return json.load(fh)
+
+
+def golden_case_names(kind=None):
+    with np.load(os.path.join(GOLDEN_DIR, "reference_outputs.npz"), allow_pickle=False) as z:
+        names = sorted({k.split("/")[0] for k in z.files if k.endswith("/input")})
+    if kind:
+        names = [n for n in names if n.startswith(kind)]
+    return names

@@ -1,0 +1,198 @@
+#!/usr/bin/env python3
+"""Generate tests/golden/*.npz + *.json by RUNNING the reference in this container.
+
+Usage (build container only; /root/reference does not exist on the GPU box):
+
+    MPLBACKEND=Agg python tools/gen_golden.py --reference /root/reference
+
+The reference's four scripts are compiled from their source text (hyphenated
+file names, so no normal import; bytecode caches are not used) with stand-in
+modules for the packages that are absent here and unrelated to the pixel
+maths (streamlit, dotenv, skimage).  Only *data* is written: the inputs this
+script synthesises and the arrays / dicts the reference functions return for
+them, plus the library versions they were produced under.
+"""
+from __future__ import annotations
+
+import argparse
+import io
+import json
+import os
+import sys
+import tempfile
+import types
+import warnings
+from unittest import mock
+
+import numpy as np
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+GOLDEN = os.path.join(os.path.dirname(HERE), "tests", "golden")
+
+
+def _load(ref_dir, filename, modname):
+    path = os.path.join(ref_dir, filename)
+    with open(path, "r", encoding="utf-8") as fh:
+        src = fh.read()
+    mod = types.ModuleType(modname)
+    mod.__file__ = path
+    exec(compile(src, path, "exec"), mod.__dict__)   # __name__ != "__main__": mains stay off
+    return mod
+
+
+def _stub_absent_modules():
+    st = mock.MagicMock(name="streamlit")
+    st.cache_resource = lambda f=None, **kw: (f if f is not None else (lambda g: g))
+    st.cache_data = st.cache_resource
+    for name, obj in {
+        "streamlit": st,
+        "dotenv": mock.MagicMock(name="dotenv"),
+        "skimage": mock.MagicMock(name="skimage"),
+        "skimage.registration": mock.MagicMock(name="skimage.registration"),
+        "skimage.color": mock.MagicMock(name="skimage.color"),
+    }.items():
+        try:
+            __import__(name)
+        except Exception:
+            sys.modules[name] = obj
+
+
+def make_cases():
+    """name -> input array.  Deterministic; small enough to commit."""
+    rng = lambda s: np.random.default_rng(s)
+    cases = {}
+    cases["u8_64x64"] = rng(0).integers(0, 256, (64, 64, 3), dtype=np.uint8)
+    cases["u8_97x113"] = rng(1).integers(0, 256, (97, 113, 3), dtype=np.uint8)
+    cases["u8_1x1"] = rng(2).integers(0, 256, (1, 1, 3), dtype=np.uint8)
+    cases["u8_rgba_5x7"] = rng(3).integers(0, 256, (5, 7, 4), dtype=np.uint8)
+    cases["u8_zero_16x16"] = np.zeros((16, 16, 3), dtype=np.uint8)
+    const = rng(4).integers(0, 256, (24, 24, 3), dtype=np.uint8)
+    const[:, :, 1] = 77
+    cases["u8_const_green_24x24"] = const
+    nored = rng(5).integers(0, 256, (24, 24, 3), dtype=np.uint8)
+    nored[:, :, 0] = 0
+    cases["u8_red_zero_24x24"] = nored
+    cases["u8_binary_32x32"] = (rng(6).integers(0, 2, (32, 32, 3)) * 255).astype(np.uint8)
+    # vegetation-like: NIR high, red low, narrow ranges -> fractional percentiles
+    g = rng(7)
+    veg = np.stack([
+        np.clip(g.normal(70, 25, (48, 80)), 0, 255),
+        np.clip(g.normal(90, 25, (48, 80)), 0, 255),
+        np.clip(g.normal(150, 40, (48, 80)), 0, 255),
+    ], axis=-1).astype(np.uint8)
+    cases["u8_veg_48x80"] = veg
+    # few distinct values -> interpolated (non-integer) percentiles
+    cases["u8_sparse_31x29"] = (rng(8).integers(0, 5, (31, 29, 3)) * 50 + 3).astype(np.uint8)
+    cases["u16_64x64"] = rng(9).integers(0, 65536, (64, 64, 3), dtype=np.uint16)
+    cases["u16_12bit_40x40"] = rng(10).integers(0, 4096, (40, 40, 3), dtype=np.uint16)
+    return cases
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--reference", default="/root/reference")
+    ap.add_argument("--out", default=GOLDEN)
+    args = ap.parse_args()
+    os.environ.setdefault("MPLBACKEND", "Agg")
+    sys.dont_write_bytecode = True
+    _stub_absent_modules()
+
+    import matplotlib
+    matplotlib.use("Agg")
+    import PIL
+    from PIL import Image
+
+    app = _load(args.reference, "process-images.py", "ref_process_images")
+    backend = _load(args.reference, "backend-process.py", "ref_backend_process")
+    ndvi_mod = _load(args.reference, "process-ndvi.py", "ref_process_ndvi")
+    rgn_mod = _load(args.reference, "process-rgn.py", "ref_process_rgn")
+
+    arrays = {}
+    dicts = {}
+    cases = make_cases()
+    with warnings.catch_warnings():
+        warnings.simplefilter("ignore")          # constant channels divide by zero upstream
+        for name, img in cases.items():
+            arrays[f"{name}/input"] = img
+            wb = app.fix_white_balance(img)
+            arrays[f"{name}/wb"] = wb
+            pcts = np.array([np.percentile(img[:, :, c].astype(np.float32), (2, 98)) for c in range(3)])
+            arrays[f"{name}/percentiles"] = pcts          # numpy's, for diagnostics
+            for kind, src in (("raw", img), ("wb", wb)):
+                for t in ("NDVI", "GNDVI", "NDWI"):
+                    idx = app.calculate_index(src, t)
+                    assert idx.dtype == np.float32
+                    arrays[f"{name}/index_{kind}_{t}"] = idx
+                    dicts[f"{name}/stats_{kind}_{t}"] = app.analyze_index(idx, t)
+                    arrays[f"{name}/hist50_{kind}_{t}"] = np.histogram(idx, bins=50, range=(-1, 1))[0]
+            # backend-process.py: PIL in / PIL out white balance, 4-arg index
+            if img.dtype == np.uint8 and img.shape[2] == 3:
+                pil_wb = backend.fix_white_balance(Image.fromarray(img))
+                arrays[f"{name}/backend_wb"] = np.array(pil_wb)
+                f = np.array(pil_wb, dtype=np.float32)
+                r, gch, n = f[:, :, 0].copy(), f[:, :, 1].copy(), f[:, :, 2].copy()
+                for t in ("NDVI", "GNDVI", "NDWI"):
+                    arrays[f"{name}/backend_index_{t}"] = backend.calculate_index(r, gch, n, t)
+                # process-rgn.py / process-ndvi.py go through files
+                with tempfile.TemporaryDirectory() as tmp:
+                    p = os.path.join(tmp, "in.png")
+                    Image.fromarray(img).save(p)
+                    arrays[f"{name}/rgn_wb"] = rgn_mod.fix_white_balance_rgnir(p)
+                    nd = ndvi_mod.calculate_ndvi(p, save_path=None, visualize=False)
+                    assert nd.dtype == np.float64
+                    arrays[f"{name}/ndvi_f64"] = nd
+                    dicts[f"{name}/ndvi_stats"] = ndvi_mod.analyze_ndvi_statistics(nd)
+                    arrays[f"{name}/ndvi_f64_hist50"] = np.histogram(nd.flatten(), bins=50, range=(-1, 1))[0]
+
+        # contract edge cases
+        dicts["contract/wb_none"] = repr(app.fix_white_balance(None))
+        dicts["contract/index_none"] = repr(app.calculate_index(None, "NDVI"))
+        dicts["contract/stats_none"] = repr(app.analyze_index(None, "NDVI"))
+        dicts["contract/wb_empty"] = repr(app.fix_white_balance(np.zeros((0, 0, 3), np.uint8)))
+        try:
+            app.calculate_index(cases["u8_64x64"], "EVI")
+        except ValueError as e:
+            dicts["contract/index_unknown"] = f"ValueError: {e}"
+        try:
+            backend.calculate_index(np.ones((2, 2), np.float32), np.ones((2, 2), np.float32),
+                                    np.ones((2, 2), np.float32), "EVI")
+        except Exception as e:
+            dicts["contract/backend_index_unknown"] = type(e).__name__
+        try:
+            app.calculate_index(np.zeros((4, 4), np.uint8), "NDVI")
+        except Exception as e:
+            dicts["contract/index_2d"] = type(e).__name__
+
+    # colormaps: the per-pixel mapping imshow(cmap, vmin=-1, vmax=1) applies
+    from matplotlib.colors import Normalize
+    probe = np.concatenate([
+        np.random.default_rng(11).uniform(-1, 1, 4096).astype(np.float32),
+        np.linspace(-1, 1, 513, dtype=np.float32),
+        np.array([-1.0, -0.0, 0.0, 1.0, np.nextafter(np.float32(1), np.float32(0)),
+                  np.nextafter(np.float32(-1), np.float32(0))], dtype=np.float32),
+    ])
+    arrays["colormap/probe"] = probe
+    for cm_name in ("RdYlGn", "RdYlBu", "bwr"):
+        cm = matplotlib.colormaps[cm_name]
+        arrays[f"colormap/{cm_name}_lut"] = cm(np.arange(256), bytes=True)       # [256,4] uint8
+        arrays[f"colormap/{cm_name}_probe_rgba"] = cm(Normalize(-1, 1)(probe), bytes=True)
+
+    meta = {
+        "numpy": np.__version__,
+        "matplotlib": matplotlib.__version__,
+        "pillow": PIL.__version__,
+        "python": sys.version.split()[0],
+        "reference": "lars-uav/lars-image-processing snapshot 2025-03-28 (mounted at /root/reference)",
+        "generator": "tools/gen_golden.py",
+    }
+    os.makedirs(args.out, exist_ok=True)
+    np.savez_compressed(os.path.join(args.out, "reference_outputs.npz"), **arrays)
+    with open(os.path.join(args.out, "reference_dicts.json"), "w") as fh:
+        json.dump({"meta": meta, "dicts": dicts}, fh, indent=1)   # insertion order kept: key order is contract
+    total = sum(a.nbytes for a in arrays.values())
+    print(f"wrote {len(arrays)} arrays ({total/1e6:.2f} MB raw), {len(dicts)} dicts -> {args.out}")
+    print(json.dumps(meta))
+
+
+if __name__ == "__main__":
+    main()

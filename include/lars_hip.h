@@ -1,0 +1,258 @@
+/*
+ * lars_hip.h -- C ABI of liblars_hip.so: the MI355X (gfx950) implementation of
+ * the per-pixel multispectral index path of lars-uav/lars-image-processing.
+ *
+ * The reference has no FFI; its boundary for this path is three Python call
+ * signatures (file:line in the upstream repository):
+ *
+ *   fix_white_balance(img_array)              process-images.py:424-447
+ *                                             backend-process.py:17-26, process-rgn.py:4-49
+ *   calculate_index(img_array, index_type)    process-images.py:449-490
+ *   calculate_index(red, green, nir, type)    backend-process.py:28-38
+ *   calculate_ndvi(image_path, ...)           process-ndvi.py:5-48   (float64 flavour)
+ *   analyze_index(index_array, index_type)    process-images.py:492-513 (+ :651-658, :830-832)
+ *   analyze_ndvi_statistics(ndvi_array)       process-ndvi.py:50-73
+ *   plt.hist(bins=50, range=(-1,1))           process-ndvi.py:97
+ *   imshow(cmap, vmin=-1, vmax=1)             process-images.py:695, backend-process.py:43
+ *
+ * Each entry point below names the interface it replaces.  A maintainer binds
+ * them with ctypes (the shipped binding is
+ * lars_image_processing_amd/_ffi.py).
+ *
+ * Conventions
+ *   - plain pointers and sizes only; no C++/torch types.
+ *   - every function returns LARS_OK (0) or a negative lars_status; the text of
+ *     the last failure on the calling thread is lars_last_error().
+ *   - "host entry points" (lars_h_*) take HOST pointers, stage through the
+ *     library's device workspace and return when the result is in the caller's
+ *     buffer.  They are re-entrant: each calling thread owns a stream and a
+ *     workspace.
+ *   - "device entry points" (lars_d_*) take DEVICE pointers (lars_malloc) and
+ *     enqueue on `stream` (NULL = the calling thread's library stream) without
+ *     synchronising; this is what the batched tile path and bench.py use.
+ *   - there is no CPU fallback anywhere: without a gfx950 device every compute
+ *     entry point fails with LARS_ERR_NO_DEVICE.
+ */
+#ifndef LARS_HIP_H
+#define LARS_HIP_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define LARS_ABI_VERSION 1
+#define LARS_HIST_BINS 50          /* process-ndvi.py:97 */
+
+typedef enum lars_status {
+    LARS_OK = 0,
+    LARS_ERR_INVALID = -1,         /* bad argument (shape, dtype, NULL, mask) */
+    LARS_ERR_NO_DEVICE = -2,       /* no usable gfx950 GPU / HIP runtime failure at init */
+    LARS_ERR_HIP = -3,             /* a HIP call failed; see lars_last_error() */
+    LARS_ERR_OOM = -4,             /* device allocation failed */
+    LARS_ERR_RCCL = -5,            /* RCCL missing or a collective failed */
+    LARS_ERR_UNSUPPORTED = -6
+} lars_status;
+
+/* sample types of interleaved images */
+#define LARS_U8  1
+#define LARS_U16 2
+
+/* index ids / mask bits (process-images.py:466-482) */
+#define LARS_NDVI  0               /* (nir - red)   / (nir + red)   */
+#define LARS_GNDVI 1               /* (nir - green) / (nir + green) */
+#define LARS_NDWI  2               /* (green - nir) / (green + nir) */
+#define LARS_MASK_NDVI  1u
+#define LARS_MASK_GNDVI 2u
+#define LARS_MASK_NDWI  4u
+#define LARS_MASK_ALL   7u
+
+/* flags of lars_fused_args.flags */
+#define LARS_F_STATS 1u            /* fill stats[tile][index] (min/max/sum/sumsq/above/count) */
+#define LARS_F_HIST  2u            /* also the 50-bin histogram (implies LARS_F_STATS) */
+
+/*
+ * Order-independent statistics record of one index over one tile (or, after a
+ * merge, over many tiles / ranks).  Everything analyze_index (process-images.py
+ * :506-512) and analyze_ndvi_statistics (process-ndvi.py:60-71) report except the
+ * median follows from it: mean = sum/count, min, max, coverage = above/count*100,
+ * std = sqrt(sumsq/count - mean^2).
+ *   sum / sumsq : exact sums of the float32 index values for uint8 tiles (fixed
+ *                 point 2^-32 accumulation), correctly rounded to double.
+ *   above       : samples with x > threshold, compared in the sample's own
+ *                 precision (float32 against float32(0.2), process-images.py:511).
+ *   hist        : numpy.histogram(x, bins=50, range=(-1, 1)) counts.
+ */
+typedef struct lars_stats {
+    double   sum;
+    double   sumsq;
+    uint64_t count;
+    uint64_t above;
+    uint64_t nans;
+    double   min;                  /* float32 samples widen exactly */
+    double   max;
+    double   threshold;
+    uint32_t index_id;
+    uint32_t reserved;
+    uint64_t hist[LARS_HIST_BINS];
+} lars_stats;
+
+/* ------------------------------------------------------------------ runtime */
+int         lars_abi_version(void);
+const char *lars_last_error(void);
+int         lars_device_count(int *count);
+int         lars_set_device(int ordinal);           /* per calling thread; default 0 */
+int         lars_get_device(int *ordinal);
+int         lars_device_name(char *buf, size_t buflen);
+int         lars_malloc(void **dptr, size_t bytes);
+int         lars_free(void *dptr);
+int         lars_memset(void *dptr, int value, size_t bytes, void *stream);
+int         lars_memcpy_h2d(void *dst_dev, const void *src_host, size_t bytes);
+int         lars_memcpy_d2h(void *dst_host, const void *src_dev, size_t bytes);
+int         lars_memcpy_d2d(void *dst_dev, const void *src_dev, size_t bytes, void *stream);
+int         lars_stream_create(void **stream);
+int         lars_stream_destroy(void *stream);
+int         lars_synchronize(void *stream);         /* NULL = calling thread's library stream */
+int         lars_shutdown(void);                    /* frees the calling thread's workspace */
+/* HIP events on a given stream (bench.py times kernels with these) */
+int         lars_event_create(void **event);
+int         lars_event_destroy(void *event);
+int         lars_event_record(void *event, void *stream);
+int         lars_event_elapsed_ms(void *start, void *stop, float *ms);   /* synchronises on stop */
+
+/* --------------------------------------------------------- device entry points */
+
+/* Per-tile, per-channel sample histograms: the pre-pass np.percentile needs
+ * (process-images.py:437).  hist is [ntiles][3][nvalues] uint32, nvalues = 256
+ * (LARS_U8) or 65536 (LARS_U16); it is zeroed by the call. */
+int lars_d_channel_hist(const void *tiles, int64_t ntiles, int64_t npix, int channels,
+                        int dtype, uint32_t *hist, void *stream);
+
+/* Histograms -> percentiles (2, 98) -> white-balance table, all on device.
+ * table is [ntiles][3][nvalues] uint8 with table[t][c][v] == fix_white_balance()
+ * of sample value v in channel c of tile t (process-images.py:437-441: float64
+ * arithmetic, clip, float32 store, truncating uint8 cast).  percentiles is
+ * [ntiles][3][2] double (may be NULL).  rgn_variant != 0 selects process-rgn.py
+ * :25-33 (extra inner clip; same table for integer input, kept for fidelity). */
+int lars_d_wb_table(const uint32_t *hist, int64_t ntiles, int64_t npix, int dtype,
+                    uint8_t *table, double *percentiles, int rgn_variant, void *stream);
+
+typedef struct lars_fused_args {
+    const void    *tiles;          /* [ntiles][h*w][channels] interleaved R,G,NIR(,...) */
+    int64_t        ntiles;
+    int64_t        npix;           /* h*w */
+    int32_t        channels;       /* >= 3 */
+    int32_t        dtype;          /* LARS_U8 | LARS_U16 */
+    const uint8_t *wb_table;       /* [ntiles][3][nvalues] or NULL: indices of the raw samples */
+    uint32_t       index_mask;     /* LARS_MASK_* */
+    uint32_t       flags;          /* LARS_F_* */
+    float         *out_index[3];   /* [ntiles][npix] float32 per index, or NULL */
+    uint8_t       *out_wb;         /* [ntiles][npix][channels] uint8 (channels >= 3 zero), or NULL */
+    uint8_t       *out_rgba[3];    /* [ntiles][npix][4] colormapped index, or NULL */
+    const uint8_t *cmap_lut[3];    /* [256][4] RGBA8 table per index (needed where out_rgba set) */
+    lars_stats    *stats;          /* [ntiles][3] (entries of unrequested indices untouched), or NULL */
+    void          *stream;
+} lars_fused_args;
+
+/* The hot path: one pass over interleaved tiles doing band de-interleave,
+ * white-balance table lookup, NDVI/GNDVI/NDWI (process-images.py:456-490, IEEE
+ * float32), optional float32 / uint8 / RGBA8 outputs and per-tile statistics. */
+int lars_d_fused(const lars_fused_args *args);
+
+/* float32 band planes -> index, backend-process.py:28-38 (literal formula with
+ * the float32 epsilon add and the clip; any float input). */
+int lars_d_index_planes_f32(const float *red, const float *green, const float *nir,
+                            int64_t n, int index_id, float *out, void *stream);
+
+/* interleaved image -> float64 NDVI, process-ndvi.py:18-31 */
+int lars_d_ndvi_f64(const void *img, int64_t npix, int channels, int dtype,
+                    double *out, void *stream);
+
+/* Statistics of an arbitrary float32 / float64 array (process-images.py:506-512,
+ * process-ndvi.py:60-71).  want_hist adds the 50-bin histogram. */
+int lars_d_array_stats_f32(const float *x, int64_t n, float threshold, int want_hist,
+                           lars_stats *out_dev, void *stream);
+int lars_d_array_stats_f64(const double *x, int64_t n, double threshold, int want_hist,
+                           lars_stats *out_dev, double *out_sumsqdev_dev, void *stream);
+
+/* np.median by radix select on device: writes the two middle order statistics
+ * ((n-1)/2 and n/2) to out_dev[0..1]. scratch must hold lars_select_scratch_bytes(). */
+size_t lars_select_scratch_bytes(void);
+int lars_d_median_pair_f32(const float *x, int64_t n, float *out_dev, void *scratch, void *stream);
+int lars_d_median_pair_f64(const double *x, int64_t n, double *out_dev, void *scratch, void *stream);
+
+/* float32 index -> RGBA8: LUT[min(int((x + 1f) * 128f), 255)], the per-pixel
+ * mapping of imshow(cmap, vmin=-1, vmax=1) (process-images.py:695). */
+int lars_d_colormap_f32(const float *x, int64_t n, const uint8_t *lut_rgba, uint8_t *out_rgba,
+                        void *stream);
+
+/* Synthetic RGNir tiles generated in HBM (bench / tests): counter hash of
+ * (seed, tile, word); profile 0 = uniform bytes, 1 = vegetation-like squeeze. */
+int lars_d_synth_u8(uint8_t *tiles, int64_t ntiles, int64_t first_tile, int64_t npix, int channels,
+                    uint32_t seed, int profile, void *stream);
+
+/* Fold n records (same index) into one: sums add, min/max fold, histograms add. */
+int lars_stats_merge(const lars_stats *records, int64_t n, lars_stats *out);
+
+/* ----------------------------------------------------------- host entry points */
+
+/* fix_white_balance(img_array) -- process-images.py:424-447 (variant 0),
+ * backend-process.py:17-26 (variant 0), process-rgn.py:25-44 (variant 1).
+ * img/out are host [h][w][channels]; out is uint8 with channels >= 3 zeroed. */
+int lars_h_fix_white_balance(const void *img, int64_t h, int64_t w, int channels, int dtype,
+                             int variant, uint8_t *out, double *percentiles /* [3][2] or NULL */);
+
+/* calculate_index(img_array, index_type) -- process-images.py:449-490.
+ * Several indices in one pass: out[k] is host [h][w] float32 or NULL. */
+int lars_h_calculate_index(const void *img, int64_t h, int64_t w, int channels, int dtype,
+                           uint32_t index_mask, float *const out[3],
+                           lars_stats *stats /* [3] or NULL */, int want_hist);
+
+/* calculate_index(red, green, nir, index_type) -- backend-process.py:28-38 */
+int lars_h_calculate_index_planes(const float *red, const float *green, const float *nir,
+                                  int64_t n, int index_id, float *out);
+
+/* calculate_ndvi maths -- process-ndvi.py:18-31 (float64 out) */
+int lars_h_ndvi_f64(const void *img, int64_t h, int64_t w, int channels, int dtype, double *out);
+
+/* analyze_index / analyze_ndvi_statistics on a host array: stats + the two
+ * middle order statistics (median = their mean) + sum of squared deviations
+ * from the mean (np.std, float64 flavour). */
+int lars_h_analyze_f32(const float *x, int64_t n, float threshold, int want_hist,
+                       lars_stats *out, float median_pair[2]);
+int lars_h_analyze_f64(const double *x, int64_t n, double threshold, int want_hist,
+                       lars_stats *out, double median_pair[2], double *sumsqdev);
+
+/* Whole reference pipeline for one host image in one upload:
+ * white balance -> requested indices -> statistics (+ medians) -> optional
+ * RGBA8 colormaps.  Any output pointer may be NULL. */
+int lars_h_process_image(const void *img, int64_t h, int64_t w, int channels, int dtype,
+                         int apply_wb, uint32_t index_mask, int want_hist,
+                         uint8_t *out_wb, float *const out_index[3],
+                         lars_stats *stats /* [3] */, float *medians /* [3][2] */,
+                         uint8_t *const out_rgba[3], const uint8_t *const cmap_lut[3]);
+
+int lars_h_colormap_f32(const float *x, int64_t n, const uint8_t *lut_rgba, uint8_t *out_rgba);
+
+/* ------------------------------------------------------------------ multi-GPU */
+/* One process per GPU.  RCCL (librccl.so) is loaded on first use.  unique_id is
+ * LARS_COMM_ID_BYTES bytes produced by lars_comm_unique_id() on rank 0 and
+ * handed to the other ranks by the launcher (file, socket, environment). */
+#define LARS_COMM_ID_BYTES 128
+int lars_comm_unique_id(uint8_t *id_out);
+int lars_comm_init(void **comm, int nranks, int rank, const uint8_t *unique_id);
+int lars_comm_destroy(void *comm);
+/* Global statistics: every rank contributes n records (device or host memory,
+ * is_device says which); on return every rank holds the fold over all ranks in
+ * rank order (one ncclAllGather over xGMI + a deterministic local fold). */
+int lars_comm_allreduce_stats(void *comm, lars_stats *records, int64_t n, int is_device, void *stream);
+/* max / sum of a double over ranks (bench timing, barriers) */
+int lars_comm_allreduce_f64(void *comm, double *values_host, int64_t n, int op /*0 sum,1 max,2 min*/);
+int lars_comm_barrier(void *comm);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* LARS_HIP_H */

@@ -1,0 +1,24 @@
+"""MI355X-native multispectral index path (white balance -> NDVI/GNDVI/NDWI -> statistics).
+
+Drop-in for the per-pixel path of lars-uav/lars-image-processing: the functions
+below keep the reference's signatures and run on hand-written HIP kernels
+(gfx950) behind a C ABI (include/lars_hip.h).  No PyTorch, no NumPy fallback.
+"""
+from .api import (  # noqa: F401
+    analyze_index,
+    analyze_index_statistics,
+    analyze_ndvi_statistics,
+    calculate_index,
+    calculate_ndvi,
+    colorize_index,
+    colormap_lut,
+    correct_white_balance,
+    fix_white_balance,
+    fix_white_balance_rgnir,
+    index_histogram,
+    process_image,
+    timeseries_row,
+)
+from .batch import TileBatch, local_fold, merge_records, shard_range, summarize  # noqa: F401
+
+__version__ = "0.1.0"

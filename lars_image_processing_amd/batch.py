@@ -1,0 +1,238 @@
+"""Batched, device-resident tile path (new entry point; BASELINE.json configs 2-5).
+
+The reference processes one image per Python call (backend-process.py:92-95 is
+its only batch loop).  Here a batch of equally sized RGNir tiles lives in HBM as
+``[ntiles][H][W][C]`` and one launch sequence covers the whole batch:
+
+    channel histograms -> white-balance tables -> fused indices + statistics
+
+Tiles are independent, so a batch shards across GPUs by tile with no data-path
+exchange; only the global statistics need one small collective (``dist.py``).
+"""
+from __future__ import annotations
+
+import ctypes as C
+
+import numpy as np
+
+from . import _ffi
+from ._ffi import FusedArgs, INDEX_IDS, INDEX_NAMES, STATS_DTYPE, DeviceBuffer
+
+MAX_TILES_PER_LAUNCH = 65535      # grid.y limit
+
+
+def shard_range(ntiles, rank, world):
+    """Contiguous block of tiles owned by ``rank`` (remainder to the low ranks)."""
+    base, rem = divmod(int(ntiles), int(world))
+    start = rank * base + min(rank, rem)
+    return start, start + base + (1 if rank < rem else 0)
+
+
+class TileBatch:
+    """A batch of interleaved uint8/uint16 tiles resident in HBM."""
+
+    def __init__(self, ntiles, h, w, channels=3, dtype=np.uint8, first_tile=0):
+        self.ntiles, self.h, self.w, self.channels = int(ntiles), int(h), int(w), int(channels)
+        self.dtype = np.dtype(dtype)
+        self.code = _ffi.dtype_code(self.dtype)
+        if self.code is None:
+            raise TypeError("tiles must be uint8 or uint16")
+        if self.ntiles < 1 or self.ntiles > MAX_TILES_PER_LAUNCH:
+            raise ValueError(f"1 <= ntiles <= {MAX_TILES_PER_LAUNCH} per batch")
+        self.first_tile = int(first_tile)
+        self.npix = self.h * self.w
+        self.nvalues = 256 if self.code == _ffi.U8 else 65536
+        self.tile_bytes = self.npix * self.channels * self.dtype.itemsize
+        self.tiles = DeviceBuffer(self.ntiles * self.tile_bytes)
+        self.hist = None
+        self.table = None
+        self.percentiles = None
+
+    # -- construction -----------------------------------------------------
+    @classmethod
+    def from_host(cls, array, first_tile=0):
+        arr = np.ascontiguousarray(array)
+        if arr.ndim != 4 or arr.shape[3] < 3:
+            raise ValueError("expected [ntiles, H, W, C>=3]")
+        b = cls(arr.shape[0], arr.shape[1], arr.shape[2], arr.shape[3], arr.dtype, first_tile)
+        b.tiles.upload(arr)
+        return b
+
+    @classmethod
+    def synthetic(cls, ntiles, h, w, seed=1234, profile="uniform", first_tile=0, channels=3):
+        """uint8 tiles generated in HBM by the counter hash (never cross PCIe)."""
+        b = cls(ntiles, h, w, channels, np.uint8, first_tile)
+        _ffi.call("lars_d_synth_u8", C.c_void_p(b.tiles.ptr), b.ntiles, b.first_tile, b.npix, b.channels,
+                  int(seed) & 0xFFFFFFFF, {"uniform": 0, "vegetation": 1}[profile], None)
+        _ffi.call("lars_synchronize", None)
+        return b
+
+    def host_tiles(self, start=0, count=None):
+        count = self.ntiles - start if count is None else count
+        return self.tiles.download(self.dtype, (count, self.h, self.w, self.channels), start * self.tile_bytes)
+
+    # -- pass 1: white-balance tables --------------------------------------
+    def compute_wb_tables(self, stream=None, rgn_variant=0):
+        """np.percentile(ch, (2, 98)) per tile and channel -> 8-bit tables, on device."""
+        if self.hist is None:
+            self.hist = DeviceBuffer(self.ntiles * 3 * self.nvalues * 4)
+            self.table = DeviceBuffer(self.ntiles * 3 * self.nvalues)
+            self.percentiles = DeviceBuffer(self.ntiles * 3 * 2 * 8)
+        _ffi.call("lars_d_channel_hist", C.c_void_p(self.tiles.ptr), self.ntiles, self.npix, self.channels, self.code,
+                  C.c_void_p(self.hist.ptr), stream)
+        _ffi.call("lars_d_wb_table", C.c_void_p(self.hist.ptr), self.ntiles, self.npix, self.code,
+                  C.c_void_p(self.table.ptr), C.c_void_p(self.percentiles.ptr), int(rgn_variant), stream)
+        return self
+
+    def host_tables(self):
+        return self.table.download(np.uint8, (self.ntiles, 3, self.nvalues))
+
+    def host_percentiles(self):
+        return self.percentiles.download(np.float64, (self.ntiles, 3, 2))
+
+    def host_hist(self):
+        return self.hist.download(np.uint32, (self.ntiles, 3, self.nvalues))
+
+    # -- pass 2: the fused kernel ------------------------------------------
+    def make_outputs(self, indices=INDEX_NAMES, index=False, wb=False, rgba=False, ring=None):
+        """Allocate output planes.  ``ring`` < ntiles reuses a ring of that many
+        tile slots (same HBM traffic, bounded footprint) -- see BatchOutputs."""
+        return BatchOutputs(self, indices, index, wb, rgba, ring)
+
+    def fused_args(self, indices=INDEX_NAMES, white_balance=True, stats=None, hist=False, outputs=None,
+                   stream=None, tile_start=0, tile_count=None):
+        tile_count = self.ntiles - tile_start if tile_count is None else tile_count
+        a = FusedArgs()
+        a.tiles = self.tiles.ptr + tile_start * self.tile_bytes
+        a.ntiles, a.npix, a.channels, a.dtype = tile_count, self.npix, self.channels, self.code
+        if white_balance:
+            if self.table is None:
+                raise RuntimeError("compute_wb_tables() first")
+            a.wb_table = self.table.ptr + tile_start * 3 * self.nvalues
+        mask = 0
+        for t in indices:
+            mask |= 1 << INDEX_IDS[t]
+        a.index_mask = mask
+        a.flags = (_ffi.F_STATS if stats is not None else 0) | (_ffi.F_HIST if (stats is not None and hist) else 0)
+        if stats is not None:
+            a.stats = stats.ptr + tile_start * 3 * STATS_DTYPE.itemsize
+        if outputs is not None:
+            slot = tile_start % outputs.slots
+            if slot + tile_count > outputs.slots:
+                raise ValueError("tile range wraps the output ring")
+            for k in range(3):
+                if outputs.index[k] is not None:
+                    a.out_index[k] = outputs.index[k].ptr + slot * self.npix * 4
+                if outputs.rgba[k] is not None:
+                    a.out_rgba[k] = outputs.rgba[k].ptr + slot * self.npix * 4
+                    a.cmap_lut[k] = outputs.luts[k].ptr
+            if outputs.wb is not None:
+                a.out_wb = outputs.wb.ptr + slot * self.npix * self.channels
+        a.stream = stream
+        return a
+
+    def new_stats(self):
+        return DeviceBuffer(self.ntiles * 3 * STATS_DTYPE.itemsize)
+
+    def run_fused(self, args):
+        _ffi.call("lars_d_fused", C.byref(args))
+
+    def process(self, indices=INDEX_NAMES, white_balance=True, hist=False, outputs=None, stream=None,
+                recompute_tables=True):
+        """Both passes over the whole batch; returns per-tile records
+        (structured ndarray ``[ntiles, 3]`` of STATS_DTYPE; rows of indices not
+        requested are zero)."""
+        if white_balance and (recompute_tables or self.table is None):
+            self.compute_wb_tables(stream)
+        stats = self.new_stats()
+        stats.zero()
+        if outputs is None or outputs.slots >= self.ntiles:
+            self.run_fused(self.fused_args(indices, white_balance, stats, hist, outputs, stream))
+        else:
+            for start in range(0, self.ntiles, outputs.slots):
+                count = min(outputs.slots, self.ntiles - start)
+                self.run_fused(self.fused_args(indices, white_balance, stats, hist, outputs, stream, start, count))
+        _ffi.call("lars_synchronize", stream)
+        rec = stats.download(STATS_DTYPE, (self.ntiles, 3))
+        stats.free()
+        return rec
+
+    def free(self):
+        for b in (self.tiles, self.hist, self.table, self.percentiles):
+            if b is not None:
+                b.free()
+
+
+class BatchOutputs:
+    """Device output planes of a batch (optionally a ring of ``slots`` tiles)."""
+
+    def __init__(self, batch, indices, index, wb, rgba, ring=None):
+        from .api import colormap_lut, _colormap_for
+        self.slots = batch.ntiles if not ring else min(int(ring), batch.ntiles)
+        self.index, self.rgba, self.luts = [None] * 3, [None] * 3, [None] * 3
+        for t in indices:
+            k = INDEX_IDS[t]
+            if index:
+                self.index[k] = DeviceBuffer(self.slots * batch.npix * 4)
+            if rgba:
+                self.rgba[k] = DeviceBuffer(self.slots * batch.npix * 4)
+                self.luts[k] = DeviceBuffer(1024)
+                self.luts[k].upload(colormap_lut(_colormap_for(t)))
+        self.wb = DeviceBuffer(self.slots * batch.npix * batch.channels) if wb else None
+        self.batch = batch
+
+    def host_index(self, index_type, slot=0, count=1):
+        k = INDEX_IDS[index_type]
+        b = self.batch
+        return self.index[k].download(np.float32, (count, b.h, b.w), slot * b.npix * 4)
+
+    def host_rgba(self, index_type, slot=0, count=1):
+        k = INDEX_IDS[index_type]
+        b = self.batch
+        return self.rgba[k].download(np.uint8, (count, b.h, b.w, 4), slot * b.npix * 4)
+
+    def host_wb(self, slot=0, count=1):
+        b = self.batch
+        return self.wb.download(np.uint8, (count, b.h, b.w, b.channels), slot * b.npix * b.channels)
+
+    def free(self):
+        for b in self.index + self.rgba + self.luts + [self.wb]:
+            if b is not None:
+                b.free()
+
+
+# ---------------------------------------------------------------------------
+# folding records
+# ---------------------------------------------------------------------------
+def merge_records(records):
+    """Fold a 1-D structured array of STATS_DTYPE records (one index) into one
+    record, in order, through ``lars_stats_merge`` (host C; no GPU needed)."""
+    rec = np.ascontiguousarray(records, dtype=STATS_DTYPE).reshape(-1)
+    out = np.zeros(1, dtype=STATS_DTYPE)
+    _ffi.call("lars_stats_merge", _ffi.ptr(rec), rec.size, _ffi.ptr(out))
+    return out[0]
+
+
+def summarize(record):
+    """Global statistics of a merged record (SURVEY.md 8(e) semantics)."""
+    count = int(record["count"])
+    mean = float(record["sum"]) / count
+    var = max(float(record["sumsq"]) / count - mean * mean, 0.0)
+    return {
+        "count": count,
+        "mean": mean,
+        "std": var ** 0.5,
+        "min": float(record["min"]),
+        "max": float(record["max"]),
+        "coverage": int(record["above"]) / count * 100.0,
+        "hist": np.array(record["hist"], dtype=np.int64),
+    }
+
+
+def local_fold(tile_records, indices=INDEX_NAMES):
+    """[ntiles, 3] per-tile records -> [3] per-index records of this rank."""
+    out = np.zeros(3, dtype=STATS_DTYPE)
+    for t in indices:
+        k = INDEX_IDS[t]
+        out[k] = merge_records(tile_records[:, k])
+    return out

@@ -1,0 +1,434 @@
+// Array-level kernels around the hot path: statistics and medians of index
+// arrays, the 4-argument band-plane index, the float64 NDVI flavour, colormaps.
+//
+// Reference semantics (lars-uav/lars-image-processing):
+//   process-images.py:506-512   analyze_index          (mean / median / min / max / coverage)
+//   process-ndvi.py:60-71       analyze_ndvi_statistics (+ population std)
+//   backend-process.py:28-38    calculate_index(red, green, nir, index_type)
+//   process-ndvi.py:18-31       float64 NDVI
+//   process-images.py:695       imshow(cmap, vmin=-1, vmax=1)
+#include "common.h"
+
+namespace lars {
+
+// ===========================================================================
+// Statistics of a float32 / float64 array
+// ===========================================================================
+// Deterministic: every block writes one partial record, a single block folds
+// them in block order.
+struct ArrPartial {
+    double sum, sumsq, mn, mx;
+    unsigned long long above, nans, count;
+    unsigned long long pad;
+};
+
+template <typename T>
+__device__ inline int hist_bin_t(T x, const T *edges)
+{
+    int b = (int)((x + (T)1) * (T)25);
+    b = b < 0 ? 0 : (b > LARS_HIST_BINS - 1 ? LARS_HIST_BINS - 1 : b);
+    if (x < edges[b]) --b;
+    else if (b != LARS_HIST_BINS - 1 && x >= edges[b + 1]) ++b;
+    return b;
+}
+
+template <typename T>
+__global__ __launch_bounds__(256) void k_array_stats(const T *__restrict__ x, long long n, T thr, int want_hist,
+                                                     ArrPartial *__restrict__ partials,
+                                                     unsigned long long *__restrict__ ghist)
+{
+    __shared__ unsigned int s_hist[LARS_HIST_BINS];
+    __shared__ T s_edges[LARS_HIST_BINS + 1];
+    __shared__ ArrPartial s_part[4];
+    const int tid = threadIdx.x;
+    if (want_hist) {
+        if (tid < LARS_HIST_BINS) s_hist[tid] = 0;
+        if (tid <= LARS_HIST_BINS) s_edges[tid] = (T)hist_edge_f64(tid);
+        __syncthreads();
+    }
+    double sum = 0, sumsq = 0;
+    double mn = __builtin_inf(), mx = -__builtin_inf();
+    unsigned long long above = 0, nans = 0, count = 0;
+    for (long long i = (long long)blockIdx.x * 256 + tid; i < n; i += (long long)gridDim.x * 256) {
+        const T v = x[i];
+        if (v != v) { ++nans; continue; }
+        const double d = (double)v;
+        sum += d; sumsq += d * d;
+        mn = fmin(mn, d); mx = fmax(mx, d);
+        above += (v > thr) ? 1 : 0;
+        ++count;
+        if (want_hist && v >= (T)-1 && v <= (T)1) atomicAdd(&s_hist[hist_bin_t<T>(v, s_edges)], 1u);
+    }
+    for (int off = 32; off >= 1; off >>= 1) {
+        sum += __shfl_xor(sum, off); sumsq += __shfl_xor(sumsq, off);
+        mn = fmin(mn, __shfl_xor(mn, off)); mx = fmax(mx, __shfl_xor(mx, off));
+        above += __shfl_xor(above, off); nans += __shfl_xor(nans, off); count += __shfl_xor(count, off);
+    }
+    if ((tid & 63) == 0) {
+        ArrPartial p; p.sum = sum; p.sumsq = sumsq; p.mn = mn; p.mx = mx; p.above = above; p.nans = nans; p.count = count; p.pad = 0;
+        s_part[tid >> 6] = p;
+    }
+    __syncthreads();
+    if (tid == 0) {
+        ArrPartial p = s_part[0];
+        for (int w = 1; w < 4; ++w) {
+            p.sum += s_part[w].sum; p.sumsq += s_part[w].sumsq;
+            p.mn = fmin(p.mn, s_part[w].mn); p.mx = fmax(p.mx, s_part[w].mx);
+            p.above += s_part[w].above; p.nans += s_part[w].nans; p.count += s_part[w].count;
+        }
+        partials[blockIdx.x] = p;
+    }
+    if (want_hist && tid < LARS_HIST_BINS && s_hist[tid]) atomicAdd(&ghist[tid], (unsigned long long)s_hist[tid]);
+}
+
+__global__ void k_array_stats_fold(const ArrPartial *__restrict__ partials, int nblocks, double thr,
+                                   const unsigned long long *__restrict__ ghist, int want_hist, lars_stats *out)
+{
+    if (threadIdx.x == 0 && blockIdx.x == 0) {
+        ArrPartial p = partials[0];
+        for (int b = 1; b < nblocks; ++b) {
+            p.sum += partials[b].sum; p.sumsq += partials[b].sumsq;
+            p.mn = fmin(p.mn, partials[b].mn); p.mx = fmax(p.mx, partials[b].mx);
+            p.above += partials[b].above; p.nans += partials[b].nans; p.count += partials[b].count;
+        }
+        out->sum = p.sum; out->sumsq = p.sumsq; out->count = p.count + p.nans; out->above = p.above; out->nans = p.nans;
+        out->min = p.mn; out->max = p.mx; out->threshold = thr; out->index_id = 0xFFFFFFFFu; out->reserved = 0;
+    }
+    if (threadIdx.x < LARS_HIST_BINS) out->hist[threadIdx.x] = want_hist ? ghist[threadIdx.x] : 0ull;
+}
+
+// sum of squared deviations from the mean (np.std's second pass, process-ndvi.py:65)
+template <typename T>
+__global__ __launch_bounds__(256) void k_sumsqdev(const T *__restrict__ x, long long n, const lars_stats *st,
+                                                  double *__restrict__ partials)
+{
+    __shared__ double s_w[4];
+    const double mean = st->sum / (double)st->count;
+    double acc = 0;
+    for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < n; i += (long long)gridDim.x * 256) {
+        const double d = (double)x[i] - mean;
+        acc += d * d;
+    }
+    for (int off = 32; off >= 1; off >>= 1) acc += __shfl_xor(acc, off);
+    if ((threadIdx.x & 63) == 0) s_w[threadIdx.x >> 6] = acc;
+    __syncthreads();
+    if (threadIdx.x == 0) partials[blockIdx.x] = s_w[0] + s_w[1] + s_w[2] + s_w[3];
+}
+__global__ void k_fold_f64(const double *partials, int nblocks, double *out)
+{
+    if (threadIdx.x == 0 && blockIdx.x == 0) {
+        double s = 0;
+        for (int b = 0; b < nblocks; ++b) s += partials[b];
+        *out = s;
+    }
+}
+
+// ===========================================================================
+// np.median: radix select of the two middle order statistics
+// ===========================================================================
+#define SEL_BITS 11
+#define SEL_BINS (1 << SEL_BITS)
+struct SelectState {
+    unsigned long long prefix;      // key bits decided so far
+    unsigned long long k;           // rank still to find inside the current prefix
+    unsigned long long k0;          // the requested rank (n-1)/2
+    unsigned long long n;
+    unsigned long long c_le;        // # keys <= selected key
+    unsigned long long next_key;    // smallest key > selected key
+    unsigned int hist[SEL_BINS];
+};
+
+template <typename T> struct KeyOf;
+template <> struct KeyOf<float> {
+    typedef unsigned int type;
+    static constexpr int BITS = 32;
+    __device__ static inline unsigned long long key(float x) { return f32_key(x); }
+    __device__ static inline float val(unsigned long long k) { return key_f32((unsigned int)k); }
+};
+template <> struct KeyOf<double> {
+    typedef unsigned long long type;
+    static constexpr int BITS = 64;
+    __device__ static inline unsigned long long key(double x) { return f64_key(x); }
+    __device__ static inline double val(unsigned long long k) { return key_f64(k); }
+};
+
+__global__ void k_sel_init(SelectState *st, long long n)
+{
+    const int tid = blockIdx.x * blockDim.x + threadIdx.x;
+    if (tid == 0) {
+        st->prefix = 0; st->k0 = (unsigned long long)((n - 1) / 2); st->k = st->k0; st->n = (unsigned long long)n;
+        st->c_le = 0; st->next_key = ~0ull;
+    }
+    if (tid < SEL_BINS) st->hist[tid] = 0;
+}
+
+// histogram of digit [shift, shift+bits) over keys that match the prefix above it
+template <typename T>
+__global__ __launch_bounds__(256) void k_sel_hist(const T *__restrict__ x, long long n, SelectState *st, int shift, int bits)
+{
+    __shared__ unsigned int s_h[SEL_BINS];
+    for (int i = threadIdx.x; i < SEL_BINS; i += 256) s_h[i] = 0;
+    __syncthreads();
+    const unsigned long long prefix = st->prefix;
+    const int hi = shift + bits;                                   // bits above the digit
+    const bool top = hi >= KeyOf<T>::BITS;
+    const unsigned long long dmask = (1ull << bits) - 1ull;
+    for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < n; i += (long long)gridDim.x * 256) {
+        const unsigned long long key = KeyOf<T>::key(x[i]);
+        if (top || (key >> hi) == (prefix >> hi)) atomicAdd(&s_h[(key >> shift) & dmask], 1u);
+    }
+    __syncthreads();
+    for (int i = threadIdx.x; i < SEL_BINS; i += 256)
+        if (s_h[i]) atomicAdd(&st->hist[i], s_h[i]);
+}
+
+__global__ __launch_bounds__(256) void k_sel_pick(SelectState *st, int shift, int bits)
+{
+    // single block: find the digit whose cumulative count covers rank k
+    __shared__ unsigned long long s_cum[256];
+    const int tid = threadIdx.x;
+    const int nb = 1 << bits;
+    const int per = (nb + 255) / 256;
+    unsigned long long local = 0;
+    for (int j = 0; j < per; ++j) { const int b = tid * per + j; if (b < nb) local += st->hist[b]; }
+    s_cum[tid] = local;
+    __syncthreads();
+    for (int off = 1; off < 256; off <<= 1) {
+        unsigned long long v = tid >= off ? s_cum[tid - off] : 0;
+        __syncthreads();
+        s_cum[tid] += v;
+        __syncthreads();
+    }
+    const unsigned long long k = st->k;
+    unsigned long long cum = s_cum[tid] - local;
+    __syncthreads();
+    for (int j = 0; j < per; ++j) {
+        const int b = tid * per + j;
+        if (b < nb) {
+            const unsigned long long c = st->hist[b];
+            if (c && k >= cum && k < cum + c) {
+                st->prefix |= ((unsigned long long)b) << shift;
+                st->k = k - cum;
+            }
+            cum += c;
+        }
+    }
+    __syncthreads();
+    for (int i = tid; i < SEL_BINS; i += 256) st->hist[i] = 0;
+}
+
+template <typename T>
+__global__ __launch_bounds__(256) void k_sel_next(const T *__restrict__ x, long long n, SelectState *st)
+{
+    __shared__ unsigned long long s_c[4], s_m[4];
+    const unsigned long long sel = st->prefix;
+    unsigned long long c_le = 0, nxt = ~0ull;
+    for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < n; i += (long long)gridDim.x * 256) {
+        const unsigned long long key = KeyOf<T>::key(x[i]);
+        if (key <= sel) ++c_le;
+        else nxt = key < nxt ? key : nxt;
+    }
+    for (int off = 32; off >= 1; off >>= 1) {
+        c_le += __shfl_xor(c_le, off);
+        const unsigned long long o = __shfl_xor(nxt, off);
+        nxt = o < nxt ? o : nxt;
+    }
+    if ((threadIdx.x & 63) == 0) { s_c[threadIdx.x >> 6] = c_le; s_m[threadIdx.x >> 6] = nxt; }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        unsigned long long c = s_c[0] + s_c[1] + s_c[2] + s_c[3];
+        unsigned long long m = s_m[0];
+        for (int w = 1; w < 4; ++w) m = s_m[w] < m ? s_m[w] : m;
+        atomicAdd(&st->c_le, c);
+        atomicMin(&st->next_key, m);
+    }
+}
+
+template <typename T>
+__global__ void k_sel_finish(const SelectState *st, T *out)
+{
+    if (threadIdx.x == 0 && blockIdx.x == 0) {
+        const T v1 = KeyOf<T>::val(st->prefix);
+        T v2 = v1;
+        const unsigned long long k2 = st->n / 2;                  // == k0 when n is odd
+        if (k2 != st->k0 && k2 >= st->c_le) v2 = KeyOf<T>::val(st->next_key);
+        out[0] = v1;
+        out[1] = v2;
+    }
+}
+
+// ===========================================================================
+// Elementwise kernels
+// ===========================================================================
+// backend-process.py:28-38: float32 planes, epsilon added in float32, np.clip.
+__global__ __launch_bounds__(256) void k_index_planes(const float *__restrict__ red, const float *__restrict__ green,
+                                                      const float *__restrict__ nir, long long n, int index_id,
+                                                      float *__restrict__ out)
+{
+    const float *pa = index_id == LARS_NDWI ? green : nir;
+    const float *pb = index_id == LARS_NDVI ? red : (index_id == LARS_GNDVI ? green : nir);
+    for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < n; i += (long long)gridDim.x * 256) {
+        const float a = pa[i], b = pb[i];
+        float s = a + b;
+        s = s + 1e-10f;
+        float q = (a - b) / s;
+        if (q == q) q = q < -1.0f ? -1.0f : (q > 1.0f ? 1.0f : q);    // np.clip keeps NaN
+        out[i] = q;
+    }
+}
+
+// process-ndvi.py:18-31: float64 NDVI of an interleaved image.
+template <typename PIX>
+__global__ __launch_bounds__(256) void k_ndvi_f64(const PIX *__restrict__ img, long long npix, int channels,
+                                                  double *__restrict__ out)
+{
+    for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < npix; i += (long long)gridDim.x * 256) {
+        const PIX *p = img + i * channels;
+        const double red = (double)p[0], nir = (double)p[2];
+        double s = nir + red;
+        s = s + 1e-10;
+        double q = (nir - red) / s;
+        q = q < -1.0 ? -1.0 : (q > 1.0 ? 1.0 : q);
+        out[i] = q;
+    }
+}
+
+// imshow(cmap, vmin=-1, vmax=1): Normalize in float32, index int(norm*256) with 256 -> 255.
+__global__ __launch_bounds__(256) void k_colormap(const float *__restrict__ x, long long n,
+                                                  const unsigned int *__restrict__ lut, unsigned int *__restrict__ out)
+{
+    __shared__ unsigned int s_lut[256];
+    s_lut[threadIdx.x] = lut[threadIdx.x];
+    __syncthreads();
+    for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < n; i += (long long)gridDim.x * 256) {
+        const float v = x[i];
+        unsigned int o = 0u;                                           // NaN -> masked -> transparent black
+        if (v == v) {
+            const float s = (v + 1.0f) * 128.0f;
+            int idx = (int)s;
+            idx = idx < 0 ? 0 : (idx > 255 ? 255 : idx);
+            o = s_lut[idx];
+        }
+        out[i] = o;
+    }
+}
+
+}  // namespace lars
+
+using namespace lars;
+
+static int grid_for(long long n)
+{
+    long long b = (n + 255) / 256;
+    if (b > 2048) b = 2048;
+    if (b < 1) b = 1;
+    return (int)b;
+}
+
+template <typename T>
+static int array_stats_impl(const T *x, int64_t n, T thr, int want_hist, lars_stats *out_dev, double *sumsqdev_dev,
+                            void *stream)
+{
+    ThreadCtx *c;
+    LARS_TRY(ensure_ctx(&c));
+    if (!x || n <= 0 || !out_dev) return fail(LARS_ERR_INVALID, "lars_d_array_stats: bad arguments");
+    hipStream_t s = pick_stream(c, stream);
+    const int nb = grid_for(n);
+    const size_t need = (size_t)nb * sizeof(ArrPartial) + LARS_HIST_BINS * sizeof(unsigned long long) + (size_t)nb * sizeof(double);
+    LARS_TRY(scratch_reserve(c, need));
+    ArrPartial *parts = static_cast<ArrPartial *>(c->scratch);
+    unsigned long long *ghist = reinterpret_cast<unsigned long long *>(parts + nb);
+    double *dparts = reinterpret_cast<double *>(ghist + LARS_HIST_BINS);
+    LARS_HIP_TRY(hipMemsetAsync(ghist, 0, LARS_HIST_BINS * sizeof(unsigned long long), s));
+    hipLaunchKernelGGL((k_array_stats<T>), dim3(nb), dim3(256), 0, s, x, (long long)n, thr, want_hist, parts, ghist);
+    hipLaunchKernelGGL(k_array_stats_fold, dim3(1), dim3(64), 0, s, parts, nb, (double)thr, ghist, want_hist, out_dev);
+    if (sumsqdev_dev) {
+        hipLaunchKernelGGL((k_sumsqdev<T>), dim3(nb), dim3(256), 0, s, x, (long long)n, out_dev, dparts);
+        hipLaunchKernelGGL(k_fold_f64, dim3(1), dim3(64), 0, s, dparts, nb, sumsqdev_dev);
+    }
+    return launch_check("lars_d_array_stats");
+}
+
+extern "C" int lars_d_array_stats_f32(const float *x, int64_t n, float threshold, int want_hist, lars_stats *out_dev,
+                                      void *stream)
+{
+    return array_stats_impl<float>(x, n, threshold, want_hist, out_dev, nullptr, stream);
+}
+extern "C" int lars_d_array_stats_f64(const double *x, int64_t n, double threshold, int want_hist, lars_stats *out_dev,
+                                      double *out_sumsqdev_dev, void *stream)
+{
+    return array_stats_impl<double>(x, n, threshold, want_hist, out_dev, out_sumsqdev_dev, stream);
+}
+
+extern "C" size_t lars_select_scratch_bytes(void) { return sizeof(SelectState); }
+
+template <typename T>
+static int median_pair_impl(const T *x, int64_t n, T *out_dev, void *scratch, void *stream)
+{
+    ThreadCtx *c;
+    LARS_TRY(ensure_ctx(&c));
+    if (!x || n <= 0 || !out_dev || !scratch) return fail(LARS_ERR_INVALID, "lars_d_median_pair: bad arguments");
+    hipStream_t s = pick_stream(c, stream);
+    SelectState *st = static_cast<SelectState *>(scratch);
+    const int nb = grid_for(n);
+    hipLaunchKernelGGL(k_sel_init, dim3(SEL_BINS / 256), dim3(256), 0, s, st, (long long)n);
+    int hi = KeyOf<T>::BITS;
+    while (hi > 0) {
+        const int bits = hi >= SEL_BITS ? SEL_BITS : hi;
+        const int shift = hi - bits;
+        hipLaunchKernelGGL((k_sel_hist<T>), dim3(nb), dim3(256), 0, s, x, (long long)n, st, shift, bits);
+        hipLaunchKernelGGL(k_sel_pick, dim3(1), dim3(256), 0, s, st, shift, bits);
+        hi = shift;
+    }
+    hipLaunchKernelGGL((k_sel_next<T>), dim3(nb), dim3(256), 0, s, x, (long long)n, st);
+    hipLaunchKernelGGL((k_sel_finish<T>), dim3(1), dim3(64), 0, s, st, out_dev);
+    return launch_check("lars_d_median_pair");
+}
+extern "C" int lars_d_median_pair_f32(const float *x, int64_t n, float *out_dev, void *scratch, void *stream)
+{
+    return median_pair_impl<float>(x, n, out_dev, scratch, stream);
+}
+extern "C" int lars_d_median_pair_f64(const double *x, int64_t n, double *out_dev, void *scratch, void *stream)
+{
+    return median_pair_impl<double>(x, n, out_dev, scratch, stream);
+}
+
+extern "C" int lars_d_index_planes_f32(const float *red, const float *green, const float *nir, int64_t n, int index_id,
+                                       float *out, void *stream)
+{
+    ThreadCtx *c;
+    LARS_TRY(ensure_ctx(&c));
+    if (!red || !green || !nir || !out || n <= 0 || index_id < 0 || index_id > 2)
+        return fail(LARS_ERR_INVALID, "lars_d_index_planes_f32: bad arguments");
+    hipStream_t s = pick_stream(c, stream);
+    hipLaunchKernelGGL(k_index_planes, dim3(grid_for(n)), dim3(256), 0, s, red, green, nir, (long long)n, index_id, out);
+    return launch_check("lars_d_index_planes_f32");
+}
+
+extern "C" int lars_d_ndvi_f64(const void *img, int64_t npix, int channels, int dtype, double *out, void *stream)
+{
+    ThreadCtx *c;
+    LARS_TRY(ensure_ctx(&c));
+    if (!img || !out || npix <= 0 || channels < 3) return fail(LARS_ERR_INVALID, "lars_d_ndvi_f64: bad arguments");
+    hipStream_t s = pick_stream(c, stream);
+    if (dtype == LARS_U8)
+        hipLaunchKernelGGL((k_ndvi_f64<uint8_t>), dim3(grid_for(npix)), dim3(256), 0, s, static_cast<const uint8_t *>(img),
+                           (long long)npix, channels, out);
+    else if (dtype == LARS_U16)
+        hipLaunchKernelGGL((k_ndvi_f64<uint16_t>), dim3(grid_for(npix)), dim3(256), 0, s,
+                           static_cast<const uint16_t *>(img), (long long)npix, channels, out);
+    else
+        return fail(LARS_ERR_INVALID, "lars_d_ndvi_f64: dtype");
+    return launch_check("lars_d_ndvi_f64");
+}
+
+extern "C" int lars_d_colormap_f32(const float *x, int64_t n, const uint8_t *lut_rgba, uint8_t *out_rgba, void *stream)
+{
+    ThreadCtx *c;
+    LARS_TRY(ensure_ctx(&c));
+    if (!x || !lut_rgba || !out_rgba || n <= 0) return fail(LARS_ERR_INVALID, "lars_d_colormap_f32: bad arguments");
+    hipStream_t s = pick_stream(c, stream);
+    hipLaunchKernelGGL(k_colormap, dim3(grid_for(n)), dim3(256), 0, s, x, (long long)n,
+                       reinterpret_cast<const unsigned int *>(lut_rgba), reinterpret_cast<unsigned int *>(out_rgba));
+    return launch_check("lars_d_colormap_f32");
+}

@@ -1,0 +1,98 @@
+// Internal helpers shared by the translation units of liblars_hip.so.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <stdio.h>
+#include <string>
+
+#include "lars_hip.h"
+
+namespace lars {
+
+// ---- error plumbing -------------------------------------------------------
+void set_error(const char *fmt, ...);
+int fail(int code, const char *fmt, ...);
+
+#define LARS_HIP_TRY(expr)                                                          \
+    do {                                                                            \
+        hipError_t _e = (expr);                                                     \
+        if (_e != hipSuccess)                                                       \
+            return ::lars::fail(_e == hipErrorOutOfMemory ? LARS_ERR_OOM : LARS_ERR_HIP, \
+                                "%s failed: %s (%s:%d)", #expr, hipGetErrorString(_e), \
+                                __FILE__, __LINE__);                                \
+    } while (0)
+
+#define LARS_TRY(expr)                \
+    do {                              \
+        int _s = (expr);              \
+        if (_s != LARS_OK) return _s; \
+    } while (0)
+
+// ---- per-thread context ---------------------------------------------------
+struct ThreadCtx {
+    int device = -1;           // -1: not initialised yet
+    hipStream_t stream = nullptr;
+    void *ws = nullptr;        // grow-only device workspace of the host entry points
+    size_t ws_bytes = 0;
+    void *scratch = nullptr;   // small device scratch of the device entry points
+    size_t scratch_bytes = 0;
+};
+
+int ensure_ctx(ThreadCtx **out);                 // initialises device 0 on first use
+int ws_reserve(ThreadCtx *c, size_t bytes);      // grow-only; synchronises when it grows
+int scratch_reserve(ThreadCtx *c, size_t bytes);
+inline hipStream_t pick_stream(ThreadCtx *c, void *stream) {
+    return stream ? reinterpret_cast<hipStream_t>(stream) : c->stream;
+}
+
+// ---- device-side shared pieces ---------------------------------------------
+// 2^32: the fixed-point scale of the statistics accumulators.
+#define LARS_FX_SCALE 4294967296.0
+#define LARS_FX_INV (1.0 / 4294967296.0)
+
+// While a fused launch is in flight a lars_stats record is used as its own
+// accumulator: sum / sumsq hold int64 fixed point, min / max hold order-
+// preserving uint64 keys.  k_stats_finalize converts in place.
+struct StatsAccView {
+    unsigned long long sum_fx;
+    unsigned long long sumsq_fx;
+    unsigned long long count;
+    unsigned long long above;
+    unsigned long long nans;
+    unsigned long long min_key;      // f64_key of the running minimum
+    unsigned long long max_key;
+    double threshold;
+    unsigned int index_id;
+    unsigned int reserved;
+    unsigned long long hist[LARS_HIST_BINS];
+};
+static_assert(sizeof(StatsAccView) == sizeof(lars_stats), "accumulator view must alias lars_stats");
+
+__host__ __device__ inline unsigned int f32_key(float x) {
+    unsigned int b = __builtin_bit_cast(unsigned int, x);
+    return (b & 0x80000000u) ? ~b : (b | 0x80000000u);
+}
+__host__ __device__ inline float key_f32(unsigned int k) {
+    unsigned int b = (k & 0x80000000u) ? (k & 0x7FFFFFFFu) : ~k;
+    return __builtin_bit_cast(float, b);
+}
+__host__ __device__ inline unsigned long long f64_key(double x) {
+    unsigned long long b = __builtin_bit_cast(unsigned long long, x);
+    return (b >> 63) ? ~b : (b | 0x8000000000000000ull);
+}
+__host__ __device__ inline double key_f64(unsigned long long k) {
+    unsigned long long b = (k >> 63) ? (k & 0x7FFFFFFFFFFFFFFFull) : ~k;
+    return __builtin_bit_cast(double, b);
+}
+
+// numpy.histogram(bins=50, range=(-1,1)) edges: linspace computes
+// arange(51) * (2/50) + (-1) in float64, pins the last edge to 1, then casts to
+// the sample dtype.
+__host__ __device__ inline double hist_edge_f64(int i) {
+    return i >= LARS_HIST_BINS ? 1.0 : (double)i * (2.0 / 50.0) + (-1.0);
+}
+
+// launch geometry helpers (host)
+int launch_check(const char *what);
+
+}  // namespace lars

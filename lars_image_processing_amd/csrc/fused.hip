@@ -1,0 +1,736 @@
+// Hot path kernels: channel histograms -> white-balance tables -> fused
+// de-interleave + white balance + NDVI/GNDVI/NDWI + outputs + statistics.
+//
+// Reference semantics (lars-uav/lars-image-processing):
+//   process-images.py:424-447  fix_white_balance   (percentile stretch, uint8 out)
+//   process-images.py:449-490  calculate_index     (float32 normalized differences)
+//   process-images.py:492-513  analyze_index       (mean/min/max/coverage)
+//   process-ndvi.py:97         50-bin histogram on [-1, 1]
+//   process-images.py:695      imshow(cmap, vmin=-1, vmax=1) per-pixel colormap
+//
+// Built with -ffp-contract=off: every float operation below rounds exactly once,
+// as the NumPy expressions do.
+#include "common.h"
+
+namespace lars {
+
+// ===========================================================================
+// Per-tile channel histograms (pre-pass of np.percentile, process-images.py:437)
+// ===========================================================================
+// uint8, 3 interleaved channels, 4-byte aligned tiles: each lane reads 12 bytes
+// (4 pixels) per step, a wave reads 768 contiguous bytes.
+__global__ __launch_bounds__(256) void k_chan_hist_u8c3(const uint8_t *__restrict__ tiles,
+                                                        long long npix, unsigned int *__restrict__ hist)
+{
+    __shared__ unsigned int s_h[4][3 * 256];          // one private copy per wave
+    const int tid = threadIdx.x;
+    const int wave = tid >> 6;
+    for (int i = tid; i < 4 * 768; i += 256) (&s_h[0][0])[i] = 0;
+    __syncthreads();
+
+    const long long tile = blockIdx.y;
+    const uint8_t *base = tiles + tile * npix * 3;
+    const long long nquads = npix >> 2;
+    unsigned int *h = s_h[wave];
+    for (long long q = (long long)blockIdx.x * 256 + tid; q < nquads; q += (long long)gridDim.x * 256) {
+        const unsigned int *p = reinterpret_cast<const unsigned int *>(base + q * 12);
+        unsigned int w0 = p[0], w1 = p[1], w2 = p[2];
+        // bytes: r0 g0 n0 r1 | g1 n1 r2 g2 | n2 r3 g3 n3
+        atomicAdd(&h[0 * 256 + (w0 & 0xFF)], 1u);
+        atomicAdd(&h[1 * 256 + ((w0 >> 8) & 0xFF)], 1u);
+        atomicAdd(&h[2 * 256 + ((w0 >> 16) & 0xFF)], 1u);
+        atomicAdd(&h[0 * 256 + (w0 >> 24)], 1u);
+        atomicAdd(&h[1 * 256 + (w1 & 0xFF)], 1u);
+        atomicAdd(&h[2 * 256 + ((w1 >> 8) & 0xFF)], 1u);
+        atomicAdd(&h[0 * 256 + ((w1 >> 16) & 0xFF)], 1u);
+        atomicAdd(&h[1 * 256 + (w1 >> 24)], 1u);
+        atomicAdd(&h[2 * 256 + (w2 & 0xFF)], 1u);
+        atomicAdd(&h[0 * 256 + ((w2 >> 8) & 0xFF)], 1u);
+        atomicAdd(&h[1 * 256 + ((w2 >> 16) & 0xFF)], 1u);
+        atomicAdd(&h[2 * 256 + (w2 >> 24)], 1u);
+    }
+    // tail pixels (npix % 4) by block 0
+    if (blockIdx.x == 0 && tid < (int)(npix & 3)) {
+        const uint8_t *p = base + (nquads * 4 + tid) * 3;
+        atomicAdd(&h[p[0]], 1u);
+        atomicAdd(&h[256 + p[1]], 1u);
+        atomicAdd(&h[512 + p[2]], 1u);
+    }
+    __syncthreads();
+    unsigned int *gh = hist + tile * 768;
+    for (int i = tid; i < 768; i += 256) {
+        unsigned int v = s_h[0][i] + s_h[1][i] + s_h[2][i] + s_h[3][i];
+        if (v) atomicAdd(&gh[i], v);
+    }
+}
+
+// Any channel count / sample type / alignment: one pixel per lane per step.
+template <typename PIX, int NVAL>
+__global__ __launch_bounds__(256) void k_chan_hist_generic(const PIX *__restrict__ tiles, long long npix,
+                                                           int channels, unsigned int *__restrict__ hist)
+{
+    const long long tile = blockIdx.y;
+    const PIX *base = tiles + tile * npix * channels;
+    unsigned int *gh = hist + tile * 3 * (long long)NVAL;
+    if (NVAL == 256) {
+        __shared__ unsigned int s_h[3 * 256];
+        for (int i = threadIdx.x; i < 768; i += 256) s_h[i] = 0;
+        __syncthreads();
+        for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < npix; i += (long long)gridDim.x * 256) {
+            const PIX *p = base + i * channels;
+            atomicAdd(&s_h[(unsigned)p[0]], 1u);
+            atomicAdd(&s_h[256 + (unsigned)p[1]], 1u);
+            atomicAdd(&s_h[512 + (unsigned)p[2]], 1u);
+        }
+        __syncthreads();
+        for (int i = threadIdx.x; i < 768; i += 256)
+            if (s_h[i]) atomicAdd(&gh[i], s_h[i]);
+    } else {
+        for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < npix; i += (long long)gridDim.x * 256) {
+            const PIX *p = base + i * channels;
+            atomicAdd(&gh[(unsigned)p[0]], 1u);
+            atomicAdd(&gh[NVAL + (unsigned)p[1]], 1u);
+            atomicAdd(&gh[2 * NVAL + (unsigned)p[2]], 1u);
+        }
+    }
+}
+
+// ===========================================================================
+// Histogram -> np.percentile(ch, (2, 98)) -> white-balance table
+// ===========================================================================
+// One block per (channel, tile).  numpy's 'linear' method: virtual index
+// (n-1)*q in float64, order statistics floor(vi) and floor(vi)+1 (clamped),
+// _lerp: a + (b-a)*t, and b - (b-a)*(1-t) where t >= 0.5.
+template <int NVAL>
+__global__ __launch_bounds__(256) void k_wb_table(const unsigned int *__restrict__ hist, long long npix,
+                                                  uint8_t *__restrict__ table, double *__restrict__ pcts,
+                                                  int rgn_variant)
+{
+    constexpr int PER = NVAL / 256;                   // bins per thread
+    __shared__ unsigned long long s_scan[256];
+    __shared__ double s_val[4];                       // order statistics: q2.lo q2.hi q98.lo q98.hi
+    __shared__ double s_p[2];
+
+    const int tid = threadIdx.x;
+    const long long slot = (long long)blockIdx.y * 3 + blockIdx.x;   // tile*3 + channel
+    const unsigned int *h = hist + slot * NVAL;
+
+    unsigned long long local = 0;
+    for (int j = 0; j < PER; ++j) local += h[tid * PER + j];
+    s_scan[tid] = local;
+    __syncthreads();
+    // inclusive Hillis-Steele scan over 256 thread sums
+    for (int off = 1; off < 256; off <<= 1) {
+        unsigned long long v = (tid >= off) ? s_scan[tid - off] : 0;
+        __syncthreads();
+        s_scan[tid] += v;
+        __syncthreads();
+    }
+    const unsigned long long before = s_scan[tid] - local;   // samples in bins below this thread's
+
+    const double nm1 = (double)(npix - 1);
+    double tq[2];
+    long long rank[4];
+    for (int k = 0; k < 2; ++k) {
+        const double q = (k == 0 ? 2.0 : 98.0) / 100.0;
+        const double vi = nm1 * q;
+        const double fl = floor(vi);
+        long long lo = (long long)fl;
+        long long hi = lo + 1;
+        if (hi > npix - 1) hi = npix - 1;
+        rank[2 * k] = lo;
+        rank[2 * k + 1] = hi;
+        tq[k] = vi - fl;
+    }
+    // value of order statistic r = the bin whose cumulative count first exceeds r
+    unsigned long long cum = before;
+    for (int j = 0; j < PER; ++j) {
+        const unsigned long long c = h[tid * PER + j];
+        if (c) {
+            for (int r = 0; r < 4; ++r)
+                if ((unsigned long long)rank[r] >= cum && (unsigned long long)rank[r] < cum + c)
+                    s_val[r] = (double)(tid * PER + j);
+        }
+        cum += c;
+    }
+    __syncthreads();
+    if (tid < 2) {
+        const double a = s_val[2 * tid], b = s_val[2 * tid + 1], t = tq[tid];
+        const double d = b - a;
+        double r = a + d * t;
+        if (t >= 0.5) r = b - d * (1.0 - t);
+        s_p[tid] = r;
+        if (pcts) pcts[slot * 2 + tid] = r;
+    }
+    __syncthreads();
+    const double p_lo = s_p[0], p_hi = s_p[1];
+    const double span = p_hi - p_lo;
+    uint8_t *out = table + slot * NVAL;
+    for (int v = tid; v < NVAL; v += 256) {
+        double x = (double)v;
+        if (rgn_variant) x = fmin(fmax(x, p_lo), p_hi);          // process-rgn.py:29
+        double y = (x - p_lo) / span * 255.0;                     // process-images.py:438
+        uint8_t o;
+        if (y != y) {
+            o = 0;                                               // NaN -> uint8 cast gives 0
+        } else {
+            y = y < 0.0 ? 0.0 : (y > 255.0 ? 255.0 : y);
+            // app flavour stores into a float32 array before the uint8 cast (:438,:441);
+            // process-rgn.py casts the float64 value directly (:44)
+            o = rgn_variant ? (uint8_t)(int)y : (uint8_t)(int)(float)y;
+        }
+        out[v] = o;
+    }
+}
+
+// ===========================================================================
+// Statistics records: init / finalize around the fused launch
+// ===========================================================================
+__global__ void k_stats_init(lars_stats *stats, long long nrec, unsigned int mask)
+{
+    const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= nrec) return;
+    const int k = (int)(i % 3);
+    if (!((mask >> k) & 1u)) return;
+    StatsAccView *a = reinterpret_cast<StatsAccView *>(stats + i);
+    a->sum_fx = 0; a->sumsq_fx = 0; a->count = 0; a->above = 0; a->nans = 0;
+    a->min_key = ~0ull; a->max_key = 0ull;
+    a->threshold = (k == LARS_NDWI) ? 0.0 : (double)0.2f;        // process-images.py:498-502 (float32 compare)
+    a->index_id = (unsigned)k; a->reserved = 0;
+    for (int b = 0; b < LARS_HIST_BINS; ++b) a->hist[b] = 0;
+}
+
+__global__ void k_stats_finalize(lars_stats *stats, long long nrec, unsigned int mask, long long npix)
+{
+    const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= nrec) return;
+    const int k = (int)(i % 3);
+    if (!((mask >> k) & 1u)) return;
+    StatsAccView *a = reinterpret_cast<StatsAccView *>(stats + i);
+    const long long s = (long long)a->sum_fx, s2 = (long long)a->sumsq_fx;
+    const unsigned long long mnk = a->min_key, mxk = a->max_key;
+    lars_stats *o = stats + i;
+    o->sum = (double)s * LARS_FX_INV;
+    o->sumsq = (double)s2 * LARS_FX_INV;
+    o->count = (uint64_t)npix;
+    o->min = key_f64(mnk);
+    o->max = key_f64(mxk);
+}
+
+// ===========================================================================
+// The fused kernel
+// ===========================================================================
+struct FusedParams {
+    const void *tiles;
+    long long npix;
+    int channels;
+    const uint8_t *wb_table;       // [ntiles][3][NVAL] or null
+    float *out_index[3];
+    uint8_t *out_wb;
+    uint8_t *out_rgba[3];
+    const uint8_t *cmap_lut[3];
+    lars_stats *stats;
+    unsigned int mask;             // runtime copy (generic kernel)
+    unsigned int flags;
+};
+
+struct Acc {
+    float mn, mx;
+    double sum, sumsq;
+    unsigned int above;
+};
+__device__ inline void acc_init(Acc &a) { a.mn = __builtin_inff(); a.mx = -__builtin_inff(); a.sum = 0; a.sumsq = 0; a.above = 0; }
+
+// IEEE float32 (a-b)/(a+b); +0.0 where a+b == 0 (the reference's epsilon only
+// matters there: process-images.py:464-482).
+__device__ inline float norm_diff(float a, float b)
+{
+    const float s = a + b;
+    const float d = a - b;
+    return d / (s == 0.0f ? 1.0f : s);
+}
+
+// bin of numpy.histogram(bins=50, range=(-1,1)) for float32 x in [-1, 1]
+__device__ inline int hist_bin_f32(float x, const float *edges)
+{
+    int b = (int)((x + 1.0f) * 25.0f);
+    b = b < 0 ? 0 : (b > LARS_HIST_BINS - 1 ? LARS_HIST_BINS - 1 : b);
+    if (x < edges[b]) --b;
+    else if (b != LARS_HIST_BINS - 1 && x >= edges[b + 1]) ++b;
+    return b;
+}
+
+__device__ inline unsigned int cmap_index(float x)
+{
+    const float s = (x + 1.0f) * 128.0f;
+    int i = (int)s;
+    i = i < 0 ? 0 : (i > 255 ? 255 : i);
+    return (unsigned)i;
+}
+
+template <int STATS>
+__device__ inline void acc_push(Acc &a, float x, float thr, unsigned int *s_hist, const float *s_edges)
+{
+    if (STATS >= 1) {
+        a.mn = fminf(a.mn, x);
+        a.mx = fmaxf(a.mx, x);
+        const double xd = (double)x;
+        a.sum += xd;
+        a.sumsq += xd * xd;
+        a.above += (x > thr) ? 1u : 0u;
+    }
+    if (STATS >= 2) atomicAdd(&s_hist[hist_bin_f32(x, s_edges)], 1u);
+}
+
+// Block-wide fold of one accumulator into the tile's record (atomics are
+// integer, so the result does not depend on arrival order).
+__device__ inline void acc_flush(Acc a, StatsAccView *rec, double (*s_red)[4], int tid)
+{
+    // wave reduce
+    for (int off = 32; off >= 1; off >>= 1) {
+        a.mn = fminf(a.mn, __shfl_xor(a.mn, off));
+        a.mx = fmaxf(a.mx, __shfl_xor(a.mx, off));
+        a.sum += __shfl_xor(a.sum, off);
+        a.sumsq += __shfl_xor(a.sumsq, off);
+        a.above += __shfl_xor(a.above, off);
+    }
+    const int wave = tid >> 6, lane = tid & 63;
+    __syncthreads();
+    if (lane == 0) {
+        s_red[0][wave] = a.sum;
+        s_red[1][wave] = a.sumsq;
+        s_red[2][wave] = (double)a.above;
+        s_red[3][wave] = __builtin_bit_cast(double, ((unsigned long long)f32_key(a.mx) << 32) | f32_key(a.mn));   // packed float keys
+    }
+    __syncthreads();
+    if (tid == 0) {
+        double sum = 0, sumsq = 0, above = 0;
+        unsigned int mnk = 0xFFFFFFFFu, mxk = 0;
+        for (int w = 0; w < 4; ++w) {
+            sum += s_red[0][w];
+            sumsq += s_red[1][w];
+            above += s_red[2][w];
+            const unsigned long long kk = __builtin_bit_cast(unsigned long long, s_red[3][w]);
+            const unsigned int kmn = (unsigned int)kk, kmx = (unsigned int)(kk >> 32);
+            mnk = kmn < mnk ? kmn : mnk;
+            mxk = kmx > mxk ? kmx : mxk;
+        }
+        atomicAdd(&rec->sum_fx, (unsigned long long)__double2ll_rn(sum * LARS_FX_SCALE));
+        atomicAdd(&rec->sumsq_fx, (unsigned long long)__double2ll_rn(sumsq * LARS_FX_SCALE));
+        atomicAdd(&rec->above, (unsigned long long)above);
+        atomicMin(&rec->min_key, f64_key((double)key_f32(mnk)));
+        atomicMax(&rec->max_key, f64_key((double)key_f32(mxk)));
+    }
+}
+
+// One pixel: white-balanced (or raw) band values in, everything out.
+template <unsigned MASK, int STATS, bool RT_MASK>
+__device__ inline void pixel_math(float r, float g, float n, unsigned rt_mask,
+                                  float &o_ndvi, float &o_gndvi, float &o_ndwi,
+                                  Acc *acc, unsigned int *s_hist, const float *s_edges)
+{
+    const bool want_ndvi = RT_MASK ? (rt_mask & 1u) : (MASK & 1u);
+    const bool want_gndvi = RT_MASK ? (rt_mask & 2u) : (MASK & 2u);
+    const bool want_ndwi = RT_MASK ? (rt_mask & 4u) : (MASK & 4u);
+    if (want_ndvi) {
+        o_ndvi = norm_diff(n, r);
+        acc_push<STATS>(acc[0], o_ndvi, 0.2f, s_hist + 0 * LARS_HIST_BINS, s_edges);
+    }
+    float gq = 0.0f;
+    if (want_gndvi || want_ndwi) gq = norm_diff(n, g);
+    if (want_gndvi) {
+        o_gndvi = gq;
+        acc_push<STATS>(acc[1], o_gndvi, 0.2f, s_hist + 1 * LARS_HIST_BINS, s_edges);
+    }
+    if (want_ndwi) {
+        // (g-n)/(g+n) == -(n-g)/(n+g) bit for bit, and +0.0 where the quotient is zero
+        o_ndwi = 0.0f - gq;
+        acc_push<STATS>(acc[2], o_ndwi, 0.0f, s_hist + 2 * LARS_HIST_BINS, s_edges);
+    }
+}
+
+// ---- fast path: uint8, 3 channels, 4-byte aligned tiles ---------------------
+// Lane l of a wave owns pixels 4l..4l+3 of each 256-pixel slab: one 12-byte
+// load (a wave reads 768 contiguous bytes), one float4 store per index plane
+// (1 KiB contiguous per wave), one 12-byte store of the white-balanced image,
+// one 16-byte store per colormapped plane.
+template <unsigned MASK, bool WB, int STATS>
+__global__ __launch_bounds__(256) void k_fused_u8c3(FusedParams P)
+{
+    __shared__ uint8_t s_lut[3 * 256];
+    __shared__ unsigned int s_hist[3 * LARS_HIST_BINS];
+    __shared__ float s_edges[LARS_HIST_BINS + 1];
+    __shared__ double s_red[4][4];
+
+    const int tid = threadIdx.x;
+    const long long tile = blockIdx.y;
+    const long long npix = P.npix;
+    const uint8_t *base = static_cast<const uint8_t *>(P.tiles) + tile * npix * 3;
+
+    if (WB) {
+        const uint8_t *t = P.wb_table + tile * 768;
+        for (int i = tid; i < 768; i += 256) s_lut[i] = t[i];
+    }
+    if (STATS >= 2) {
+        for (int i = tid; i < 3 * LARS_HIST_BINS; i += 256) s_hist[i] = 0;
+        if (tid <= LARS_HIST_BINS) s_edges[tid] = (float)hist_edge_f64(tid);
+    }
+    if (WB || STATS >= 2) __syncthreads();
+
+    Acc acc[3];
+    acc_init(acc[0]); acc_init(acc[1]); acc_init(acc[2]);
+
+    float *const oi0 = P.out_index[0] ? P.out_index[0] + tile * npix : nullptr;
+    float *const oi1 = P.out_index[1] ? P.out_index[1] + tile * npix : nullptr;
+    float *const oi2 = P.out_index[2] ? P.out_index[2] + tile * npix : nullptr;
+    uint8_t *const owb = P.out_wb ? P.out_wb + tile * npix * 3 : nullptr;
+    uint8_t *const oc0 = P.out_rgba[0] ? P.out_rgba[0] + tile * npix * 4 : nullptr;
+    uint8_t *const oc1 = P.out_rgba[1] ? P.out_rgba[1] + tile * npix * 4 : nullptr;
+    uint8_t *const oc2 = P.out_rgba[2] ? P.out_rgba[2] + tile * npix * 4 : nullptr;
+    const unsigned int *lut0 = reinterpret_cast<const unsigned int *>(P.cmap_lut[0]);
+    const unsigned int *lut1 = reinterpret_cast<const unsigned int *>(P.cmap_lut[1]);
+    const unsigned int *lut2 = reinterpret_cast<const unsigned int *>(P.cmap_lut[2]);
+
+    const long long nquads = npix >> 2;
+    const long long stride = (long long)gridDim.x * 256;
+    for (long long q = (long long)blockIdx.x * 256 + tid; q < nquads; q += stride) {
+        const unsigned int *p = reinterpret_cast<const unsigned int *>(base + q * 12);
+        unsigned int w0 = p[0], w1 = p[1], w2 = p[2];
+        unsigned int b[12] = {w0 & 0xFF, (w0 >> 8) & 0xFF, (w0 >> 16) & 0xFF, w0 >> 24,
+                              w1 & 0xFF, (w1 >> 8) & 0xFF, (w1 >> 16) & 0xFF, w1 >> 24,
+                              w2 & 0xFF, (w2 >> 8) & 0xFF, (w2 >> 16) & 0xFF, w2 >> 24};
+        if (WB) {
+#pragma unroll
+            for (int i = 0; i < 12; ++i) b[i] = s_lut[(i % 3) * 256 + b[i]];
+            if (owb) {
+                unsigned int *o = reinterpret_cast<unsigned int *>(owb + q * 12);
+                o[0] = b[0] | (b[1] << 8) | (b[2] << 16) | (b[3] << 24);
+                o[1] = b[4] | (b[5] << 8) | (b[6] << 16) | (b[7] << 24);
+                o[2] = b[8] | (b[9] << 8) | (b[10] << 16) | (b[11] << 24);
+            }
+        }
+        float v0[4], v1[4], v2[4];
+#pragma unroll
+        for (int px = 0; px < 4; ++px) {
+            v0[px] = v1[px] = v2[px] = 0.0f;
+            pixel_math<MASK, STATS, false>((float)b[3 * px], (float)b[3 * px + 1], (float)b[3 * px + 2], 0u,
+                                           v0[px], v1[px], v2[px], acc, s_hist, s_edges);
+        }
+        if ((MASK & 1u) && oi0) *reinterpret_cast<float4 *>(oi0 + q * 4) = make_float4(v0[0], v0[1], v0[2], v0[3]);
+        if ((MASK & 2u) && oi1) *reinterpret_cast<float4 *>(oi1 + q * 4) = make_float4(v1[0], v1[1], v1[2], v1[3]);
+        if ((MASK & 4u) && oi2) *reinterpret_cast<float4 *>(oi2 + q * 4) = make_float4(v2[0], v2[1], v2[2], v2[3]);
+        if ((MASK & 1u) && oc0)
+            *reinterpret_cast<uint4 *>(oc0 + q * 16) = make_uint4(lut0[cmap_index(v0[0])], lut0[cmap_index(v0[1])],
+                                                                  lut0[cmap_index(v0[2])], lut0[cmap_index(v0[3])]);
+        if ((MASK & 2u) && oc1)
+            *reinterpret_cast<uint4 *>(oc1 + q * 16) = make_uint4(lut1[cmap_index(v1[0])], lut1[cmap_index(v1[1])],
+                                                                  lut1[cmap_index(v1[2])], lut1[cmap_index(v1[3])]);
+        if ((MASK & 4u) && oc2)
+            *reinterpret_cast<uint4 *>(oc2 + q * 16) = make_uint4(lut2[cmap_index(v2[0])], lut2[cmap_index(v2[1])],
+                                                                  lut2[cmap_index(v2[2])], lut2[cmap_index(v2[3])]);
+    }
+    // tail pixels (npix % 4): lanes 0..2 of block 0
+    if (blockIdx.x == 0 && tid < (int)(npix & 3)) {
+        const long long i = nquads * 4 + tid;
+        unsigned int r = base[i * 3], g = base[i * 3 + 1], n = base[i * 3 + 2];
+        if (WB) { r = s_lut[r]; g = s_lut[256 + g]; n = s_lut[512 + n]; }
+        if (WB && owb) { owb[i * 3] = (uint8_t)r; owb[i * 3 + 1] = (uint8_t)g; owb[i * 3 + 2] = (uint8_t)n; }
+        float a = 0, bq = 0, c = 0;
+        pixel_math<MASK, STATS, false>((float)r, (float)g, (float)n, 0u, a, bq, c, acc, s_hist, s_edges);
+        if ((MASK & 1u) && oi0) oi0[i] = a;
+        if ((MASK & 2u) && oi1) oi1[i] = bq;
+        if ((MASK & 4u) && oi2) oi2[i] = c;
+        if ((MASK & 1u) && oc0) reinterpret_cast<unsigned int *>(oc0)[i] = lut0[cmap_index(a)];
+        if ((MASK & 2u) && oc1) reinterpret_cast<unsigned int *>(oc1)[i] = lut1[cmap_index(bq)];
+        if ((MASK & 4u) && oc2) reinterpret_cast<unsigned int *>(oc2)[i] = lut2[cmap_index(c)];
+    }
+
+    if (STATS >= 1) {
+        StatsAccView *rec = reinterpret_cast<StatsAccView *>(P.stats + tile * 3);
+#pragma unroll
+        for (int k = 0; k < 3; ++k)
+            if (MASK & (1u << k)) acc_flush(acc[k], rec + k, s_red, tid);
+        if (STATS >= 2) {
+            __syncthreads();
+            for (int i = tid; i < 3 * LARS_HIST_BINS; i += 256) {
+                const int k = i / LARS_HIST_BINS;
+                if ((MASK & (1u << k)) && s_hist[i])
+                    atomicAdd(&rec[k].hist[i - k * LARS_HIST_BINS], (unsigned long long)s_hist[i]);
+            }
+        }
+    }
+}
+
+// ---- generic path: any channel count >= 3, uint8 / uint16, any alignment ---
+template <typename PIX, int NVAL>
+__global__ __launch_bounds__(256) void k_fused_generic(FusedParams P)
+{
+    __shared__ unsigned int s_hist[3 * LARS_HIST_BINS];
+    __shared__ float s_edges[LARS_HIST_BINS + 1];
+    __shared__ double s_red[4][4];
+
+    const int tid = threadIdx.x;
+    const long long tile = blockIdx.y;
+    const long long npix = P.npix;
+    const int C = P.channels;
+    const unsigned mask = P.mask;
+    const bool stats = P.flags & (LARS_F_STATS | LARS_F_HIST);
+    const bool hist = P.flags & LARS_F_HIST;
+    const PIX *base = static_cast<const PIX *>(P.tiles) + tile * npix * C;
+    const uint8_t *tab = P.wb_table ? P.wb_table + tile * 3 * (long long)NVAL : nullptr;
+
+    for (int i = tid; i < 3 * LARS_HIST_BINS; i += 256) s_hist[i] = 0;
+    if (tid <= LARS_HIST_BINS) s_edges[tid] = (float)hist_edge_f64(tid);
+    __syncthreads();
+
+    Acc acc[3];
+    acc_init(acc[0]); acc_init(acc[1]); acc_init(acc[2]);
+    float *const oi0 = P.out_index[0] ? P.out_index[0] + tile * npix : nullptr;
+    float *const oi1 = P.out_index[1] ? P.out_index[1] + tile * npix : nullptr;
+    float *const oi2 = P.out_index[2] ? P.out_index[2] + tile * npix : nullptr;
+    uint8_t *const owb = P.out_wb ? P.out_wb + tile * npix * C : nullptr;
+    unsigned int *const oc0 = P.out_rgba[0] ? reinterpret_cast<unsigned int *>(P.out_rgba[0]) + tile * npix : nullptr;
+    unsigned int *const oc1 = P.out_rgba[1] ? reinterpret_cast<unsigned int *>(P.out_rgba[1]) + tile * npix : nullptr;
+    unsigned int *const oc2 = P.out_rgba[2] ? reinterpret_cast<unsigned int *>(P.out_rgba[2]) + tile * npix : nullptr;
+    const unsigned int *lut0 = reinterpret_cast<const unsigned int *>(P.cmap_lut[0]);
+    const unsigned int *lut1 = reinterpret_cast<const unsigned int *>(P.cmap_lut[1]);
+    const unsigned int *lut2 = reinterpret_cast<const unsigned int *>(P.cmap_lut[2]);
+
+    for (long long i = (long long)blockIdx.x * 256 + tid; i < npix; i += (long long)gridDim.x * 256) {
+        const PIX *p = base + i * C;
+        unsigned int r = p[0], g = p[1], n = p[2];
+        if (tab) {
+            r = tab[r]; g = tab[NVAL + g]; n = tab[2 * NVAL + n];
+            if (owb) {
+                uint8_t *o = owb + i * C;
+                o[0] = (uint8_t)r; o[1] = (uint8_t)g; o[2] = (uint8_t)n;
+                for (int c = 3; c < C; ++c) o[c] = 0;            // zeros_like, process-images.py:432
+            }
+        }
+        float a = 0, b = 0, c = 0;
+        if (stats) {
+            if (hist) pixel_math<7u, 2, true>((float)r, (float)g, (float)n, mask, a, b, c, acc, s_hist, s_edges);
+            else pixel_math<7u, 1, true>((float)r, (float)g, (float)n, mask, a, b, c, acc, s_hist, s_edges);
+        } else {
+            pixel_math<7u, 0, true>((float)r, (float)g, (float)n, mask, a, b, c, acc, s_hist, s_edges);
+        }
+        if ((mask & 1u) && oi0) oi0[i] = a;
+        if ((mask & 2u) && oi1) oi1[i] = b;
+        if ((mask & 4u) && oi2) oi2[i] = c;
+        if ((mask & 1u) && oc0) oc0[i] = lut0[cmap_index(a)];
+        if ((mask & 2u) && oc1) oc1[i] = lut1[cmap_index(b)];
+        if ((mask & 4u) && oc2) oc2[i] = lut2[cmap_index(c)];
+    }
+    if (stats) {
+        StatsAccView *rec = reinterpret_cast<StatsAccView *>(P.stats + tile * 3);
+        for (int k = 0; k < 3; ++k)
+            if (mask & (1u << k)) acc_flush(acc[k], rec + k, s_red, tid);
+        if (hist) {
+            __syncthreads();
+            for (int i = tid; i < 3 * LARS_HIST_BINS; i += 256) {
+                const int k = i / LARS_HIST_BINS;
+                if ((mask & (1u << k)) && s_hist[i])
+                    atomicAdd(&rec[k].hist[i - k * LARS_HIST_BINS], (unsigned long long)s_hist[i]);
+            }
+        }
+    }
+}
+
+// ===========================================================================
+// Synthetic tiles
+// ===========================================================================
+__device__ inline unsigned int mix32(unsigned int x)
+{
+    x ^= x >> 16; x *= 0x7FEB352Du; x ^= x >> 15; x *= 0x846CA68Bu; x ^= x >> 16;
+    return x;
+}
+__device__ inline unsigned int veg_byte(unsigned int v, int ch)
+{
+    return ch == 0 ? 20u + (v * 3u) / 8u : ch == 1 ? 40u + v / 2u : ch == 2 ? 60u + (v * 3u) / 4u : v;
+}
+
+__global__ __launch_bounds__(256) void k_synth_u8(uint8_t *tiles, long long first_tile, long long nbytes,
+                                                  int channels, unsigned int seed, int profile)
+{
+    const long long tile_local = blockIdx.y;
+    const unsigned int salt = (unsigned int)(first_tile + tile_local) * 0x9E3779B9u;
+    uint8_t *base = tiles + tile_local * nbytes;
+    const long long nwords = (nbytes + 3) >> 2;
+    for (long long k = (long long)blockIdx.x * 256 + threadIdx.x; k < nwords; k += (long long)gridDim.x * 256) {
+        unsigned int w = mix32(mix32((unsigned int)k + seed) ^ salt);
+        if (profile == 1) {
+            unsigned int o = 0;
+            for (int j = 0; j < 4; ++j) {
+                const int ch = (int)((k * 4 + j) % channels);
+                o |= (veg_byte((w >> (8 * j)) & 0xFF, ch) & 0xFF) << (8 * j);
+            }
+            w = o;
+        }
+        const long long off = k * 4;
+        if (off + 4 <= nbytes && ((reinterpret_cast<uintptr_t>(base + off) & 3) == 0)) {
+            *reinterpret_cast<unsigned int *>(base + off) = w;
+        } else {
+            for (int j = 0; j < 4 && off + j < nbytes; ++j) base[off + j] = (uint8_t)(w >> (8 * j));
+        }
+    }
+}
+
+}  // namespace lars
+
+// ===========================================================================
+// Launchers (device entry points)
+// ===========================================================================
+using namespace lars;
+
+static int blocks_per_tile(long long work_items, long long ntiles)
+{
+    // enough blocks to keep 256 CUs x 8 resident blocks busy, never more than the work
+    long long want = (2048 * 4 + ntiles - 1) / ntiles;
+    long long cap = (work_items + 255) / 256;
+    if (want > cap) want = cap;
+    if (want < 1) want = 1;
+    if (want > 65535) want = 65535;
+    return (int)want;
+}
+
+extern "C" int lars_d_channel_hist(const void *tiles, int64_t ntiles, int64_t npix, int channels, int dtype,
+                                   uint32_t *hist, void *stream)
+{
+    ThreadCtx *c;
+    LARS_TRY(ensure_ctx(&c));
+    if (!tiles || !hist || ntiles <= 0 || npix <= 0 || channels < 3)
+        return fail(LARS_ERR_INVALID, "lars_d_channel_hist: bad arguments");
+    if (ntiles > 65535) return fail(LARS_ERR_INVALID, "lars_d_channel_hist: ntiles > 65535 per call");
+    hipStream_t s = pick_stream(c, stream);
+    const int nval = dtype == LARS_U8 ? 256 : 65536;
+    if (dtype != LARS_U8 && dtype != LARS_U16) return fail(LARS_ERR_INVALID, "lars_d_channel_hist: dtype");
+    LARS_HIP_TRY(hipMemsetAsync(hist, 0, (size_t)ntiles * 3 * nval * sizeof(uint32_t), s));
+    const bool fast = dtype == LARS_U8 && channels == 3 && (ntiles == 1 || (npix & 3) == 0) &&
+                      ((reinterpret_cast<uintptr_t>(tiles) & 3) == 0);
+    if (fast) {
+        dim3 grid(blocks_per_tile(npix / 4 + 1, ntiles), (unsigned)ntiles);
+        hipLaunchKernelGGL(k_chan_hist_u8c3, grid, dim3(256), 0, s, static_cast<const uint8_t *>(tiles),
+                           (long long)npix, hist);
+    } else if (dtype == LARS_U8) {
+        dim3 grid(blocks_per_tile(npix, ntiles), (unsigned)ntiles);
+        hipLaunchKernelGGL((k_chan_hist_generic<uint8_t, 256>), grid, dim3(256), 0, s,
+                           static_cast<const uint8_t *>(tiles), (long long)npix, channels, hist);
+    } else {
+        dim3 grid(blocks_per_tile(npix, ntiles), (unsigned)ntiles);
+        hipLaunchKernelGGL((k_chan_hist_generic<uint16_t, 65536>), grid, dim3(256), 0, s,
+                           static_cast<const uint16_t *>(tiles), (long long)npix, channels, hist);
+    }
+    return launch_check("lars_d_channel_hist");
+}
+
+extern "C" int lars_d_wb_table(const uint32_t *hist, int64_t ntiles, int64_t npix, int dtype, uint8_t *table,
+                               double *percentiles, int rgn_variant, void *stream)
+{
+    ThreadCtx *c;
+    LARS_TRY(ensure_ctx(&c));
+    if (!hist || !table || ntiles <= 0 || npix <= 0) return fail(LARS_ERR_INVALID, "lars_d_wb_table: bad arguments");
+    if (ntiles > 65535) return fail(LARS_ERR_INVALID, "lars_d_wb_table: ntiles > 65535 per call");
+    hipStream_t s = pick_stream(c, stream);
+    dim3 grid(3, (unsigned)ntiles);
+    if (dtype == LARS_U8)
+        hipLaunchKernelGGL((k_wb_table<256>), grid, dim3(256), 0, s, hist, (long long)npix, table, percentiles, rgn_variant);
+    else if (dtype == LARS_U16)
+        hipLaunchKernelGGL((k_wb_table<65536>), grid, dim3(256), 0, s, hist, (long long)npix, table, percentiles, rgn_variant);
+    else
+        return fail(LARS_ERR_INVALID, "lars_d_wb_table: dtype");
+    return launch_check("lars_d_wb_table");
+}
+
+template <unsigned MASK, bool WB>
+static void launch_fast_stats(int stats_mode, dim3 grid, hipStream_t s, const FusedParams &P)
+{
+    if (stats_mode == 0) hipLaunchKernelGGL((k_fused_u8c3<MASK, WB, 0>), grid, dim3(256), 0, s, P);
+    else if (stats_mode == 1) hipLaunchKernelGGL((k_fused_u8c3<MASK, WB, 1>), grid, dim3(256), 0, s, P);
+    else hipLaunchKernelGGL((k_fused_u8c3<MASK, WB, 2>), grid, dim3(256), 0, s, P);
+}
+template <unsigned MASK>
+static void launch_fast_wb(bool wb, int stats_mode, dim3 grid, hipStream_t s, const FusedParams &P)
+{
+    if (wb) launch_fast_stats<MASK, true>(stats_mode, grid, s, P);
+    else launch_fast_stats<MASK, false>(stats_mode, grid, s, P);
+}
+
+extern "C" int lars_d_fused(const lars_fused_args *a)
+{
+    ThreadCtx *c;
+    LARS_TRY(ensure_ctx(&c));
+    if (!a || !a->tiles || a->ntiles <= 0 || a->npix <= 0 || a->channels < 3)
+        return fail(LARS_ERR_INVALID, "lars_d_fused: bad arguments");
+    if (a->ntiles > 65535) return fail(LARS_ERR_INVALID, "lars_d_fused: ntiles > 65535 per call");
+    if (a->dtype != LARS_U8 && a->dtype != LARS_U16) return fail(LARS_ERR_INVALID, "lars_d_fused: dtype");
+    const unsigned mask = a->index_mask & LARS_MASK_ALL;
+    if (a->index_mask & ~LARS_MASK_ALL) return fail(LARS_ERR_INVALID, "lars_d_fused: unknown index bits in mask");
+    const int stats_mode = (a->flags & LARS_F_HIST) ? 2 : (a->flags & LARS_F_STATS) ? 1 : 0;
+    if (stats_mode && !a->stats) return fail(LARS_ERR_INVALID, "lars_d_fused: stats requested but stats == NULL");
+    if (a->out_wb && !a->wb_table) return fail(LARS_ERR_INVALID, "lars_d_fused: out_wb needs wb_table");
+    for (int k = 0; k < 3; ++k)
+        if (a->out_rgba[k] && !a->cmap_lut[k]) return fail(LARS_ERR_INVALID, "lars_d_fused: out_rgba needs cmap_lut");
+    if (mask == 0 && !a->out_wb) return fail(LARS_ERR_INVALID, "lars_d_fused: nothing to do");
+    hipStream_t s = pick_stream(c, a->stream);
+
+    FusedParams P;
+    P.tiles = a->tiles; P.npix = a->npix; P.channels = a->channels; P.wb_table = a->wb_table;
+    for (int k = 0; k < 3; ++k) {
+        const bool on = (mask >> k) & 1u;
+        P.out_index[k] = on ? a->out_index[k] : nullptr;
+        P.out_rgba[k] = on ? a->out_rgba[k] : nullptr;
+        P.cmap_lut[k] = a->cmap_lut[k];
+    }
+    P.out_wb = a->out_wb; P.stats = a->stats; P.mask = mask; P.flags = a->flags;
+
+    const long long nrec = a->ntiles * 3;
+    if (stats_mode)
+        hipLaunchKernelGGL(k_stats_init, dim3((unsigned)((nrec + 255) / 256)), dim3(256), 0, s, a->stats, nrec, mask);
+
+    const bool aligned = (reinterpret_cast<uintptr_t>(a->tiles) & 3) == 0 &&
+                         (!a->out_wb || (reinterpret_cast<uintptr_t>(a->out_wb) & 3) == 0) &&
+                         (!P.out_index[0] || (reinterpret_cast<uintptr_t>(P.out_index[0]) & 15) == 0) &&
+                         (!P.out_index[1] || (reinterpret_cast<uintptr_t>(P.out_index[1]) & 15) == 0) &&
+                         (!P.out_index[2] || (reinterpret_cast<uintptr_t>(P.out_index[2]) & 15) == 0) &&
+                         (!P.out_rgba[0] || (reinterpret_cast<uintptr_t>(P.out_rgba[0]) & 15) == 0) &&
+                         (!P.out_rgba[1] || (reinterpret_cast<uintptr_t>(P.out_rgba[1]) & 15) == 0) &&
+                         (!P.out_rgba[2] || (reinterpret_cast<uintptr_t>(P.out_rgba[2]) & 15) == 0);
+    // the specialised kernels exist for "white balance only" (0), one index (1, 2, 4) and all three (7);
+    // two-index masks take the generic kernel so that unrequested records stay untouched
+    const bool mask_ok = mask == 0u || mask == 1u || mask == 2u || mask == 4u || mask == 7u;
+    const bool fast = a->dtype == LARS_U8 && a->channels == 3 && aligned && mask_ok &&
+                      (a->ntiles == 1 || (a->npix & 3) == 0);
+    if (fast) {
+        dim3 grid(blocks_per_tile(a->npix / 4 + 1, a->ntiles), (unsigned)a->ntiles);
+        const bool wb = a->wb_table != nullptr;
+        switch (mask) {
+        case 0u: hipLaunchKernelGGL((k_fused_u8c3<0u, true, 0>), grid, dim3(256), 0, s, P); break;
+        case 1u: launch_fast_wb<1u>(wb, stats_mode, grid, s, P); break;
+        case 2u: launch_fast_wb<2u>(wb, stats_mode, grid, s, P); break;
+        case 4u: launch_fast_wb<4u>(wb, stats_mode, grid, s, P); break;
+        default: launch_fast_wb<7u>(wb, stats_mode, grid, s, P); break;
+        }
+    } else {
+        dim3 grid(blocks_per_tile(a->npix, a->ntiles), (unsigned)a->ntiles);
+        if (a->dtype == LARS_U8) hipLaunchKernelGGL((k_fused_generic<uint8_t, 256>), grid, dim3(256), 0, s, P);
+        else hipLaunchKernelGGL((k_fused_generic<uint16_t, 65536>), grid, dim3(256), 0, s, P);
+    }
+    if (stats_mode)
+        hipLaunchKernelGGL(k_stats_finalize, dim3((unsigned)((nrec + 255) / 256)), dim3(256), 0, s, a->stats, nrec, mask,
+                           (long long)a->npix);
+    return launch_check("lars_d_fused");
+}
+
+extern "C" int lars_d_synth_u8(uint8_t *tiles, int64_t ntiles, int64_t first_tile, int64_t npix, int channels,
+                               uint32_t seed, int profile, void *stream)
+{
+    ThreadCtx *c;
+    LARS_TRY(ensure_ctx(&c));
+    if (!tiles || ntiles <= 0 || npix <= 0 || channels < 1 || ntiles > 65535)
+        return fail(LARS_ERR_INVALID, "lars_d_synth_u8: bad arguments");
+    hipStream_t s = pick_stream(c, stream);
+    const long long nbytes = (long long)npix * channels;
+    dim3 grid(blocks_per_tile((nbytes + 3) / 4, ntiles), (unsigned)ntiles);
+    hipLaunchKernelGGL(k_synth_u8, grid, dim3(256), 0, s, tiles, (long long)first_tile, nbytes, channels, seed, profile);
+    return launch_check("lars_d_synth_u8");
+}

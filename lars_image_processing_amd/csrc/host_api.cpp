@@ -1,0 +1,302 @@
+// Host entry points (lars_h_*): host pointers in, host pointers out.  These are
+// what the Python mirror of the reference's functions binds (one call per
+// reference function).  Each call stages through the calling
+// thread's grow-only device workspace and stream, so concurrent Streamlit
+// sessions (threads) do not share mutable state.
+#include <string.h>
+
+#include "common.h"
+
+using namespace lars;
+
+namespace {
+
+struct Carver {
+    char *base;
+    size_t off = 0;
+    explicit Carver(void *b) : base(static_cast<char *>(b)) {}
+    template <typename T>
+    T *take(size_t count)
+    {
+        off = (off + 255) & ~(size_t)255;
+        T *p = base ? reinterpret_cast<T *>(base + off) : nullptr;
+        off += count * sizeof(T);
+        return p;
+    }
+};
+
+struct ImageJob {
+    const void *img;
+    int64_t h, w;
+    int channels, dtype;
+    int apply_wb, wb_variant;
+    uint32_t mask;
+    int want_stats, want_hist, want_median;
+    uint8_t *out_wb;
+    float *out_index[3];
+    lars_stats *stats;
+    float *medians;               // [3][2]
+    uint8_t *out_rgba[3];
+    const uint8_t *cmap[3];
+    double *pcts;                 // [3][2]
+};
+
+struct Layout {
+    uint8_t *img; uint32_t *hist; uint8_t *table; double *pcts; uint8_t *wb;
+    float *idx[3]; lars_stats *stats; float *med; char *sel; uint8_t *rgba[3]; uint8_t *cmap[3];
+    size_t total;
+};
+
+Layout plan(const ImageJob &j, void *base)
+{
+    Carver c(base);
+    Layout L;
+    const size_t npix = (size_t)j.h * j.w;
+    const size_t esz = j.dtype == LARS_U8 ? 1 : 2;
+    const size_t nval = j.dtype == LARS_U8 ? 256 : 65536;
+    L.img = c.take<uint8_t>(npix * j.channels * esz);
+    L.hist = j.apply_wb ? c.take<uint32_t>(3 * nval) : nullptr;
+    L.table = j.apply_wb ? c.take<uint8_t>(3 * nval) : nullptr;
+    L.pcts = j.apply_wb ? c.take<double>(6) : nullptr;
+    L.wb = (j.apply_wb && j.out_wb) ? c.take<uint8_t>(npix * j.channels) : nullptr;
+    for (int k = 0; k < 3; ++k) {
+        const bool on = (j.mask >> k) & 1u;
+        L.idx[k] = (on && (j.out_index[k] || j.want_median)) ? c.take<float>(npix) : nullptr;
+        L.rgba[k] = (on && j.out_rgba[k]) ? c.take<uint8_t>(npix * 4) : nullptr;
+        L.cmap[k] = (on && j.out_rgba[k]) ? c.take<uint8_t>(1024) : nullptr;
+    }
+    L.stats = c.take<lars_stats>(3);
+    L.med = c.take<float>(6);
+    L.sel = c.take<char>(3 * ((lars_select_scratch_bytes() + 255) & ~(size_t)255));
+    L.total = c.off + 256;
+    return L;
+}
+
+int run_image(const ImageJob &j)
+{
+    ThreadCtx *c;
+    LARS_TRY(ensure_ctx(&c));
+    if (!j.img || j.h <= 0 || j.w <= 0 || j.channels < 3)
+        return fail(LARS_ERR_INVALID, "image must be a non-empty [h][w][>=3] array");
+    if (j.dtype != LARS_U8 && j.dtype != LARS_U16) return fail(LARS_ERR_INVALID, "dtype must be LARS_U8 or LARS_U16");
+    if (j.mask & ~LARS_MASK_ALL) return fail(LARS_ERR_INVALID, "unknown index bits in mask");
+    const size_t npix = (size_t)j.h * j.w;
+    const size_t esz = j.dtype == LARS_U8 ? 1 : 2;
+    Layout L = plan(j, nullptr);
+    LARS_TRY(ws_reserve(c, L.total));
+    L = plan(j, c->ws);
+    hipStream_t s = c->stream;
+
+    LARS_HIP_TRY(hipMemcpyAsync(L.img, j.img, npix * j.channels * esz, hipMemcpyHostToDevice, s));
+    if (j.apply_wb) {
+        LARS_TRY(lars_d_channel_hist(L.img, 1, (int64_t)npix, j.channels, j.dtype, L.hist, s));
+        LARS_TRY(lars_d_wb_table(L.hist, 1, (int64_t)npix, j.dtype, L.table, L.pcts, j.wb_variant, s));
+    }
+    const bool stats = j.want_stats && j.mask;
+    if (j.mask || L.wb) {
+        lars_fused_args a;
+        memset(&a, 0, sizeof a);
+        a.tiles = L.img; a.ntiles = 1; a.npix = (int64_t)npix; a.channels = j.channels; a.dtype = j.dtype;
+        a.wb_table = j.apply_wb ? L.table : nullptr;
+        a.index_mask = j.mask;
+        a.flags = stats ? (LARS_F_STATS | (j.want_hist ? LARS_F_HIST : 0u)) : 0u;
+        for (int k = 0; k < 3; ++k) {
+            a.out_index[k] = L.idx[k];
+            a.out_rgba[k] = L.rgba[k];
+            a.cmap_lut[k] = L.cmap[k];
+            if (L.cmap[k]) LARS_HIP_TRY(hipMemcpyAsync(L.cmap[k], j.cmap[k], 1024, hipMemcpyHostToDevice, s));
+        }
+        a.out_wb = L.wb;
+        a.stats = stats ? L.stats : nullptr;
+        a.stream = s;
+        LARS_TRY(lars_d_fused(&a));
+    }
+    const size_t selsz = (lars_select_scratch_bytes() + 255) & ~(size_t)255;
+    for (int k = 0; k < 3; ++k) {
+        if (!((j.mask >> k) & 1u)) continue;
+        if (j.want_median && j.medians)
+            LARS_TRY(lars_d_median_pair_f32(L.idx[k], (int64_t)npix, L.med + 2 * k, L.sel + k * selsz, s));
+    }
+    // results back
+    if (L.wb) LARS_HIP_TRY(hipMemcpyAsync(j.out_wb, L.wb, npix * j.channels, hipMemcpyDeviceToHost, s));
+    for (int k = 0; k < 3; ++k) {
+        if (!((j.mask >> k) & 1u)) continue;
+        if (j.out_index[k]) LARS_HIP_TRY(hipMemcpyAsync(j.out_index[k], L.idx[k], npix * 4, hipMemcpyDeviceToHost, s));
+        if (L.rgba[k]) LARS_HIP_TRY(hipMemcpyAsync(j.out_rgba[k], L.rgba[k], npix * 4, hipMemcpyDeviceToHost, s));
+    }
+    lars_stats hstats[3];
+    float hmed[6];
+    double hp[6];
+    if (stats) LARS_HIP_TRY(hipMemcpyAsync(hstats, L.stats, sizeof hstats, hipMemcpyDeviceToHost, s));
+    if (j.want_median && j.medians && j.mask) LARS_HIP_TRY(hipMemcpyAsync(hmed, L.med, sizeof hmed, hipMemcpyDeviceToHost, s));
+    if (j.apply_wb && j.pcts) LARS_HIP_TRY(hipMemcpyAsync(hp, L.pcts, sizeof hp, hipMemcpyDeviceToHost, s));
+    LARS_HIP_TRY(hipStreamSynchronize(s));
+    for (int k = 0; k < 3; ++k) {
+        if (!((j.mask >> k) & 1u)) continue;
+        if (stats && j.stats) j.stats[k] = hstats[k];
+        if (j.want_median && j.medians) { j.medians[2 * k] = hmed[2 * k]; j.medians[2 * k + 1] = hmed[2 * k + 1]; }
+    }
+    if (j.apply_wb && j.pcts) memcpy(j.pcts, hp, sizeof hp);
+    return LARS_OK;
+}
+
+}  // namespace
+
+template <typename T>
+static int analyze_impl(const T *x, int64_t n, T thr, int want_hist, lars_stats *out, T *median_pair, double *sumsqdev)
+{
+    ThreadCtx *c;
+    LARS_TRY(ensure_ctx(&c));
+    if (!x || n <= 0 || !out) return fail(LARS_ERR_INVALID, "lars_h_analyze: bad arguments");
+    Carver cv(nullptr);
+    cv.take<T>(n); cv.take<lars_stats>(1); cv.take<T>(2); cv.take<double>(1); cv.take<char>(lars_select_scratch_bytes());
+    LARS_TRY(ws_reserve(c, cv.off + 256));
+    Carver d(c->ws);
+    T *dx = d.take<T>(n);
+    lars_stats *dst = d.take<lars_stats>(1);
+    T *dmed = d.take<T>(2);
+    double *dss = d.take<double>(1);
+    char *dsel = d.take<char>(lars_select_scratch_bytes());
+    hipStream_t s = c->stream;
+    LARS_HIP_TRY(hipMemcpyAsync(dx, x, (size_t)n * sizeof(T), hipMemcpyHostToDevice, s));
+    if (sizeof(T) == 4) {
+        LARS_TRY(lars_d_array_stats_f32(reinterpret_cast<const float *>(dx), n, (float)thr, want_hist, dst, s));
+        if (median_pair)
+            LARS_TRY(lars_d_median_pair_f32(reinterpret_cast<const float *>(dx), n, reinterpret_cast<float *>(dmed), dsel, s));
+    } else {
+        LARS_TRY(lars_d_array_stats_f64(reinterpret_cast<const double *>(dx), n, (double)thr, want_hist, dst,
+                                        sumsqdev ? dss : nullptr, s));
+        if (median_pair)
+            LARS_TRY(lars_d_median_pair_f64(reinterpret_cast<const double *>(dx), n, reinterpret_cast<double *>(dmed), dsel, s));
+    }
+    LARS_HIP_TRY(hipMemcpyAsync(out, dst, sizeof(lars_stats), hipMemcpyDeviceToHost, s));
+    if (median_pair) LARS_HIP_TRY(hipMemcpyAsync(median_pair, dmed, 2 * sizeof(T), hipMemcpyDeviceToHost, s));
+    if (sumsqdev) LARS_HIP_TRY(hipMemcpyAsync(sumsqdev, dss, sizeof(double), hipMemcpyDeviceToHost, s));
+    LARS_HIP_TRY(hipStreamSynchronize(s));
+    return LARS_OK;
+}
+
+extern "C" {
+
+int lars_h_fix_white_balance(const void *img, int64_t h, int64_t w, int channels, int dtype, int variant, uint8_t *out,
+                             double *percentiles)
+{
+    if (!out) return fail(LARS_ERR_INVALID, "lars_h_fix_white_balance: out == NULL");
+    ImageJob j;
+    memset(&j, 0, sizeof j);
+    j.img = img; j.h = h; j.w = w; j.channels = channels; j.dtype = dtype;
+    j.apply_wb = 1; j.wb_variant = variant; j.mask = 0; j.out_wb = out; j.pcts = percentiles;
+    return run_image(j);
+}
+
+int lars_h_calculate_index(const void *img, int64_t h, int64_t w, int channels, int dtype, uint32_t index_mask,
+                           float *const out[3], lars_stats *stats, int want_hist)
+{
+    if (!index_mask) return fail(LARS_ERR_INVALID, "lars_h_calculate_index: empty index mask");
+    ImageJob j;
+    memset(&j, 0, sizeof j);
+    j.img = img; j.h = h; j.w = w; j.channels = channels; j.dtype = dtype;
+    j.mask = index_mask;
+    for (int k = 0; k < 3; ++k) j.out_index[k] = out ? out[k] : nullptr;
+    j.stats = stats; j.want_stats = stats != nullptr; j.want_hist = want_hist;
+    return run_image(j);
+}
+
+int lars_h_process_image(const void *img, int64_t h, int64_t w, int channels, int dtype, int apply_wb,
+                         uint32_t index_mask, int want_hist, uint8_t *out_wb, float *const out_index[3],
+                         lars_stats *stats, float *medians, uint8_t *const out_rgba[3], const uint8_t *const cmap_lut[3])
+{
+    ImageJob j;
+    memset(&j, 0, sizeof j);
+    j.img = img; j.h = h; j.w = w; j.channels = channels; j.dtype = dtype;
+    j.apply_wb = apply_wb; j.mask = index_mask; j.out_wb = out_wb;
+    for (int k = 0; k < 3; ++k) {
+        j.out_index[k] = out_index ? out_index[k] : nullptr;
+        j.out_rgba[k] = out_rgba ? out_rgba[k] : nullptr;
+        j.cmap[k] = cmap_lut ? cmap_lut[k] : nullptr;
+        if (j.out_rgba[k] && !j.cmap[k]) return fail(LARS_ERR_INVALID, "lars_h_process_image: out_rgba needs cmap_lut");
+    }
+    j.stats = stats; j.want_stats = stats != nullptr; j.want_hist = want_hist;
+    j.medians = medians; j.want_median = medians != nullptr;
+    if (!index_mask && !(apply_wb && out_wb)) return fail(LARS_ERR_INVALID, "lars_h_process_image: nothing requested");
+    return run_image(j);
+}
+
+int lars_h_calculate_index_planes(const float *red, const float *green, const float *nir, int64_t n, int index_id,
+                                  float *out)
+{
+    ThreadCtx *c;
+    LARS_TRY(ensure_ctx(&c));
+    if (!red || !green || !nir || !out || n <= 0) return fail(LARS_ERR_INVALID, "lars_h_calculate_index_planes: bad arguments");
+    Carver cv(nullptr);
+    cv.take<float>(n); cv.take<float>(n); cv.take<float>(n); cv.take<float>(n);
+    LARS_TRY(ws_reserve(c, cv.off + 256));
+    Carver d(c->ws);
+    float *dr = d.take<float>(n), *dg = d.take<float>(n), *dn = d.take<float>(n), *dout = d.take<float>(n);
+    hipStream_t s = c->stream;
+    // only the two bands the index reads cross PCIe
+    const float *ha = index_id == LARS_NDWI ? green : nir;
+    const float *hb = index_id == LARS_NDVI ? red : (index_id == LARS_GNDVI ? green : nir);
+    float *da = index_id == LARS_NDWI ? dg : dn;
+    float *db = index_id == LARS_NDVI ? dr : (index_id == LARS_GNDVI ? dg : dn);
+    LARS_HIP_TRY(hipMemcpyAsync(da, ha, (size_t)n * 4, hipMemcpyHostToDevice, s));
+    LARS_HIP_TRY(hipMemcpyAsync(db, hb, (size_t)n * 4, hipMemcpyHostToDevice, s));
+    LARS_TRY(lars_d_index_planes_f32(dr, dg, dn, n, index_id, dout, s));
+    LARS_HIP_TRY(hipMemcpyAsync(out, dout, (size_t)n * 4, hipMemcpyDeviceToHost, s));
+    LARS_HIP_TRY(hipStreamSynchronize(s));
+    return LARS_OK;
+}
+
+int lars_h_ndvi_f64(const void *img, int64_t h, int64_t w, int channels, int dtype, double *out)
+{
+    ThreadCtx *c;
+    LARS_TRY(ensure_ctx(&c));
+    if (!img || !out || h <= 0 || w <= 0 || channels < 3) return fail(LARS_ERR_INVALID, "lars_h_ndvi_f64: bad arguments");
+    if (dtype != LARS_U8 && dtype != LARS_U16) return fail(LARS_ERR_INVALID, "lars_h_ndvi_f64: dtype");
+    const size_t npix = (size_t)h * w, esz = dtype == LARS_U8 ? 1 : 2;
+    Carver cv(nullptr);
+    cv.take<uint8_t>(npix * channels * esz); cv.take<double>(npix);
+    LARS_TRY(ws_reserve(c, cv.off + 256));
+    Carver d(c->ws);
+    uint8_t *dimg = d.take<uint8_t>(npix * channels * esz);
+    double *dout = d.take<double>(npix);
+    hipStream_t s = c->stream;
+    LARS_HIP_TRY(hipMemcpyAsync(dimg, img, npix * channels * esz, hipMemcpyHostToDevice, s));
+    LARS_TRY(lars_d_ndvi_f64(dimg, (int64_t)npix, channels, dtype, dout, s));
+    LARS_HIP_TRY(hipMemcpyAsync(out, dout, npix * 8, hipMemcpyDeviceToHost, s));
+    LARS_HIP_TRY(hipStreamSynchronize(s));
+    return LARS_OK;
+}
+
+int lars_h_analyze_f32(const float *x, int64_t n, float threshold, int want_hist, lars_stats *out, float median_pair[2])
+{
+    return analyze_impl<float>(x, n, threshold, want_hist, out, median_pair, nullptr);
+}
+int lars_h_analyze_f64(const double *x, int64_t n, double threshold, int want_hist, lars_stats *out, double median_pair[2],
+                       double *sumsqdev)
+{
+    return analyze_impl<double>(x, n, threshold, want_hist, out, median_pair, sumsqdev);
+}
+
+int lars_h_colormap_f32(const float *x, int64_t n, const uint8_t *lut_rgba, uint8_t *out_rgba)
+{
+    ThreadCtx *c;
+    LARS_TRY(ensure_ctx(&c));
+    if (!x || !lut_rgba || !out_rgba || n <= 0) return fail(LARS_ERR_INVALID, "lars_h_colormap_f32: bad arguments");
+    Carver cv(nullptr);
+    cv.take<float>(n); cv.take<uint8_t>(1024); cv.take<uint8_t>((size_t)n * 4);
+    LARS_TRY(ws_reserve(c, cv.off + 256));
+    Carver d(c->ws);
+    float *dx = d.take<float>(n);
+    uint8_t *dl = d.take<uint8_t>(1024);
+    uint8_t *dout = d.take<uint8_t>((size_t)n * 4);
+    hipStream_t s = c->stream;
+    LARS_HIP_TRY(hipMemcpyAsync(dx, x, (size_t)n * 4, hipMemcpyHostToDevice, s));
+    LARS_HIP_TRY(hipMemcpyAsync(dl, lut_rgba, 1024, hipMemcpyHostToDevice, s));
+    LARS_TRY(lars_d_colormap_f32(dx, n, dl, dout, s));
+    LARS_HIP_TRY(hipMemcpyAsync(out_rgba, dout, (size_t)n * 4, hipMemcpyDeviceToHost, s));
+    LARS_HIP_TRY(hipStreamSynchronize(s));
+    return LARS_OK;
+}
+
+}  // extern "C"

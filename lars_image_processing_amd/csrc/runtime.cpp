@@ -1,0 +1,264 @@
+// Runtime plumbing of liblars_hip.so: per-thread context, errors, memory,
+// streams, events, and the host-side fold of statistics records.
+#include <stdarg.h>
+#include <string.h>
+
+#include <cmath>
+#include <mutex>
+
+#include "common.h"
+
+namespace lars {
+
+static thread_local std::string g_last_error;
+static thread_local ThreadCtx g_ctx;
+
+void set_error(const char *fmt, ...)
+{
+    char buf[1024];
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(buf, sizeof buf, fmt, ap);
+    va_end(ap);
+    g_last_error = buf;
+}
+
+int fail(int code, const char *fmt, ...)
+{
+    char buf[1024];
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(buf, sizeof buf, fmt, ap);
+    va_end(ap);
+    g_last_error = buf;
+    return code;
+}
+
+static int bind_device(ThreadCtx *c, int ordinal)
+{
+    int count = 0;
+    hipError_t e = hipGetDeviceCount(&count);
+    if (e != hipSuccess || count <= 0)
+        return fail(LARS_ERR_NO_DEVICE, "no HIP device available (%s); liblars_hip has no CPU fallback",
+                    e == hipSuccess ? "device count 0" : hipGetErrorString(e));
+    if (ordinal < 0 || ordinal >= count) return fail(LARS_ERR_INVALID, "device ordinal %d out of range [0,%d)", ordinal, count);
+    hipDeviceProp_t prop;
+    LARS_HIP_TRY(hipGetDeviceProperties(&prop, ordinal));
+    if (strncmp(prop.gcnArchName, "gfx950", 6) != 0)
+        return fail(LARS_ERR_NO_DEVICE, "device %d is %s; liblars_hip is built for gfx950 (MI355X) only", ordinal,
+                    prop.gcnArchName);
+    LARS_HIP_TRY(hipSetDevice(ordinal));
+    if (c->stream) { hipStreamDestroy(c->stream); c->stream = nullptr; }
+    if (c->ws) { hipFree(c->ws); c->ws = nullptr; c->ws_bytes = 0; }
+    if (c->scratch) { hipFree(c->scratch); c->scratch = nullptr; c->scratch_bytes = 0; }
+    LARS_HIP_TRY(hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking));
+    c->device = ordinal;
+    return LARS_OK;
+}
+
+int ensure_ctx(ThreadCtx **out)
+{
+    ThreadCtx *c = &g_ctx;
+    if (c->device < 0) LARS_TRY(bind_device(c, 0));
+    else LARS_HIP_TRY(hipSetDevice(c->device));
+    *out = c;
+    return LARS_OK;
+}
+
+static int reserve(void **p, size_t *have, size_t bytes, hipStream_t s)
+{
+    if (bytes <= *have) return LARS_OK;
+    if (*p) {
+        LARS_HIP_TRY(hipStreamSynchronize(s));
+        LARS_HIP_TRY(hipFree(*p));
+        *p = nullptr; *have = 0;
+    }
+    size_t want = bytes + (bytes >> 3);                  // 12.5 % slack against regrowth
+    want = (want + 0xFFFFF) & ~(size_t)0xFFFFF;
+    hipError_t e = hipMalloc(p, want);
+    if (e != hipSuccess) {
+        *p = nullptr;
+        return fail(LARS_ERR_OOM, "hipMalloc(%zu) for the library workspace failed: %s", want, hipGetErrorString(e));
+    }
+    *have = want;
+    return LARS_OK;
+}
+int ws_reserve(ThreadCtx *c, size_t bytes) { return reserve(&c->ws, &c->ws_bytes, bytes, c->stream); }
+int scratch_reserve(ThreadCtx *c, size_t bytes) { return reserve(&c->scratch, &c->scratch_bytes, bytes, c->stream); }
+
+int launch_check(const char *what)
+{
+    hipError_t e = hipGetLastError();
+    if (e != hipSuccess) return fail(LARS_ERR_HIP, "%s: kernel launch failed: %s", what, hipGetErrorString(e));
+    return LARS_OK;
+}
+
+}  // namespace lars
+
+using namespace lars;
+
+extern "C" {
+
+int lars_abi_version(void) { return LARS_ABI_VERSION; }
+const char *lars_last_error(void) { return g_last_error.c_str(); }
+
+int lars_device_count(int *count)
+{
+    if (!count) return fail(LARS_ERR_INVALID, "lars_device_count: NULL");
+    int n = 0;
+    hipError_t e = hipGetDeviceCount(&n);
+    if (e != hipSuccess) { *count = 0; return fail(LARS_ERR_NO_DEVICE, "hipGetDeviceCount: %s", hipGetErrorString(e)); }
+    *count = n;
+    return LARS_OK;
+}
+
+int lars_set_device(int ordinal) { return bind_device(&g_ctx, ordinal); }
+
+int lars_get_device(int *ordinal)
+{
+    ThreadCtx *c;
+    LARS_TRY(ensure_ctx(&c));
+    if (ordinal) *ordinal = c->device;
+    return LARS_OK;
+}
+
+int lars_device_name(char *buf, size_t buflen)
+{
+    ThreadCtx *c;
+    LARS_TRY(ensure_ctx(&c));
+    hipDeviceProp_t prop;
+    LARS_HIP_TRY(hipGetDeviceProperties(&prop, c->device));
+    snprintf(buf, buflen, "%s (%s, %d CUs, %.1f GiB)", prop.name, prop.gcnArchName, prop.multiProcessorCount,
+             (double)prop.totalGlobalMem / (1024.0 * 1024.0 * 1024.0));
+    return LARS_OK;
+}
+
+int lars_malloc(void **dptr, size_t bytes)
+{
+    ThreadCtx *c;
+    LARS_TRY(ensure_ctx(&c));
+    if (!dptr) return fail(LARS_ERR_INVALID, "lars_malloc: NULL");
+    hipError_t e = hipMalloc(dptr, bytes ? bytes : 1);
+    if (e != hipSuccess) { *dptr = nullptr; return fail(LARS_ERR_OOM, "hipMalloc(%zu): %s", bytes, hipGetErrorString(e)); }
+    return LARS_OK;
+}
+int lars_free(void *dptr)
+{
+    if (!dptr) return LARS_OK;
+    ThreadCtx *c;
+    LARS_TRY(ensure_ctx(&c));
+    LARS_HIP_TRY(hipFree(dptr));
+    return LARS_OK;
+}
+int lars_memset(void *dptr, int value, size_t bytes, void *stream)
+{
+    ThreadCtx *c;
+    LARS_TRY(ensure_ctx(&c));
+    LARS_HIP_TRY(hipMemsetAsync(dptr, value, bytes, pick_stream(c, stream)));
+    return LARS_OK;
+}
+int lars_memcpy_h2d(void *dst, const void *src, size_t bytes)
+{
+    ThreadCtx *c;
+    LARS_TRY(ensure_ctx(&c));
+    LARS_HIP_TRY(hipMemcpyAsync(dst, src, bytes, hipMemcpyHostToDevice, c->stream));
+    LARS_HIP_TRY(hipStreamSynchronize(c->stream));
+    return LARS_OK;
+}
+int lars_memcpy_d2h(void *dst, const void *src, size_t bytes)
+{
+    ThreadCtx *c;
+    LARS_TRY(ensure_ctx(&c));
+    LARS_HIP_TRY(hipMemcpyAsync(dst, src, bytes, hipMemcpyDeviceToHost, c->stream));
+    LARS_HIP_TRY(hipStreamSynchronize(c->stream));
+    return LARS_OK;
+}
+int lars_memcpy_d2d(void *dst, const void *src, size_t bytes, void *stream)
+{
+    ThreadCtx *c;
+    LARS_TRY(ensure_ctx(&c));
+    LARS_HIP_TRY(hipMemcpyAsync(dst, src, bytes, hipMemcpyDeviceToDevice, pick_stream(c, stream)));
+    return LARS_OK;
+}
+int lars_stream_create(void **stream)
+{
+    ThreadCtx *c;
+    LARS_TRY(ensure_ctx(&c));
+    hipStream_t s;
+    LARS_HIP_TRY(hipStreamCreateWithFlags(&s, hipStreamNonBlocking));
+    *stream = s;
+    return LARS_OK;
+}
+int lars_stream_destroy(void *stream)
+{
+    if (stream) LARS_HIP_TRY(hipStreamDestroy(reinterpret_cast<hipStream_t>(stream)));
+    return LARS_OK;
+}
+int lars_synchronize(void *stream)
+{
+    ThreadCtx *c;
+    LARS_TRY(ensure_ctx(&c));
+    LARS_HIP_TRY(hipStreamSynchronize(pick_stream(c, stream)));
+    return LARS_OK;
+}
+int lars_shutdown(void)
+{
+    ThreadCtx *c = &g_ctx;
+    if (c->device < 0) return LARS_OK;
+    hipSetDevice(c->device);
+    if (c->stream) { hipStreamSynchronize(c->stream); hipStreamDestroy(c->stream); c->stream = nullptr; }
+    if (c->ws) { hipFree(c->ws); c->ws = nullptr; c->ws_bytes = 0; }
+    if (c->scratch) { hipFree(c->scratch); c->scratch = nullptr; c->scratch_bytes = 0; }
+    c->device = -1;
+    return LARS_OK;
+}
+
+int lars_event_create(void **event)
+{
+    ThreadCtx *c;
+    LARS_TRY(ensure_ctx(&c));
+    hipEvent_t e;
+    LARS_HIP_TRY(hipEventCreate(&e));
+    *event = e;
+    return LARS_OK;
+}
+int lars_event_destroy(void *event)
+{
+    if (event) LARS_HIP_TRY(hipEventDestroy(reinterpret_cast<hipEvent_t>(event)));
+    return LARS_OK;
+}
+int lars_event_record(void *event, void *stream)
+{
+    ThreadCtx *c;
+    LARS_TRY(ensure_ctx(&c));
+    LARS_HIP_TRY(hipEventRecord(reinterpret_cast<hipEvent_t>(event), pick_stream(c, stream)));
+    return LARS_OK;
+}
+int lars_event_elapsed_ms(void *start, void *stop, float *ms)
+{
+    LARS_HIP_TRY(hipEventSynchronize(reinterpret_cast<hipEvent_t>(stop)));
+    LARS_HIP_TRY(hipEventElapsedTime(ms, reinterpret_cast<hipEvent_t>(start), reinterpret_cast<hipEvent_t>(stop)));
+    return LARS_OK;
+}
+
+// Fold records of one index (tiles of a batch, or ranks): sums in the given
+// order (deterministic), min/max fold, integer fields add.
+int lars_stats_merge(const lars_stats *r, int64_t n, lars_stats *out)
+{
+    if (!r || !out || n <= 0) return fail(LARS_ERR_INVALID, "lars_stats_merge: bad arguments");
+    lars_stats m = r[0];
+    for (int64_t i = 1; i < n; ++i) {
+        m.sum += r[i].sum;
+        m.sumsq += r[i].sumsq;
+        m.count += r[i].count;
+        m.above += r[i].above;
+        m.nans += r[i].nans;
+        m.min = std::fmin(m.min, r[i].min);
+        m.max = std::fmax(m.max, r[i].max);
+        for (int b = 0; b < LARS_HIST_BINS; ++b) m.hist[b] += r[i].hist[b];
+    }
+    *out = m;
+    return LARS_OK;
+}
+
+}  // extern "C"

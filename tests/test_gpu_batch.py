@@ -1,0 +1,158 @@
+"""The batched, device-resident tile path against the oracle (needs a MI355X)."""
+import warnings
+
+import numpy as np
+import pytest
+
+from oracle import index_oracle as orc
+
+pytestmark = pytest.mark.gpu
+TYPES = ("NDVI", "GNDVI", "NDWI")
+
+
+@pytest.fixture(scope="module")
+def lars():
+    import lars_image_processing_amd as mod
+    from lars_image_processing_amd import _ffi
+    assert _ffi.device_count() >= 1
+    return mod
+
+
+def bits(a):
+    return np.ascontiguousarray(a).view(np.uint32)
+
+
+@pytest.mark.parametrize("profile", ["uniform", "vegetation"])
+@pytest.mark.parametrize("shape", [(64, 64), (30, 50), (33, 35)])
+def test_device_generator_equals_host_generator(lars, profile, shape):
+    b = lars.TileBatch.synthetic(5, shape[0], shape[1], seed=1234, profile=profile, first_tile=7)
+    got = b.host_tiles()
+    for i in range(5):
+        np.testing.assert_array_equal(got[i], orc.synth_tile_u8(1234, 7 + i, shape[0], shape[1], profile=profile))
+    b.free()
+
+
+@pytest.mark.parametrize("profile", ["uniform", "vegetation"])
+@pytest.mark.parametrize("shape", [(64, 64), (96, 160), (33, 35)])
+def test_batch_matches_oracle_per_tile(lars, profile, shape):
+    from lars_image_processing_amd import batch as lb
+    ntiles = 6
+    b = lars.TileBatch.synthetic(ntiles, shape[0], shape[1], seed=42, profile=profile)
+    tiles = b.host_tiles()
+    outs = b.make_outputs(index=True, wb=True, rgba=True)
+    rec = b.process(hist=True, outputs=outs)
+    tables = b.host_tables()
+    pcts = b.host_percentiles()
+    wb = outs.host_wb(0, ntiles)
+    for i in range(ntiles):
+        with warnings.catch_warnings():
+            warnings.simplefilter("ignore")
+            want_wb = orc.wb_app(tiles[i])
+        np.testing.assert_array_equal(wb[i], want_wb)
+        for c in range(3):
+            hist = np.bincount(tiles[i][:, :, c].ravel(), minlength=256)
+            lo, hi = orc.percentile_from_hist(hist, 2), orc.percentile_from_hist(hist, 98)
+            assert pcts[i, c, 0] == lo and pcts[i, c, 1] == hi
+            present = hist > 0
+            np.testing.assert_array_equal(tables[i, c][present], orc.wb_lut_from_percentiles(lo, hi)[present])
+        for k, t in enumerate(TYPES):
+            want = orc.index_app(want_wb, t)
+            np.testing.assert_array_equal(bits(outs.host_index(t, i, 1)[0]), bits(want))
+            part = orc.tile_partials(want, t)
+            r = rec[i, k]
+            assert int(r["count"]) == part["count"] and int(r["above"]) == part["above"]
+            assert float(r["min"]) == part["min"] and float(r["max"]) == part["max"]
+            assert float(r["sum"]) == part["sum"]                      # exact fixed-point sum
+            assert float(r["sumsq"]) == pytest.approx(part["sumsq"], rel=1e-9)
+            np.testing.assert_array_equal(np.array(r["hist"], dtype=np.int64), part["hist"])
+            lut = lars.colormap_lut("RdYlBu" if t == "NDWI" else "RdYlGn")
+            np.testing.assert_array_equal(outs.host_rgba(t, i, 1)[0], orc.colormap_closed_form(want, lut))
+    # global statistics == statistics of the union
+    for k, t in enumerate(TYPES):
+        merged = lb.summarize(lb.merge_records(rec[:, k]))
+        parts = []
+        for i in range(ntiles):
+            with warnings.catch_warnings():
+                warnings.simplefilter("ignore")
+                parts.append(orc.tile_partials(orc.index_app(orc.wb_app(tiles[i]), t), t))
+        want = orc.merge_partials(parts)
+        assert merged["count"] == want["count"] and merged["coverage"] == want["coverage"]
+        assert merged["min"] == want["min"] and merged["max"] == want["max"]
+        assert merged["mean"] == pytest.approx(want["mean"], rel=1e-12, abs=1e-15)
+        np.testing.assert_array_equal(merged["hist"], want["hist"])
+    outs.free()
+    b.free()
+
+
+def test_stats_only_equals_stats_with_outputs_and_ring(lars):
+    b = lars.TileBatch.synthetic(8, 128, 128, seed=7, profile="vegetation")
+    rec_a = b.process(hist=True)
+    outs = b.make_outputs(index=True, ring=3)
+    rec_b = b.process(hist=True, outputs=outs)
+    assert rec_a.tobytes() == rec_b.tobytes()
+    # the ring holds the last chunk: tiles 6, 7 in slots 0, 1
+    tiles = b.host_tiles()
+    with warnings.catch_warnings():
+        warnings.simplefilter("ignore")
+        want = orc.index_app(orc.wb_app(tiles[7]), "NDVI")
+    np.testing.assert_array_equal(bits(outs.host_index("NDVI", 1, 1)[0]), bits(want))
+    # no white balance: indices of the raw samples
+    rec_raw = b.process(white_balance=False)
+    for i in (0, 5):
+        part = orc.tile_partials(orc.index_app(tiles[i], "GNDVI"), "GNDVI")
+        assert float(rec_raw[i, 1]["sum"]) == part["sum"] and int(rec_raw[i, 1]["above"]) == part["above"]
+    outs.free()
+    b.free()
+
+
+def test_single_index_masks_leave_other_records_untouched(lars):
+    b = lars.TileBatch.synthetic(3, 64, 64, seed=3)
+    tiles = b.host_tiles()
+    for k, t in enumerate(TYPES):
+        rec = b.process(indices=(t,), white_balance=False)
+        for j in range(3):
+            if j != k:
+                assert rec[:, j].tobytes() == bytes(rec[:, j].nbytes)
+        part = orc.tile_partials(orc.index_app(tiles[1], t), t)
+        assert float(rec[1, k]["sum"]) == part["sum"] and float(rec[1, k]["min"]) == part["min"]
+    rec2 = b.process(indices=("NDVI", "NDWI"), white_balance=False)       # two-index mask -> generic kernel
+    assert rec2[:, 1].tobytes() == bytes(rec2[:, 1].nbytes)
+    part = orc.tile_partials(orc.index_app(tiles[2], "NDWI"), "NDWI")
+    assert float(rec2[2, 2]["sum"]) == part["sum"] and int(rec2[2, 2]["above"]) == part["above"]
+    b.free()
+
+
+def test_full_size_tile_properties(lars):
+    """4096x4096 (BASELINE config size): size-independent properties + one oracle spot check."""
+    from lars_image_processing_amd import batch as lb
+    b = lars.TileBatch.synthetic(2, 4096, 4096, seed=1234, profile="vegetation")
+    outs = b.make_outputs(index=True, wb=True)
+    rec = b.process(hist=True, outputs=outs)
+    n = 4096 * 4096
+    for i in range(2):
+        for k in range(3):
+            r = rec[i, k]
+            assert int(r["count"]) == n and int(np.sum(r["hist"])) == n
+            assert -1.0 <= float(r["min"]) <= float(r["max"]) <= 1.0
+        # NDWI == -GNDVI: sums negate exactly, extrema swap
+        assert float(rec[i, 2]["sum"]) == -float(rec[i, 1]["sum"])
+        assert float(rec[i, 2]["min"]) == -float(rec[i, 1]["max"]) and float(rec[i, 2]["max"]) == -float(rec[i, 1]["min"])
+    ndvi = outs.host_index("NDVI", 1, 1)[0]
+    wb = outs.host_wb(1, 1)[0]
+    exact = int((ndvi.astype(np.float64) * 2.0 ** 32).astype(np.int64).sum())      # samples are multiples of 2^-32
+    assert float(rec[1, 0]["sum"]) == float(exact) / 2.0 ** 32
+    assert float(rec[1, 0]["min"]) == float(ndvi.min()) and int(rec[1, 0]["above"]) == int((ndvi > np.float32(0.2)).sum())
+    np.testing.assert_array_equal(bits(ndvi), bits(orc.index_closed_form(wb[:, :, 2], wb[:, :, 0])))
+    # white balance is idempotent on its table: every output value is a table value of its input
+    tiles1 = b.host_tiles(1, 1)[0]
+    tab = b.host_tables()[1]
+    for c in range(3):
+        np.testing.assert_array_equal(wb[:, :, c], tab[c][tiles1[:, :, c]])
+    # a 1024-row strip against the reference statement
+    with warnings.catch_warnings():
+        warnings.simplefilter("ignore")
+        want_wb = orc.wb_app(tiles1)
+    np.testing.assert_array_equal(wb, want_wb)
+    assert lb.summarize(lb.merge_records(rec[:, 0]))["count"] == 2 * n
+    outs.free()
+    b.free()

@@ -1,0 +1,190 @@
+"""Parity of the HIP path (through the C ABI) against the committed reference
+outputs and against the oracle on seeded inputs.  Needs a real MI355X.
+
+Bars: uint8 outputs and index arrays BIT-EXACT; min / max / median / coverage /
+histogram exact; mean within 1e-6 relative (the reference's float32 pairwise
+sum is itself ~2.5e-7 from the exact mean).
+"""
+import warnings
+
+import numpy as np
+import pytest
+
+from conftest import golden_case_names
+from oracle import index_oracle as orc
+
+pytestmark = pytest.mark.gpu
+
+CASES = golden_case_names()
+U8_RGB = [c for c in CASES if c.startswith("u8_") and "rgba" not in c]
+TYPES = ("NDVI", "GNDVI", "NDWI")
+MEAN_RTOL = 1e-6
+
+
+@pytest.fixture(scope="module")
+def lars():
+    import lars_image_processing_amd as mod
+    from lars_image_processing_amd import _ffi
+    assert _ffi.device_count() >= 1, "GPU tests need a gfx950 device"
+    return mod
+
+
+def bits(a):
+    a = np.ascontiguousarray(a)
+    return a.view({4: np.uint32, 8: np.uint64}[a.dtype.itemsize])
+
+
+def assert_stats_close(got, want):
+    assert list(got.keys()) == list(want.keys())
+    for key in want:
+        if key.startswith("Mean") or key in ("Mean", "mean_ndvi"):
+            assert got[key] == pytest.approx(want[key], rel=MEAN_RTOL, abs=1e-9), key
+        elif key in ("std_ndvi",):
+            assert got[key] == pytest.approx(want[key], rel=1e-9, abs=1e-12), key
+        else:
+            assert got[key] == want[key], (key, got[key], want[key])
+
+
+# ---------------------------------------------------------------- goldens ---
+@pytest.mark.parametrize("case", CASES)
+def test_white_balance_matches_reference(lars, golden, case):
+    got = lars.fix_white_balance(golden[f"{case}/input"])
+    assert got.dtype == np.uint8 and got.shape == golden[f"{case}/wb"].shape
+    np.testing.assert_array_equal(got, golden[f"{case}/wb"])
+
+
+@pytest.mark.parametrize("case", CASES)
+@pytest.mark.parametrize("kind", ["raw", "wb"])
+@pytest.mark.parametrize("t", TYPES)
+def test_index_bit_exact(lars, golden, case, kind, t):
+    src = golden[f"{case}/input"] if kind == "raw" else golden[f"{case}/wb"]
+    got = lars.calculate_index(src, t)
+    want = golden[f"{case}/index_{kind}_{t}"]
+    assert got.dtype == np.float32 and got.shape == want.shape
+    np.testing.assert_array_equal(bits(got), bits(want))
+
+
+@pytest.mark.parametrize("case", CASES)
+@pytest.mark.parametrize("t", TYPES)
+def test_analyze_index_matches_reference(lars, golden, golden_dicts, case, t):
+    idx = golden[f"{case}/index_wb_{t}"]
+    assert_stats_close(lars.analyze_index(idx, t), golden_dicts["dicts"][f"{case}/stats_wb_{t}"])
+    np.testing.assert_array_equal(lars.index_histogram(idx), golden[f"{case}/hist50_wb_{t}"])
+    row = lars.timeseries_row(idx, t, "2025-01-01")
+    assert row["Date"] == "2025-01-01" and row["Median"] == golden_dicts["dicts"][f"{case}/stats_wb_{t}"][f"Median {t}"]
+
+
+@pytest.mark.parametrize("case", U8_RGB)
+def test_script_variants_match_reference(lars, golden, golden_dicts, case, tmp_path):
+    from PIL import Image
+    img = golden[f"{case}/input"]
+    # backend-process.py: PIL in, PIL out; 4-argument index
+    pil = lars.fix_white_balance(Image.fromarray(img))
+    np.testing.assert_array_equal(np.array(pil), golden[f"{case}/backend_wb"])
+    f = golden[f"{case}/backend_wb"].astype(np.float32)
+    for t in TYPES:
+        got = lars.calculate_index(f[:, :, 0].copy(), f[:, :, 1].copy(), f[:, :, 2].copy(), t)
+        np.testing.assert_array_equal(bits(got), bits(golden[f"{case}/backend_index_{t}"]))
+    # process-rgn.py / process-ndvi.py: through files
+    p = tmp_path / "in.png"
+    Image.fromarray(img).save(p)
+    np.testing.assert_array_equal(lars.fix_white_balance_rgnir(str(p)), golden[f"{case}/rgn_wb"])
+    out = tmp_path / "out.png"
+    assert lars.fix_white_balance_rgnir(str(p), str(out)) is None
+    np.testing.assert_array_equal(np.array(Image.open(out)), golden[f"{case}/rgn_wb"])
+    nd = lars.calculate_ndvi(str(p), save_path=None, visualize=False)
+    assert nd.dtype == np.float64
+    np.testing.assert_array_equal(bits(nd), bits(golden[f"{case}/ndvi_f64"]))
+    assert_stats_close(lars.analyze_ndvi_statistics(nd), golden_dicts["dicts"][f"{case}/ndvi_stats"])
+    np.testing.assert_array_equal(lars.index_histogram(nd), golden[f"{case}/ndvi_f64_hist50"])
+
+
+@pytest.mark.parametrize("name,t", [("RdYlGn", "NDVI"), ("RdYlBu", "NDWI")])
+def test_colormap_matches_matplotlib(lars, golden, name, t):
+    got = lars.colorize_index(golden["colormap/probe"], t)
+    np.testing.assert_array_equal(got, golden[f"colormap/{name}_probe_rgba"])
+
+
+@pytest.mark.parametrize("case", [c for c in CASES if "rgba" not in c])
+def test_process_image_one_upload(lars, golden, golden_dicts, case):
+    img = golden[f"{case}/input"]
+    res = lars.process_image(img, want_hist=True, want_rgba=True)
+    np.testing.assert_array_equal(res["corrected"], golden[f"{case}/wb"])
+    for t in TYPES:
+        r = res["indices"][t]
+        np.testing.assert_array_equal(bits(r["index"]), bits(golden[f"{case}/index_wb_{t}"]))
+        assert_stats_close(r["stats"], golden_dicts["dicts"][f"{case}/stats_wb_{t}"])
+        np.testing.assert_array_equal(r["hist"], golden[f"{case}/hist50_wb_{t}"])
+        lut = lars.colormap_lut("RdYlBu" if t == "NDWI" else "RdYlGn")
+        np.testing.assert_array_equal(r["rgba"], orc.colormap_closed_form(golden[f"{case}/index_wb_{t}"], lut))
+
+
+# ------------------------------------------------- oracle on seeded inputs ---
+@pytest.mark.parametrize("shape", [(1, 1), (1, 2), (3, 5), (7, 9), (64, 64), (255, 257), (512, 512), (1000, 1003)])
+@pytest.mark.parametrize("profile", ["uniform", "vegetation"])
+def test_odd_shapes_against_oracle(lars, shape, profile):
+    img = orc.synth_tile_u8(99, shape[0] * 1000 + shape[1], shape[0], shape[1], profile=profile)
+    with warnings.catch_warnings():
+        warnings.simplefilter("ignore")
+        want_wb = orc.wb_app(img)
+    res = lars.process_image(img, want_hist=True)
+    np.testing.assert_array_equal(res["corrected"], want_wb)
+    for t in TYPES:
+        want = orc.index_app(want_wb, t)
+        np.testing.assert_array_equal(bits(res["indices"][t]["index"]), bits(want))
+        assert_stats_close(res["indices"][t]["stats"], orc.stats_app(want, t))
+        np.testing.assert_array_equal(res["indices"][t]["hist"], orc.hist50(want))
+
+
+def test_rgba_and_uint16_inputs(lars):
+    rng = np.random.default_rng(17)
+    rgba = rng.integers(0, 256, (37, 41, 4), dtype=np.uint8)
+    got = lars.fix_white_balance(rgba)
+    with warnings.catch_warnings():
+        warnings.simplefilter("ignore")
+        np.testing.assert_array_equal(got, orc.wb_app(rgba))
+    assert (got[:, :, 3] == 0).all()                       # zeros_like + range(3), process-images.py:432-435
+    u16 = rng.integers(0, 65536, (50, 60, 3), dtype=np.uint16)
+    np.testing.assert_array_equal(lars.fix_white_balance(u16), orc.wb_app(u16))
+    for t in TYPES:
+        np.testing.assert_array_equal(bits(lars.calculate_index(u16, t)), bits(orc.index_app(u16, t)))
+        np.testing.assert_array_equal(bits(lars.calculate_index(rgba, t)), bits(orc.index_app(rgba, t)))
+    f32img = rng.uniform(0, 1, (20, 30, 3)).astype(np.float32)
+    for t in TYPES:
+        np.testing.assert_array_equal(bits(lars.calculate_index(f32img, t)), bits(orc.index_app(f32img, t)))
+
+
+def test_division_exhaustive_uint8_pairs(lars):
+    """Every (a, b) byte pair: the kernel's quotient is the IEEE float32 quotient."""
+    a, b = np.meshgrid(np.arange(256, dtype=np.uint8), np.arange(256, dtype=np.uint8), indexing="ij")
+    img = np.stack([b, b, a], axis=-1)                     # red = green = b, nir = a
+    for t in TYPES:
+        np.testing.assert_array_equal(bits(lars.calculate_index(img, t)), bits(orc.index_app(img, t)))
+
+
+def test_median_and_stats_on_arbitrary_arrays(lars):
+    rng = np.random.default_rng(5)
+    for n in (1, 2, 3, 10, 1001, 4096, 100000):
+        x = rng.uniform(-1, 1, n).astype(np.float32)
+        x[rng.integers(0, n, max(1, n // 10))] = np.float32(0.25)       # ties
+        assert_stats_close(lars.analyze_index(x, "NDVI"), orc.stats_app(x, "NDVI"))
+        assert_stats_close(lars.analyze_index(x, "NDWI"), orc.stats_app(x, "NDWI"))
+        np.testing.assert_array_equal(lars.index_histogram(x), orc.hist50(x))
+        x64 = x.astype(np.float64) * 0.999
+        assert_stats_close(lars.analyze_ndvi_statistics(x64), orc.stats_ndvi(x64))
+    z = np.zeros((5, 5), np.float32)
+    z[0, 0] = -0.0
+    assert lars.analyze_index(z, "NDVI")["Median NDVI"] == 0.0
+
+
+def test_inputs_are_not_modified_and_outputs_are_fresh(lars):
+    img = orc.synth_tile_u8(1, 1, 32, 32)
+    keep = img.copy()
+    a = lars.fix_white_balance(img)
+    b = lars.fix_white_balance(img)
+    np.testing.assert_array_equal(img, keep)
+    assert a is not b and a.flags["OWNDATA"] and a.flags["WRITEABLE"]
+    view = img[::2, ::2, :]                                 # non-contiguous input
+    with warnings.catch_warnings():
+        warnings.simplefilter("ignore")
+        np.testing.assert_array_equal(lars.fix_white_balance(view), orc.wb_app(view))

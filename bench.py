@@ -1,0 +1,247 @@
+#!/usr/bin/env python3
+"""Headline benchmark: Mpixels/s of the fused white-balance + NDVI/GNDVI/NDWI +
+statistics path on 4096x4096 uint8 RGNir tiles (BASELINE.json), with the
+achieved HBM GB/s of the fused kernel against the ~8 TB/s roofline and the
+NumPy oracle timed on this box's host cores as a baseline.
+
+    python bench.py --gpus 1 --steps 5 --warmup 2
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 \
+        --master-port P bench.py --gpus N --steps K --warmup W
+
+One process per GPU (RANK / LOCAL_RANK / WORLD_SIZE from the environment).
+Tiles shard by tile with no data-path collective; each step ends with the
+RCCL fold of the global per-index statistics (csrc/comm.cpp).  No PyTorch is
+imported: device memory, streams, events and RCCL all go through liblars_hip.so.
+
+A step = one pass of the hot path over this rank's batch of synthetic tiles
+that are already resident in HBM:
+    channel histograms -> percentile white-balance tables -> fused kernel
+    (band de-interleave, table lookup, three float32 index planes written,
+    min/max/sum/coverage per index) -> fold of per-tile records -> global fold.
+"""
+from __future__ import annotations
+
+import argparse
+import ctypes as C
+import json
+import os
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+HBM_PEAK_GBS = 8000.0            # MI355X_MICROARCH.md: 8.0 TB/s spec (6.29 TB/s measured float4 copy)
+MODES = {
+    # name: (indices, write index planes, hist, algorithmic bytes / pixel of the fused kernel)
+    "wb3idx_out_stats": (("NDVI", "GNDVI", "NDWI"), True, False, 3 + 12),     # BASELINE configs[1]
+    "wb3idx_out_stats_hist": (("NDVI", "GNDVI", "NDWI"), True, True, 3 + 12),  # configs[2]
+    "wb_ndvi_out_stats": (("NDVI",), True, False, 3 + 4),
+    "wb3idx_stats_only": (("NDVI", "GNDVI", "NDWI"), False, False, 3),
+    "wb_ndvi_stats_only": (("NDVI",), False, False, 3),
+}
+
+
+def parse():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=5)
+    ap.add_argument("--warmup", type=int, default=2)
+    ap.add_argument("--tiles", type=int, default=1024, help="tiles per GPU (weak scaling)")
+    ap.add_argument("--tile", type=int, default=4096, help="tile edge in pixels")
+    ap.add_argument("--ring", type=int, default=64, help="output ring, in tiles (same traffic, bounded footprint)")
+    ap.add_argument("--mode", default="wb3idx_out_stats", choices=sorted(MODES))
+    ap.add_argument("--all-modes", action="store_true", help="also time the other modes (extra JSON field)")
+    ap.add_argument("--profile", default="vegetation", choices=["uniform", "vegetation"])
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--cpu-tiles", type=int, default=2)
+    return ap.parse_args()
+
+
+class Runner:
+    """Owns the resident batch and times steps of one mode."""
+
+    def __init__(self, args, comm, rank, world):
+        import lars_image_processing_amd as lars
+        from lars_image_processing_amd import _ffi, batch as lb
+        self.lars, self.ffi, self.lb = lars, _ffi, lb
+        self.comm, self.rank, self.world = comm, rank, world
+        self.args = args
+        first = rank * args.tiles
+        self.batch = lars.TileBatch.synthetic(args.tiles, args.tile, args.tile, seed=1234, profile=args.profile,
+                                              first_tile=first)
+        self.stats = self.batch.new_stats()
+        self.ev = []
+        for _ in range(4):
+            e = C.c_void_p()
+            _ffi.call("lars_event_create", C.byref(e))
+            self.ev.append(e)
+        self.outputs = {}
+
+    def outputs_for(self, indices, write):
+        if not write:
+            return None
+        key = tuple(indices)
+        if key not in self.outputs:
+            self.outputs[key] = self.batch.make_outputs(indices=indices, index=True, ring=self.args.ring)
+        return self.outputs[key]
+
+    def step(self, mode, timed=None):
+        """One pass over the batch.  ``timed`` collects (hist_ms, fused_ms, n_fused_launches)."""
+        indices, write, hist, _ = MODES[mode]
+        b, ffi = self.batch, self.ffi
+        outs = self.outputs_for(indices, write)
+        ffi.call("lars_event_record", self.ev[0], None)
+        b.compute_wb_tables()
+        ffi.call("lars_event_record", self.ev[1], None)
+        launches = 0
+        if outs is None or outs.slots >= b.ntiles:
+            b.run_fused(b.fused_args(indices, True, self.stats, hist, outs))
+            launches = 1
+        else:
+            for start in range(0, b.ntiles, outs.slots):
+                count = min(outs.slots, b.ntiles - start)
+                b.run_fused(b.fused_args(indices, True, self.stats, hist, outs, None, start, count))
+                launches += 1
+        ffi.call("lars_event_record", self.ev[2], None)
+        rec = self.stats.download(ffi.STATS_DTYPE, (b.ntiles, 3))         # synchronises the stream
+        local = self.lb.local_fold(rec, indices)
+        glob = self.comm.allreduce_stats(local)
+        if timed is not None:
+            ms = C.c_float(0)
+            ffi.call("lars_event_elapsed_ms", self.ev[0], self.ev[1], C.byref(ms))
+            hist_ms = ms.value
+            ffi.call("lars_event_elapsed_ms", self.ev[1], self.ev[2], C.byref(ms))
+            timed.append((hist_ms, ms.value, launches))
+        return glob
+
+    def run(self, mode, steps, warmup):
+        for _ in range(warmup):
+            self.step(mode)
+        timed = []
+        self.ffi.call("lars_synchronize", None)
+        self.comm.barrier()
+        t0 = time.perf_counter()
+        glob = None
+        for _ in range(steps):
+            glob = self.step(mode, timed)
+        self.ffi.call("lars_synchronize", None)
+        self.comm.barrier()
+        dt = time.perf_counter() - t0
+        dt = float(self.comm.allreduce_f64([dt], "max")[0])
+        return dt, timed, glob
+
+
+def cpu_baseline(args):
+    """The NumPy oracle (oracle/index_oracle.py == the reference's expressions) on a bounded sample."""
+    import warnings
+    from oracle import index_oracle as orc
+    n = max(1, args.cpu_tiles)
+    tiles = [orc.synth_tile_u8(1234, i, args.tile, args.tile, profile=args.profile) for i in range(n)]
+    t0 = time.perf_counter()
+    with warnings.catch_warnings():
+        warnings.simplefilter("ignore")
+        for img in tiles:
+            wb = orc.wb_app(img)
+            for t in ("NDVI", "GNDVI", "NDWI"):
+                idx = orc.index_app(wb, t)
+                orc.stats_app(idx, t)
+    dt = time.perf_counter() - t0
+    pix = n * args.tile * args.tile
+    return {
+        "value": pix / dt / 1e6, "unit": "Mpix/s", "cores": 1, "kind": "port",
+        "sample": f"{n} tiles {args.tile}x{args.tile} uint8 ({args.profile}): fix_white_balance + 3x calculate_index "
+                  f"+ 3x analyze_index (incl. median), NumPy {np.__version__}, single process, {dt:.1f} s",
+        "host_cpus": os.cpu_count(),
+    }
+
+
+def traffic_from_profiles(mode):
+    """Per-launch HBM bytes from the committed PMC summary, if one exists for this mode."""
+    path = os.path.join(ROOT, "profiles", "traffic.json")
+    try:
+        with open(path) as fh:
+            return json.load(fh).get(mode)
+    except Exception:
+        return None
+
+
+def main():
+    args = parse()
+    from lars_image_processing_amd import _ffi
+    from lars_image_processing_amd import dist
+    rank, local_rank, world = dist.env_rank_world()
+    if world != max(1, args.gpus) and world > 1:
+        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}")
+    if world > 1:
+        comm = dist.Comm.from_env()
+    else:
+        _ffi.call("lars_set_device", 0)
+        comm = dist.SingleProcessComm()
+
+    runner = Runner(args, comm, rank, world)
+    npix_rank = args.tiles * args.tile * args.tile
+    dt, timed, glob = runner.run(args.mode, args.steps, args.warmup)
+    total_pix = npix_rank * world * args.steps
+    value = total_pix / dt / 1e6
+
+    indices, write, hist, bpp = MODES[args.mode]
+    fused_ms = float(np.mean([t[1] for t in timed]))
+    hist_ms = float(np.mean([t[0] for t in timed]))
+    launches = timed[0][2]
+    bytes_per_launch = npix_rank * bpp / launches
+    achieved = bytes_per_launch / (fused_ms / launches * 1e-3) / 1e9
+    traffic = traffic_from_profiles(args.mode)
+
+    extra = {}
+    if args.all_modes:
+        for m in MODES:
+            if m == args.mode:
+                continue
+            d, tm, _ = runner.run(m, max(2, args.steps // 2), 1)
+            f_ms = float(np.mean([t[1] for t in tm]))
+            extra[m] = {
+                "Mpix_s": npix_rank * world * max(2, args.steps // 2) / d / 1e6,
+                "fused_ms": f_ms, "hist_pass_ms": float(np.mean([t[0] for t in tm])),
+                "fused_GBs_algorithmic": npix_rank * MODES[m][3] / (f_ms * 1e-3) / 1e9,
+                "fused_frac_of_8TBs": npix_rank * MODES[m][3] / (f_ms * 1e-3) / 1e9 / HBM_PEAK_GBS,
+            }
+
+    if rank == 0:
+        cpu = None if args.no_cpu_baseline or world > 1 else cpu_baseline(args)
+        g = {t: runner.lb.summarize(glob[_ffi.INDEX_IDS[t]]) for t in indices}
+        line = {
+            "metric": "Mpixels/sec fused white-balance + NDVI/GNDVI/NDWI + stats on 4096x4096 uint8 RGNir tiles",
+            "value": value, "unit": "Mpix/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "ms_per_step": dt / args.steps * 1e3, "higher_is_better": True, "scaling": "weak",
+            "vs_baseline": None, "dtype": "u8 in / f32 index arithmetic", "data": "synthetic",
+            "config": {
+                "workload": f"{args.tiles}-tile batch per GPU of {args.tile}x{args.tile} uint8 RGNir ({args.profile} "
+                            f"counter-hash tiles generated in HBM), mode {args.mode}: percentile white balance + "
+                            f"{'/'.join(indices)}" + (" float32 planes written" if write else " (stats only)") +
+                            " + min/max/mean/coverage" + ("/50-bin histogram" if hist else "") + " per tile, "
+                            "then global fold" + (" over RCCL" if world > 1 else ""),
+                "tiles_per_gpu": args.tiles, "tile": [args.tile, args.tile, 3], "mode": args.mode,
+                "output_ring_tiles": args.ring if write else 0, "parallelism": f"tile-sharded x{world}",
+                "device": _ffi.device_name(),
+            },
+            "roofline": {
+                "bound": "hbm", "kernel": "k_fused_u8c3", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
+                "algorithmic_bytes_per_pixel": bpp, "bytes_per_launch": bytes_per_launch,
+                "launches_per_step": launches, "avg_launch_ms": fused_ms / launches,
+            },
+            "passes_ms": {"histogram+tables": hist_ms, "fused": fused_ms},
+            "cpu_baseline": cpu,
+            "global_stats": {t: {k: v for k, v in s.items() if k != "hist"} for t, s in g.items()},
+        }
+        if extra:
+            line["modes"] = extra
+        print(json.dumps(line))
+    comm.destroy()
+
+
+if __name__ == "__main__":
+    main()

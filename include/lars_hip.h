@@ -71,7 +71,7 @@ typedef enum lars_status {
 
 /* flags of lars_fused_args.flags */
 #define LARS_F_STATS 1u            /* fill stats[tile][index] (min/max/sum/sumsq/above/count) */
-#define LARS_F_HIST  2u            /* also the 50-bin histogram (implies LARS_F_STATS) */
+#define LARS_F_HIST  2u            /* full statistics: also the 50-bin histogram and sumsq (implies LARS_F_STATS) */
 
 /*
  * Order-independent statistics record of one index over one tile (or, after a
@@ -79,8 +79,10 @@ typedef enum lars_status {
  * :506-512) and analyze_ndvi_statistics (process-ndvi.py:60-71) report except the
  * median follows from it: mean = sum/count, min, max, coverage = above/count*100,
  * std = sqrt(sumsq/count - mean^2).
- *   sum / sumsq : exact sums of the float32 index values for uint8 tiles (fixed
- *                 point 2^-32 accumulation), correctly rounded to double.
+ *   sum / sumsq : sums of the float32 index values (fixed point 2^-32 accumulation,
+ *                 order independent); sum is exact for uint8 tiles and correctly
+ *                 rounded to double.  The fused kernel fills sumsq only with
+ *                 LARS_F_HIST (it is 0 otherwise).
  *   above       : samples with x > threshold, compared in the sample's own
  *                 precision (float32 against float32(0.2), process-images.py:511).
  *   hist        : numpy.histogram(x, bins=50, range=(-1, 1)) counts.
@@ -192,6 +194,21 @@ int lars_d_colormap_f32(const float *x, int64_t n, const uint8_t *lut_rgba, uint
  * (seed, tile, word); profile 0 = uniform bytes, 1 = vegetation-like squeeze. */
 int lars_d_synth_u8(uint8_t *tiles, int64_t ntiles, int64_t first_tile, int64_t npix, int channels,
                     uint32_t seed, int profile, void *stream);
+
+/* Tuning knobs (per process): "fused_impl" 1|2, "hist_impl" 1|2, "nt_stores" 0|1,
+ * "blocks_per_tile" 0 = automatic.  Results never depend on them. */
+int lars_set_tuning(const char *key, int value);
+int lars_get_tuning(const char *key, int *value);
+
+/* Device self-check: number of (num, den) pairs, 1 <= den <= max_den, |num| <= den,
+ * for which the kernels' rcp+fma quotient differs from IEEE float32 division
+ * (must be 0; tests run it for the uint8 and the uint16 operand ranges). */
+int lars_d_quot_selfcheck(uint32_t max_den, uint64_t *mismatches, uint32_t first_bad[2]);
+
+/* Roofline probes (bench.py reports them beside the kernel numbers): kind 0 reads
+ * 16 B/lane, 1 reads 12 B/lane (the fused kernel's load shape), 2 copies 16 B/lane
+ * (traffic = 2 x bytes), 3 writes 16 B/lane.  src/dst are device buffers of `bytes`. */
+int lars_d_probe(int kind, int unroll, int blocks, const void *src, void *dst, int64_t bytes, void *stream);
 
 /* Fold n records (same index) into one: sums add, min/max fold, histograms add. */
 int lars_stats_merge(const lars_stats *records, int64_t n, lars_stats *out);

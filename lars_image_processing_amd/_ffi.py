@@ -100,6 +100,10 @@ SIGNATURES = {
     "lars_d_colormap_f32": (_I, [_P, _I64, _P, _P, _P]),
     "lars_d_synth_u8": (_I, [_P, _I64, _I64, _I64, _I, _U32, _I, _P]),
     "lars_stats_merge": (_I, [_P, _I64, _P]),
+    "lars_d_probe": (_I, [_I, _I, _I, _P, _P, _I64, _P]),
+    "lars_set_tuning": (_I, [C.c_char_p, _I]),
+    "lars_get_tuning": (_I, [C.c_char_p, C.POINTER(_I)]),
+    "lars_d_quot_selfcheck": (_I, [_U32, C.POINTER(C.c_uint64), C.POINTER(_U32 * 2)]),
     "lars_h_fix_white_balance": (_I, [_P, _I64, _I64, _I, _I, _I, _P, _P]),
     "lars_h_calculate_index": (_I, [_P, _I64, _I64, _I, _I, _U32, C.POINTER(_P * 3), _P, _I]),
     "lars_h_calculate_index_planes": (_I, [_P, _P, _P, _I64, _I, _P]),
@@ -185,6 +189,18 @@ def dtype_code(dt):
     if dt == np.uint16:
         return U16
     return None
+
+
+def set_tuning(**kw):
+    """e.g. set_tuning(fused_impl=1, nt_stores=1); results never depend on tuning."""
+    for k, v in kw.items():
+        call("lars_set_tuning", k.encode(), int(v))
+
+
+def get_tuning(key):
+    v = C.c_int(0)
+    call("lars_get_tuning", key.encode(), C.byref(v))
+    return v.value
 
 
 def device_count():

@@ -95,4 +95,19 @@ __host__ __device__ inline double hist_edge_f64(int i) {
 // launch geometry helpers (host)
 int launch_check(const char *what);
 
+// tuning knobs (lars_set_tuning)
+struct Tuning {
+    int fused_impl = 2;        // 1: first-generation kernels (fused.hip), 2: fused_v2.hip
+    int hist_impl = 2;
+    int nt_stores = 0;         // non-temporal stores for the float32 planes
+    int blocks_per_tile = 0;   // 0 = automatic
+    int sumsq_everywhere = 0;
+};
+Tuning &tuning();
+
+struct FusedParams;
+void fused_v2_launch(unsigned mask, bool wb, int stats, bool nt, dim3 grid, hipStream_t s, const FusedParams &P);
+void chan_hist_v2_launch(const uint8_t *tiles, long long npix, unsigned int *hist, dim3 grid, hipStream_t s);
+int quot_check_launch(unsigned int max_den, unsigned long long *mismatches_dev, unsigned int *first_bad_dev, hipStream_t s);
+
 }  // namespace lars

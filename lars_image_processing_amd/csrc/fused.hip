@@ -11,6 +11,7 @@
 // Built with -ffp-contract=off: every float operation below rounds exactly once,
 // as the NumPy expressions do.
 #include "common.h"
+#include "device_common.h"
 
 namespace lars {
 
@@ -220,54 +221,6 @@ __global__ void k_stats_finalize(lars_stats *stats, long long nrec, unsigned int
 // ===========================================================================
 // The fused kernel
 // ===========================================================================
-struct FusedParams {
-    const void *tiles;
-    long long npix;
-    int channels;
-    const uint8_t *wb_table;       // [ntiles][3][NVAL] or null
-    float *out_index[3];
-    uint8_t *out_wb;
-    uint8_t *out_rgba[3];
-    const uint8_t *cmap_lut[3];
-    lars_stats *stats;
-    unsigned int mask;             // runtime copy (generic kernel)
-    unsigned int flags;
-};
-
-struct Acc {
-    float mn, mx;
-    double sum, sumsq;
-    unsigned int above;
-};
-__device__ inline void acc_init(Acc &a) { a.mn = __builtin_inff(); a.mx = -__builtin_inff(); a.sum = 0; a.sumsq = 0; a.above = 0; }
-
-// IEEE float32 (a-b)/(a+b); +0.0 where a+b == 0 (the reference's epsilon only
-// matters there: process-images.py:464-482).
-__device__ inline float norm_diff(float a, float b)
-{
-    const float s = a + b;
-    const float d = a - b;
-    return d / (s == 0.0f ? 1.0f : s);
-}
-
-// bin of numpy.histogram(bins=50, range=(-1,1)) for float32 x in [-1, 1]
-__device__ inline int hist_bin_f32(float x, const float *edges)
-{
-    int b = (int)((x + 1.0f) * 25.0f);
-    b = b < 0 ? 0 : (b > LARS_HIST_BINS - 1 ? LARS_HIST_BINS - 1 : b);
-    if (x < edges[b]) --b;
-    else if (b != LARS_HIST_BINS - 1 && x >= edges[b + 1]) ++b;
-    return b;
-}
-
-__device__ inline unsigned int cmap_index(float x)
-{
-    const float s = (x + 1.0f) * 128.0f;
-    int i = (int)s;
-    i = i < 0 ? 0 : (i > 255 ? 255 : i);
-    return (unsigned)i;
-}
-
 template <int STATS>
 __device__ inline void acc_push(Acc &a, float x, float thr, unsigned int *s_hist, const float *s_edges)
 {
@@ -276,7 +229,7 @@ __device__ inline void acc_push(Acc &a, float x, float thr, unsigned int *s_hist
         a.mx = fmaxf(a.mx, x);
         const double xd = (double)x;
         a.sum += xd;
-        a.sumsq += xd * xd;
+        if (STATS >= 2) a.sumsq += xd * xd;
         a.above += (x > thr) ? 1u : 0u;
     }
     if (STATS >= 2) atomicAdd(&s_hist[hist_bin_f32(x, s_edges)], 1u);
@@ -582,11 +535,12 @@ __global__ __launch_bounds__(256) void k_synth_u8(uint8_t *tiles, long long firs
 // ===========================================================================
 using namespace lars;
 
-static int blocks_per_tile(long long work_items, long long ntiles)
+static int blocks_per_tile(long long work_items, long long ntiles, int threads = 256)
 {
     // enough blocks to keep 256 CUs x 8 resident blocks busy, never more than the work
-    long long want = (2048 * 4 + ntiles - 1) / ntiles;
-    long long cap = (work_items + 255) / 256;
+    long long want = (2048 * 4 * 256 / threads + ntiles - 1) / ntiles;
+    if (tuning().blocks_per_tile > 0) want = tuning().blocks_per_tile;
+    long long cap = (work_items + threads - 1) / threads;
     if (want > cap) want = cap;
     if (want < 1) want = 1;
     if (want > 65535) want = 65535;
@@ -607,7 +561,15 @@ extern "C" int lars_d_channel_hist(const void *tiles, int64_t ntiles, int64_t np
     LARS_HIP_TRY(hipMemsetAsync(hist, 0, (size_t)ntiles * 3 * nval * sizeof(uint32_t), s));
     const bool fast = dtype == LARS_U8 && channels == 3 && (ntiles == 1 || (npix & 3) == 0) &&
                       ((reinterpret_cast<uintptr_t>(tiles) & 3) == 0);
-    if (fast) {
+    if (fast && tuning().hist_impl >= 2) {
+        // 96 KiB of LDS per block: one 1024-thread block per CU, a few waves of blocks per tile
+        long long want = tuning().blocks_per_tile > 0 ? tuning().blocks_per_tile : (1024 + ntiles - 1) / ntiles;
+        const long long cap = (npix / 4 + 1023) / 1024;
+        if (want > cap) want = cap;
+        if (want < 1) want = 1;
+        dim3 grid((unsigned)want, (unsigned)ntiles);
+        chan_hist_v2_launch(static_cast<const uint8_t *>(tiles), (long long)npix, hist, grid, s);
+    } else if (fast) {
         dim3 grid(blocks_per_tile(npix / 4 + 1, ntiles), (unsigned)ntiles);
         hipLaunchKernelGGL(k_chan_hist_u8c3, grid, dim3(256), 0, s, static_cast<const uint8_t *>(tiles),
                            (long long)npix, hist);
@@ -700,7 +662,10 @@ extern "C" int lars_d_fused(const lars_fused_args *a)
     const bool mask_ok = mask == 0u || mask == 1u || mask == 2u || mask == 4u || mask == 7u;
     const bool fast = a->dtype == LARS_U8 && a->channels == 3 && aligned && mask_ok &&
                       (a->ntiles == 1 || (a->npix & 3) == 0);
-    if (fast) {
+    if (fast && tuning().fused_impl >= 2) {
+        dim3 grid(blocks_per_tile(a->npix / 4 + 1, a->ntiles, 512), (unsigned)a->ntiles);
+        fused_v2_launch(mask, a->wb_table != nullptr, stats_mode, tuning().nt_stores != 0, grid, s, P);
+    } else if (fast) {
         dim3 grid(blocks_per_tile(a->npix / 4 + 1, a->ntiles), (unsigned)a->ntiles);
         const bool wb = a->wb_table != nullptr;
         switch (mask) {

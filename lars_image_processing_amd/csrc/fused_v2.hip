@@ -1,0 +1,531 @@
+// Second-generation hot-path kernels, written for the CDNA4 issue budget.
+//
+// The stats-only configurations move 3 bytes per pixel, so at HBM rate a CU has
+// only ~35 vector-instruction slots per pixel.  What this file does about it:
+//
+//   * white-balance table as ONE packed dword per sample value
+//     {R'[v], G'[v], N'[v], 0}, replicated 64x in LDS so that lane l only ever
+//     touches bank l%32 (conflict-free ds_read_b32); the byte address
+//     (v << 8 | lane*4) is built by a single v_perm_b32 and the wanted channel
+//     is converted with v_cvt_f32_ubyte{0,1,2}: 2 VALU + 1 LDS per sample.
+//   * IEEE-exact float32 quotient as rcp + mul + 2 fma (no div_scale / div_fmas
+//     / div_fixup); tests/test_gpu_parity.py proves it bit-identical to the
+//     correctly rounded quotient for every operand pair the domain allows.
+//   * coverage counters live in scalar registers: v_cmp + s_bcnt1 + s_add.
+//   * NDWI statistics are derived from GNDVI's at flush time (NDWI == -GNDVI
+//     exactly): sum negates, extrema swap, only the coverage count (g < 0)
+//     is kept per pixel.
+//   * sums stay exact: float32 index values of uint8 tiles are multiples of
+//     2^-32, double adds of them are exact, blocks publish int64 fixed point.
+//   * the channel histogram pre-pass uses 32 lane-private copies of each
+//     256-bin histogram (96 KiB of LDS) so ds_add_u32 never conflicts.
+//
+// Reference semantics: see fused.hip.  Built with -ffp-contract=off.
+#include "common.h"
+#include "device_common.h"
+
+namespace lars {
+
+// ---------------------------------------------------------------------------
+// exact quotient for integer-valued operands: |num| <= den, 1 <= den < 2^24
+// ---------------------------------------------------------------------------
+__device__ inline float exact_quot(float num, float den)
+{
+#ifdef ABL_NODIV
+    return num * 0.001f + den * 0.0001f;
+#endif
+    const float r = __builtin_amdgcn_rcpf(den);
+    const float q0 = num * r;
+    const float e = __builtin_fmaf(-q0, den, num);
+    return __builtin_fmaf(e, r, q0);
+}
+// (a-b)/(a+b) with +0.0 where a+b == 0
+__device__ inline float norm_diff_fast(float a, float b)
+{
+    const float s = a + b;
+    const float d = a - b;
+    return exact_quot(d, fmaxf(s, 1.0f));
+}
+
+// Exhaustive self-check kernel: counts operand pairs where exact_quot differs
+// from the compiler's correctly rounded division.  num in [-den, den].
+__global__ __launch_bounds__(256) void k_quot_check(unsigned int max_den, unsigned long long *mismatches,
+                                                    unsigned int *first_bad)
+{
+    unsigned long long bad = 0;
+    for (unsigned int den = blockIdx.x + 1; den <= max_den; den += gridDim.x) {
+        const float fd = (float)den;
+        for (long long num = -(long long)den + threadIdx.x; num <= (long long)den; num += 256) {
+            const float fn = (float)num;
+            const float want = fn / fd;
+            const float got = exact_quot(fn, fd);
+            if (__builtin_bit_cast(unsigned int, want) != __builtin_bit_cast(unsigned int, got)) {
+                if (!bad) { first_bad[0] = den; first_bad[1] = (unsigned int)(int)num; }
+                ++bad;
+            }
+        }
+    }
+    if (bad) atomicAdd(mismatches, bad);
+}
+
+// ---------------------------------------------------------------------------
+// channel histograms, conflict-free
+// ---------------------------------------------------------------------------
+// LDS: [3 channels][256 bins][32 copies] u32 = 96 KiB; copy = lane % 32.
+__global__ __launch_bounds__(1024) void k_chan_hist_u8c3_v2(const uint8_t *__restrict__ tiles, long long npix,
+                                                            unsigned int *__restrict__ hist)
+{
+    __shared__ unsigned int s_h[3 * 256 * 32];             // 96 KiB
+    const int tid = threadIdx.x;
+    for (int i = tid; i < 3 * 256 * 32; i += 1024) s_h[i] = 0;
+    __syncthreads();
+
+    const long long tile = blockIdx.y;
+    const uint8_t *base = tiles + tile * npix * 3;
+    const long long nquads = npix >> 2;
+    const unsigned int lane_off = (tid & 31) << 2;         // byte offset of this lane's copy
+    char *hb = reinterpret_cast<char *>(s_h);
+#define HADD(word, shift, ch)                                                                          \
+    atomicAdd(reinterpret_cast<unsigned int *>(hb + (ch) * 32768 + ((((word) >> (shift)) & 0xFFu) << 7) + lane_off), 1u)
+    // software pipeline: four 12-byte loads in flight per lane (48 KiB per CU at 16 waves)
+    const long long step = (long long)gridDim.x * 1024;
+    const long long q0 = (long long)blockIdx.x * 1024 + tid;
+    const long long niter = (nquads + step - 1) / step;            // same for every lane of the grid
+    unsigned int w[4][3];
+#define HLOAD(k, qq)                                                                                   \
+    {                                                                                                  \
+        const long long qc = (qq) < nquads ? (qq) : nquads - 1;                                        \
+        const unsigned int *p_ = reinterpret_cast<const unsigned int *>(base + qc * 12);               \
+        w[k][0] = p_[0]; w[k][1] = p_[1]; w[k][2] = p_[2];                                             \
+    }
+    if (nquads > 0) {
+#pragma unroll
+        for (int k = 0; k < 4; ++k) HLOAD(k, q0 + k * step)
+        for (long long it = 0; it < niter; it += 4) {
+#pragma unroll
+            for (int k = 0; k < 4; ++k) {
+                const long long qq = q0 + (it + k) * step;
+                const unsigned int a0 = w[k][0], a1 = w[k][1], a2 = w[k][2];
+                if (it + k + 4 < niter) HLOAD(k, qq + 4 * step)
+                if (qq < nquads) {
+                    HADD(a0, 0, 0); HADD(a0, 8, 1); HADD(a0, 16, 2); HADD(a0, 24, 0);
+                    HADD(a1, 0, 1); HADD(a1, 8, 2); HADD(a1, 16, 0); HADD(a1, 24, 1);
+                    HADD(a2, 0, 2); HADD(a2, 8, 0); HADD(a2, 16, 1); HADD(a2, 24, 2);
+                }
+            }
+        }
+    }
+#undef HLOAD
+    if (blockIdx.x == 0 && tid < (int)(npix & 3)) {
+        const uint8_t *p = base + (nquads * 4 + tid) * 3;
+        HADD((unsigned)p[0], 0, 0); HADD((unsigned)p[1], 0, 1); HADD((unsigned)p[2], 0, 2);
+    }
+#undef HADD
+    __syncthreads();
+    // fold the 32 copies: 768 bins, one per thread (rotated start keeps banks apart)
+    if (tid < 768) {
+        const unsigned int *row = s_h + tid * 32;
+        unsigned int v = 0;
+        for (int j = 0; j < 32; ++j) v += row[(j + tid) & 31];
+        if (v) atomicAdd(&hist[tile * 768 + tid], v);
+    }
+}
+
+// ---------------------------------------------------------------------------
+// fused kernel, generation 2 (uint8, 3 channels, 4-byte aligned tiles)
+// ---------------------------------------------------------------------------
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+template <bool NT>
+__device__ inline void store4(float *dst, float a, float b, float c, float d)
+{
+    f32x4 v = {a, b, c, d};
+    if (NT) __builtin_nontemporal_store(v, reinterpret_cast<f32x4 *>(dst));
+    else *reinterpret_cast<f32x4 *>(dst) = v;
+}
+
+struct WaveAcc {
+    float mn, mx;
+    double sum, sumsq;
+#ifdef ABL_F32SUM
+    float fsum = 0;
+#endif
+};
+
+// LDS layout (dynamic): [WB table 64 KiB][hist 3*50*32 u32][edges 51 f32][reduce scratch]
+#define V2_TABLE_BYTES 65536
+#define V2_HIST_WORDS (3 * LARS_HIST_BINS * 32)
+
+template <bool WB>
+__device__ inline float sample(unsigned int word, int byte, int ch, unsigned int lane_off4, const char *s_tab)
+{
+    if (!WB) return (float)((word >> (8 * byte)) & 0xFFu);            // v_cvt_f32_ubyteN
+    // address = sample << 8 | lane*4 in one v_perm_b32 (S0 = word: selectors 4..7, S1 = lane_off4: 0..3)
+    const unsigned int sel = 0x0c0c0000u | ((4u + (unsigned)byte) << 8);
+    const unsigned int addr = __builtin_amdgcn_perm(word, lane_off4, sel);
+    const unsigned int entry = *reinterpret_cast<const unsigned int *>(s_tab + addr);
+    return (float)((entry >> (8 * ch)) & 0xFFu);
+}
+template <bool WB>
+__device__ inline unsigned int sample_entry(unsigned int word, int byte, unsigned int lane_off4, const char *s_tab)
+{
+    const unsigned int sel = 0x0c0c0000u | ((4u + (unsigned)byte) << 8);
+    const unsigned int addr = __builtin_amdgcn_perm(word, lane_off4, sel);
+    return *reinterpret_cast<const unsigned int *>(s_tab + addr);
+}
+
+template <int STATS>
+__device__ inline void push(WaveAcc &a, unsigned int &above, float x, float thr)
+{
+    a.mn = fminf(a.mn, x);
+    a.mx = fmaxf(a.mx, x);
+#if defined(ABL_NOSUM)
+    asm volatile("" ::"v"(x));
+#elif defined(ABL_F32SUM)
+    a.fsum += x;
+#else
+    const double xd = (double)x;
+    a.sum += xd;
+    if (STATS >= 2) a.sumsq += xd * xd;
+#endif
+    above += (unsigned int)__popcll(__ballot(x > thr));              // wave-uniform scalar counter
+}
+
+__device__ inline void hist_add(unsigned int *s_hist, const float *s_edges, int index, float x, unsigned int lane32)
+{
+    const int b = hist_bin_f32(x, s_edges);
+    atomicAdd(&s_hist[(index * LARS_HIST_BINS + b) * 32 + lane32], 1u);
+}
+
+template <unsigned MASK, bool WB, int STATS, bool OUT, bool NT>
+__global__ __launch_bounds__(512, 4) void k_fused_v2(FusedParams P)
+{
+    __shared__ __attribute__((aligned(16))) char s_mem[(WB ? V2_TABLE_BYTES : 0) +
+                                                       (STATS >= 2 ? V2_HIST_WORDS * 4 + 64 * 4 : 0) + 8 * 16 * sizeof(double)];
+    char *s_tab = s_mem;                                                             // 64 KiB when WB
+    unsigned int *s_hist = reinterpret_cast<unsigned int *>(s_mem + (WB ? V2_TABLE_BYTES : 0));
+    float *s_edges = reinterpret_cast<float *>(s_hist + (STATS >= 2 ? V2_HIST_WORDS : 0));
+    double *s_red = reinterpret_cast<double *>(s_edges + (STATS >= 2 ? 64 : 0));     // [8 waves][16]
+
+    constexpr bool NEED_R = (MASK & 1u) != 0;
+    constexpr bool NEED_G = (MASK & 6u) != 0;
+    constexpr bool WANT_NDVI = (MASK & 1u) != 0, WANT_GNDVI = (MASK & 2u) != 0, WANT_NDWI = (MASK & 4u) != 0;
+
+    const int tid = threadIdx.x;
+    const unsigned int lane = tid & 63;
+    const unsigned int lane_off4 = lane << 2;
+    const unsigned int lane32 = lane & 31;
+    const long long tile = blockIdx.y;
+    const long long npix = P.npix;
+    const uint8_t *base = static_cast<const uint8_t *>(P.tiles) + tile * npix * 3;
+
+    if (WB) {
+        const uint8_t *t = P.wb_table + tile * 768;
+        unsigned int *tab = reinterpret_cast<unsigned int *>(s_tab);
+        // entry (v, copy) at dword v*64 + copy
+        for (int i = tid; i < 256 * 64; i += 512) {
+            const int v = i >> 6;
+            tab[i] = (unsigned)t[v] | ((unsigned)t[256 + v] << 8) | ((unsigned)t[512 + v] << 16);
+        }
+    }
+    if (STATS >= 2) {
+        for (int i = tid; i < V2_HIST_WORDS; i += 512) s_hist[i] = 0;
+        if (tid <= LARS_HIST_BINS) s_edges[tid] = (float)hist_edge_f64(tid);
+    }
+    if (WB || STATS >= 2) __syncthreads();
+
+    WaveAcc acc_v, acc_g;                                  // NDVI, GNDVI-quotient (NDWI derives from it)
+    acc_v.mn = acc_g.mn = __builtin_inff(); acc_v.mx = acc_g.mx = -__builtin_inff();
+    acc_v.sum = acc_g.sum = 0; acc_v.sumsq = acc_g.sumsq = 0;
+    unsigned int above_v = 0, above_g = 0, above_w = 0;
+
+    // OUT == false: statistics only, every output pointer is known to be null at compile time
+    float *const oi0 = (OUT && P.out_index[0]) ? P.out_index[0] + tile * npix : nullptr;
+    float *const oi1 = (OUT && P.out_index[1]) ? P.out_index[1] + tile * npix : nullptr;
+    float *const oi2 = (OUT && P.out_index[2]) ? P.out_index[2] + tile * npix : nullptr;
+    uint8_t *const owb = (OUT && P.out_wb) ? P.out_wb + tile * npix * 3 : nullptr;
+    uint8_t *const oc0 = (OUT && P.out_rgba[0]) ? P.out_rgba[0] + tile * npix * 4 : nullptr;
+    uint8_t *const oc1 = (OUT && P.out_rgba[1]) ? P.out_rgba[1] + tile * npix * 4 : nullptr;
+    uint8_t *const oc2 = (OUT && P.out_rgba[2]) ? P.out_rgba[2] + tile * npix * 4 : nullptr;
+    const unsigned int *lut0 = reinterpret_cast<const unsigned int *>(P.cmap_lut[0]);
+    const unsigned int *lut1 = reinterpret_cast<const unsigned int *>(P.cmap_lut[1]);
+    const unsigned int *lut2 = reinterpret_cast<const unsigned int *>(P.cmap_lut[2]);
+
+    const long long nquads = npix >> 2;
+    const long long stride = (long long)gridDim.x * 512;
+
+    auto do_quad = [&](long long q, unsigned int w0, unsigned int w1, unsigned int w2) {
+        // bytes: r0 g0 n0 r1 | g1 n1 r2 g2 | n2 r3 g3 n3
+        const unsigned int wr[4] = {w0, w0, w1, w2}, wg[4] = {w0, w1, w1, w2}, wn[4] = {w0, w1, w2, w2};
+        constexpr int br[4] = {0, 3, 2, 1}, bg[4] = {1, 0, 3, 2}, bn[4] = {2, 1, 0, 3};
+        if (WB && owb) {
+            unsigned int e[12];
+#pragma unroll
+            for (int px = 0; px < 4; ++px) {
+                e[3 * px] = sample_entry<WB>(wr[px], br[px], lane_off4, s_tab) & 0xFFu;
+                e[3 * px + 1] = (sample_entry<WB>(wg[px], bg[px], lane_off4, s_tab) >> 8) & 0xFFu;
+                e[3 * px + 2] = (sample_entry<WB>(wn[px], bn[px], lane_off4, s_tab) >> 16) & 0xFFu;
+            }
+            unsigned int *o = reinterpret_cast<unsigned int *>(owb + q * 12);
+            o[0] = e[0] | (e[1] << 8) | (e[2] << 16) | (e[3] << 24);
+            o[1] = e[4] | (e[5] << 8) | (e[6] << 16) | (e[7] << 24);
+            o[2] = e[8] | (e[9] << 8) | (e[10] << 16) | (e[11] << 24);
+        }
+        if (MASK == 0u) return;
+        float v0[4], v1[4], v2[4];
+#pragma unroll
+        for (int px = 0; px < 4; ++px) {
+            const float n = sample<WB>(wn[px], bn[px], 2, lane_off4, s_tab);
+            if (WANT_NDVI) {
+                const float r = sample<WB>(wr[px], br[px], 0, lane_off4, s_tab);
+                const float x = norm_diff_fast(n, r);
+                v0[px] = x;
+                if (STATS >= 1) push<STATS>(acc_v, above_v, x, 0.2f);
+                if (STATS >= 2) hist_add(s_hist, s_edges, 0, x, lane32);
+            }
+            if (NEED_G) {
+                const float g = sample<WB>(wg[px], bg[px], 1, lane_off4, s_tab);
+                const float x = norm_diff_fast(n, g);
+                v1[px] = x;
+                if (STATS >= 1) {
+                    acc_g.mn = fminf(acc_g.mn, x);
+                    acc_g.mx = fmaxf(acc_g.mx, x);
+#if defined(ABL_NOSUM)
+                    asm volatile("" ::"v"(x));
+#elif defined(ABL_F32SUM)
+                    acc_g.fsum += x;
+#else
+                    const double xd = (double)x;
+                    acc_g.sum += xd;
+                    if (STATS >= 2) acc_g.sumsq += xd * xd;
+#endif
+                    if (WANT_GNDVI) above_g += (unsigned int)__popcll(__ballot(x > 0.2f));
+                    if (WANT_NDWI) above_w += (unsigned int)__popcll(__ballot(x < 0.0f));   // -x > 0
+                }
+                if (STATS >= 2 && WANT_GNDVI) hist_add(s_hist, s_edges, 1, x, lane32);
+                if (WANT_NDWI) {
+                    v2[px] = 0.0f - x;                     // +0.0 where the quotient is zero
+                    if (STATS >= 2) hist_add(s_hist, s_edges, 2, v2[px], lane32);
+                }
+            }
+        }
+        if (WANT_NDVI && oi0) {
+            store4<NT>(oi0 + q * 4, v0[0], v0[1], v0[2], v0[3]);
+        }
+        if (WANT_GNDVI && oi1) {
+            store4<NT>(oi1 + q * 4, v1[0], v1[1], v1[2], v1[3]);
+        }
+        if (WANT_NDWI && oi2) {
+            store4<NT>(oi2 + q * 4, v2[0], v2[1], v2[2], v2[3]);
+        }
+        if (WANT_NDVI && oc0)
+            *reinterpret_cast<uint4 *>(oc0 + q * 16) = make_uint4(lut0[cmap_index(v0[0])], lut0[cmap_index(v0[1])],
+                                                                  lut0[cmap_index(v0[2])], lut0[cmap_index(v0[3])]);
+        if (WANT_GNDVI && oc1)
+            *reinterpret_cast<uint4 *>(oc1 + q * 16) = make_uint4(lut1[cmap_index(v1[0])], lut1[cmap_index(v1[1])],
+                                                                  lut1[cmap_index(v1[2])], lut1[cmap_index(v1[3])]);
+        if (WANT_NDWI && oc2)
+            *reinterpret_cast<uint4 *>(oc2 + q * 16) = make_uint4(lut2[cmap_index(v2[0])], lut2[cmap_index(v2[1])],
+                                                                  lut2[cmap_index(v2[2])], lut2[cmap_index(v2[3])]);
+    };
+
+    // software pipeline: four 12-byte loads in flight per lane while the oldest quad is processed
+    const long long q0 = (long long)blockIdx.x * 512 + tid;
+    const long long niter = (nquads + stride - 1) / stride;          // same for every lane of the grid
+    if (nquads > 0) {
+        unsigned int w[4][3];
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            const long long qq = q0 + k * stride;
+            const long long qc = qq < nquads ? qq : nquads - 1;
+            const unsigned int *p_ = reinterpret_cast<const unsigned int *>(base + qc * 12);
+            w[k][0] = p_[0]; w[k][1] = p_[1]; w[k][2] = p_[2];
+        }
+        for (long long it = 0; it < niter; it += 4) {
+#pragma unroll
+            for (int k = 0; k < 4; ++k) {
+                const long long qq = q0 + (it + k) * stride;
+                const unsigned int a0 = w[k][0], a1 = w[k][1], a2 = w[k][2];
+                if (it + k + 4 < niter) {
+                    const long long qn = qq + 4 * stride;
+                    const long long qc = qn < nquads ? qn : nquads - 1;
+                    const unsigned int *p_ = reinterpret_cast<const unsigned int *>(base + qc * 12);
+                    w[k][0] = p_[0]; w[k][1] = p_[1]; w[k][2] = p_[2];
+                }
+                if (qq < nquads) do_quad(qq, a0, a1, a2);
+                __builtin_amdgcn_sched_barrier(0);       // keep the four quads' work apart: bounded registers
+            }
+        }
+    }
+
+    // tail pixels (npix % 4): lanes 0..2 of block 0, scalar path
+    if (blockIdx.x == 0 && tid < (int)(npix & 3)) {
+        const long long i = nquads * 4 + tid;
+        unsigned int r = base[i * 3], g = base[i * 3 + 1], n = base[i * 3 + 2];
+        if (WB) {
+            const unsigned int *tab = reinterpret_cast<const unsigned int *>(s_tab);
+            r = tab[r * 64] & 0xFFu; g = (tab[g * 64] >> 8) & 0xFFu; n = (tab[n * 64] >> 16) & 0xFFu;
+            if (owb) { owb[i * 3] = (uint8_t)r; owb[i * 3 + 1] = (uint8_t)g; owb[i * 3 + 2] = (uint8_t)n; }
+        }
+        const float fr = (float)r, fg = (float)g, fn = (float)n;
+        if (WANT_NDVI) {
+            const float x = norm_diff_fast(fn, fr);
+            if (STATS >= 1) push<STATS>(acc_v, above_v, x, 0.2f);
+            if (STATS >= 2) hist_add(s_hist, s_edges, 0, x, lane32);
+            if (oi0) oi0[i] = x;
+            if (oc0) reinterpret_cast<unsigned int *>(oc0)[i] = lut0[cmap_index(x)];
+        }
+        if (NEED_G) {
+            const float x = norm_diff_fast(fn, fg);
+            if (STATS >= 1) {
+                acc_g.mn = fminf(acc_g.mn, x); acc_g.mx = fmaxf(acc_g.mx, x);
+                const double xd = (double)x;
+                acc_g.sum += xd;
+                if (STATS >= 2) acc_g.sumsq += xd * xd;
+                if (WANT_GNDVI) above_g += (unsigned int)__popcll(__ballot(x > 0.2f));
+                if (WANT_NDWI) above_w += (unsigned int)__popcll(__ballot(x < 0.0f));
+            }
+            if (WANT_GNDVI) {
+                if (STATS >= 2) hist_add(s_hist, s_edges, 1, x, lane32);
+                if (oi1) oi1[i] = x;
+                if (oc1) reinterpret_cast<unsigned int *>(oc1)[i] = lut1[cmap_index(x)];
+            }
+            if (WANT_NDWI) {
+                const float w = 0.0f - x;
+                if (STATS >= 2) hist_add(s_hist, s_edges, 2, w, lane32);
+                if (oi2) oi2[i] = w;
+                if (oc2) reinterpret_cast<unsigned int *>(oc2)[i] = lut2[cmap_index(w)];
+            }
+        }
+    }
+
+    if (STATS >= 1) {
+        // wave fold (above_* are already wave totals)
+        for (int off = 32; off >= 1; off >>= 1) {
+            if (WANT_NDVI) {
+                acc_v.mn = fminf(acc_v.mn, __shfl_xor(acc_v.mn, off)); acc_v.mx = fmaxf(acc_v.mx, __shfl_xor(acc_v.mx, off));
+                acc_v.sum += __shfl_xor(acc_v.sum, off);
+                if (STATS >= 2) acc_v.sumsq += __shfl_xor(acc_v.sumsq, off);
+            }
+            if (NEED_G) {
+                acc_g.mn = fminf(acc_g.mn, __shfl_xor(acc_g.mn, off)); acc_g.mx = fmaxf(acc_g.mx, __shfl_xor(acc_g.mx, off));
+                acc_g.sum += __shfl_xor(acc_g.sum, off);
+                if (STATS >= 2) acc_g.sumsq += __shfl_xor(acc_g.sumsq, off);
+            }
+        }
+        const int wave = tid >> 6;
+        double *row = s_red + wave * 16;
+        if (lane == 0) {
+#ifdef ABL_F32SUM
+            acc_v.sum = acc_v.fsum; acc_g.sum = acc_g.fsum;
+#endif
+            row[0] = acc_v.sum; row[1] = acc_v.sumsq; row[2] = (double)acc_v.mn; row[3] = (double)acc_v.mx; row[4] = (double)above_v;
+            row[5] = acc_g.sum; row[6] = acc_g.sumsq; row[7] = (double)acc_g.mn; row[8] = (double)acc_g.mx;
+            row[9] = (double)above_g; row[10] = (double)above_w;
+        }
+        __syncthreads();
+        if (tid == 0) {
+            double t[11];
+            for (int j = 0; j < 11; ++j) t[j] = s_red[j];
+            for (int w = 1; w < 8; ++w) {
+                const double *o = s_red + w * 16;
+                t[0] += o[0]; t[1] += o[1]; t[2] = fmin(t[2], o[2]); t[3] = fmax(t[3], o[3]); t[4] += o[4];
+                t[5] += o[5]; t[6] += o[6]; t[7] = fmin(t[7], o[7]); t[8] = fmax(t[8], o[8]); t[9] += o[9]; t[10] += o[10];
+            }
+            StatsAccView *rec = reinterpret_cast<StatsAccView *>(P.stats + tile * 3);
+            if (WANT_NDVI) {
+                atomicAdd(&rec[0].sum_fx, (unsigned long long)__double2ll_rn(t[0] * LARS_FX_SCALE));
+                if (STATS >= 2) atomicAdd(&rec[0].sumsq_fx, (unsigned long long)__double2ll_rn(t[1] * LARS_FX_SCALE));
+                atomicAdd(&rec[0].above, (unsigned long long)t[4]);
+                atomicMin(&rec[0].min_key, f64_key(t[2]));
+                atomicMax(&rec[0].max_key, f64_key(t[3]));
+            }
+            if (WANT_GNDVI) {
+                atomicAdd(&rec[1].sum_fx, (unsigned long long)__double2ll_rn(t[5] * LARS_FX_SCALE));
+                if (STATS >= 2) atomicAdd(&rec[1].sumsq_fx, (unsigned long long)__double2ll_rn(t[6] * LARS_FX_SCALE));
+                atomicAdd(&rec[1].above, (unsigned long long)t[9]);
+                atomicMin(&rec[1].min_key, f64_key(t[7]));
+                atomicMax(&rec[1].max_key, f64_key(t[8]));
+            }
+            if (WANT_NDWI) {
+                // NDWI = -GNDVI: sum negates, squares equal, extrema swap (0.0 - x keeps zeros positive,
+                // which the double keys below reproduce: -(+0.0) never occurs because min/max of the
+                // quotient only reach 0 as +0.0 and 0.0 - 0.0 = +0.0)
+                atomicAdd(&rec[2].sum_fx, (unsigned long long)__double2ll_rn((0.0 - t[5]) * LARS_FX_SCALE));
+                if (STATS >= 2) atomicAdd(&rec[2].sumsq_fx, (unsigned long long)__double2ll_rn(t[6] * LARS_FX_SCALE));
+                atomicAdd(&rec[2].above, (unsigned long long)t[10]);
+                atomicMin(&rec[2].min_key, f64_key(0.0 - t[8]));
+                atomicMax(&rec[2].max_key, f64_key(0.0 - t[7]));
+            }
+        }
+        if (STATS >= 2) {
+            __syncthreads();
+            StatsAccView *rec = reinterpret_cast<StatsAccView *>(P.stats + tile * 3);
+            if (tid < 3 * LARS_HIST_BINS) {
+                const int k = tid / LARS_HIST_BINS;
+                if (MASK & (1u << k)) {
+                    const unsigned int *rowh = s_hist + tid * 32;
+                    unsigned int v = 0;
+                    for (int j = 0; j < 32; ++j) v += rowh[(j + tid) & 31];
+                    if (v) atomicAdd(&rec[k].hist[tid - k * LARS_HIST_BINS], (unsigned long long)v);
+                }
+            }
+        }
+    }
+}
+
+}  // namespace lars
+
+// ===========================================================================
+// launch glue used by fused.hip's entry points
+// ===========================================================================
+using namespace lars;
+
+namespace lars {
+
+
+template <unsigned MASK, bool WB, int STATS>
+static void v2_launch_out(bool out, bool nt, dim3 grid, hipStream_t s, const FusedParams &P)
+{
+    if (!out) hipLaunchKernelGGL((k_fused_v2<MASK, WB, STATS, false, false>), grid, dim3(512), 0, s, P);
+    else if (nt) hipLaunchKernelGGL((k_fused_v2<MASK, WB, STATS, true, true>), grid, dim3(512), 0, s, P);
+    else hipLaunchKernelGGL((k_fused_v2<MASK, WB, STATS, true, false>), grid, dim3(512), 0, s, P);
+}
+template <unsigned MASK, bool WB>
+static void v2_launch_stats(int stats, bool out, bool nt, dim3 grid, hipStream_t s, const FusedParams &P)
+{
+    if (stats == 0) v2_launch_out<MASK, WB, 0>(out, nt, grid, s, P);
+    else if (stats == 1) v2_launch_out<MASK, WB, 1>(out, nt, grid, s, P);
+    else v2_launch_out<MASK, WB, 2>(out, nt, grid, s, P);
+}
+template <unsigned MASK>
+static void v2_launch_wb(bool wb, int stats, bool out, bool nt, dim3 grid, hipStream_t s, const FusedParams &P)
+{
+    if (wb) v2_launch_stats<MASK, true>(stats, out, nt, grid, s, P);
+    else v2_launch_stats<MASK, false>(stats, out, nt, grid, s, P);
+}
+
+void fused_v2_launch(unsigned mask, bool wb, int stats, bool nt, dim3 grid, hipStream_t s, const FusedParams &P)
+{
+    const bool out = P.out_wb || P.out_index[0] || P.out_index[1] || P.out_index[2] || P.out_rgba[0] || P.out_rgba[1] ||
+                     P.out_rgba[2];
+    switch (mask) {
+    case 0u: hipLaunchKernelGGL((k_fused_v2<0u, true, 0, true, false>), grid, dim3(512), 0, s, P); break;
+    case 1u: v2_launch_wb<1u>(wb, stats, out, nt, grid, s, P); break;
+    case 2u: v2_launch_wb<2u>(wb, stats, out, nt, grid, s, P); break;
+    case 4u: v2_launch_wb<4u>(wb, stats, out, nt, grid, s, P); break;
+    default: v2_launch_wb<7u>(wb, stats, out, nt, grid, s, P); break;
+    }
+}
+
+void chan_hist_v2_launch(const uint8_t *tiles, long long npix, unsigned int *hist, dim3 grid, hipStream_t s)
+{
+    hipLaunchKernelGGL(k_chan_hist_u8c3_v2, grid, dim3(1024), 0, s, tiles, npix, hist);
+}
+
+int quot_check_launch(unsigned int max_den, unsigned long long *mismatches_dev, unsigned int *first_bad_dev, hipStream_t s)
+{
+    hipLaunchKernelGGL(k_quot_check, dim3(2048), dim3(256), 0, s, max_den, mismatches_dev, first_bad_dev);
+    return launch_check("k_quot_check");
+}
+
+}  // namespace lars

@@ -1,0 +1,87 @@
+// Roofline probes: what this device sustains for plain streaming reads / copies
+// with the access shapes the hot path uses.  Reported by bench.py next to the
+// kernel numbers ("verify the peak with a STREAM-like kernel").
+#include "common.h"
+
+namespace lars {
+
+template <int WORDS, int UNROLL>
+__global__ __launch_bounds__(256) void k_probe_read(const unsigned int *__restrict__ src, long long nvec,
+                                                    unsigned int *__restrict__ sink)
+{
+    // nvec vectors of WORDS dwords; lane-contiguous
+    unsigned int acc = 0;
+    const long long stride = (long long)gridDim.x * 256;
+    long long i = (long long)blockIdx.x * 256 + threadIdx.x;
+    for (; i + (UNROLL - 1) * stride < nvec; i += UNROLL * stride) {
+        unsigned int v[UNROLL][WORDS];
+#pragma unroll
+        for (int u = 0; u < UNROLL; ++u) {
+            const unsigned int *p = src + (i + u * stride) * WORDS;
+            if (WORDS == 4) {
+                const uint4 t = *reinterpret_cast<const uint4 *>(p);
+                v[u][0] = t.x; v[u][1] = t.y; v[u][2] = t.z; v[u][3] = t.w;
+            } else {
+#pragma unroll
+                for (int w = 0; w < WORDS; ++w) v[u][w] = p[w];
+            }
+        }
+#pragma unroll
+        for (int u = 0; u < UNROLL; ++u)
+#pragma unroll
+            for (int w = 0; w < WORDS; ++w) acc ^= v[u][w];
+    }
+    for (; i < nvec; i += stride)
+        for (int w = 0; w < WORDS; ++w) acc ^= src[i * WORDS + w];
+    if (acc == 0x12345678u) sink[0] = acc;     // practically never; keeps the loads alive
+}
+
+__global__ __launch_bounds__(256) void k_probe_copy(const uint4 *__restrict__ src, uint4 *__restrict__ dst, long long nvec)
+{
+    const long long stride = (long long)gridDim.x * 256;
+    for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < nvec; i += stride) dst[i] = src[i];
+}
+
+__global__ __launch_bounds__(256) void k_probe_write(uint4 *__restrict__ dst, long long nvec)
+{
+    const long long stride = (long long)gridDim.x * 256;
+    const uint4 v = make_uint4(threadIdx.x, blockIdx.x, 3, 4);
+    for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < nvec; i += stride) dst[i] = v;
+}
+
+}  // namespace lars
+
+using namespace lars;
+
+// kind: 0 read 16 B/lane, 1 read 12 B/lane, 2 copy 16 B/lane (bytes read + bytes written = 2*bytes), 3 write 16 B/lane
+extern "C" int lars_d_probe(int kind, int unroll, int blocks, const void *src, void *dst, int64_t bytes, void *stream)
+{
+    ThreadCtx *c;
+    LARS_TRY(ensure_ctx(&c));
+    if (bytes <= 0 || blocks <= 0) return fail(LARS_ERR_INVALID, "lars_d_probe: bad arguments");
+    hipStream_t s = pick_stream(c, stream);
+    LARS_TRY(scratch_reserve(c, 64));
+    unsigned int *sink = static_cast<unsigned int *>(c->scratch);
+    const unsigned int *p = static_cast<const unsigned int *>(src);
+    if (kind == 0) {
+        const long long n = bytes / 16;
+        if (unroll >= 8) hipLaunchKernelGGL((k_probe_read<4, 8>), dim3(blocks), dim3(256), 0, s, p, n, sink);
+        else if (unroll >= 4) hipLaunchKernelGGL((k_probe_read<4, 4>), dim3(blocks), dim3(256), 0, s, p, n, sink);
+        else if (unroll >= 2) hipLaunchKernelGGL((k_probe_read<4, 2>), dim3(blocks), dim3(256), 0, s, p, n, sink);
+        else hipLaunchKernelGGL((k_probe_read<4, 1>), dim3(blocks), dim3(256), 0, s, p, n, sink);
+    } else if (kind == 1) {
+        const long long n = bytes / 12;
+        if (unroll >= 8) hipLaunchKernelGGL((k_probe_read<3, 8>), dim3(blocks), dim3(256), 0, s, p, n, sink);
+        else if (unroll >= 4) hipLaunchKernelGGL((k_probe_read<3, 4>), dim3(blocks), dim3(256), 0, s, p, n, sink);
+        else if (unroll >= 2) hipLaunchKernelGGL((k_probe_read<3, 2>), dim3(blocks), dim3(256), 0, s, p, n, sink);
+        else hipLaunchKernelGGL((k_probe_read<3, 1>), dim3(blocks), dim3(256), 0, s, p, n, sink);
+    } else if (kind == 2) {
+        hipLaunchKernelGGL(k_probe_copy, dim3(blocks), dim3(256), 0, s, static_cast<const uint4 *>(src),
+                           static_cast<uint4 *>(dst), (long long)(bytes / 16));
+    } else if (kind == 3) {
+        hipLaunchKernelGGL(k_probe_write, dim3(blocks), dim3(256), 0, s, static_cast<uint4 *>(dst), (long long)(bytes / 16));
+    } else {
+        return fail(LARS_ERR_INVALID, "lars_d_probe: kind");
+    }
+    return launch_check("lars_d_probe");
+}

@@ -86,6 +86,9 @@ static int reserve(void **p, size_t *have, size_t bytes, hipStream_t s)
 int ws_reserve(ThreadCtx *c, size_t bytes) { return reserve(&c->ws, &c->ws_bytes, bytes, c->stream); }
 int scratch_reserve(ThreadCtx *c, size_t bytes) { return reserve(&c->scratch, &c->scratch_bytes, bytes, c->stream); }
 
+static Tuning g_tuning;
+Tuning &tuning() { return g_tuning; }
+
 int launch_check(const char *what)
 {
     hipError_t e = hipGetLastError();
@@ -238,6 +241,48 @@ int lars_event_elapsed_ms(void *start, void *stop, float *ms)
 {
     LARS_HIP_TRY(hipEventSynchronize(reinterpret_cast<hipEvent_t>(stop)));
     LARS_HIP_TRY(hipEventElapsedTime(ms, reinterpret_cast<hipEvent_t>(start), reinterpret_cast<hipEvent_t>(stop)));
+    return LARS_OK;
+}
+
+int lars_set_tuning(const char *key, int value)
+{
+    if (!key) return fail(LARS_ERR_INVALID, "lars_set_tuning: NULL key");
+    Tuning &t = tuning();
+    if (!strcmp(key, "fused_impl")) t.fused_impl = value;
+    else if (!strcmp(key, "hist_impl")) t.hist_impl = value;
+    else if (!strcmp(key, "nt_stores")) t.nt_stores = value;
+    else if (!strcmp(key, "blocks_per_tile")) t.blocks_per_tile = value;
+    else return fail(LARS_ERR_INVALID, "lars_set_tuning: unknown key %s", key);
+    return LARS_OK;
+}
+int lars_get_tuning(const char *key, int *value)
+{
+    if (!key || !value) return fail(LARS_ERR_INVALID, "lars_get_tuning: NULL");
+    const Tuning &t = tuning();
+    if (!strcmp(key, "fused_impl")) *value = t.fused_impl;
+    else if (!strcmp(key, "hist_impl")) *value = t.hist_impl;
+    else if (!strcmp(key, "nt_stores")) *value = t.nt_stores;
+    else if (!strcmp(key, "blocks_per_tile")) *value = t.blocks_per_tile;
+    else return fail(LARS_ERR_INVALID, "lars_get_tuning: unknown key %s", key);
+    return LARS_OK;
+}
+
+// Exhaustive device self-check of the rcp+fma quotient against IEEE division.
+int lars_d_quot_selfcheck(uint32_t max_den, uint64_t *mismatches, uint32_t first_bad[2])
+{
+    ThreadCtx *c;
+    LARS_TRY(ensure_ctx(&c));
+    if (!mismatches || !first_bad || max_den < 1) return fail(LARS_ERR_INVALID, "lars_d_quot_selfcheck: bad arguments");
+    LARS_TRY(scratch_reserve(c, 64));
+    unsigned long long *d = static_cast<unsigned long long *>(c->scratch);
+    LARS_HIP_TRY(hipMemsetAsync(d, 0, 64, c->stream));
+    LARS_TRY(quot_check_launch(max_den, d, reinterpret_cast<unsigned int *>(d + 1), c->stream));
+    unsigned long long h[2];
+    LARS_HIP_TRY(hipMemcpyAsync(h, d, 16, hipMemcpyDeviceToHost, c->stream));
+    LARS_HIP_TRY(hipStreamSynchronize(c->stream));
+    *mismatches = h[0];
+    first_bad[0] = (uint32_t)(h[1] & 0xFFFFFFFFu);
+    first_bad[1] = (uint32_t)(h[1] >> 32);
     return LARS_OK;
 }
 

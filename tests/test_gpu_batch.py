@@ -10,12 +10,15 @@ pytestmark = pytest.mark.gpu
 TYPES = ("NDVI", "GNDVI", "NDWI")
 
 
-@pytest.fixture(scope="module")
-def lars():
+@pytest.fixture(scope="module", params=[2, 1], ids=["impl2", "impl1"])
+def lars(request):
+    """Every batch test runs against both kernel generations (results must not depend on tuning)."""
     import lars_image_processing_amd as mod
     from lars_image_processing_amd import _ffi
     assert _ffi.device_count() >= 1
-    return mod
+    _ffi.set_tuning(fused_impl=request.param, hist_impl=request.param)
+    yield mod
+    _ffi.set_tuning(fused_impl=2, hist_impl=2)
 
 
 def bits(a):
@@ -63,7 +66,7 @@ def test_batch_matches_oracle_per_tile(lars, profile, shape):
             assert int(r["count"]) == part["count"] and int(r["above"]) == part["above"]
             assert float(r["min"]) == part["min"] and float(r["max"]) == part["max"]
             assert float(r["sum"]) == part["sum"]                      # exact fixed-point sum
-            assert float(r["sumsq"]) == pytest.approx(part["sumsq"], rel=1e-9)
+            assert float(r["sumsq"]) == pytest.approx(part["sumsq"], rel=1e-9)   # filled because hist=True
             np.testing.assert_array_equal(np.array(r["hist"], dtype=np.int64), part["hist"])
             lut = lars.colormap_lut("RdYlBu" if t == "NDWI" else "RdYlGn")
             np.testing.assert_array_equal(outs.host_rgba(t, i, 1)[0], orc.colormap_closed_form(want, lut))
@@ -89,6 +92,8 @@ def test_stats_only_equals_stats_with_outputs_and_ring(lars):
     rec_a = b.process(hist=True)
     outs = b.make_outputs(index=True, ring=3)
     rec_b = b.process(hist=True, outputs=outs)
+    np.testing.assert_allclose(rec_a["sumsq"], rec_b["sumsq"], rtol=1e-12)
+    rec_a["sumsq"] = rec_b["sumsq"] = 0     # every other field is order-independent, hence identical
     assert rec_a.tobytes() == rec_b.tobytes()
     # the ring holds the last chunk: tiles 6, 7 in slots 0, 1
     tiles = b.host_tiles()
@@ -154,5 +159,40 @@ def test_full_size_tile_properties(lars):
         want_wb = orc.wb_app(tiles1)
     np.testing.assert_array_equal(wb, want_wb)
     assert lb.summarize(lb.merge_records(rec[:, 0]))["count"] == 2 * n
+    outs.free()
+    b.free()
+
+
+def test_quotient_selfcheck_exhaustive(lars):
+    """rcp + mul + 2 fma == IEEE float32 division for EVERY operand pair of the uint8 (den <= 510)
+    and uint16 (den <= 131070) domains, checked on the device itself (1.7e10 pairs)."""
+    import ctypes as C
+    from lars_image_processing_amd import _ffi
+    for max_den in (510, 131070):
+        bad = C.c_uint64(123)
+        first = (C.c_uint32 * 2)()
+        _ffi.call("lars_d_quot_selfcheck", max_den, C.byref(bad), C.byref(first))
+        assert bad.value == 0, (max_den, bad.value, first[0], C.c_int32(first[1]).value)
+
+
+def test_tuning_does_not_change_results(lars):
+    from lars_image_processing_amd import _ffi
+    b = lars.TileBatch.synthetic(4, 200, 300, seed=11, profile="vegetation")
+    outs = b.make_outputs(index=True)
+    ref = None
+    keep = (_ffi.get_tuning("fused_impl"), _ffi.get_tuning("hist_impl"))
+    for impl in (1, 2):
+        for nt in (0, 1):
+            for bpt in (0, 1, 7):
+                _ffi.set_tuning(fused_impl=impl, hist_impl=impl, nt_stores=nt, blocks_per_tile=bpt)
+                rec = b.process(hist=True, outputs=outs)
+                sumsq = rec["sumsq"].copy()
+                rec["sumsq"] = 0            # the only order-dependent field (double sums of squares)
+                got = (rec.tobytes(), outs.host_index("NDWI", 0, 4).tobytes(), b.host_tables().tobytes())
+                if ref is None:
+                    ref, ref_sumsq = got, sumsq
+                assert got == ref, (impl, nt, bpt)
+                np.testing.assert_allclose(sumsq, ref_sumsq, rtol=1e-12)
+    _ffi.set_tuning(fused_impl=keep[0], hist_impl=keep[1], nt_stores=0, blocks_per_tile=0)
     outs.free()
     b.free()

@@ -1,0 +1,33 @@
+#!/usr/bin/env python3
+"""What the device sustains for plain streaming with the hot path's access shapes."""
+import ctypes as C, json, os, sys
+import numpy as np
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+from lars_image_processing_amd import _ffi
+
+def main():
+    gib = int(sys.argv[1]) if len(sys.argv) > 1 else 12
+    nbytes = gib << 30
+    nbytes -= nbytes % (48 * 1024)
+    src, dst = _ffi.DeviceBuffer(nbytes), _ffi.DeviceBuffer(nbytes)
+    _ffi.call("lars_d_probe", 3, 1, 8192, None, C.c_void_p(src.ptr), nbytes, None)
+    a, b = C.c_void_p(), C.c_void_p()
+    _ffi.call("lars_event_create", C.byref(a)); _ffi.call("lars_event_create", C.byref(b))
+    res = {}
+    for kind, name, mult in ((0, "read16", 1), (1, "read12", 1), (2, "copy16", 2), (3, "write16", 1)):
+        for unroll in ((1, 2, 4, 8) if kind < 2 else (1,)):
+            for blocks in (2048, 4096, 8192, 16384, 65536):
+                ts = []
+                for _ in range(4):
+                    _ffi.call("lars_event_record", a, None)
+                    _ffi.call("lars_d_probe", kind, unroll, blocks, C.c_void_p(src.ptr), C.c_void_p(dst.ptr), nbytes, None)
+                    _ffi.call("lars_event_record", b, None)
+                    ms = C.c_float(0); _ffi.call("lars_event_elapsed_ms", a, b, C.byref(ms)); ts.append(ms.value)
+                t = float(np.median(ts[1:]))
+                res[f"{name} unroll={unroll} blocks={blocks}"] = nbytes * mult / t / 1e6
+    for k, v in res.items():
+        print(f"{k:40s} {v:9.1f} GB/s")
+    print(json.dumps(res))
+
+if __name__ == "__main__":
+    main()

@@ -26,6 +26,8 @@
 
 namespace lars {
 
+typedef unsigned int u32x3 __attribute__((ext_vector_type(3)));
+
 // ---------------------------------------------------------------------------
 // exact quotient for integer-valued operands: |num| <= den, 1 <= den < 2^24
 // ---------------------------------------------------------------------------
@@ -38,6 +40,20 @@ __device__ inline float exact_quot(float num, float den)
     const float q0 = num * r;
     const float e = __builtin_fmaf(-q0, den, num);
     return __builtin_fmaf(e, r, q0);
+}
+// two quotients per instruction: v_pk_mul_f32 / v_pk_fma_f32 (the VALU issues one wave64
+// instruction per 4 cycles, packed or not -- rocprofv3: SQ_ACTIVE_INST_VALU / SQ_INSTS_VALU = 1.05 quad-cycles)
+typedef float f32x2 __attribute__((ext_vector_type(2)));
+__device__ inline f32x2 exact_quot2(f32x2 num, f32x2 den)
+{
+    den.x = fmaxf(den.x, 1.0f);                            // a+b == 0 -> (+0)/1 = +0.0
+    den.y = fmaxf(den.y, 1.0f);
+    f32x2 r;
+    r.x = __builtin_amdgcn_rcpf(den.x);
+    r.y = __builtin_amdgcn_rcpf(den.y);
+    const f32x2 q0 = num * r;
+    const f32x2 e = __builtin_elementwise_fma(-q0, den, num);
+    return __builtin_elementwise_fma(e, r, q0);
 }
 // (a-b)/(a+b) with +0.0 where a+b == 0
 __device__ inline float norm_diff_fast(float a, float b)
@@ -87,35 +103,40 @@ __global__ __launch_bounds__(1024) void k_chan_hist_u8c3_v2(const uint8_t *__res
     char *hb = reinterpret_cast<char *>(s_h);
 #define HADD(word, shift, ch)                                                                          \
     atomicAdd(reinterpret_cast<unsigned int *>(hb + (ch) * 32768 + ((((word) >> (shift)) & 0xFFu) << 7) + lane_off), 1u)
-    // software pipeline: four 12-byte loads in flight per lane (48 KiB per CU at 16 waves)
+    // software pipeline: four 12-byte buffer loads in flight per lane (48 KiB per CU at 16 waves)
     const long long step = (long long)gridDim.x * 1024;
     const long long q0 = (long long)blockIdx.x * 1024 + tid;
     const long long niter = (nquads + step - 1) / step;            // same for every lane of the grid
-    unsigned int w[4][3];
-#define HLOAD(k, qq)                                                                                   \
-    {                                                                                                  \
-        const long long qc = (qq) < nquads ? (qq) : nquads - 1;                                        \
-        const unsigned int *p_ = reinterpret_cast<const unsigned int *>(base + qc * 12);               \
-        w[k][0] = p_[0]; w[k][1] = p_[1]; w[k][2] = p_[2];                                             \
-    }
-    if (nquads > 0) {
+#define HQUAD(a0, a1, a2)                                                                              \
+    HADD(a0, 0, 0); HADD(a0, 8, 1); HADD(a0, 16, 2); HADD(a0, 24, 0);                                 \
+    HADD(a1, 0, 1); HADD(a1, 8, 2); HADD(a1, 16, 0); HADD(a1, 24, 1);                                 \
+    HADD(a2, 0, 2); HADD(a2, 8, 0); HADD(a2, 16, 1); HADD(a2, 24, 2);
+    if (niter > 0) {
+        const __amdgpu_buffer_rsrc_t rsrc =
+            __builtin_amdgcn_make_buffer_rsrc(const_cast<uint8_t *>(base), 0, (int)(nquads * 12), 0x00020000);
+        const unsigned int voff = (unsigned int)q0 * 12u;
+        const unsigned int step_b = (unsigned int)step * 12u;
+        u32x3 w[4];
 #pragma unroll
-        for (int k = 0; k < 4; ++k) HLOAD(k, q0 + k * step)
-        for (long long it = 0; it < niter; it += 4) {
+        for (int k = 0; k < 4; ++k) w[k] = __builtin_amdgcn_raw_buffer_load_b96(rsrc, voff, (unsigned)k * step_b, 0);
+        long long it = 0;
+        unsigned int soff = 4u * step_b;
+        for (; it + 4 <= niter - 1; it += 4) {
 #pragma unroll
             for (int k = 0; k < 4; ++k) {
-                const long long qq = q0 + (it + k) * step;
-                const unsigned int a0 = w[k][0], a1 = w[k][1], a2 = w[k][2];
-                if (it + k + 4 < niter) HLOAD(k, qq + 4 * step)
-                if (qq < nquads) {
-                    HADD(a0, 0, 0); HADD(a0, 8, 1); HADD(a0, 16, 2); HADD(a0, 24, 0);
-                    HADD(a1, 0, 1); HADD(a1, 8, 2); HADD(a1, 16, 0); HADD(a1, 24, 1);
-                    HADD(a2, 0, 2); HADD(a2, 8, 0); HADD(a2, 16, 1); HADD(a2, 24, 2);
-                }
+                HQUAD(w[k].x, w[k].y, w[k].z)
+                __builtin_amdgcn_sched_barrier(0);
+                w[k] = __builtin_amdgcn_raw_buffer_load_b96(rsrc, voff, soff + (unsigned)k * step_b, 0);
+                __builtin_amdgcn_sched_barrier(0);
             }
+            soff += 4u * step_b;
+        }
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            if (it + k < niter && q0 + (it + k) * step < nquads) { HQUAD(w[k].x, w[k].y, w[k].z) }
         }
     }
-#undef HLOAD
+#undef HQUAD
     if (blockIdx.x == 0 && tid < (int)(npix & 3)) {
         const uint8_t *p = base + (nquads * 4 + tid) * 3;
         HADD((unsigned)p[0], 0, 0); HADD((unsigned)p[1], 0, 1); HADD((unsigned)p[2], 0, 2);
@@ -155,15 +176,30 @@ struct WaveAcc {
 #define V2_TABLE_BYTES 65536
 #define V2_HIST_WORDS (3 * LARS_HIST_BINS * 32)
 
+// byte k of a dword -> float in one VALU instruction.  Kept opaque (asm) so that hipcc does not
+// turn "float(a) +/- float(b)" into integer SDWA adds plus conversions (5 instructions per pixel
+// instead of 2 conversions + packed add/sub).
+__device__ inline float cvt_ubyte(unsigned int w, int k)
+{
+    float f;
+    switch (k) {
+    case 0: asm("v_cvt_f32_ubyte0 %0, %1" : "=v"(f) : "v"(w)); break;
+    case 1: asm("v_cvt_f32_ubyte1 %0, %1" : "=v"(f) : "v"(w)); break;
+    case 2: asm("v_cvt_f32_ubyte2 %0, %1" : "=v"(f) : "v"(w)); break;
+    default: asm("v_cvt_f32_ubyte3 %0, %1" : "=v"(f) : "v"(w)); break;
+    }
+    return f;
+}
+
 template <bool WB>
 __device__ inline float sample(unsigned int word, int byte, int ch, unsigned int lane_off4, const char *s_tab)
 {
-    if (!WB) return (float)((word >> (8 * byte)) & 0xFFu);            // v_cvt_f32_ubyteN
+    if (!WB) return cvt_ubyte(word, byte);
     // address = sample << 8 | lane*4 in one v_perm_b32 (S0 = word: selectors 4..7, S1 = lane_off4: 0..3)
     const unsigned int sel = 0x0c0c0000u | ((4u + (unsigned)byte) << 8);
     const unsigned int addr = __builtin_amdgcn_perm(word, lane_off4, sel);
     const unsigned int entry = *reinterpret_cast<const unsigned int *>(s_tab + addr);
-    return (float)((entry >> (8 * ch)) & 0xFFu);
+    return cvt_ubyte(entry, ch);
 }
 template <bool WB>
 __device__ inline unsigned int sample_entry(unsigned int word, int byte, unsigned int lane_off4, const char *s_tab)
@@ -271,21 +307,39 @@ __global__ __launch_bounds__(512, 4) void k_fused_v2(FusedParams P)
             o[2] = e[8] | (e[9] << 8) | (e[10] << 16) | (e[11] << 24);
         }
         if (MASK == 0u) return;
-        float v0[4], v1[4], v2[4];
+        // samples -> float (white balanced through the LDS table when WB)
+        float fn[4], fr[4], fg[4];
 #pragma unroll
         for (int px = 0; px < 4; ++px) {
-            const float n = sample<WB>(wn[px], bn[px], 2, lane_off4, s_tab);
+            fn[px] = sample<WB>(wn[px], bn[px], 2, lane_off4, s_tab);
+            if (NEED_R) fr[px] = sample<WB>(wr[px], br[px], 0, lane_off4, s_tab);
+            if (NEED_G) fg[px] = sample<WB>(wg[px], bg[px], 1, lane_off4, s_tab);
+        }
+        // quotients, two pixels per packed instruction (v_pk_add/mul/fma_f32)
+        float v0[4], v1[4], v2[4];
+#pragma unroll
+        for (int h = 0; h < 2; ++h) {
+            const f32x2 N = {fn[2 * h], fn[2 * h + 1]};
             if (WANT_NDVI) {
-                const float r = sample<WB>(wr[px], br[px], 0, lane_off4, s_tab);
-                const float x = norm_diff_fast(n, r);
-                v0[px] = x;
+                const f32x2 R = {fr[2 * h], fr[2 * h + 1]};
+                const f32x2 x = exact_quot2(N - R, N + R);
+                v0[2 * h] = x.x; v0[2 * h + 1] = x.y;
+            }
+            if (NEED_G) {
+                const f32x2 G = {fg[2 * h], fg[2 * h + 1]};
+                const f32x2 x = exact_quot2(N - G, N + G);
+                v1[2 * h] = x.x; v1[2 * h + 1] = x.y;
+            }
+        }
+#pragma unroll
+        for (int px = 0; px < 4; ++px) {
+            if (WANT_NDVI) {
+                const float x = v0[px];
                 if (STATS >= 1) push<STATS>(acc_v, above_v, x, 0.2f);
                 if (STATS >= 2) hist_add(s_hist, s_edges, 0, x, lane32);
             }
             if (NEED_G) {
-                const float g = sample<WB>(wg[px], bg[px], 1, lane_off4, s_tab);
-                const float x = norm_diff_fast(n, g);
-                v1[px] = x;
+                const float x = v1[px];
                 if (STATS >= 1) {
                     acc_g.mn = fminf(acc_g.mn, x);
                     acc_g.mx = fmaxf(acc_g.mx, x);
@@ -328,32 +382,38 @@ __global__ __launch_bounds__(512, 4) void k_fused_v2(FusedParams P)
                                                                   lut2[cmap_index(v2[2])], lut2[cmap_index(v2[3])]);
     };
 
-    // software pipeline: four 12-byte loads in flight per lane while the oldest quad is processed
+    // Software pipeline: four 12-byte loads in flight per lane while the oldest quad is processed.
+    // buffer_load with the tile as a raw buffer: the lane offset is fixed, the per-iteration offset
+    // is a scalar (no vector address arithmetic), and loads past the end return zeros (no clamps).
     const long long q0 = (long long)blockIdx.x * 512 + tid;
     const long long niter = (nquads + stride - 1) / stride;          // same for every lane of the grid
-    if (nquads > 0) {
-        unsigned int w[4][3];
+    if (niter > 0) {
+        const __amdgpu_buffer_rsrc_t rsrc =
+            __builtin_amdgcn_make_buffer_rsrc(const_cast<uint8_t *>(base), 0, (int)(nquads * 12), 0x00020000);
+        const unsigned int voff = (unsigned int)q0 * 12u;
+        const unsigned int step_b = (unsigned int)stride * 12u;
+        u32x3 w[4];
 #pragma unroll
-        for (int k = 0; k < 4; ++k) {
-            const long long qq = q0 + k * stride;
-            const long long qc = qq < nquads ? qq : nquads - 1;
-            const unsigned int *p_ = reinterpret_cast<const unsigned int *>(base + qc * 12);
-            w[k][0] = p_[0]; w[k][1] = p_[1]; w[k][2] = p_[2];
-        }
-        for (long long it = 0; it < niter; it += 4) {
+        for (int k = 0; k < 4; ++k) w[k] = __builtin_amdgcn_raw_buffer_load_b96(rsrc, voff, (unsigned)k * step_b, 0);
+        long long it = 0;
+        unsigned int soff = 4u * step_b;
+        // every lane's quad is in range while it < niter - 1
+        for (; it + 4 <= niter - 1; it += 4) {
 #pragma unroll
             for (int k = 0; k < 4; ++k) {
-                const long long qq = q0 + (it + k) * stride;
-                const unsigned int a0 = w[k][0], a1 = w[k][1], a2 = w[k][2];
-                if (it + k + 4 < niter) {
-                    const long long qn = qq + 4 * stride;
-                    const long long qc = qn < nquads ? qn : nquads - 1;
-                    const unsigned int *p_ = reinterpret_cast<const unsigned int *>(base + qc * 12);
-                    w[k][0] = p_[0]; w[k][1] = p_[1]; w[k][2] = p_[2];
-                }
-                if (qq < nquads) do_quad(qq, a0, a1, a2);
-                __builtin_amdgcn_sched_barrier(0);       // keep the four quads' work apart: bounded registers
+                // consume slot k, then refill it: the refill lands in the registers just freed
+                // (no copies, no vmcnt(0) at the loop head) and has three quads of work to hide behind
+                do_quad(q0 + (it + k) * stride, w[k].x, w[k].y, w[k].z);
+                __builtin_amdgcn_sched_barrier(0);
+                w[k] = __builtin_amdgcn_raw_buffer_load_b96(rsrc, voff, soff + (unsigned)k * step_b, 0);
+                __builtin_amdgcn_sched_barrier(0);
             }
+            soff += 4u * step_b;
+        }
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            const long long qq = q0 + (it + k) * stride;
+            if (it + k < niter && qq < nquads) do_quad(qq, w[k].x, w[k].y, w[k].z);
         }
     }
 

@@ -53,10 +53,12 @@ def parse():
     ap.add_argument("--tile", type=int, default=4096, help="tile edge in pixels")
     ap.add_argument("--ring", type=int, default=64, help="output ring, in tiles (same traffic, bounded footprint)")
     ap.add_argument("--mode", default="wb3idx_out_stats", choices=sorted(MODES))
-    ap.add_argument("--all-modes", action="store_true", help="also time the other modes (extra JSON field)")
+    ap.add_argument("--no-all-modes", dest="all_modes", action="store_false",
+                    help="skip timing the other modes (extra JSON field 'modes')")
+    ap.add_argument("--no-probe", dest="probe", action="store_false", help="skip the streaming-roofline probes")
     ap.add_argument("--profile", default="vegetation", choices=["uniform", "vegetation"])
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--cpu-tiles", type=int, default=2)
+    ap.add_argument("--cpu-tiles", type=int, default=8)
     return ap.parse_args()
 
 
@@ -158,12 +160,36 @@ def cpu_baseline(args):
     }
 
 
-def traffic_from_profiles(mode):
-    """Per-launch HBM bytes from the committed PMC summary, if one exists for this mode."""
+def device_probe(runner):
+    """Plain streaming kernels with the hot path's access shapes: what this device sustains (GB/s)."""
+    ffi = runner.ffi
+    nbytes = min(runner.batch.ntiles, 256) * runner.batch.tile_bytes
+    nbytes -= nbytes % 960
+    dst = ffi.DeviceBuffer(nbytes)
+    src = runner.batch.tiles.ptr
+    out = {}
+    for kind, name, mult in ((1, "read_12B_per_lane", 1), (3, "write_16B_per_lane", 1), (2, "copy_16B_per_lane", 2),
+                             (5, "mix_12B_read_48B_write", 1)):
+        ts = []
+        for _ in range(4):
+            ffi.call("lars_event_record", runner.ev[0], None)
+            ffi.call("lars_d_probe", kind, 1, 65536, C.c_void_p(src), C.c_void_p(dst.ptr), nbytes, None)
+            ffi.call("lars_event_record", runner.ev[1], None)
+            ms = C.c_float(0)
+            ffi.call("lars_event_elapsed_ms", runner.ev[0], runner.ev[1], C.byref(ms))
+            ts.append(ms.value)
+        out[name] = nbytes * mult / float(np.median(ts[1:])) / 1e6
+    dst.free()
+    return out
+
+
+def traffic_from_profiles(mode, pixels_per_launch):
+    """Per-launch HBM bytes of the fused kernel from the committed PMC summary (profiles/traffic.json:
+    rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, separate passes, corrected as MI355X_MICROARCH.md says)."""
     path = os.path.join(ROOT, "profiles", "traffic.json")
     try:
         with open(path) as fh:
-            return json.load(fh).get(mode)
+            return json.load(fh)[mode]["bytes_per_pixel"] * pixels_per_launch
     except Exception:
         return None
 
@@ -193,7 +219,7 @@ def main():
     launches = timed[0][2]
     bytes_per_launch = npix_rank * bpp / launches
     achieved = bytes_per_launch / (fused_ms / launches * 1e-3) / 1e9
-    traffic = traffic_from_profiles(args.mode)
+    traffic = traffic_from_profiles(args.mode, npix_rank / launches)
 
     extra = {}
     if args.all_modes:
@@ -209,6 +235,7 @@ def main():
                 "fused_frac_of_8TBs": npix_rank * MODES[m][3] / (f_ms * 1e-3) / 1e9 / HBM_PEAK_GBS,
             }
 
+    probe = device_probe(runner) if (args.probe and rank == 0) else None
     if rank == 0:
         cpu = None if args.no_cpu_baseline or world > 1 else cpu_baseline(args)
         g = {t: runner.lb.summarize(glob[_ffi.INDEX_IDS[t]]) for t in indices}
@@ -228,7 +255,7 @@ def main():
                 "device": _ffi.device_name(),
             },
             "roofline": {
-                "bound": "hbm", "kernel": "k_fused_u8c3", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                "bound": "hbm", "kernel": "k_fused_u8c3 (outputs) / k_fused_v2 (statistics only)", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                 "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
                 "algorithmic_bytes_per_pixel": bpp, "bytes_per_launch": bytes_per_launch,
                 "launches_per_step": launches, "avg_launch_ms": fused_ms / launches,
@@ -239,6 +266,8 @@ def main():
         }
         if extra:
             line["modes"] = extra
+        if probe:
+            line["device_probe_GBs"] = probe
         print(json.dumps(line))
     comm.destroy()
 

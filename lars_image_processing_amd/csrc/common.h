@@ -97,7 +97,7 @@ int launch_check(const char *what);
 
 // tuning knobs (lars_set_tuning)
 struct Tuning {
-    int fused_impl = 2;        // 1: first-generation kernels (fused.hip), 2: fused_v2.hip
+    int fused_impl = 0;        // 0: automatic, 1: first-generation kernels (fused.hip), 2: fused_v2.hip
     int hist_impl = 2;
     int nt_stores = 0;         // non-temporal stores for the float32 planes
     int blocks_per_tile = 0;   // 0 = automatic

@@ -662,7 +662,14 @@ extern "C" int lars_d_fused(const lars_fused_args *a)
     const bool mask_ok = mask == 0u || mask == 1u || mask == 2u || mask == 4u || mask == 7u;
     const bool fast = a->dtype == LARS_U8 && a->channels == 3 && aligned && mask_ok &&
                       (a->ntiles == 1 || (a->npix & 3) == 0);
-    if (fast && tuning().fused_impl >= 2) {
+    // fused_impl 0 = automatic: the second-generation kernels win where the launch is read-bound
+    // (statistics only); with output planes the launch is write-bound and the lighter first-generation
+    // kernel (more resident waves, no LDS table) is as fast or faster (tools/kbench.py)
+    const bool any_out = P.out_wb || P.out_index[0] || P.out_index[1] || P.out_index[2] || P.out_rgba[0] ||
+                         P.out_rgba[1] || P.out_rgba[2];
+    int impl = tuning().fused_impl;
+    if (impl == 0) impl = (any_out && mask != 0u) ? 1 : 2;
+    if (fast && impl >= 2) {
         dim3 grid(blocks_per_tile(a->npix / 4 + 1, a->ntiles, 512), (unsigned)a->ntiles);
         fused_v2_launch(mask, a->wb_table != nullptr, stats_mode, tuning().nt_stores != 0, grid, s, P);
     } else if (fast) {

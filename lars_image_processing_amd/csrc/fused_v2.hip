@@ -174,7 +174,8 @@ struct WaveAcc {
 
 // LDS layout (dynamic): [WB table 64 KiB][hist 3*50*32 u32][edges 51 f32][reduce scratch]
 #define V2_TABLE_BYTES 65536
-#define V2_HIST_WORDS (3 * LARS_HIST_BINS * 32)
+#define V2_HIST_COPIES 4     // lane-private copies of each index histogram (keeps two blocks per CU)
+#define V2_HIST_WORDS (3 * LARS_HIST_BINS * V2_HIST_COPIES)
 
 // byte k of a dword -> float in one VALU instruction.  Kept opaque (asm) so that hipcc does not
 // turn "float(a) +/- float(b)" into integer SDWA adds plus conversions (5 instructions per pixel
@@ -229,7 +230,7 @@ __device__ inline void push(WaveAcc &a, unsigned int &above, float x, float thr)
 __device__ inline void hist_add(unsigned int *s_hist, const float *s_edges, int index, float x, unsigned int lane32)
 {
     const int b = hist_bin_f32(x, s_edges);
-    atomicAdd(&s_hist[(index * LARS_HIST_BINS + b) * 32 + lane32], 1u);
+    atomicAdd(&s_hist[(index * LARS_HIST_BINS + b) * V2_HIST_COPIES + (lane32 & (V2_HIST_COPIES - 1))], 1u);
 }
 
 template <unsigned MASK, bool WB, int STATS, bool OUT, bool NT>
@@ -523,9 +524,9 @@ __global__ __launch_bounds__(512, 4) void k_fused_v2(FusedParams P)
             if (tid < 3 * LARS_HIST_BINS) {
                 const int k = tid / LARS_HIST_BINS;
                 if (MASK & (1u << k)) {
-                    const unsigned int *rowh = s_hist + tid * 32;
+                    const unsigned int *rowh = s_hist + tid * V2_HIST_COPIES;
                     unsigned int v = 0;
-                    for (int j = 0; j < 32; ++j) v += rowh[(j + tid) & 31];
+                    for (int j = 0; j < V2_HIST_COPIES; ++j) v += rowh[j];
                     if (v) atomicAdd(&rec[k].hist[tid - k * LARS_HIST_BINS], (unsigned long long)v);
                 }
             }

@@ -49,11 +49,41 @@ __global__ __launch_bounds__(256) void k_probe_write(uint4 *__restrict__ dst, lo
     for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < nvec; i += stride) dst[i] = v;
 }
 
+typedef unsigned int pu32x4 __attribute__((ext_vector_type(4)));
+
+__global__ __launch_bounds__(256) void k_probe_write_nt(pu32x4 *__restrict__ dst, long long nvec)
+{
+    const long long stride = (long long)gridDim.x * 256;
+    const pu32x4 v = {threadIdx.x, blockIdx.x, 3u, 4u};
+    for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < nvec; i += stride)
+        __builtin_nontemporal_store(v, dst + i);
+}
+
+// the fused kernel's traffic mix: 12 bytes read, 3 x 16 bytes written per lane and step
+template <bool NT>
+__global__ __launch_bounds__(256) void k_probe_mix(const unsigned int *__restrict__ src, pu32x4 *__restrict__ d0,
+                                                   pu32x4 *__restrict__ d1, pu32x4 *__restrict__ d2, long long nquads)
+{
+    const long long stride = (long long)gridDim.x * 256;
+    for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < nquads; i += stride) {
+        const unsigned int a = src[i * 3], b = src[i * 3 + 1], c = src[i * 3 + 2];
+        const pu32x4 v0 = {a, b, c, a ^ b}, v1 = {b, c, a, b ^ c}, v2 = {c, a, b, c ^ a};
+        if (NT) {
+            __builtin_nontemporal_store(v0, d0 + i);
+            __builtin_nontemporal_store(v1, d1 + i);
+            __builtin_nontemporal_store(v2, d2 + i);
+        } else {
+            d0[i] = v0; d1[i] = v1; d2[i] = v2;
+        }
+    }
+}
+
 }  // namespace lars
 
 using namespace lars;
 
-// kind: 0 read 16 B/lane, 1 read 12 B/lane, 2 copy 16 B/lane (bytes read + bytes written = 2*bytes), 3 write 16 B/lane
+// kind: 0 read 16 B/lane, 1 read 12 B/lane, 2 copy 16 B/lane (bytes read + bytes written = 2*bytes), 3 write 16 B/lane,
+// 4 non-temporal write, 5 / 6 the fused kernel's mix (12 B read + 48 B written per lane; plain / non-temporal stores)
 extern "C" int lars_d_probe(int kind, int unroll, int blocks, const void *src, void *dst, int64_t bytes, void *stream)
 {
     ThreadCtx *c;
@@ -80,6 +110,16 @@ extern "C" int lars_d_probe(int kind, int unroll, int blocks, const void *src, v
                            static_cast<uint4 *>(dst), (long long)(bytes / 16));
     } else if (kind == 3) {
         hipLaunchKernelGGL(k_probe_write, dim3(blocks), dim3(256), 0, s, static_cast<uint4 *>(dst), (long long)(bytes / 16));
+    } else if (kind == 4) {
+        hipLaunchKernelGGL(k_probe_write_nt, dim3(blocks), dim3(256), 0, s, static_cast<pu32x4 *>(dst), (long long)(bytes / 16));
+    } else if (kind == 5 || kind == 6) {
+        // src: bytes/5 read as 12-byte quads; dst: three planes of 16-byte vectors (total traffic = bytes)
+        const long long nquads = bytes / 60;
+        pu32x4 *d = static_cast<pu32x4 *>(dst);
+        if (kind == 5)
+            hipLaunchKernelGGL((k_probe_mix<false>), dim3(blocks), dim3(256), 0, s, p, d, d + nquads, d + 2 * nquads, nquads);
+        else
+            hipLaunchKernelGGL((k_probe_mix<true>), dim3(blocks), dim3(256), 0, s, p, d, d + nquads, d + 2 * nquads, nquads);
     } else {
         return fail(LARS_ERR_INVALID, "lars_d_probe: kind");
     }

@@ -18,7 +18,7 @@ def lars(request):
     assert _ffi.device_count() >= 1
     _ffi.set_tuning(fused_impl=request.param, hist_impl=request.param)
     yield mod
-    _ffi.set_tuning(fused_impl=2, hist_impl=2)
+    _ffi.set_tuning(fused_impl=0, hist_impl=2)
 
 
 def bits(a):

@@ -201,7 +201,7 @@ def main():
     rank, local_rank, world = dist.env_rank_world()
     if world != max(1, args.gpus) and world > 1:
         raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}")
-    if world > 1:
+    if world > 1 or os.environ.get("LARS_FORCE_RCCL"):
         comm = dist.Comm.from_env()
     else:
         _ffi.call("lars_set_device", 0)

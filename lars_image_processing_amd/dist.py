@@ -44,17 +44,23 @@ def _rendezvous_path():
     return os.path.join(d, f"lars_rccl_id_{run}_{port}_{boss}")
 
 
-def exchange_unique_id(rank, world, timeout_s=120.0):
+def _rccl_unique_id():
+    buf = (C.c_uint8 * _ffi.COMM_ID_BYTES)()
+    _ffi.call("lars_comm_unique_id", buf)
+    return bytes(buf)
+
+
+def exchange_unique_id(rank, world, timeout_s=120.0, make_id=_rccl_unique_id):
     """Rank 0 creates the RCCL unique id and publishes it atomically; the others poll."""
     path = _rendezvous_path()
     if rank == 0:
-        buf = (C.c_uint8 * _ffi.COMM_ID_BYTES)()
-        _ffi.call("lars_comm_unique_id", buf)
+        data = make_id()
+        assert len(data) == _ffi.COMM_ID_BYTES
         tmp = f"{path}.tmp{os.getpid()}"
         with open(tmp, "wb") as fh:
-            fh.write(bytes(buf))
+            fh.write(data)
         os.replace(tmp, path)
-        return bytes(buf)
+        return data
     deadline = time.time() + timeout_s
     while time.time() < deadline:
         try:

@@ -1,0 +1,107 @@
+"""Worker of tests/test_dist_gloo.py: one rank of a world_size-N CPU run (gloo).
+
+Exercises everything of the N>1 path that is not a GPU kernel: the launcher
+environment, the file rendezvous that carries the RCCL unique id, tile
+sharding, the per-rank fold and the rank-order fold that
+lars_comm_allreduce_stats applies after its all-gather.  Per-tile records come
+from the oracle here (test infrastructure; on a GPU box they come from the
+fused kernel).
+"""
+import json
+import os
+import sys
+import warnings
+
+import numpy as np
+import torch
+import torch.distributed as td
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+sys.path.insert(0, os.path.join(ROOT, "tests"))
+
+from lars_image_processing_amd import _ffi, batch, dist  # noqa: E402
+from oracle import index_oracle as orc  # noqa: E402
+from test_abi_cpu import to_records  # noqa: E402
+
+TYPES = ("NDVI", "GNDVI", "NDWI")
+
+
+class GlooComm:
+    """dist.Comm's interface over torch.distributed/gloo (tests only)."""
+
+    def __init__(self):
+        self.rank, self.world = td.get_rank(), td.get_world_size()
+
+    def allreduce_stats(self, records):
+        rec = np.ascontiguousarray(records, dtype=_ffi.STATS_DTYPE).reshape(-1)
+        mine = torch.from_numpy(rec.view(np.uint8).copy())
+        gathered = [torch.empty_like(mine) for _ in range(self.world)]
+        td.all_gather(gathered, mine)                         # what ncclAllGather does on the GPU path
+        per_rank = [g.numpy().view(_ffi.STATS_DTYPE) for g in gathered]
+        return dist.fold_gathered(per_rank)                   # the fold csrc/comm.cpp applies
+
+    def barrier(self):
+        td.barrier()
+
+
+def tile_records(tile_ids, h, w):
+    rec = np.zeros((len(tile_ids), 3), dtype=_ffi.STATS_DTYPE)
+    for j, t in enumerate(tile_ids):
+        img = orc.synth_tile_u8(77, t, h, w, profile="vegetation")
+        with warnings.catch_warnings():
+            warnings.simplefilter("ignore")
+            wb = orc.wb_app(img)
+        for k, name in enumerate(TYPES):
+            rec[j, k] = to_records([orc.tile_partials(orc.index_app(wb, name), name)], k)[0]
+    return rec
+
+
+def main():
+    out_path = sys.argv[1]
+    rank, local_rank, world = dist.env_rank_world()
+    td.init_process_group("gloo", rank=rank, world_size=world)
+    assert (td.get_rank(), td.get_world_size()) == (rank, world)
+
+    # 1. the rendezvous that carries the RCCL unique id (a random stand-in id here)
+    uid = dist.exchange_unique_id(rank, world, timeout_s=60, make_id=lambda: os.urandom(_ffi.COMM_ID_BYTES))
+    t = torch.tensor(list(uid), dtype=torch.uint8)
+    ref = t.clone()
+    td.broadcast(ref, src=0)
+    assert torch.equal(t, ref), "ranks disagree on the unique id"
+
+    # 2. shard, process, fold locally, fold globally
+    ntiles, h, w = 7, 40, 56
+    lo, hi = batch.shard_range(ntiles, rank, world)
+    mine = tile_records(list(range(lo, hi)), h, w)
+    comm = GlooComm()
+    local = batch.local_fold(mine) if hi > lo else np.zeros(3, dtype=_ffi.STATS_DTYPE)
+    if hi == lo:                                  # a rank with no tiles contributes neutral records
+        local["min"], local["max"] = np.inf, -np.inf
+    glob = comm.allreduce_stats(local)
+    comm.barrier()
+
+    # 3. every rank must hold the same bytes, equal to the single-process fold over all tiles
+    everything = tile_records(list(range(ntiles)), h, w)
+    want = batch.local_fold(everything)
+    summary = {}
+    for k, name in enumerate(TYPES):
+        g, s = batch.summarize(glob[k]), batch.summarize(want[k])
+        assert g["count"] == s["count"] == ntiles * h * w
+        assert g["min"] == s["min"] and g["max"] == s["max"] and g["coverage"] == s["coverage"]
+        assert np.array_equal(g["hist"], s["hist"])
+        assert abs(g["mean"] - s["mean"]) <= 1e-15
+        summary[name] = {"mean": g["mean"], "coverage": g["coverage"]}
+    blob = torch.from_numpy(glob.view(np.uint8).copy())
+    ref = blob.clone()
+    td.broadcast(ref, src=0)
+    assert torch.equal(blob, ref), "global records differ between ranks"
+    if rank == 0:
+        with open(out_path, "w") as fh:
+            json.dump({"world": world, "shards": [batch.shard_range(ntiles, r, world) for r in range(world)],
+                       "summary": summary}, fh)
+    td.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

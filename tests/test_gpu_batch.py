@@ -196,3 +196,22 @@ def test_tuning_does_not_change_results(lars):
     _ffi.set_tuning(fused_impl=keep[0], hist_impl=keep[1], nt_stores=0, blocks_per_tile=0)
     outs.free()
     b.free()
+
+
+def test_rccl_communicator_single_rank(lars):
+    """librccl loads, a 1-rank communicator initialises, and the stats all-gather + fold and the
+    f64 all-reduce round-trip through device memory (the N>1 code path with N = 1)."""
+    from lars_image_processing_amd import _ffi, dist, batch as lb
+    uid = dist._rccl_unique_id()
+    assert len(uid) == _ffi.COMM_ID_BYTES and any(uid)
+    comm = dist.Comm(0, 1, uid)
+    b = lars.TileBatch.synthetic(3, 64, 64, seed=5)
+    rec = b.process(hist=True)
+    local = lb.local_fold(rec)
+    glob = comm.allreduce_stats(local)
+    assert glob.tobytes() == local.tobytes()
+    assert comm.allreduce_f64([1.5, -2.0], "max").tolist() == [1.5, -2.0]
+    assert comm.allreduce_f64([1.5, -2.0], "sum").tolist() == [1.5, -2.0]
+    comm.barrier()
+    comm.destroy()
+    b.free()

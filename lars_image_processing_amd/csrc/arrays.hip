@@ -8,6 +8,7 @@
 //   process-ndvi.py:18-31       float64 NDVI
 //   process-images.py:695       imshow(cmap, vmin=-1, vmax=1)
 #include "common.h"
+#include "device_common.h"
 
 namespace lars {
 
@@ -23,27 +24,17 @@ struct ArrPartial {
 };
 
 template <typename T>
-__device__ inline int hist_bin_t(T x, const T *edges)
-{
-    int b = (int)((x + (T)1) * (T)25);
-    b = b < 0 ? 0 : (b > LARS_HIST_BINS - 1 ? LARS_HIST_BINS - 1 : b);
-    if (x < edges[b]) --b;
-    else if (b != LARS_HIST_BINS - 1 && x >= edges[b + 1]) ++b;
-    return b;
-}
-
-template <typename T>
 __global__ __launch_bounds__(256) void k_array_stats(const T *__restrict__ x, long long n, T thr, int want_hist,
                                                      ArrPartial *__restrict__ partials,
                                                      unsigned long long *__restrict__ ghist)
 {
     __shared__ unsigned int s_hist[LARS_HIST_BINS];
-    __shared__ T s_edges[LARS_HIST_BINS + 1];
+    __shared__ HistCell<T> s_edges[LARS_HIST_CELLS];
     __shared__ ArrPartial s_part[4];
     const int tid = threadIdx.x;
     if (want_hist) {
         if (tid < LARS_HIST_BINS) s_hist[tid] = 0;
-        if (tid <= LARS_HIST_BINS) s_edges[tid] = (T)hist_edge_f64(tid);
+        hist_cells_init<T>(s_edges, tid);
         __syncthreads();
     }
     double sum = 0, sumsq = 0;
@@ -57,7 +48,7 @@ __global__ __launch_bounds__(256) void k_array_stats(const T *__restrict__ x, lo
         mn = fmin(mn, d); mx = fmax(mx, d);
         above += (v > thr) ? 1 : 0;
         ++count;
-        if (want_hist && v >= (T)-1 && v <= (T)1) atomicAdd(&s_hist[hist_bin_t<T>(v, s_edges)], 1u);
+        if (want_hist && v >= (T)-1 && v <= (T)1) atomicAdd(&s_hist[hist_bin_cell<T>(v, s_edges)], 1u);
     }
     for (int off = 32; off >= 1; off >>= 1) {
         sum += __shfl_xor(sum, off); sumsq += __shfl_xor(sumsq, off);

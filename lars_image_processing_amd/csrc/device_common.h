@@ -34,14 +34,52 @@ __device__ inline float norm_diff(float a, float b)
     return d / (s == 0.0f ? 1.0f : s);
 }
 
-// bin of numpy.histogram(bins=50, range=(-1,1)) for float32 x in [-1, 1]
-__device__ inline int hist_bin_f32(float x, const float *edges)
+// Bin of numpy.histogram(bins=50, range=(-1,1)) for x in [-1, 1] without searching the edges.
+// [-1, 1] is cut into 64 cells of width 1/32 (< the bin width 0.04, so a cell holds at most one
+// edge).  cell = trunc((x+1)*32); entry = {the edge inside the cell or +inf, number of edges below
+// the cell - 1}; bin = base + (x >= edge).  Rounding of x+1 can only move x onto a cell boundary
+// from below, and edges that coincide with a boundary (-1, 0) are stored as that cell's edge, so
+// the compare still classifies such an x correctly.  The last edge (1.0) is not counted: the last
+// bin is closed.
+#define LARS_HIST_CELLS 65
+template <typename T>
+struct HistCell {
+    T edge;
+    long long base;      // same size as a double edge; int would do
+};
+template <>
+struct HistCell<float> {
+    float edge;
+    int base;
+};
+template <typename T>
+__device__ inline void hist_cells_init(HistCell<T> *cells, int tid)
 {
-    int b = (int)((x + 1.0f) * 25.0f);
-    b = b < 0 ? 0 : (b > LARS_HIST_BINS - 1 ? LARS_HIST_BINS - 1 : b);
-    if (x < edges[b]) --b;
-    else if (b != LARS_HIST_BINS - 1 && x >= edges[b + 1]) ++b;
-    return b;
+    if (tid < LARS_HIST_CELLS) {
+        const T lo = (T)tid / (T)32 - (T)1, hi = (T)(tid + 1) / (T)32 - (T)1;
+        int below = 0;
+        T inside = (T)__builtin_inf();
+        for (int i = 0; i < LARS_HIST_BINS; ++i) {            // edges 0..49; edge 50 closes the last bin
+            const T e = (T)hist_edge_f64(i);
+            if (e < lo) ++below;
+            else if (e < hi) inside = e;
+        }
+        cells[tid].edge = inside;
+        cells[tid].base = below - 1;
+    }
+}
+template <typename T>
+__device__ inline int hist_bin_cell(T x, const HistCell<T> *cells)
+{
+    const int c = (int)__builtin_fma(x, (T)32, (T)32);
+    const HistCell<T> e = cells[c];
+    return (int)e.base + (x >= e.edge ? 1 : 0);
+}
+__device__ inline int hist_bin_f32(float x, const HistCell<float> *cells)
+{
+    const int c = (int)__builtin_fmaf(x, 32.0f, 32.0f);
+    const HistCell<float> e = cells[c];
+    return e.base + (x >= e.edge ? 1 : 0);
 }
 
 __device__ inline unsigned int cmap_index(float x)

@@ -222,7 +222,7 @@ __global__ void k_stats_finalize(lars_stats *stats, long long nrec, unsigned int
 // The fused kernel
 // ===========================================================================
 template <int STATS>
-__device__ inline void acc_push(Acc &a, float x, float thr, unsigned int *s_hist, const float *s_edges)
+__device__ inline void acc_push(Acc &a, float x, float thr, unsigned int *s_hist, const HistCell<float> *s_edges)
 {
     if (STATS >= 1) {
         a.mn = fminf(a.mn, x);
@@ -280,7 +280,7 @@ __device__ inline void acc_flush(Acc a, StatsAccView *rec, double (*s_red)[4], i
 template <unsigned MASK, int STATS, bool RT_MASK>
 __device__ inline void pixel_math(float r, float g, float n, unsigned rt_mask,
                                   float &o_ndvi, float &o_gndvi, float &o_ndwi,
-                                  Acc *acc, unsigned int *s_hist, const float *s_edges)
+                                  Acc *acc, unsigned int *s_hist, const HistCell<float> *s_edges)
 {
     const bool want_ndvi = RT_MASK ? (rt_mask & 1u) : (MASK & 1u);
     const bool want_gndvi = RT_MASK ? (rt_mask & 2u) : (MASK & 2u);
@@ -312,7 +312,7 @@ __global__ __launch_bounds__(256) void k_fused_u8c3(FusedParams P)
 {
     __shared__ uint8_t s_lut[3 * 256];
     __shared__ unsigned int s_hist[3 * LARS_HIST_BINS];
-    __shared__ float s_edges[LARS_HIST_BINS + 1];
+    __shared__ HistCell<float> s_edges[LARS_HIST_CELLS];
     __shared__ double s_red[4][4];
 
     const int tid = threadIdx.x;
@@ -326,7 +326,7 @@ __global__ __launch_bounds__(256) void k_fused_u8c3(FusedParams P)
     }
     if (STATS >= 2) {
         for (int i = tid; i < 3 * LARS_HIST_BINS; i += 256) s_hist[i] = 0;
-        if (tid <= LARS_HIST_BINS) s_edges[tid] = (float)hist_edge_f64(tid);
+        hist_cells_init<float>(s_edges, tid);
     }
     if (WB || STATS >= 2) __syncthreads();
 
@@ -419,7 +419,7 @@ template <typename PIX, int NVAL>
 __global__ __launch_bounds__(256) void k_fused_generic(FusedParams P)
 {
     __shared__ unsigned int s_hist[3 * LARS_HIST_BINS];
-    __shared__ float s_edges[LARS_HIST_BINS + 1];
+    __shared__ HistCell<float> s_edges[LARS_HIST_CELLS];
     __shared__ double s_red[4][4];
 
     const int tid = threadIdx.x;
@@ -433,7 +433,7 @@ __global__ __launch_bounds__(256) void k_fused_generic(FusedParams P)
     const uint8_t *tab = P.wb_table ? P.wb_table + tile * 3 * (long long)NVAL : nullptr;
 
     for (int i = tid; i < 3 * LARS_HIST_BINS; i += 256) s_hist[i] = 0;
-    if (tid <= LARS_HIST_BINS) s_edges[tid] = (float)hist_edge_f64(tid);
+    hist_cells_init<float>(s_edges, tid);
     __syncthreads();
 
     Acc acc[3];
@@ -561,7 +561,7 @@ extern "C" int lars_d_channel_hist(const void *tiles, int64_t ntiles, int64_t np
     LARS_HIP_TRY(hipMemsetAsync(hist, 0, (size_t)ntiles * 3 * nval * sizeof(uint32_t), s));
     const bool fast = dtype == LARS_U8 && channels == 3 && (ntiles == 1 || (npix & 3) == 0) &&
                       ((reinterpret_cast<uintptr_t>(tiles) & 3) == 0);
-    if (fast && tuning().hist_impl >= 2) {
+    if (fast && tuning().hist_impl >= 2 && (long long)npix * 3 < (1ll << 30)) {
         // 96 KiB of LDS per block: one 1024-thread block per CU, a few waves of blocks per tile
         long long want = tuning().blocks_per_tile > 0 ? tuning().blocks_per_tile : (1024 + ntiles - 1) / ntiles;
         const long long cap = (npix / 4 + 1023) / 1024;
@@ -669,7 +669,9 @@ extern "C" int lars_d_fused(const lars_fused_args *a)
                          P.out_rgba[1] || P.out_rgba[2];
     int impl = tuning().fused_impl;
     if (impl == 0) impl = (any_out && mask != 0u) ? 1 : 2;
-    if (fast && impl >= 2) {
+    // the second-generation kernels address a tile through a raw buffer descriptor with 32-bit offsets
+    const bool small_tile = (long long)a->npix * 3 < (1ll << 30);
+    if (fast && impl >= 2 && small_tile) {
         dim3 grid(blocks_per_tile(a->npix / 4 + 1, a->ntiles, 512), (unsigned)a->ntiles);
         fused_v2_launch(mask, a->wb_table != nullptr, stats_mode, tuning().nt_stores != 0, grid, s, P);
     } else if (fast) {

@@ -227,7 +227,7 @@ __device__ inline void push(WaveAcc &a, unsigned int &above, float x, float thr)
     above += (unsigned int)__popcll(__ballot(x > thr));              // wave-uniform scalar counter
 }
 
-__device__ inline void hist_add(unsigned int *s_hist, const float *s_edges, int index, float x, unsigned int lane32)
+__device__ inline void hist_add(unsigned int *s_hist, const HistCell<float> *s_edges, int index, float x, unsigned int lane32)
 {
     const int b = hist_bin_f32(x, s_edges);
     atomicAdd(&s_hist[(index * LARS_HIST_BINS + b) * V2_HIST_COPIES + (lane32 & (V2_HIST_COPIES - 1))], 1u);
@@ -237,11 +237,11 @@ template <unsigned MASK, bool WB, int STATS, bool OUT, bool NT>
 __global__ __launch_bounds__(512, 4) void k_fused_v2(FusedParams P)
 {
     __shared__ __attribute__((aligned(16))) char s_mem[(WB ? V2_TABLE_BYTES : 0) +
-                                                       (STATS >= 2 ? V2_HIST_WORDS * 4 + 64 * 4 : 0) + 8 * 16 * sizeof(double)];
+                                                       (STATS >= 2 ? V2_HIST_WORDS * 4 + 66 * 8 : 0) + 8 * 16 * sizeof(double)];
     char *s_tab = s_mem;                                                             // 64 KiB when WB
     unsigned int *s_hist = reinterpret_cast<unsigned int *>(s_mem + (WB ? V2_TABLE_BYTES : 0));
-    float *s_edges = reinterpret_cast<float *>(s_hist + (STATS >= 2 ? V2_HIST_WORDS : 0));
-    double *s_red = reinterpret_cast<double *>(s_edges + (STATS >= 2 ? 64 : 0));     // [8 waves][16]
+    HistCell<float> *s_edges = reinterpret_cast<HistCell<float> *>(s_hist + (STATS >= 2 ? V2_HIST_WORDS : 0));
+    double *s_red = reinterpret_cast<double *>(s_edges + (STATS >= 2 ? 66 : 0));     // [8 waves][16]
 
     constexpr bool NEED_R = (MASK & 1u) != 0;
     constexpr bool NEED_G = (MASK & 6u) != 0;
@@ -266,7 +266,7 @@ __global__ __launch_bounds__(512, 4) void k_fused_v2(FusedParams P)
     }
     if (STATS >= 2) {
         for (int i = tid; i < V2_HIST_WORDS; i += 512) s_hist[i] = 0;
-        if (tid <= LARS_HIST_BINS) s_edges[tid] = (float)hist_edge_f64(tid);
+        hist_cells_init<float>(s_edges, tid);
     }
     if (WB || STATS >= 2) __syncthreads();
 

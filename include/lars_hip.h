@@ -133,7 +133,7 @@ int lars_d_channel_hist(const void *tiles, int64_t ntiles, int64_t npix, int cha
                         int dtype, uint32_t *hist, void *stream);
 
 /* Histograms -> percentiles (2, 98) -> white-balance table, all on device.
- * table is [ntiles][3][nvalues] uint8 with table[t][c][v] == fix_white_balance()
+ * table is [ntiles] x lars_wb_table_bytes(dtype) with table[t][c][v] == fix_white_balance()
  * of sample value v in channel c of tile t (process-images.py:437-441: float64
  * arithmetic, clip, float32 store, truncating uint8 cast).  percentiles is
  * [ntiles][3][2] double (may be NULL).  rgn_variant != 0 selects process-rgn.py
@@ -141,13 +141,26 @@ int lars_d_channel_hist(const void *tiles, int64_t ntiles, int64_t npix, int cha
 int lars_d_wb_table(const uint32_t *hist, int64_t ntiles, int64_t npix, int dtype,
                     uint8_t *table, double *percentiles, int rgn_variant, void *stream);
 
+/* Bytes of one tile's white-balance table: 768 for LARS_U8 ([3][256] uint8); for LARS_U16 a blob of
+ * 196608 + 4096 bytes: the [3][65536] uint8 table, then its threshold form (uint32 T[3][260],
+ * T[c][k] = smallest sample value with table >= k) and double {p2, 255/(p98-p2)}[3] used by the
+ * fast uint16 kernel.  wb_table arguments are [ntiles] of these. */
+size_t lars_wb_table_bytes(int dtype);
+
+/* The whole white-balance pre-pass of a batch in one call (histogram pass(es) + tables), both
+ * sample types.  For LARS_U16 the percentiles come from a two-level radix pass (high-byte
+ * histograms, then low-byte histograms of the bins that hold the order statistics) instead of a
+ * 65536-bin histogram per channel.  Scratch comes from the calling thread's library workspace. */
+int lars_d_wb_prepare(const void *tiles, int64_t ntiles, int64_t npix, int channels, int dtype,
+                      uint8_t *table, double *percentiles, int rgn_variant, void *stream);
+
 typedef struct lars_fused_args {
     const void    *tiles;          /* [ntiles][h*w][channels] interleaved R,G,NIR(,...) */
     int64_t        ntiles;
     int64_t        npix;           /* h*w */
     int32_t        channels;       /* >= 3 */
     int32_t        dtype;          /* LARS_U8 | LARS_U16 */
-    const uint8_t *wb_table;       /* [ntiles][3][nvalues] or NULL: indices of the raw samples */
+    const uint8_t *wb_table;       /* [ntiles] x lars_wb_table_bytes(dtype), or NULL: indices of the raw samples */
     uint32_t       index_mask;     /* LARS_MASK_* */
     uint32_t       flags;          /* LARS_F_* */
     float         *out_index[3];   /* [ntiles][npix] float32 per index, or NULL */

@@ -89,6 +89,8 @@ SIGNATURES = {
     "lars_event_elapsed_ms": (_I, [_P, _P, C.POINTER(_F)]),
     "lars_d_channel_hist": (_I, [_P, _I64, _I64, _I, _I, _P, _P]),
     "lars_d_wb_table": (_I, [_P, _I64, _I64, _I, _P, _P, _I, _P]),
+    "lars_wb_table_bytes": (_SZ, [_I]),
+    "lars_d_wb_prepare": (_I, [_P, _I64, _I64, _I, _I, _P, _P, _I, _P]),
     "lars_d_fused": (_I, [C.POINTER(FusedArgs)]),
     "lars_d_index_planes_f32": (_I, [_P, _P, _P, _I64, _I, _P, _P]),
     "lars_d_ndvi_f64": (_I, [_P, _I64, _I, _I, _P, _P]),

@@ -42,6 +42,7 @@ class TileBatch:
         self.first_tile = int(first_tile)
         self.npix = self.h * self.w
         self.nvalues = 256 if self.code == _ffi.U8 else 65536
+        self.table_bytes = int(_ffi.load().lars_wb_table_bytes(self.code))     # per tile
         self.tile_bytes = self.npix * self.channels * self.dtype.itemsize
         self.tiles = DeviceBuffer(self.ntiles * self.tile_bytes)
         self.hist = None
@@ -74,24 +75,32 @@ class TileBatch:
     # -- pass 1: white-balance tables --------------------------------------
     def compute_wb_tables(self, stream=None, rgn_variant=0):
         """np.percentile(ch, (2, 98)) per tile and channel -> 8-bit tables, on device."""
-        if self.hist is None:
-            self.hist = DeviceBuffer(self.ntiles * 3 * self.nvalues * 4)
-            self.table = DeviceBuffer(self.ntiles * 3 * self.nvalues)
+        if self.table is None:
+            self.table = DeviceBuffer(self.ntiles * self.table_bytes)
             self.percentiles = DeviceBuffer(self.ntiles * 3 * 2 * 8)
-        _ffi.call("lars_d_channel_hist", C.c_void_p(self.tiles.ptr), self.ntiles, self.npix, self.channels, self.code,
-                  C.c_void_p(self.hist.ptr), stream)
-        _ffi.call("lars_d_wb_table", C.c_void_p(self.hist.ptr), self.ntiles, self.npix, self.code,
-                  C.c_void_p(self.table.ptr), C.c_void_p(self.percentiles.ptr), int(rgn_variant), stream)
+        if self.code == _ffi.U8:
+            if self.hist is None:
+                self.hist = DeviceBuffer(self.ntiles * 3 * 256 * 4)
+            _ffi.call("lars_d_channel_hist", C.c_void_p(self.tiles.ptr), self.ntiles, self.npix, self.channels,
+                      self.code, C.c_void_p(self.hist.ptr), stream)
+            _ffi.call("lars_d_wb_table", C.c_void_p(self.hist.ptr), self.ntiles, self.npix, self.code,
+                      C.c_void_p(self.table.ptr), C.c_void_p(self.percentiles.ptr), int(rgn_variant), stream)
+        else:
+            # uint16: two-level radix percentiles, no 65536-bin histograms
+            _ffi.call("lars_d_wb_prepare", C.c_void_p(self.tiles.ptr), self.ntiles, self.npix, self.channels,
+                      self.code, C.c_void_p(self.table.ptr), C.c_void_p(self.percentiles.ptr), int(rgn_variant), stream)
         return self
 
     def host_tables(self):
-        return self.table.download(np.uint8, (self.ntiles, 3, self.nvalues))
+        blob = self.table.download(np.uint8, (self.ntiles, self.table_bytes))
+        return np.ascontiguousarray(blob[:, :3 * self.nvalues]).reshape(self.ntiles, 3, self.nvalues)
 
     def host_percentiles(self):
         return self.percentiles.download(np.float64, (self.ntiles, 3, 2))
 
     def host_hist(self):
-        return self.hist.download(np.uint32, (self.ntiles, 3, self.nvalues))
+        """uint8 batches only (uint16 percentiles come from two radix levels, no full histogram)."""
+        return self.hist.download(np.uint32, (self.ntiles, 3, 256))
 
     # -- pass 2: the fused kernel ------------------------------------------
     def make_outputs(self, indices=INDEX_NAMES, index=False, wb=False, rgba=False, ring=None):
@@ -108,7 +117,7 @@ class TileBatch:
         if white_balance:
             if self.table is None:
                 raise RuntimeError("compute_wb_tables() first")
-            a.wb_table = self.table.ptr + tile_start * 3 * self.nvalues
+            a.wb_table = self.table.ptr + tile_start * self.table_bytes
         mask = 0
         for t in indices:
             mask |= 1 << INDEX_IDS[t]

@@ -92,6 +92,11 @@ __host__ __device__ inline double hist_edge_f64(int i) {
     return i >= LARS_HIST_BINS ? 1.0 : (double)i * (2.0 / 50.0) + (-1.0);
 }
 
+// white-balance table blob of a uint16 tile: [3][65536] uint8 table | uint32 thr[3][260] | double par[3][2]
+#define LARS_U16_THR_OFFSET 196608
+#define LARS_U16_PAR_OFFSET (196608 + 3 * 260 * 4)
+#define LARS_U16_BLOB_BYTES (196608 + 4096)
+
 // launch geometry helpers (host)
 int launch_check(const char *what);
 

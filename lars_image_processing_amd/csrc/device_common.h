@@ -91,4 +91,44 @@ __device__ inline unsigned int cmap_index(float x)
 }
 
 
+// White-balance level of sample value v: process-images.py:438/:441 (float64 arithmetic, clip,
+// float32 store, truncating uint8 cast) or process-rgn.py:29-33/:44 (inner clip, direct cast).
+__device__ inline unsigned int wb_level(int v, double p_lo, double p_hi, int rgn_variant)
+{
+    double x = (double)v;
+    if (rgn_variant) x = fmin(fmax(x, p_lo), p_hi);
+    double y = (x - p_lo) / (p_hi - p_lo) * 255.0;
+    if (y != y) return 0u;                                  // NaN -> uint8 cast gives 0
+    y = y < 0.0 ? 0.0 : (y > 255.0 ? 255.0 : y);
+    return rgn_variant ? (unsigned int)(int)y : (unsigned int)(int)(float)y;
+}
+
+// Fill one channel of a uint16 tile's table blob: the 65536-entry table, its threshold form
+// T[k] = smallest v with table[v] >= k (T[0] = 0, T[256..] = 65536), and (p2, 255/(p98-p2)).
+// 256 threads; s_thr is 260 words of LDS.
+__device__ inline void u16_fill_blob(uint8_t *blob, int c, double p_lo, double p_hi, int rgn_variant,
+                                     unsigned int *s_thr, int tid)
+{
+    for (int k = tid; k < 260; k += 256) s_thr[k] = 65536u;
+    __syncthreads();
+    uint8_t *out = blob + (long long)c * 65536;
+    unsigned int prev = tid == 0 ? 0u : wb_level(tid * 256 - 1, p_lo, p_hi, rgn_variant);
+    for (int j = 0; j < 256; ++j) {
+        const int v = tid * 256 + j;
+        const unsigned int o = wb_level(v, p_lo, p_hi, rgn_variant);
+        out[v] = (uint8_t)o;
+        for (unsigned int k = prev + 1; k <= o; ++k) s_thr[k] = (unsigned)v;     // monotone staircase
+        prev = o > prev ? o : prev;
+    }
+    __syncthreads();
+    unsigned int *thr = reinterpret_cast<unsigned int *>(blob + LARS_U16_THR_OFFSET) + c * 260;
+    for (int k = tid; k < 260; k += 256) thr[k] = k == 0 ? 0u : (k >= 256 ? 65536u : s_thr[k]);
+    if (tid == 0) {
+        double *par = reinterpret_cast<double *>(blob + LARS_U16_PAR_OFFSET) + c * 2;
+        const double span = p_hi - p_lo;
+        par[0] = p_lo;
+        par[1] = span > 0.0 ? 255.0 / span : 1e300;        // degenerate channel: <= p -> 0, above -> 255
+    }
+}
+
 }  // namespace lars

@@ -111,6 +111,7 @@ __global__ __launch_bounds__(256) void k_wb_table(const unsigned int *__restrict
     __shared__ unsigned long long s_scan[256];
     __shared__ double s_val[4];                       // order statistics: q2.lo q2.hi q98.lo q98.hi
     __shared__ double s_p[2];
+    __shared__ unsigned int s_thr[NVAL == 256 ? 4 : 260];
 
     const int tid = threadIdx.x;
     const long long slot = (long long)blockIdx.y * 3 + blockIdx.x;   // tile*3 + channel
@@ -165,22 +166,12 @@ __global__ __launch_bounds__(256) void k_wb_table(const unsigned int *__restrict
     }
     __syncthreads();
     const double p_lo = s_p[0], p_hi = s_p[1];
-    const double span = p_hi - p_lo;
-    uint8_t *out = table + slot * NVAL;
-    for (int v = tid; v < NVAL; v += 256) {
-        double x = (double)v;
-        if (rgn_variant) x = fmin(fmax(x, p_lo), p_hi);          // process-rgn.py:29
-        double y = (x - p_lo) / span * 255.0;                     // process-images.py:438
-        uint8_t o;
-        if (y != y) {
-            o = 0;                                               // NaN -> uint8 cast gives 0
-        } else {
-            y = y < 0.0 ? 0.0 : (y > 255.0 ? 255.0 : y);
-            // app flavour stores into a float32 array before the uint8 cast (:438,:441);
-            // process-rgn.py casts the float64 value directly (:44)
-            o = rgn_variant ? (uint8_t)(int)y : (uint8_t)(int)(float)y;
-        }
-        out[v] = o;
+    if (NVAL == 256) {
+        uint8_t *out = table + slot * 256;
+        out[tid] = (uint8_t)wb_level(tid, p_lo, p_hi, rgn_variant);
+    } else {
+        // uint16: the table lives in the tile's blob together with its threshold form
+        u16_fill_blob(table + (long long)blockIdx.y * LARS_U16_BLOB_BYTES, (int)blockIdx.x, p_lo, p_hi, rgn_variant, s_thr, tid);
     }
 }
 
@@ -307,10 +298,21 @@ __device__ inline void pixel_math(float r, float g, float n, unsigned rt_mask,
 // load (a wave reads 768 contiguous bytes), one float4 store per index plane
 // (1 KiB contiguous per wave), one 12-byte store of the white-balanced image,
 // one 16-byte store per colormapped plane.
-template <unsigned MASK, bool WB, int STATS>
+//
+// The same kernel serves uint16 tiles (PIX = uint16_t): 24 bytes per lane and step, white balance by
+// "guess and correct" against the table's threshold form T[k] (smallest v with table[v] >= k, kept in
+// LDS): g = trunc((v - p2) * 255/(p98 - p2)) in float64 is within one level of the reference's
+// trunc(float32(float64 expression)), and two threshold compares settle it exactly.
+typedef unsigned int fu32x4 __attribute__((ext_vector_type(4)));
+typedef unsigned int fu32x2 __attribute__((ext_vector_type(2)));
+
+template <typename PIX, unsigned MASK, bool WB, int STATS>
 __global__ __launch_bounds__(256) void k_fused_u8c3(FusedParams P)
 {
-    __shared__ uint8_t s_lut[3 * 256];
+    constexpr bool U16 = sizeof(PIX) == 2;
+    __shared__ uint8_t s_lut[U16 ? 16 : 3 * 256];
+    __shared__ unsigned int s_thr[U16 ? 3 * 260 : 4];
+    __shared__ double s_par[U16 ? 6 : 1];
     __shared__ unsigned int s_hist[3 * LARS_HIST_BINS];
     __shared__ HistCell<float> s_edges[LARS_HIST_CELLS];
     __shared__ double s_red[4][4];
@@ -318,17 +320,36 @@ __global__ __launch_bounds__(256) void k_fused_u8c3(FusedParams P)
     const int tid = threadIdx.x;
     const long long tile = blockIdx.y;
     const long long npix = P.npix;
-    const uint8_t *base = static_cast<const uint8_t *>(P.tiles) + tile * npix * 3;
+    const PIX *base = static_cast<const PIX *>(P.tiles) + tile * npix * 3;
 
     if (WB) {
-        const uint8_t *t = P.wb_table + tile * 768;
-        for (int i = tid; i < 768; i += 256) s_lut[i] = t[i];
+        if (U16) {
+            const uint8_t *blob = P.wb_table + tile * LARS_U16_BLOB_BYTES;
+            const unsigned int *thr = reinterpret_cast<const unsigned int *>(blob + LARS_U16_THR_OFFSET);
+            const double *par = reinterpret_cast<const double *>(blob + LARS_U16_PAR_OFFSET);
+            for (int i = tid; i < 3 * 260; i += 256) s_thr[i] = thr[i];
+            if (tid < 6) s_par[tid] = par[tid];
+        } else {
+            const uint8_t *t = P.wb_table + tile * 768;
+            for (int i = tid; i < 768; i += 256) s_lut[i] = t[i];
+        }
     }
     if (STATS >= 2) {
         for (int i = tid; i < 3 * LARS_HIST_BINS; i += 256) s_hist[i] = 0;
         hist_cells_init<float>(s_edges, tid);
     }
     if (WB || STATS >= 2) __syncthreads();
+
+    // white balance of one sample of channel c
+    auto wb_map = [&](unsigned int v, int c) -> unsigned int {
+        if (!U16) return s_lut[c * 256 + v];
+        const double y = ((double)v - s_par[2 * c]) * s_par[2 * c + 1];
+        int g = (int)y;                                        // saturating; NaN -> 0
+        g = g < 0 ? 0 : (g > 255 ? 255 : g);
+        const unsigned int *t = s_thr + c * 260;
+        g += (v >= t[g + 1] ? 1 : 0) - (v < t[g] ? 1 : 0);
+        return (unsigned int)g;
+    };
 
     Acc acc[3];
     acc_init(acc[0]); acc_init(acc[1]); acc_init(acc[2]);
@@ -346,15 +367,29 @@ __global__ __launch_bounds__(256) void k_fused_u8c3(FusedParams P)
 
     const long long nquads = npix >> 2;
     const long long stride = (long long)gridDim.x * 256;
+    __amdgpu_buffer_rsrc_t rsrc16;
+    if (U16) rsrc16 = __builtin_amdgcn_make_buffer_rsrc(const_cast<PIX *>(base), 0, (int)(nquads * 24), 0x00020000);
     for (long long q = (long long)blockIdx.x * 256 + tid; q < nquads; q += stride) {
-        const unsigned int *p = reinterpret_cast<const unsigned int *>(base + q * 12);
-        unsigned int w0 = p[0], w1 = p[1], w2 = p[2];
-        unsigned int b[12] = {w0 & 0xFF, (w0 >> 8) & 0xFF, (w0 >> 16) & 0xFF, w0 >> 24,
-                              w1 & 0xFF, (w1 >> 8) & 0xFF, (w1 >> 16) & 0xFF, w1 >> 24,
-                              w2 & 0xFF, (w2 >> 8) & 0xFF, (w2 >> 16) & 0xFF, w2 >> 24};
+        unsigned int b[12];
+        if (U16) {
+            const unsigned int off = (unsigned int)q * 24u;
+            const fu32x4 a4 = __builtin_amdgcn_raw_buffer_load_b128(rsrc16, off, 0, 0);
+            const fu32x2 a2 = __builtin_amdgcn_raw_buffer_load_b64(rsrc16, off + 16u, 0, 0);
+            const unsigned int w[6] = {a4.x, a4.y, a4.z, a4.w, a2.x, a2.y};
+#pragma unroll
+            for (int i = 0; i < 6; ++i) { b[2 * i] = w[i] & 0xFFFFu; b[2 * i + 1] = w[i] >> 16; }
+        } else {
+            const unsigned int *p = reinterpret_cast<const unsigned int *>(reinterpret_cast<const uint8_t *>(base) + q * 12);
+            const unsigned int w0 = p[0], w1 = p[1], w2 = p[2];
+            const unsigned int t[12] = {w0 & 0xFF, (w0 >> 8) & 0xFF, (w0 >> 16) & 0xFF, w0 >> 24,
+                                        w1 & 0xFF, (w1 >> 8) & 0xFF, (w1 >> 16) & 0xFF, w1 >> 24,
+                                        w2 & 0xFF, (w2 >> 8) & 0xFF, (w2 >> 16) & 0xFF, w2 >> 24};
+#pragma unroll
+            for (int i = 0; i < 12; ++i) b[i] = t[i];
+        }
         if (WB) {
 #pragma unroll
-            for (int i = 0; i < 12; ++i) b[i] = s_lut[(i % 3) * 256 + b[i]];
+            for (int i = 0; i < 12; ++i) b[i] = wb_map(b[i], i % 3);
             if (owb) {
                 unsigned int *o = reinterpret_cast<unsigned int *>(owb + q * 12);
                 o[0] = b[0] | (b[1] << 8) | (b[2] << 16) | (b[3] << 24);
@@ -386,7 +421,7 @@ __global__ __launch_bounds__(256) void k_fused_u8c3(FusedParams P)
     if (blockIdx.x == 0 && tid < (int)(npix & 3)) {
         const long long i = nquads * 4 + tid;
         unsigned int r = base[i * 3], g = base[i * 3 + 1], n = base[i * 3 + 2];
-        if (WB) { r = s_lut[r]; g = s_lut[256 + g]; n = s_lut[512 + n]; }
+        if (WB) { r = wb_map(r, 0); g = wb_map(g, 1); n = wb_map(n, 2); }
         if (WB && owb) { owb[i * 3] = (uint8_t)r; owb[i * 3 + 1] = (uint8_t)g; owb[i * 3 + 2] = (uint8_t)n; }
         float a = 0, bq = 0, c = 0;
         pixel_math<MASK, STATS, false>((float)r, (float)g, (float)n, 0u, a, bq, c, acc, s_hist, s_edges);
@@ -430,7 +465,7 @@ __global__ __launch_bounds__(256) void k_fused_generic(FusedParams P)
     const bool stats = P.flags & (LARS_F_STATS | LARS_F_HIST);
     const bool hist = P.flags & LARS_F_HIST;
     const PIX *base = static_cast<const PIX *>(P.tiles) + tile * npix * C;
-    const uint8_t *tab = P.wb_table ? P.wb_table + tile * 3 * (long long)NVAL : nullptr;
+    const uint8_t *tab = P.wb_table ? P.wb_table + tile * (NVAL == 256 ? 768ll : (long long)LARS_U16_BLOB_BYTES) : nullptr;
 
     for (int i = tid; i < 3 * LARS_HIST_BINS; i += 256) s_hist[i] = 0;
     hist_cells_init<float>(s_edges, tid);
@@ -603,18 +638,29 @@ extern "C" int lars_d_wb_table(const uint32_t *hist, int64_t ntiles, int64_t npi
     return launch_check("lars_d_wb_table");
 }
 
-template <unsigned MASK, bool WB>
+template <typename PIX, unsigned MASK, bool WB>
 static void launch_fast_stats(int stats_mode, dim3 grid, hipStream_t s, const FusedParams &P)
 {
-    if (stats_mode == 0) hipLaunchKernelGGL((k_fused_u8c3<MASK, WB, 0>), grid, dim3(256), 0, s, P);
-    else if (stats_mode == 1) hipLaunchKernelGGL((k_fused_u8c3<MASK, WB, 1>), grid, dim3(256), 0, s, P);
-    else hipLaunchKernelGGL((k_fused_u8c3<MASK, WB, 2>), grid, dim3(256), 0, s, P);
+    if (stats_mode == 0) hipLaunchKernelGGL((k_fused_u8c3<PIX, MASK, WB, 0>), grid, dim3(256), 0, s, P);
+    else if (stats_mode == 1) hipLaunchKernelGGL((k_fused_u8c3<PIX, MASK, WB, 1>), grid, dim3(256), 0, s, P);
+    else hipLaunchKernelGGL((k_fused_u8c3<PIX, MASK, WB, 2>), grid, dim3(256), 0, s, P);
 }
-template <unsigned MASK>
+template <typename PIX, unsigned MASK>
 static void launch_fast_wb(bool wb, int stats_mode, dim3 grid, hipStream_t s, const FusedParams &P)
 {
-    if (wb) launch_fast_stats<MASK, true>(stats_mode, grid, s, P);
-    else launch_fast_stats<MASK, false>(stats_mode, grid, s, P);
+    if (wb) launch_fast_stats<PIX, MASK, true>(stats_mode, grid, s, P);
+    else launch_fast_stats<PIX, MASK, false>(stats_mode, grid, s, P);
+}
+template <typename PIX>
+static void launch_fast(unsigned mask, bool wb, int stats_mode, dim3 grid, hipStream_t s, const FusedParams &P)
+{
+    switch (mask) {
+    case 0u: hipLaunchKernelGGL((k_fused_u8c3<PIX, 0u, true, 0>), grid, dim3(256), 0, s, P); break;
+    case 1u: launch_fast_wb<PIX, 1u>(wb, stats_mode, grid, s, P); break;
+    case 2u: launch_fast_wb<PIX, 2u>(wb, stats_mode, grid, s, P); break;
+    case 4u: launch_fast_wb<PIX, 4u>(wb, stats_mode, grid, s, P); break;
+    default: launch_fast_wb<PIX, 7u>(wb, stats_mode, grid, s, P); break;
+    }
 }
 
 extern "C" int lars_d_fused(const lars_fused_args *a)
@@ -660,8 +706,7 @@ extern "C" int lars_d_fused(const lars_fused_args *a)
     // the specialised kernels exist for "white balance only" (0), one index (1, 2, 4) and all three (7);
     // two-index masks take the generic kernel so that unrequested records stay untouched
     const bool mask_ok = mask == 0u || mask == 1u || mask == 2u || mask == 4u || mask == 7u;
-    const bool fast = a->dtype == LARS_U8 && a->channels == 3 && aligned && mask_ok &&
-                      (a->ntiles == 1 || (a->npix & 3) == 0);
+    const bool fast = a->channels == 3 && aligned && mask_ok && (a->ntiles == 1 || (a->npix & 3) == 0);
     // fused_impl 0 = automatic: the second-generation kernels win where the launch is read-bound
     // (statistics only); with output planes the launch is write-bound and the lighter first-generation
     // kernel (more resident waves, no LDS table) is as fast or faster (tools/kbench.py)
@@ -670,20 +715,16 @@ extern "C" int lars_d_fused(const lars_fused_args *a)
     int impl = tuning().fused_impl;
     if (impl == 0) impl = (any_out && mask != 0u) ? 1 : 2;
     // the second-generation kernels address a tile through a raw buffer descriptor with 32-bit offsets
-    const bool small_tile = (long long)a->npix * 3 < (1ll << 30);
-    if (fast && impl >= 2 && small_tile) {
+    const bool small_tile = (long long)a->npix * 6 < (1ll << 30);
+    if (fast && a->dtype == LARS_U8 && impl >= 2 && small_tile) {
         dim3 grid(blocks_per_tile(a->npix / 4 + 1, a->ntiles, 512), (unsigned)a->ntiles);
         fused_v2_launch(mask, a->wb_table != nullptr, stats_mode, tuning().nt_stores != 0, grid, s, P);
-    } else if (fast) {
+    } else if (fast && a->dtype == LARS_U8) {
         dim3 grid(blocks_per_tile(a->npix / 4 + 1, a->ntiles), (unsigned)a->ntiles);
-        const bool wb = a->wb_table != nullptr;
-        switch (mask) {
-        case 0u: hipLaunchKernelGGL((k_fused_u8c3<0u, true, 0>), grid, dim3(256), 0, s, P); break;
-        case 1u: launch_fast_wb<1u>(wb, stats_mode, grid, s, P); break;
-        case 2u: launch_fast_wb<2u>(wb, stats_mode, grid, s, P); break;
-        case 4u: launch_fast_wb<4u>(wb, stats_mode, grid, s, P); break;
-        default: launch_fast_wb<7u>(wb, stats_mode, grid, s, P); break;
-        }
+        launch_fast<uint8_t>(mask, a->wb_table != nullptr, stats_mode, grid, s, P);
+    } else if (fast && a->dtype == LARS_U16 && small_tile) {
+        dim3 grid(blocks_per_tile(a->npix / 4 + 1, a->ntiles), (unsigned)a->ntiles);
+        launch_fast<uint16_t>(mask, a->wb_table != nullptr, stats_mode, grid, s, P);
     } else {
         dim3 grid(blocks_per_tile(a->npix, a->ntiles), (unsigned)a->ntiles);
         if (a->dtype == LARS_U8) hipLaunchKernelGGL((k_fused_generic<uint8_t, 256>), grid, dim3(256), 0, s, P);

@@ -55,8 +55,9 @@ Layout plan(const ImageJob &j, void *base)
     const size_t esz = j.dtype == LARS_U8 ? 1 : 2;
     const size_t nval = j.dtype == LARS_U8 ? 256 : 65536;
     L.img = c.take<uint8_t>(npix * j.channels * esz);
-    L.hist = j.apply_wb ? c.take<uint32_t>(3 * nval) : nullptr;
-    L.table = j.apply_wb ? c.take<uint8_t>(3 * nval) : nullptr;
+    L.hist = nullptr;
+    (void)nval;
+    L.table = j.apply_wb ? c.take<uint8_t>(lars_wb_table_bytes(j.dtype)) : nullptr;
     L.pcts = j.apply_wb ? c.take<double>(6) : nullptr;
     L.wb = (j.apply_wb && j.out_wb) ? c.take<uint8_t>(npix * j.channels) : nullptr;
     for (int k = 0; k < 3; ++k) {
@@ -89,8 +90,7 @@ int run_image(const ImageJob &j)
 
     LARS_HIP_TRY(hipMemcpyAsync(L.img, j.img, npix * j.channels * esz, hipMemcpyHostToDevice, s));
     if (j.apply_wb) {
-        LARS_TRY(lars_d_channel_hist(L.img, 1, (int64_t)npix, j.channels, j.dtype, L.hist, s));
-        LARS_TRY(lars_d_wb_table(L.hist, 1, (int64_t)npix, j.dtype, L.table, L.pcts, j.wb_variant, s));
+        LARS_TRY(lars_d_wb_prepare(L.img, 1, (int64_t)npix, j.channels, j.dtype, L.table, L.pcts, j.wb_variant, s));
     }
     const bool stats = j.want_stats && j.mask;
     if (j.mask || L.wb) {

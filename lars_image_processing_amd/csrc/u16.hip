@@ -1,0 +1,290 @@
+// uint16 white-balance pre-pass: exact np.percentile(ch, (2, 98)) of 16-bit samples
+// without a 65536-bin histogram per channel.
+//
+// Two radix levels (the same idea as the median select in arrays.hip):
+//   pass 1  histogram of the HIGH byte of every sample (3 x 256 bins, LDS, conflict-free copies)
+//   pick    which high-byte bins hold the four order statistics np.percentile needs
+//           (floor/ceil neighbours of the 2nd and 98th percentile) and the ranks inside them
+//   pass 2  histogram of the LOW byte of the samples whose high byte is one of those bins
+//   table   order statistics -> percentiles (numpy 'linear' + _lerp, float64) -> the 65536-entry
+//           uint8 table (process-images.py:438-441 evaluated for every sample value), and its
+//           threshold form T[k] = smallest v with table[v] >= k (the table is a monotone staircase)
+//           which the fast fused kernel keeps in LDS.
+//
+// Both data passes stream the tile once at HBM rate; a 3 x 65536-bin histogram would need one
+// global atomic per sample instead.
+#include "common.h"
+#include "device_common.h"
+
+namespace lars {
+
+typedef unsigned int u32x4v __attribute__((ext_vector_type(4)));
+typedef unsigned int u32x2v __attribute__((ext_vector_type(2)));
+
+struct U16Pick {
+    unsigned int target[4];          // high byte holding order statistic r (q2.lo, q2.hi, q98.lo, q98.hi)
+    unsigned int slot[4];            // pass-2 histogram slot of rank r (ranks sharing a high byte share a slot)
+    unsigned long long resid[4];     // rank inside that high-byte bin
+    double tq[2];                    // interpolation weights of the two percentiles
+};
+
+// ---- pass 1: high-byte histograms --------------------------------------------------------
+// lane owns 4 pixels = 24 bytes (6 dwords: r0g0 n0r1 g1n1 r2g2 n2r3 g3n3, two samples per dword)
+__global__ __launch_bounds__(1024) void k_hist_u16_hi(const uint16_t *__restrict__ tiles, long long npix,
+                                                      unsigned int *__restrict__ hist)
+{
+    __shared__ unsigned int s_h[3 * 256 * 32];             // [channel][bin][copy = lane % 32]
+    const int tid = threadIdx.x;
+    for (int i = tid; i < 3 * 256 * 32; i += 1024) s_h[i] = 0;
+    __syncthreads();
+    const long long tile = blockIdx.y;
+    const uint16_t *base = tiles + tile * npix * 3;
+    const long long nquads = npix >> 2;
+    const unsigned int lane_off = (tid & 31) << 2;
+    char *hb = reinterpret_cast<char *>(s_h);
+#define HADD16(word, half, ch)                                                                         \
+    atomicAdd(reinterpret_cast<unsigned int *>(hb + (ch) * 32768 + ((((word) >> ((half) * 16 + 8)) & 0xFFu) << 7) + lane_off), 1u)
+    const long long step = (long long)gridDim.x * 1024;
+    if (nquads > 0) {
+        const __amdgpu_buffer_rsrc_t rsrc =
+            __builtin_amdgcn_make_buffer_rsrc(const_cast<uint16_t *>(base), 0, (int)(nquads * 24), 0x00020000);
+        for (long long q = (long long)blockIdx.x * 1024 + tid; q < nquads; q += step) {
+            const unsigned int off = (unsigned int)q * 24u;
+            const u32x4v a = __builtin_amdgcn_raw_buffer_load_b128(rsrc, off, 0, 0);
+            const u32x2v b = __builtin_amdgcn_raw_buffer_load_b64(rsrc, off + 16u, 0, 0);
+            HADD16(a.x, 0, 0); HADD16(a.x, 1, 1); HADD16(a.y, 0, 2); HADD16(a.y, 1, 0);
+            HADD16(a.z, 0, 1); HADD16(a.z, 1, 2); HADD16(a.w, 0, 0); HADD16(a.w, 1, 1);
+            HADD16(b.x, 0, 2); HADD16(b.x, 1, 0); HADD16(b.y, 0, 1); HADD16(b.y, 1, 2);
+        }
+    }
+    if (blockIdx.x == 0 && tid < (int)(npix & 3)) {
+        const uint16_t *p = base + (nquads * 4 + tid) * 3;
+        HADD16((unsigned)p[0], 0, 0); HADD16((unsigned)p[1], 0, 1); HADD16((unsigned)p[2], 0, 2);
+    }
+#undef HADD16
+    __syncthreads();
+    if (tid < 768) {
+        const unsigned int *row = s_h + tid * 32;
+        unsigned int v = 0;
+        for (int j = 0; j < 32; ++j) v += row[(j + tid) & 31];
+        if (v) atomicAdd(&hist[tile * 768 + tid], v);
+    }
+}
+
+// any channel count / alignment
+__global__ __launch_bounds__(256) void k_hist_u16_hi_generic(const uint16_t *__restrict__ tiles, long long npix,
+                                                             int channels, unsigned int *__restrict__ hist)
+{
+    __shared__ unsigned int s_h[768];
+    for (int i = threadIdx.x; i < 768; i += 256) s_h[i] = 0;
+    __syncthreads();
+    const long long tile = blockIdx.y;
+    const uint16_t *base = tiles + tile * npix * channels;
+    for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < npix; i += (long long)gridDim.x * 256) {
+        const uint16_t *p = base + i * channels;
+        atomicAdd(&s_h[p[0] >> 8], 1u);
+        atomicAdd(&s_h[256 + (p[1] >> 8)], 1u);
+        atomicAdd(&s_h[512 + (p[2] >> 8)], 1u);
+    }
+    __syncthreads();
+    for (int i = threadIdx.x; i < 768; i += 256)
+        if (s_h[i]) atomicAdd(&hist[tile * 768 + i], s_h[i]);
+}
+
+// ---- pick: which high bytes hold the order statistics -------------------------------------
+__global__ __launch_bounds__(256) void k_u16_pick(const unsigned int *__restrict__ hist, long long npix,
+                                                  U16Pick *__restrict__ picks)
+{
+    __shared__ unsigned long long s_scan[256];
+    __shared__ U16Pick s_pick;
+    const int tid = threadIdx.x;
+    const long long slot = (long long)blockIdx.y * 3 + blockIdx.x;
+    const unsigned long long c = hist[slot * 256 + tid];
+    s_scan[tid] = c;
+    __syncthreads();
+    for (int off = 1; off < 256; off <<= 1) {
+        unsigned long long v = (tid >= off) ? s_scan[tid - off] : 0;
+        __syncthreads();
+        s_scan[tid] += v;
+        __syncthreads();
+    }
+    const unsigned long long before = s_scan[tid] - c;
+    const double nm1 = (double)(npix - 1);
+    for (int k = 0; k < 2; ++k) {
+        const double q = (k == 0 ? 2.0 : 98.0) / 100.0;
+        const double vi = nm1 * q;
+        const double fl = floor(vi);
+        long long lo = (long long)fl, hi = lo + 1;
+        if (hi > npix - 1) hi = npix - 1;
+        const long long rank[2] = {lo, hi};
+        for (int j = 0; j < 2; ++j) {
+            const unsigned long long r = (unsigned long long)rank[j];
+            if (c && r >= before && r < before + c) {
+                s_pick.target[2 * k + j] = (unsigned)tid;
+                s_pick.resid[2 * k + j] = r - before;
+            }
+        }
+        if (tid == 0) s_pick.tq[k] = vi - fl;
+    }
+    __syncthreads();
+    if (tid == 0) {
+        for (int r = 0; r < 4; ++r) {
+            unsigned int sl = (unsigned)r;
+            for (int p = 0; p < r; ++p)
+                if (s_pick.target[p] == s_pick.target[r]) { sl = s_pick.slot[p]; break; }
+            s_pick.slot[r] = sl;
+        }
+        picks[slot] = s_pick;
+    }
+}
+
+// ---- pass 2: low-byte histograms of the samples in the picked high-byte bins ---------------
+template <bool FAST>
+__global__ __launch_bounds__(1024) void k_hist_u16_lo(const uint16_t *__restrict__ tiles, long long npix, int channels,
+                                                      const U16Pick *__restrict__ picks, unsigned int *__restrict__ lohist)
+{
+    __shared__ unsigned int s_h[3 * 4 * 256];
+    __shared__ unsigned char s_slot[3 * 256];
+    const int tid = threadIdx.x;
+    const long long tile = blockIdx.y;
+    for (int i = tid; i < 3 * 4 * 256; i += 1024) s_h[i] = 0;
+    if (tid < 768) s_slot[tid] = 0xFF;
+    __syncthreads();
+    if (tid < 12) {
+        const int c = tid >> 2, r = tid & 3;
+        const U16Pick &p = picks[tile * 3 + c];
+        if (p.slot[r] == (unsigned)r) s_slot[c * 256 + p.target[r]] = (unsigned char)r;   // first rank of each bin owns the slot
+    }
+    __syncthreads();
+    const uint16_t *base = tiles + tile * npix * channels;
+#define LADD(sample, ch)                                                                               \
+    {                                                                                                  \
+        const unsigned int s_ = (sample);                                                              \
+        const unsigned int sl_ = s_slot[(ch) * 256 + (s_ >> 8)];                                       \
+        if (sl_ != 0xFFu) atomicAdd(&s_h[((ch) * 4 + sl_) * 256 + (s_ & 0xFFu)], 1u);                  \
+    }
+    if (FAST) {
+        const long long nquads = npix >> 2;
+        const long long step = (long long)gridDim.x * 1024;
+        if (nquads > 0) {
+            const __amdgpu_buffer_rsrc_t rsrc =
+                __builtin_amdgcn_make_buffer_rsrc(const_cast<uint16_t *>(base), 0, (int)(nquads * 24), 0x00020000);
+            for (long long q = (long long)blockIdx.x * 1024 + tid; q < nquads; q += step) {
+                const unsigned int off = (unsigned int)q * 24u;
+                const u32x4v a = __builtin_amdgcn_raw_buffer_load_b128(rsrc, off, 0, 0);
+                const u32x2v b = __builtin_amdgcn_raw_buffer_load_b64(rsrc, off + 16u, 0, 0);
+                LADD(a.x & 0xFFFFu, 0) LADD(a.x >> 16, 1) LADD(a.y & 0xFFFFu, 2) LADD(a.y >> 16, 0)
+                LADD(a.z & 0xFFFFu, 1) LADD(a.z >> 16, 2) LADD(a.w & 0xFFFFu, 0) LADD(a.w >> 16, 1)
+                LADD(b.x & 0xFFFFu, 2) LADD(b.x >> 16, 0) LADD(b.y & 0xFFFFu, 1) LADD(b.y >> 16, 2)
+            }
+        }
+        if (blockIdx.x == 0 && tid < (int)(npix & 3)) {
+            const uint16_t *p = base + (nquads * 4 + tid) * 3;
+            LADD((unsigned)p[0], 0) LADD((unsigned)p[1], 1) LADD((unsigned)p[2], 2)
+        }
+    } else {
+        for (long long i = (long long)blockIdx.x * 1024 + tid; i < npix; i += (long long)gridDim.x * 1024) {
+            const uint16_t *p = base + i * channels;
+            LADD((unsigned)p[0], 0) LADD((unsigned)p[1], 1) LADD((unsigned)p[2], 2)
+        }
+    }
+#undef LADD
+    __syncthreads();
+    unsigned int *g = lohist + tile * (3 * 4 * 256);
+    for (int i = tid; i < 3 * 4 * 256; i += 1024)
+        if (s_h[i]) atomicAdd(&g[i], s_h[i]);
+}
+
+// ---- table: order statistics -> percentiles -> 65536-entry table + thresholds ----------------
+__global__ __launch_bounds__(256) void k_wb_table_u16(const unsigned int *__restrict__ lohist, const U16Pick *__restrict__ picks,
+                                                      uint8_t *__restrict__ blobs, double *__restrict__ pcts, int rgn_variant)
+{
+    __shared__ unsigned long long s_scan[256];
+    __shared__ double s_val[4];
+    __shared__ double s_p[2];
+    __shared__ unsigned int s_thr[260];
+    const int tid = threadIdx.x;
+    const int c = blockIdx.x;
+    const long long tile = blockIdx.y;
+    const long long slot = tile * 3 + c;
+    const U16Pick pk = picks[slot];
+
+    for (int r = 0; r < 4; ++r) {
+        // scan the slot of rank r (ranks sharing a high byte rescan the same slot)
+        const unsigned int *h = lohist + ((tile * 3 + c) * 4 + pk.slot[r]) * 256;
+        const unsigned long long cnt = h[tid];
+        __syncthreads();
+        s_scan[tid] = cnt;
+        __syncthreads();
+        for (int off = 1; off < 256; off <<= 1) {
+            unsigned long long v = (tid >= off) ? s_scan[tid - off] : 0;
+            __syncthreads();
+            s_scan[tid] += v;
+            __syncthreads();
+        }
+        const unsigned long long before = s_scan[tid] - cnt;
+        if (cnt && pk.resid[r] >= before && pk.resid[r] < before + cnt) s_val[r] = (double)(pk.target[r] * 256u + (unsigned)tid);
+    }
+    __syncthreads();
+    if (tid < 2) {
+        const double a = s_val[2 * tid], b = s_val[2 * tid + 1], t = pk.tq[tid];
+        const double d = b - a;
+        double r = a + d * t;
+        if (t >= 0.5) r = b - d * (1.0 - t);
+        s_p[tid] = r;
+        if (pcts) pcts[slot * 2 + tid] = r;
+    }
+    __syncthreads();
+    u16_fill_blob(blobs + tile * LARS_U16_BLOB_BYTES, c, s_p[0], s_p[1], rgn_variant, s_thr, tid);
+}
+
+}  // namespace lars
+
+using namespace lars;
+
+extern "C" size_t lars_wb_table_bytes(int dtype)
+{
+    return dtype == LARS_U16 ? (size_t)LARS_U16_BLOB_BYTES : (size_t)768;
+}
+
+// One call for the whole white-balance pre-pass of a batch, both sample types.
+extern "C" int lars_d_wb_prepare(const void *tiles, int64_t ntiles, int64_t npix, int channels, int dtype, uint8_t *table,
+                                 double *percentiles, int rgn_variant, void *stream)
+{
+    ThreadCtx *c;
+    LARS_TRY(ensure_ctx(&c));
+    if (!tiles || !table || ntiles <= 0 || npix <= 0 || channels < 3 || ntiles > 65535)
+        return fail(LARS_ERR_INVALID, "lars_d_wb_prepare: bad arguments");
+    hipStream_t s = pick_stream(c, stream);
+    if (dtype == LARS_U8) {
+        LARS_TRY(scratch_reserve(c, (size_t)ntiles * 768 * sizeof(uint32_t)));
+        uint32_t *hist = static_cast<uint32_t *>(c->scratch);
+        LARS_TRY(lars_d_channel_hist(tiles, ntiles, npix, channels, dtype, hist, s));
+        return lars_d_wb_table(hist, ntiles, npix, dtype, table, percentiles, rgn_variant, s);
+    }
+    if (dtype != LARS_U16) return fail(LARS_ERR_INVALID, "lars_d_wb_prepare: dtype");
+    const size_t hi_bytes = (size_t)ntiles * 768 * 4, pick_bytes = (size_t)ntiles * 3 * sizeof(U16Pick),
+                 lo_bytes = (size_t)ntiles * 3 * 4 * 256 * 4;
+    LARS_TRY(scratch_reserve(c, hi_bytes + pick_bytes + lo_bytes + 512));
+    char *p = static_cast<char *>(c->scratch);
+    unsigned int *hi = reinterpret_cast<unsigned int *>(p);
+    U16Pick *picks = reinterpret_cast<U16Pick *>(p + ((hi_bytes + 255) & ~(size_t)255));
+    unsigned int *lo = reinterpret_cast<unsigned int *>(reinterpret_cast<char *>(picks) + ((pick_bytes + 255) & ~(size_t)255));
+    LARS_HIP_TRY(hipMemsetAsync(hi, 0, hi_bytes, s));
+    LARS_HIP_TRY(hipMemsetAsync(lo, 0, lo_bytes, s));
+    const uint16_t *t16 = static_cast<const uint16_t *>(tiles);
+    const bool fast = channels == 3 && (ntiles == 1 || (npix & 3) == 0) && ((reinterpret_cast<uintptr_t>(tiles) & 3) == 0) &&
+                      (long long)npix * 6 < (1ll << 30);
+    long long want = (1024 + ntiles - 1) / ntiles;
+    const long long cap = (npix / 4 + 1023) / 1024;
+    if (want > cap) want = cap;
+    if (want < 1) want = 1;
+    dim3 grid((unsigned)want, (unsigned)ntiles);
+    if (fast) hipLaunchKernelGGL(k_hist_u16_hi, grid, dim3(1024), 0, s, t16, (long long)npix, hi);
+    else hipLaunchKernelGGL(k_hist_u16_hi_generic, dim3((unsigned)want * 4, (unsigned)ntiles), dim3(256), 0, s, t16, (long long)npix, channels, hi);
+    hipLaunchKernelGGL(k_u16_pick, dim3(3, (unsigned)ntiles), dim3(256), 0, s, hi, (long long)npix, picks);
+    if (fast) hipLaunchKernelGGL((k_hist_u16_lo<true>), grid, dim3(1024), 0, s, t16, (long long)npix, channels, picks, lo);
+    else hipLaunchKernelGGL((k_hist_u16_lo<false>), grid, dim3(1024), 0, s, t16, (long long)npix, channels, picks, lo);
+    hipLaunchKernelGGL(k_wb_table_u16, dim3(3, (unsigned)ntiles), dim3(256), 0, s, lo, picks, table, percentiles, rgn_variant);
+    return launch_check("lars_d_wb_prepare");
+}

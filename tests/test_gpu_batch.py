@@ -215,3 +215,84 @@ def test_rccl_communicator_single_rank(lars):
     comm.barrier()
     comm.destroy()
     b.free()
+
+
+@pytest.mark.parametrize("kind", ["full16", "12bit", "narrow", "constant_channel", "odd_shape"])
+def test_uint16_batch_against_oracle(lars, kind):
+    """uint16 tiles: two-level radix percentiles, threshold-table white balance, fast 24-byte-per-lane kernel."""
+    import ctypes as C
+    from lars_image_processing_amd import _ffi
+    rng = np.random.default_rng({"full16": 1, "12bit": 2, "narrow": 3, "constant_channel": 4, "odd_shape": 5}[kind])
+    h, w = (61, 67) if kind == "odd_shape" else (96, 128)
+    n = 3
+    if kind == "full16":
+        tiles = rng.integers(0, 65536, (n, h, w, 3), dtype=np.uint16)
+    elif kind == "12bit":
+        tiles = rng.integers(0, 4096, (n, h, w, 3), dtype=np.uint16)
+    elif kind == "narrow":                      # few distinct values: fractional percentiles, steep staircase
+        tiles = (rng.integers(0, 4, (n, h, w, 3)) * 257 + 30000).astype(np.uint16)
+    elif kind == "constant_channel":
+        tiles = rng.integers(0, 65536, (n, h, w, 3), dtype=np.uint16)
+        tiles[..., 1] = 1234
+    else:
+        tiles = rng.integers(100, 60000, (n, h, w, 3), dtype=np.uint16)
+    b = lars.TileBatch.from_host(tiles)
+    outs = b.make_outputs(index=True, wb=True, rgba=True)
+    rec = b.process(hist=True, outputs=outs)
+    pcts = b.host_percentiles()
+    tables = b.host_tables()
+    wb = outs.host_wb(0, n)
+    for i in range(n):
+        with warnings.catch_warnings():
+            warnings.simplefilter("ignore")
+            want_wb = orc.wb_app(tiles[i])
+        np.testing.assert_array_equal(wb[i], want_wb)
+        for c in range(3):
+            plane = tiles[i][:, :, c]
+            lo, hi = np.percentile(plane.astype(np.float32), (2, 98))
+            assert pcts[i, c, 0] == lo and pcts[i, c, 1] == hi
+            present = np.unique(plane)
+            np.testing.assert_array_equal(tables[i, c][present], orc.wb_lut_from_percentiles(lo, hi, 65536)[present])
+        for k, t in enumerate(TYPES):
+            want = orc.index_app(want_wb, t)
+            np.testing.assert_array_equal(bits(outs.host_index(t, i, 1)[0]), bits(want))
+            part = orc.tile_partials(want, t)
+            r = rec[i, k]
+            assert int(r["above"]) == part["above"] and float(r["min"]) == part["min"] and float(r["max"]) == part["max"]
+            assert float(r["sum"]) == part["sum"]
+            np.testing.assert_array_equal(np.array(r["hist"], dtype=np.int64), part["hist"])
+    # raw uint16 indices (no white balance): operands up to 65535
+    outs_raw = b.make_outputs(index=True)
+    b.process(white_balance=False, outputs=outs_raw)
+    for t in TYPES:
+        np.testing.assert_array_equal(bits(outs_raw.host_index(t, 1, 1)[0]), bits(orc.index_app(tiles[1], t)))
+    outs_raw.free()
+    # the full-histogram route (lars_d_channel_hist + lars_d_wb_table) must produce the same table blob
+    blob_fast = b.table.download(np.uint8, (n, b.table_bytes))
+    hist = _ffi.DeviceBuffer(n * 3 * 65536 * 4)
+    _ffi.call("lars_d_channel_hist", C.c_void_p(b.tiles.ptr), n, b.npix, 3, _ffi.U16, C.c_void_p(hist.ptr), None)
+    _ffi.call("lars_d_wb_table", C.c_void_p(hist.ptr), n, b.npix, _ffi.U16, C.c_void_p(b.table.ptr),
+              C.c_void_p(b.percentiles.ptr), 0, None)
+    _ffi.call("lars_synchronize", None)
+    blob_full = b.table.download(np.uint8, (n, b.table_bytes))
+    used = 196608 + 3 * 260 * 4 + 48
+    np.testing.assert_array_equal(blob_fast[:, :used], blob_full[:, :used])
+    h16 = hist.download(np.uint32, (n, 3, 65536))
+    np.testing.assert_array_equal(h16[0, 2], np.bincount(tiles[0][:, :, 2].ravel(), minlength=65536))
+    hist.free(); outs.free(); b.free()
+
+
+def test_uint16_rgba_channels_take_generic_path(lars):
+    rng = np.random.default_rng(9)
+    tiles = rng.integers(0, 65536, (2, 33, 47, 4), dtype=np.uint16)
+    b = lars.TileBatch.from_host(tiles)
+    outs = b.make_outputs(index=True, wb=True)
+    b.process(outputs=outs)
+    wb = outs.host_wb(0, 2)
+    for i in range(2):
+        with warnings.catch_warnings():
+            warnings.simplefilter("ignore")
+            want = orc.wb_app(tiles[i])
+        np.testing.assert_array_equal(wb[i], want)
+        np.testing.assert_array_equal(bits(outs.host_index("NDVI", i, 1)[0]), bits(orc.index_app(want, "NDVI")))
+    outs.free(); b.free()

@@ -1,0 +1,99 @@
+"""Directory driver: decode -> white balance -> indices -> files.
+
+Mirrors ``backend-process.py:49-97`` (``process_image`` / ``batch_process``): same
+directory layout (``white_balanced/<name>_wb.tif``, ``<INDEX>/<name>_<index>.png``), same
+extension filter, same per-file ``try``/``print`` error policy -- but each image crosses PCIe
+once (``lars_h_process_image``: white balance, all requested indices and their colormaps in one
+upload) and decoding / encoding overlap the GPU work on a thread pool (PIL releases the GIL;
+the library gives every thread its own stream and workspace).
+
+``render="figure"`` reproduces the reference's matplotlib figure (imshow + colorbar, axes off);
+``render="lut"`` writes the per-pixel RGBA image of the same colormap at full resolution
+(no axes / colorbar: a different picture, hence opt-in).
+"""
+from __future__ import annotations
+
+import os
+from concurrent.futures import ThreadPoolExecutor
+from pathlib import Path
+
+import numpy as np
+
+from . import api
+
+EXTENSIONS = {".tif", ".tiff", ".png", ".jpg", ".jpeg"}      # backend-process.py:89
+
+
+def _figure_png(index_array, index_type, path):
+    """backend-process.py:40-47, verbatim behaviour (plumbing; the index came from the GPU)."""
+    import matplotlib
+    matplotlib.use("Agg", force=False)
+    import matplotlib.pyplot as plt
+    plt.figure(figsize=(10, 8), dpi=100)
+    cmap = "RdYlBu" if index_type == "NDWI" else "RdYlGn"
+    plt.imshow(index_array, cmap=cmap, vmin=-1, vmax=1)
+    plt.colorbar(label=index_type)
+    plt.axis("off")
+    plt.savefig(path, bbox_inches="tight", pad_inches=0)
+    plt.close()
+
+
+def process_image(image_path, output_dir, process_wb=False, indices=None, render="figure"):
+    """One file: same outputs as backend-process.py:49-73.  Returns the statistics dicts."""
+    from PIL import Image
+    image_path, output_dir = Path(image_path), Path(output_dir)
+    name = image_path.stem
+    arr = np.array(Image.open(image_path))
+    if arr.ndim != 3 or arr.shape[2] < 3:
+        raise ValueError(f"{image_path.name}: expected an image with at least 3 channels, got shape {arr.shape}")
+    indices = list(indices or [])
+    res = api.process_image(arr, indices=indices, white_balance=True, want_arrays=(render == "figure"),
+                            want_rgba=(render == "lut")) if indices else None
+    corrected = res["corrected"] if res else api.fix_white_balance(arr)
+    if process_wb:
+        (output_dir / "white_balanced").mkdir(parents=True, exist_ok=True)
+        Image.fromarray(corrected[:, :, :3] if corrected.shape[2] > 4 else corrected).save(
+            output_dir / "white_balanced" / f"{name}_wb.tif")
+    stats = {}
+    for t in indices:
+        (output_dir / t).mkdir(parents=True, exist_ok=True)
+        out = output_dir / t / f"{name}_{t.lower()}.png"
+        entry = res["indices"][t]
+        if render == "lut":
+            Image.fromarray(entry["rgba"], "RGBA").save(out)
+        else:
+            _figure_png(entry["index"], t, out)
+        stats[t] = entry["stats"]
+    return stats
+
+
+def batch_process(input_dir, output_dir, process_wb=False, process_ndvi=False, process_gndvi=False,
+                  process_ndwi=True, render="figure", workers=4, verbose=True):
+    """backend-process.py:75-97 with its module constants as arguments.  Returns ``{file name: stats | error}``."""
+    input_path, output_path = Path(input_dir), Path(output_dir)
+    indices = [t for t, on in (("NDVI", process_ndvi), ("GNDVI", process_gndvi), ("NDWI", process_ndwi)) if on]
+    files = sorted(f for f in input_path.glob("*") if f.suffix.lower() in EXTENSIONS)
+    total = len(files)
+    results = {}
+
+    def one(job):
+        idx, f = job
+        try:
+            if verbose:
+                print(f"Processing {idx}/{total}: {f.name}")
+            return f.name, process_image(f, output_path, process_wb, indices or None, render)
+        except Exception as e:                              # same policy as upstream :96-97
+            if verbose:
+                print(f"Error processing {f.name}: {str(e)}")
+            return f.name, e
+
+    if render == "figure" or workers <= 1:
+        # matplotlib's pyplot state machine is not thread-safe: keep the figure path serial
+        for job in enumerate(files, 1):
+            k, v = one(job)
+            results[k] = v
+    else:
+        with ThreadPoolExecutor(max_workers=min(workers, os.cpu_count() or 1)) as pool:
+            for k, v in pool.map(one, enumerate(files, 1)):
+                results[k] = v
+    return results

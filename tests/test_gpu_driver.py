@@ -1,0 +1,48 @@
+"""Directory driver against the oracle; needs a MI355X."""
+import warnings
+
+import numpy as np
+import pytest
+
+from oracle import index_oracle as orc
+
+pytestmark = pytest.mark.gpu
+
+
+def test_batch_process_directory(tmp_path):
+    from PIL import Image
+    import lars_image_processing_amd as lars
+    from lars_image_processing_amd import driver
+    src, dst = tmp_path / "in", tmp_path / "out"
+    src.mkdir()
+    rng = np.random.default_rng(21)
+    imgs = {"a.png": rng.integers(0, 256, (70, 90, 3), dtype=np.uint8),
+            "b.tif": rng.integers(0, 256, (33, 41, 3), dtype=np.uint8),
+            "c.PNG": orc.synth_tile_u8(5, 1, 64, 64, profile="vegetation")}
+    for name, arr in imgs.items():
+        Image.fromarray(arr).save(src / name)
+    Image.fromarray(rng.integers(0, 256, (20, 20), dtype=np.uint8)).save(src / "gray.png")   # fails like upstream: skipped
+    (src / "notes.txt").write_text("not an image")
+    res = driver.batch_process(src, dst, process_wb=True, process_ndvi=True, process_gndvi=True, process_ndwi=True,
+                               render="lut", workers=3, verbose=False)
+    assert set(res) == {"a.png", "b.tif", "c.PNG", "gray.png"} and isinstance(res["gray.png"], Exception)
+    for name, arr in imgs.items():
+        stem = name.rsplit(".", 1)[0]
+        with warnings.catch_warnings():
+            warnings.simplefilter("ignore")
+            want_wb = orc.wb_app(arr)
+        np.testing.assert_array_equal(np.array(Image.open(dst / "white_balanced" / f"{stem}_wb.tif")), want_wb)
+        for t in ("NDVI", "GNDVI", "NDWI"):
+            want = orc.index_app(want_wb, t)
+            lut = lars.colormap_lut("RdYlBu" if t == "NDWI" else "RdYlGn")
+            got = np.array(Image.open(dst / t / f"{stem}_{t.lower()}.png"))
+            np.testing.assert_array_equal(got, orc.colormap_closed_form(want, lut))
+            ws = orc.stats_app(want, t)
+            for key, val in ws.items():
+                assert res[name][t][key] == pytest.approx(val, rel=1e-6, abs=1e-9)
+                if not key.startswith("Mean"):
+                    assert res[name][t][key] == val
+    # the reference's own figure style, serial path
+    res2 = driver.batch_process(src, tmp_path / "fig", process_wb=False, process_ndwi=True, render="figure", verbose=False)
+    assert (tmp_path / "fig" / "NDWI" / "a_ndwi.png").stat().st_size > 1000
+    assert not (tmp_path / "fig" / "white_balanced").exists() and "Water Coverage (%)" in res2["a.png"]["NDWI"]

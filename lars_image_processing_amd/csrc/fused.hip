@@ -596,7 +596,7 @@ extern "C" int lars_d_channel_hist(const void *tiles, int64_t ntiles, int64_t np
     LARS_HIP_TRY(hipMemsetAsync(hist, 0, (size_t)ntiles * 3 * nval * sizeof(uint32_t), s));
     const bool fast = dtype == LARS_U8 && channels == 3 && (ntiles == 1 || (npix & 3) == 0) &&
                       ((reinterpret_cast<uintptr_t>(tiles) & 3) == 0);
-    if (fast && tuning().hist_impl >= 2 && (long long)npix * 3 < (1ll << 30)) {
+    if (fast && tuning().hist_impl != 1 && (long long)npix * 3 < (1ll << 30)) {
         // 96 KiB of LDS per block: one 1024-thread block per CU, a few waves of blocks per tile
         long long want = tuning().blocks_per_tile > 0 ? tuning().blocks_per_tile : (1024 + ntiles - 1) / ntiles;
         const long long cap = (npix / 4 + 1023) / 1024;
@@ -749,3 +749,4 @@ extern "C" int lars_d_synth_u8(uint8_t *tiles, int64_t ntiles, int64_t first_til
     hipLaunchKernelGGL(k_synth_u8, grid, dim3(256), 0, s, tiles, (long long)first_tile, nbytes, channels, seed, profile);
     return launch_check("lars_d_synth_u8");
 }
+

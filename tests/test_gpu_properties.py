@@ -1,0 +1,59 @@
+"""Property tests through the C ABI (hypothesis drives shapes and contents; needs a MI355X)."""
+import warnings
+
+import numpy as np
+import pytest
+from hypothesis import given, settings, strategies as st
+from hypothesis.extra import numpy as hnp
+
+from oracle import index_oracle as orc
+
+pytestmark = pytest.mark.gpu
+TYPES = ("NDVI", "GNDVI", "NDWI")
+
+
+def bits(a):
+    return np.ascontiguousarray(a).view(np.uint32)
+
+
+images = st.one_of(
+    hnp.arrays(np.uint8, st.tuples(st.integers(1, 40), st.integers(1, 40), st.sampled_from([3, 4]))),
+    hnp.arrays(np.uint16, st.tuples(st.integers(1, 24), st.integers(1, 24), st.just(3))),
+    # few distinct values: interpolated percentiles, constant channels, steep tables
+    hnp.arrays(np.uint8, st.tuples(st.integers(1, 40), st.integers(1, 40), st.just(3)), elements=st.sampled_from([0, 1, 2, 127, 254, 255])),
+)
+
+
+@settings(max_examples=120, deadline=None)
+@given(images)
+def test_process_image_equals_oracle(img):
+    import lars_image_processing_amd as lars
+    with warnings.catch_warnings():
+        warnings.simplefilter("ignore")
+        want_wb = orc.wb_app(img)
+    res = lars.process_image(img, want_hist=True)
+    np.testing.assert_array_equal(res["corrected"], want_wb)
+    for t in TYPES:
+        want = orc.index_app(want_wb, t)
+        r = res["indices"][t]
+        np.testing.assert_array_equal(bits(r["index"]), bits(want))
+        ws = orc.stats_app(want, t)
+        for key, val in ws.items():
+            if key.startswith("Mean"):
+                assert r["stats"][key] == pytest.approx(val, rel=1e-6, abs=1e-7)
+            else:
+                assert r["stats"][key] == val, key
+        np.testing.assert_array_equal(r["hist"], orc.hist50(want))
+
+
+@settings(max_examples=60, deadline=None)
+@given(hnp.arrays(np.float32, st.integers(1, 3000), elements=st.floats(-1, 1, width=32)), st.sampled_from(TYPES))
+def test_analyze_index_on_arbitrary_float32(x, t):
+    import lars_image_processing_amd as lars
+    got, want = lars.analyze_index(x, t), orc.stats_app(x, t)
+    for key, val in want.items():
+        if key.startswith("Mean"):
+            assert got[key] == pytest.approx(val, rel=1e-6, abs=1e-7)
+        else:
+            assert got[key] == val, key
+    np.testing.assert_array_equal(lars.index_histogram(x), orc.hist50(x))

@@ -1,0 +1,56 @@
+"""Property tests of the oracle's closed forms (CPU; hypothesis)."""
+import warnings
+
+import numpy as np
+from hypothesis import given, settings, strategies as st
+from hypothesis.extra import numpy as hnp
+
+from oracle import index_oracle as orc
+
+small_images = hnp.arrays(np.uint8, st.tuples(st.integers(1, 12), st.integers(1, 12), st.just(3)))
+
+
+def bits(a):
+    return np.ascontiguousarray(a).view(np.uint32)
+
+
+@settings(max_examples=60, deadline=None)
+@given(small_images)
+def test_white_balance_closed_form_equals_statement(img):
+    with warnings.catch_warnings():
+        warnings.simplefilter("ignore")
+        np.testing.assert_array_equal(orc.wb_closed_form(img), orc.wb_app(img))
+
+
+@settings(max_examples=60, deadline=None)
+@given(small_images)
+def test_index_properties(img):
+    g = orc.index_app(img, "GNDVI")
+    w = orc.index_app(img, "NDWI")
+    v = orc.index_app(img, "NDVI")
+    assert (np.abs(v) <= 1).all() and (np.abs(g) <= 1).all()
+    np.testing.assert_array_equal(bits((-g) + np.float32(0)), bits(w))
+    np.testing.assert_array_equal(bits(orc.index_closed_form(img[:, :, 2], img[:, :, 0])), bits(v))
+    np.testing.assert_array_equal(orc.hist50_closed_form(v), orc.hist50(v))
+    assert orc.hist50(v).sum() == v.size
+
+
+@settings(max_examples=60, deadline=None)
+@given(hnp.arrays(np.int64, 256, elements=st.integers(0, 50)), st.sampled_from([0, 2, 50, 98, 100]))
+def test_percentile_from_histogram(hist, q):
+    if hist.sum() == 0:
+        hist[7] = 1
+    samples = np.repeat(np.arange(256), hist).astype(np.float32)
+    assert orc.percentile_from_hist(hist, q) == np.percentile(samples, (q,))[0]
+
+
+@settings(max_examples=30, deadline=None)
+@given(st.lists(small_images, min_size=2, max_size=5), st.sampled_from(["NDVI", "GNDVI", "NDWI"]))
+def test_merge_of_partials_is_statistics_of_the_union(tiles, t):
+    idx = [orc.index_app(x, t) for x in tiles]
+    merged = orc.merge_partials(orc.tile_partials(i, t) for i in idx)
+    union = np.concatenate([i.ravel() for i in idx])
+    assert merged["count"] == union.size and merged["min"] == float(union.min()) and merged["max"] == float(union.max())
+    _, thr = orc.coverage_rule(t)
+    assert merged["coverage"] == np.count_nonzero(union > np.float32(thr)) / union.size * 100.0
+    np.testing.assert_array_equal(merged["hist"], orc.hist50(union))

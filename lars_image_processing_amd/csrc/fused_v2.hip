@@ -41,13 +41,19 @@ __device__ inline float exact_quot(float num, float den)
     const float e = __builtin_fmaf(-q0, den, num);
     return __builtin_fmaf(e, r, q0);
 }
+// a+b == 0 (both samples 0) must give +0.0.  Instead of a max(den, 1) per quotient, the NIR value gets
+// a tiny epsilon once per pixel pair (one packed add shared by NDVI and GNDVI): float32(n + 1e-10) == n
+// for every n >= 1 and the epsilon is absorbed again by any other sample >= 1, so the denominator is
+// unchanged unless both samples are 0, where it becomes 1e-10 and the quotient (+0) * 1e10 = +0.0 --
+// the same device the reference uses (process-images.py:464).
+#define LARS_DEN_EPS 1e-10f
+
 // two quotients per instruction: v_pk_mul_f32 / v_pk_fma_f32 (the VALU issues one wave64
 // instruction per 4 cycles, packed or not -- rocprofv3: SQ_ACTIVE_INST_VALU / SQ_INSTS_VALU = 1.05 quad-cycles)
 typedef float f32x2 __attribute__((ext_vector_type(2)));
+// den must be >= 1 or the tiny positive stand-in for a zero sum (see LARS_DEN_EPS)
 __device__ inline f32x2 exact_quot2(f32x2 num, f32x2 den)
 {
-    den.x = fmaxf(den.x, 1.0f);                            // a+b == 0 -> (+0)/1 = +0.0
-    den.y = fmaxf(den.y, 1.0f);
     f32x2 r;
     r.x = __builtin_amdgcn_rcpf(den.x);
     r.y = __builtin_amdgcn_rcpf(den.y);
@@ -321,14 +327,15 @@ __global__ __launch_bounds__(512, 4) void k_fused_v2(FusedParams P)
 #pragma unroll
         for (int h = 0; h < 2; ++h) {
             const f32x2 N = {fn[2 * h], fn[2 * h + 1]};
+            const f32x2 Ne = N + (f32x2){LARS_DEN_EPS, LARS_DEN_EPS};
             if (WANT_NDVI) {
                 const f32x2 R = {fr[2 * h], fr[2 * h + 1]};
-                const f32x2 x = exact_quot2(N - R, N + R);
+                const f32x2 x = exact_quot2(N - R, Ne + R);
                 v0[2 * h] = x.x; v0[2 * h + 1] = x.y;
             }
             if (NEED_G) {
                 const f32x2 G = {fg[2 * h], fg[2 * h + 1]};
-                const f32x2 x = exact_quot2(N - G, N + G);
+                const f32x2 x = exact_quot2(N - G, Ne + G);
                 v1[2 * h] = x.x; v1[2 * h + 1] = x.y;
             }
         }

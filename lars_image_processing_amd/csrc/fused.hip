@@ -304,6 +304,13 @@ __device__ inline void pixel_math(float r, float g, float n, unsigned rt_mask,
 // LDS): g = trunc((v - p2) * 255/(p98 - p2)) in float64 is within one level of the reference's
 // trunc(float32(float64 expression)), and two threshold compares settle it exactly.
 typedef unsigned int fu32x4 __attribute__((ext_vector_type(4)));
+typedef float ff32x4 __attribute__((ext_vector_type(4)));
+__device__ inline void store_plane4(float *dst, const float (&v)[4], bool nt)
+{
+    const ff32x4 x = {v[0], v[1], v[2], v[3]};
+    if (nt) __builtin_nontemporal_store(x, reinterpret_cast<ff32x4 *>(dst));
+    else *reinterpret_cast<ff32x4 *>(dst) = x;
+}
 typedef unsigned int fu32x2 __attribute__((ext_vector_type(2)));
 
 template <typename PIX, unsigned MASK, bool WB, int STATS>
@@ -367,6 +374,7 @@ __global__ __launch_bounds__(256) void k_fused_u8c3(FusedParams P)
 
     const long long nquads = npix >> 2;
     const long long stride = (long long)gridDim.x * 256;
+    const bool nt_ld = (P.flags & 0x40000000u) != 0, nt_st = (P.flags & 0x20000000u) != 0;
     __amdgpu_buffer_rsrc_t rsrc16;
     if (U16) rsrc16 = __builtin_amdgcn_make_buffer_rsrc(const_cast<PIX *>(base), 0, (int)(nquads * 24), 0x00020000);
     for (long long q = (long long)blockIdx.x * 256 + tid; q < nquads; q += stride) {
@@ -380,7 +388,9 @@ __global__ __launch_bounds__(256) void k_fused_u8c3(FusedParams P)
             for (int i = 0; i < 6; ++i) { b[2 * i] = w[i] & 0xFFFFu; b[2 * i + 1] = w[i] >> 16; }
         } else {
             const unsigned int *p = reinterpret_cast<const unsigned int *>(reinterpret_cast<const uint8_t *>(base) + q * 12);
-            const unsigned int w0 = p[0], w1 = p[1], w2 = p[2];
+            unsigned int w0, w1, w2;
+            if (nt_ld) { w0 = __builtin_nontemporal_load(p); w1 = __builtin_nontemporal_load(p + 1); w2 = __builtin_nontemporal_load(p + 2); }
+            else { w0 = p[0]; w1 = p[1]; w2 = p[2]; }
             const unsigned int t[12] = {w0 & 0xFF, (w0 >> 8) & 0xFF, (w0 >> 16) & 0xFF, w0 >> 24,
                                         w1 & 0xFF, (w1 >> 8) & 0xFF, (w1 >> 16) & 0xFF, w1 >> 24,
                                         w2 & 0xFF, (w2 >> 8) & 0xFF, (w2 >> 16) & 0xFF, w2 >> 24};
@@ -404,9 +414,9 @@ __global__ __launch_bounds__(256) void k_fused_u8c3(FusedParams P)
             pixel_math<MASK, STATS, false>((float)b[3 * px], (float)b[3 * px + 1], (float)b[3 * px + 2], 0u,
                                            v0[px], v1[px], v2[px], acc, s_hist, s_edges);
         }
-        if ((MASK & 1u) && oi0) *reinterpret_cast<float4 *>(oi0 + q * 4) = make_float4(v0[0], v0[1], v0[2], v0[3]);
-        if ((MASK & 2u) && oi1) *reinterpret_cast<float4 *>(oi1 + q * 4) = make_float4(v1[0], v1[1], v1[2], v1[3]);
-        if ((MASK & 4u) && oi2) *reinterpret_cast<float4 *>(oi2 + q * 4) = make_float4(v2[0], v2[1], v2[2], v2[3]);
+        if ((MASK & 1u) && oi0) store_plane4(oi0 + q * 4, v0, nt_st);
+        if ((MASK & 2u) && oi1) store_plane4(oi1 + q * 4, v1, nt_st);
+        if ((MASK & 4u) && oi2) store_plane4(oi2 + q * 4, v2, nt_st);
         if ((MASK & 1u) && oc0)
             *reinterpret_cast<uint4 *>(oc0 + q * 16) = make_uint4(lut0[cmap_index(v0[0])], lut0[cmap_index(v0[1])],
                                                                   lut0[cmap_index(v0[2])], lut0[cmap_index(v0[3])]);
@@ -689,7 +699,8 @@ extern "C" int lars_d_fused(const lars_fused_args *a)
         P.out_rgba[k] = on ? a->out_rgba[k] : nullptr;
         P.cmap_lut[k] = a->cmap_lut[k];
     }
-    P.out_wb = a->out_wb; P.stats = a->stats; P.mask = mask; P.flags = a->flags;
+    P.out_wb = a->out_wb; P.stats = a->stats; P.mask = mask;
+    P.flags = (a->flags & 3u) | (tuning().nt_loads ? 0x40000000u : 0u) | (tuning().nt_stores ? 0x20000000u : 0u);
 
     const long long nrec = a->ntiles * 3;
     if (stats_mode)

@@ -95,8 +95,9 @@ __global__ __launch_bounds__(256) void k_quot_check(unsigned int max_den, unsign
 // ---------------------------------------------------------------------------
 // LDS: [3 channels][256 bins][32 copies] u32 = 96 KiB; copy = lane % 32.
 __global__ __launch_bounds__(1024) void k_chan_hist_u8c3_v2(const uint8_t *__restrict__ tiles, long long npix,
-                                                            unsigned int *__restrict__ hist)
+                                                            unsigned int *__restrict__ hist, int nt_loads)
 {
+    const bool nt_ld = nt_loads != 0;
     __shared__ unsigned int s_h[3 * 256 * 32];             // 96 KiB
     const int tid = threadIdx.x;
     for (int i = tid; i < 3 * 256 * 32; i += 1024) s_h[i] = 0;
@@ -124,7 +125,7 @@ __global__ __launch_bounds__(1024) void k_chan_hist_u8c3_v2(const uint8_t *__res
         const unsigned int step_b = (unsigned int)step * 12u;
         u32x3 w[4];
 #pragma unroll
-        for (int k = 0; k < 4; ++k) w[k] = __builtin_amdgcn_raw_buffer_load_b96(rsrc, voff, (unsigned)k * step_b, 0);
+        for (int k = 0; k < 4; ++k) w[k] = nt_ld ? __builtin_amdgcn_raw_buffer_load_b96(rsrc, voff, (unsigned)k * step_b, 2) : __builtin_amdgcn_raw_buffer_load_b96(rsrc, voff, (unsigned)k * step_b, 0);
         long long it = 0;
         unsigned int soff = 4u * step_b;
         for (; it + 4 <= niter - 1; it += 4) {
@@ -132,7 +133,7 @@ __global__ __launch_bounds__(1024) void k_chan_hist_u8c3_v2(const uint8_t *__res
             for (int k = 0; k < 4; ++k) {
                 HQUAD(w[k].x, w[k].y, w[k].z)
                 __builtin_amdgcn_sched_barrier(0);
-                w[k] = __builtin_amdgcn_raw_buffer_load_b96(rsrc, voff, soff + (unsigned)k * step_b, 0);
+                w[k] = nt_ld ? __builtin_amdgcn_raw_buffer_load_b96(rsrc, voff, soff + (unsigned)k * step_b, 2) : __builtin_amdgcn_raw_buffer_load_b96(rsrc, voff, soff + (unsigned)k * step_b, 0);
                 __builtin_amdgcn_sched_barrier(0);
             }
             soff += 4u * step_b;
@@ -395,6 +396,7 @@ __global__ __launch_bounds__(512, 4) void k_fused_v2(FusedParams P)
     // is a scalar (no vector address arithmetic), and loads past the end return zeros (no clamps).
     const long long q0 = (long long)blockIdx.x * 512 + tid;
     const long long niter = (nquads + stride - 1) / stride;          // same for every lane of the grid
+    const bool nt_ld = (P.flags & 0x40000000u) != 0;
     if (niter > 0) {
         const __amdgpu_buffer_rsrc_t rsrc =
             __builtin_amdgcn_make_buffer_rsrc(const_cast<uint8_t *>(base), 0, (int)(nquads * 12), 0x00020000);
@@ -402,7 +404,7 @@ __global__ __launch_bounds__(512, 4) void k_fused_v2(FusedParams P)
         const unsigned int step_b = (unsigned int)stride * 12u;
         u32x3 w[4];
 #pragma unroll
-        for (int k = 0; k < 4; ++k) w[k] = __builtin_amdgcn_raw_buffer_load_b96(rsrc, voff, (unsigned)k * step_b, 0);
+        for (int k = 0; k < 4; ++k) w[k] = nt_ld ? __builtin_amdgcn_raw_buffer_load_b96(rsrc, voff, (unsigned)k * step_b, 2) : __builtin_amdgcn_raw_buffer_load_b96(rsrc, voff, (unsigned)k * step_b, 0);
         long long it = 0;
         unsigned int soff = 4u * step_b;
         // every lane's quad is in range while it < niter - 1
@@ -413,7 +415,7 @@ __global__ __launch_bounds__(512, 4) void k_fused_v2(FusedParams P)
                 // (no copies, no vmcnt(0) at the loop head) and has three quads of work to hide behind
                 do_quad(q0 + (it + k) * stride, w[k].x, w[k].y, w[k].z);
                 __builtin_amdgcn_sched_barrier(0);
-                w[k] = __builtin_amdgcn_raw_buffer_load_b96(rsrc, voff, soff + (unsigned)k * step_b, 0);
+                w[k] = nt_ld ? __builtin_amdgcn_raw_buffer_load_b96(rsrc, voff, soff + (unsigned)k * step_b, 2) : __builtin_amdgcn_raw_buffer_load_b96(rsrc, voff, soff + (unsigned)k * step_b, 0);
                 __builtin_amdgcn_sched_barrier(0);
             }
             soff += 4u * step_b;
@@ -587,7 +589,7 @@ void fused_v2_launch(unsigned mask, bool wb, int stats, bool nt, dim3 grid, hipS
 
 void chan_hist_v2_launch(const uint8_t *tiles, long long npix, unsigned int *hist, dim3 grid, hipStream_t s)
 {
-    hipLaunchKernelGGL(k_chan_hist_u8c3_v2, grid, dim3(1024), 0, s, tiles, npix, hist);
+    hipLaunchKernelGGL(k_chan_hist_u8c3_v2, grid, dim3(1024), 0, s, tiles, npix, hist, tuning().nt_loads);
 }
 
 int quot_check_launch(unsigned int max_den, unsigned long long *mismatches_dev, unsigned int *first_bad_dev, hipStream_t s)

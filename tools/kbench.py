@@ -56,6 +56,7 @@ def main():
     ap.add_argument("--modes", default=",".join(MODES))
     ap.add_argument("--impls", default="1,2")
     ap.add_argument("--nt", default="0,1")
+    ap.add_argument("--ntl", default="0", help="non-temporal loads: 0, 1 or 0,1")
     ap.add_argument("--bpt", default="0")
     ap.add_argument("--wb", default="1")
     ap.add_argument("--profile", default="vegetation")
@@ -69,17 +70,18 @@ def main():
     results = {}
 
     if "hist" in args.what:
-        variants = [(i, bp) for i in map(int, args.impls.split(",")) for bp in map(int, args.bpt.split(","))]
+        variants = [(i, bp, nl) for i in map(int, args.impls.split(",")) for bp in map(int, args.bpt.split(","))
+                    for nl in map(int, args.ntl.split(","))]
         times = {v: [] for v in variants}
         for _ in range(args.rounds + 1):
             for v in variants:
-                _ffi.set_tuning(hist_impl=v[0], blocks_per_tile=v[1])
+                _ffi.set_tuning(hist_impl=v[0], blocks_per_tile=v[1], nt_loads=v[2])
                 times[v].append(timer.time(lambda: _ffi.call(
                     "lars_d_channel_hist", C.c_void_p(b.tiles.ptr), b.ntiles, b.npix, 3, _ffi.U8,
                     C.c_void_p(b.hist.ptr), None)))
         for v, t in times.items():
             med = float(np.median(t[1:]))
-            results[f"hist impl={v[0]} bpt={v[1]}"] = {"ms": med, "min_ms": float(min(t[1:])), "GBs": npix * 3 / med / 1e6}
+            results[f"hist impl={v[0]} bpt={v[1]} ntl={v[2]}"] = {"ms": med, "min_ms": float(min(t[1:])), "GBs": npix * 3 / med / 1e6}
         _ffi.set_tuning(blocks_per_tile=0)
 
     if "fused" in args.what:
@@ -89,22 +91,23 @@ def main():
         for m in modes:
             for impl in map(int, args.impls.split(",")):
                 for nt in map(int, args.nt.split(",")):
-                    if nt and (impl == 1 or not MODES[m][1]):
+                    if nt and not MODES[m][1]:
                         continue
                     for bp in map(int, args.bpt.split(",")):
                         for wb in map(int, args.wb.split(",")):
-                            variants.append((m, impl, nt, bp, wb))
+                            for nl in map(int, args.ntl.split(",")):
+                                variants.append((m, impl, nt, bp, wb, nl))
         times = {v: [] for v in variants}
         for _ in range(args.rounds + 1):
             for v in variants:
-                m, impl, nt, bp, wb = v
+                m, impl, nt, bp, wb, nl = v
                 indices, write, hist, bpp = MODES[m]
                 outs = None
                 if write:
                     if indices not in outs_cache:
                         outs_cache[indices] = b.make_outputs(indices=indices, index=True, ring=args.ring)
                     outs = outs_cache[indices]
-                _ffi.set_tuning(fused_impl=impl, nt_stores=nt, blocks_per_tile=bp)
+                _ffi.set_tuning(fused_impl=impl, nt_stores=nt, blocks_per_tile=bp, nt_loads=nl)
 
                 def run():
                     if outs is None:
@@ -115,10 +118,10 @@ def main():
                             b.run_fused(b.fused_args(indices, bool(wb), stats, hist, outs, None, start, cnt))
                 times[v].append(timer.time(run))
         for v, t in times.items():
-            m, impl, nt, bp, wb = v
+            m, impl, nt, bp, wb, nl = v
             med = float(np.median(t[1:]))
             bpp = MODES[m][3]
-            results[f"fused {m} impl={impl} nt={nt} bpt={bp} wb={wb}"] = {
+            results[f"fused {m} impl={impl} nt={nt} ntl={nl} bpt={bp} wb={wb}"] = {
                 "ms": med, "min_ms": float(min(t[1:])), "GBs": npix * bpp / med / 1e6,
                 "frac_8TBs": npix * bpp / med / 1e6 / 8000.0, "Gpix_s": npix / med / 1e6}
     for k, v in results.items():

@@ -197,6 +197,10 @@ int lars_d_array_stats_f64(const double *x, int64_t n, double threshold, int wan
 size_t lars_select_scratch_bytes(void);
 int lars_d_median_pair_f32(const float *x, int64_t n, float *out_dev, void *scratch, void *stream);
 int lars_d_median_pair_f64(const double *x, int64_t n, double *out_dev, void *scratch, void *stream);
+/* Batched: `items` arrays of n float32 values, `stride` values apart (the index planes of a batch of
+ * tiles); out_dev is [items][2]; scratch must hold items * lars_select_scratch_bytes(). */
+int lars_d_median_pair_batch_f32(const float *x, int64_t n, int64_t items, int64_t stride, float *out_dev,
+                                 void *scratch, void *stream);
 
 /* float32 index -> RGBA8: LUT[min(int((x + 1f) * 128f), 255)], the per-pixel
  * mapping of imshow(cmap, vmin=-1, vmax=1) (process-images.py:695). */

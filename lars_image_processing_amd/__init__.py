@@ -19,6 +19,6 @@ from .api import (  # noqa: F401
     process_image,
     timeseries_row,
 )
-from .batch import TileBatch, local_fold, merge_records, shard_range, summarize  # noqa: F401
+from .batch import TileBatch, local_fold, merge_records, shard_range, summarize, timeseries_rows  # noqa: F401
 
 __version__ = "0.1.0"

@@ -99,6 +99,7 @@ SIGNATURES = {
     "lars_select_scratch_bytes": (_SZ, []),
     "lars_d_median_pair_f32": (_I, [_P, _I64, _P, _P, _P]),
     "lars_d_median_pair_f64": (_I, [_P, _I64, _P, _P, _P]),
+    "lars_d_median_pair_batch_f32": (_I, [_P, _I64, _I64, _I64, _P, _P, _P]),
     "lars_d_colormap_f32": (_I, [_P, _I64, _P, _P, _P]),
     "lars_d_synth_u8": (_I, [_P, _I64, _I64, _I64, _I, _U32, _I, _P]),
     "lars_stats_merge": (_I, [_P, _I64, _P]),

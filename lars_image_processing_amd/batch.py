@@ -147,24 +147,50 @@ class TileBatch:
         _ffi.call("lars_d_fused", C.byref(args))
 
     def process(self, indices=INDEX_NAMES, white_balance=True, hist=False, outputs=None, stream=None,
-                recompute_tables=True):
+                recompute_tables=True, medians=False):
         """Both passes over the whole batch; returns per-tile records
         (structured ndarray ``[ntiles, 3]`` of STATS_DTYPE; rows of indices not
-        requested are zero)."""
+        requested are zero).  ``medians=True`` also returns ``float64[ntiles, 3]``
+        with np.median of each tile's index plane (exact: batched radix select on
+        the float32 planes, which must then be written -- a small ring is
+        allocated when ``outputs`` has none)."""
         if white_balance and (recompute_tables or self.table is None):
             self.compute_wb_tables(stream)
         stats = self.new_stats()
         stats.zero()
-        if outputs is None or outputs.slots >= self.ntiles:
-            self.run_fused(self.fused_args(indices, white_balance, stats, hist, outputs, stream))
-        else:
-            for start in range(0, self.ntiles, outputs.slots):
-                count = min(outputs.slots, self.ntiles - start)
-                self.run_fused(self.fused_args(indices, white_balance, stats, hist, outputs, stream, start, count))
+        own_outputs = None
+        if medians and (outputs is None or any(outputs.index[INDEX_IDS[t]] is None for t in indices)):
+            own_outputs = outputs = self.make_outputs(indices=indices, index=True, ring=min(self.ntiles, 16))
+        med_dev = sel = None
+        if medians:
+            med_dev = DeviceBuffer(self.ntiles * 3 * 2 * 4)
+            med_dev.zero()
+            sel = DeviceBuffer(outputs.slots * int(_ffi.load().lars_select_scratch_bytes()))
+        chunk = self.ntiles if outputs is None else outputs.slots
+        for start in range(0, self.ntiles, chunk):
+            count = min(chunk, self.ntiles - start)
+            self.run_fused(self.fused_args(indices, white_balance, stats, hist, outputs, stream, start, count))
+            if medians:
+                for t in indices:
+                    k = INDEX_IDS[t]
+                    # medians land in med_dev[k][tile][2]
+                    _ffi.call("lars_d_median_pair_batch_f32", C.c_void_p(outputs.index[k].ptr), self.npix, count, self.npix,
+                              C.c_void_p(med_dev.ptr + (k * self.ntiles + start) * 8), C.c_void_p(sel.ptr), stream)
         _ffi.call("lars_synchronize", stream)
         rec = stats.download(STATS_DTYPE, (self.ntiles, 3))
         stats.free()
-        return rec
+        if not medians:
+            return rec
+        pairs = med_dev.download(np.float32, (3, self.ntiles, 2))
+        med = ((pairs[:, :, 0] + pairs[:, :, 1]) / np.float32(2)).astype(np.float64).T.copy()   # float32 mean of the middles
+        for t in INDEX_NAMES:
+            if t not in indices:
+                med[:, INDEX_IDS[t]] = np.nan
+        med_dev.free()
+        sel.free()
+        if own_outputs is not None:
+            own_outputs.free()
+        return rec, med
 
     def free(self):
         for b in (self.tiles, self.hist, self.table, self.percentiles):
@@ -245,3 +271,24 @@ def local_fold(tile_records, indices=INDEX_NAMES):
         k = INDEX_IDS[t]
         out[k] = merge_records(tile_records[:, k])
     return out
+
+
+def timeseries_rows(records, medians, index_type, dates=None):
+    """Rows of the reference's time-series table (process-images.py:646-658: ``Date``, ``Mean``, ``Median``,
+    ``Min``, ``Max``, ``<feature> Coverage (%)``) for every tile of a processed batch -- one pass over
+    the batch instead of one ``calculate_index`` + five NumPy reductions per image."""
+    k = INDEX_IDS[index_type]
+    feature = "Water" if index_type == "NDWI" else "Vegetation"
+    rows = []
+    for i in range(records.shape[0]):
+        r = records[i, k]
+        count = int(r["count"])
+        rows.append({
+            "Date": None if dates is None else dates[i],
+            "Mean": float(r["sum"]) / count,
+            "Median": float(medians[i, k]),
+            "Min": float(r["min"]),
+            "Max": float(r["max"]),
+            f"{feature} Coverage (%)": int(r["above"]) / count * 100,
+        })
+    return rows

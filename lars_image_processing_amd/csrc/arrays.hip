@@ -143,24 +143,30 @@ template <> struct KeyOf<double> {
     __device__ static inline double val(unsigned long long k) { return key_f64(k); }
 };
 
+// All select kernels are batched: blockIdx.y = item (one array of n values, e.g. one tile's plane),
+// st[item] its state, x + item * stride its data.
 __global__ void k_sel_init(SelectState *st, long long n)
 {
+    SelectState *s = st + blockIdx.y;
     const int tid = blockIdx.x * blockDim.x + threadIdx.x;
     if (tid == 0) {
-        st->prefix = 0; st->k0 = (unsigned long long)((n - 1) / 2); st->k = st->k0; st->n = (unsigned long long)n;
-        st->c_le = 0; st->next_key = ~0ull;
+        s->prefix = 0; s->k0 = (unsigned long long)((n - 1) / 2); s->k = s->k0; s->n = (unsigned long long)n;
+        s->c_le = 0; s->next_key = ~0ull;
     }
-    if (tid < SEL_BINS) st->hist[tid] = 0;
+    if (tid < SEL_BINS) s->hist[tid] = 0;
 }
 
 // histogram of digit [shift, shift+bits) over keys that match the prefix above it
 template <typename T>
-__global__ __launch_bounds__(256) void k_sel_hist(const T *__restrict__ x, long long n, SelectState *st, int shift, int bits)
+__global__ __launch_bounds__(256) void k_sel_hist(const T *__restrict__ x, long long n, long long stride, SelectState *st,
+                                                  int shift, int bits)
 {
     __shared__ unsigned int s_h[SEL_BINS];
     for (int i = threadIdx.x; i < SEL_BINS; i += 256) s_h[i] = 0;
     __syncthreads();
-    const unsigned long long prefix = st->prefix;
+    SelectState *s = st + blockIdx.y;
+    x += (long long)blockIdx.y * stride;
+    const unsigned long long prefix = s->prefix;
     const int hi = shift + bits;                                   // bits above the digit
     const bool top = hi >= KeyOf<T>::BITS;
     const unsigned long long dmask = (1ull << bits) - 1ull;
@@ -170,18 +176,19 @@ __global__ __launch_bounds__(256) void k_sel_hist(const T *__restrict__ x, long 
     }
     __syncthreads();
     for (int i = threadIdx.x; i < SEL_BINS; i += 256)
-        if (s_h[i]) atomicAdd(&st->hist[i], s_h[i]);
+        if (s_h[i]) atomicAdd(&s->hist[i], s_h[i]);
 }
 
 __global__ __launch_bounds__(256) void k_sel_pick(SelectState *st, int shift, int bits)
 {
-    // single block: find the digit whose cumulative count covers rank k
+    // one block per item: find the digit whose cumulative count covers rank k
     __shared__ unsigned long long s_cum[256];
+    SelectState *s = st + blockIdx.y;
     const int tid = threadIdx.x;
     const int nb = 1 << bits;
     const int per = (nb + 255) / 256;
     unsigned long long local = 0;
-    for (int j = 0; j < per; ++j) { const int b = tid * per + j; if (b < nb) local += st->hist[b]; }
+    for (int j = 0; j < per; ++j) { const int b = tid * per + j; if (b < nb) local += s->hist[b]; }
     s_cum[tid] = local;
     __syncthreads();
     for (int off = 1; off < 256; off <<= 1) {
@@ -190,29 +197,31 @@ __global__ __launch_bounds__(256) void k_sel_pick(SelectState *st, int shift, in
         s_cum[tid] += v;
         __syncthreads();
     }
-    const unsigned long long k = st->k;
+    const unsigned long long k = s->k;
     unsigned long long cum = s_cum[tid] - local;
     __syncthreads();
     for (int j = 0; j < per; ++j) {
         const int b = tid * per + j;
         if (b < nb) {
-            const unsigned long long c = st->hist[b];
+            const unsigned long long c = s->hist[b];
             if (c && k >= cum && k < cum + c) {
-                st->prefix |= ((unsigned long long)b) << shift;
-                st->k = k - cum;
+                s->prefix |= ((unsigned long long)b) << shift;
+                s->k = k - cum;
             }
             cum += c;
         }
     }
     __syncthreads();
-    for (int i = tid; i < SEL_BINS; i += 256) st->hist[i] = 0;
+    for (int i = tid; i < SEL_BINS; i += 256) s->hist[i] = 0;
 }
 
 template <typename T>
-__global__ __launch_bounds__(256) void k_sel_next(const T *__restrict__ x, long long n, SelectState *st)
+__global__ __launch_bounds__(256) void k_sel_next(const T *__restrict__ x, long long n, long long stride, SelectState *st)
 {
     __shared__ unsigned long long s_c[4], s_m[4];
-    const unsigned long long sel = st->prefix;
+    SelectState *s = st + blockIdx.y;
+    x += (long long)blockIdx.y * stride;
+    const unsigned long long sel = s->prefix;
     unsigned long long c_le = 0, nxt = ~0ull;
     for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < n; i += (long long)gridDim.x * 256) {
         const unsigned long long key = KeyOf<T>::key(x[i]);
@@ -230,21 +239,23 @@ __global__ __launch_bounds__(256) void k_sel_next(const T *__restrict__ x, long 
         unsigned long long c = s_c[0] + s_c[1] + s_c[2] + s_c[3];
         unsigned long long m = s_m[0];
         for (int w = 1; w < 4; ++w) m = s_m[w] < m ? s_m[w] : m;
-        atomicAdd(&st->c_le, c);
-        atomicMin(&st->next_key, m);
+        atomicAdd(&s->c_le, c);
+        atomicMin(&s->next_key, m);
     }
 }
 
 template <typename T>
-__global__ void k_sel_finish(const SelectState *st, T *out)
+__global__ void k_sel_finish(const SelectState *st, T *out, long long items)
 {
-    if (threadIdx.x == 0 && blockIdx.x == 0) {
-        const T v1 = KeyOf<T>::val(st->prefix);
+    const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < items) {
+        const SelectState *s = st + i;
+        const T v1 = KeyOf<T>::val(s->prefix);
         T v2 = v1;
-        const unsigned long long k2 = st->n / 2;                  // == k0 when n is odd
-        if (k2 != st->k0 && k2 >= st->c_le) v2 = KeyOf<T>::val(st->next_key);
-        out[0] = v1;
-        out[1] = v2;
+        const unsigned long long k2 = s->n / 2;                   // == k0 when n is odd
+        if (k2 != s->k0 && k2 >= s->c_le) v2 = KeyOf<T>::val(s->next_key);
+        out[2 * i] = v1;
+        out[2 * i + 1] = v2;
     }
 }
 
@@ -354,34 +365,46 @@ extern "C" int lars_d_array_stats_f64(const double *x, int64_t n, double thresho
 extern "C" size_t lars_select_scratch_bytes(void) { return sizeof(SelectState); }
 
 template <typename T>
-static int median_pair_impl(const T *x, int64_t n, T *out_dev, void *scratch, void *stream)
+static int median_pair_impl(const T *x, int64_t n, int64_t items, int64_t stride, T *out_dev, void *scratch, void *stream)
 {
     ThreadCtx *c;
     LARS_TRY(ensure_ctx(&c));
-    if (!x || n <= 0 || !out_dev || !scratch) return fail(LARS_ERR_INVALID, "lars_d_median_pair: bad arguments");
+    if (!x || n <= 0 || items <= 0 || items > 65535 || !out_dev || !scratch)
+        return fail(LARS_ERR_INVALID, "lars_d_median_pair: bad arguments");
     hipStream_t s = pick_stream(c, stream);
     SelectState *st = static_cast<SelectState *>(scratch);
-    const int nb = grid_for(n);
-    hipLaunchKernelGGL(k_sel_init, dim3(SEL_BINS / 256), dim3(256), 0, s, st, (long long)n);
+    int nb = grid_for(n);
+    if (items > 1) {                                      // enough blocks in total, not per item
+        long long want = (4096 + items - 1) / items;
+        if (nb > want) nb = (int)(want < 1 ? 1 : want);
+    }
+    const unsigned it = (unsigned)items;
+    hipLaunchKernelGGL(k_sel_init, dim3(SEL_BINS / 256, it), dim3(256), 0, s, st, (long long)n);
     int hi = KeyOf<T>::BITS;
     while (hi > 0) {
         const int bits = hi >= SEL_BITS ? SEL_BITS : hi;
         const int shift = hi - bits;
-        hipLaunchKernelGGL((k_sel_hist<T>), dim3(nb), dim3(256), 0, s, x, (long long)n, st, shift, bits);
-        hipLaunchKernelGGL(k_sel_pick, dim3(1), dim3(256), 0, s, st, shift, bits);
+        hipLaunchKernelGGL((k_sel_hist<T>), dim3(nb, it), dim3(256), 0, s, x, (long long)n, (long long)stride, st, shift, bits);
+        hipLaunchKernelGGL(k_sel_pick, dim3(1, it), dim3(256), 0, s, st, shift, bits);
         hi = shift;
     }
-    hipLaunchKernelGGL((k_sel_next<T>), dim3(nb), dim3(256), 0, s, x, (long long)n, st);
-    hipLaunchKernelGGL((k_sel_finish<T>), dim3(1), dim3(64), 0, s, st, out_dev);
+    hipLaunchKernelGGL((k_sel_next<T>), dim3(nb, it), dim3(256), 0, s, x, (long long)n, (long long)stride, st);
+    hipLaunchKernelGGL((k_sel_finish<T>), dim3((it + 63) / 64), dim3(64), 0, s, st, out_dev, (long long)items);
     return launch_check("lars_d_median_pair");
 }
 extern "C" int lars_d_median_pair_f32(const float *x, int64_t n, float *out_dev, void *scratch, void *stream)
 {
-    return median_pair_impl<float>(x, n, out_dev, scratch, stream);
+    return median_pair_impl<float>(x, n, 1, n, out_dev, scratch, stream);
 }
 extern "C" int lars_d_median_pair_f64(const double *x, int64_t n, double *out_dev, void *scratch, void *stream)
 {
-    return median_pair_impl<double>(x, n, out_dev, scratch, stream);
+    return median_pair_impl<double>(x, n, 1, n, out_dev, scratch, stream);
+}
+// items arrays of n float32 values each, `stride` values apart (planes of a batch): out_dev[items][2]
+extern "C" int lars_d_median_pair_batch_f32(const float *x, int64_t n, int64_t items, int64_t stride, float *out_dev,
+                                            void *scratch, void *stream)
+{
+    return median_pair_impl<float>(x, n, items, stride, out_dev, scratch, stream);
 }
 
 extern "C" int lars_d_index_planes_f32(const float *red, const float *green, const float *nir, int64_t n, int index_id,

@@ -296,3 +296,28 @@ def test_uint16_rgba_channels_take_generic_path(lars):
         np.testing.assert_array_equal(wb[i], want)
         np.testing.assert_array_equal(bits(outs.host_index("NDVI", i, 1)[0]), bits(orc.index_app(want, "NDVI")))
     outs.free(); b.free()
+
+
+def test_batch_medians_are_numpy_medians(lars):
+    b = lars.TileBatch.synthetic(21, 64, 96, seed=13, profile="vegetation")        # 21 tiles over a ring of 16: two chunks
+    rec, med = b.process(medians=True)
+    tiles = b.host_tiles()
+    for i in (0, 7, 15, 16, 20):
+        with warnings.catch_warnings():
+            warnings.simplefilter("ignore")
+            wb = orc.wb_app(tiles[i])
+        for k, t in enumerate(TYPES):
+            assert med[i, k] == float(np.median(orc.index_app(wb, t))), (i, t)
+    rows = lars.timeseries_rows(rec, med, "NDVI", dates=[f"2025-01-{d + 1:02d}" for d in range(21)])
+    with warnings.catch_warnings():
+        warnings.simplefilter("ignore")
+        want = orc.stats_timeseries_row(orc.index_app(orc.wb_app(tiles[7]), "NDVI"), "NDVI", "2025-01-08")
+    assert list(rows[7].keys()) == list(want.keys())
+    for key, val in want.items():
+        assert rows[7][key] == (pytest.approx(val, rel=1e-6) if key == "Mean" else val), key
+    rec2, med2 = b.process(indices=("NDWI",), medians=True, white_balance=False)
+    assert np.isnan(med2[:, 0]).all() and med2[3, 2] == float(np.median(orc.index_app(tiles[3], "NDWI")))
+    odd = lars.TileBatch.synthetic(2, 5, 7, seed=1)                                # odd sample count: single middle element
+    _, m = odd.process(medians=True, white_balance=False)
+    assert m[1, 0] == float(np.median(orc.index_app(odd.host_tiles()[1], "NDVI")))
+    b.free(); odd.free()

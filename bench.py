@@ -169,7 +169,7 @@ def device_probe(runner):
     src = runner.batch.tiles.ptr
     out = {}
     for kind, name, mult in ((1, "read_12B_per_lane", 1), (3, "write_16B_per_lane", 1), (2, "copy_16B_per_lane", 2),
-                             (5, "mix_12B_read_48B_write", 1)):
+                             (5, "mix_12B_read_48B_write", 1), (7, "mix_12B_read_16B_write", 1)):
         ts = []
         for _ in range(4):
             ffi.call("lars_event_record", runner.ev[0], None)

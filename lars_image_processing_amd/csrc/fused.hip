@@ -580,13 +580,18 @@ __global__ __launch_bounds__(256) void k_synth_u8(uint8_t *tiles, long long firs
 // ===========================================================================
 using namespace lars;
 
-static int blocks_per_tile(long long work_items, long long ntiles, int threads = 256)
+static int blocks_per_tile(long long work_items, long long ntiles, int threads = 256, long long target_total = 8192)
 {
-    // enough blocks to keep 256 CUs x 8 resident blocks busy, never more than the work
-    long long want = (2048 * 4 * 256 / threads + ntiles - 1) / ntiles;
+    // target_total workgroups per launch (many more than the 256 CUs hold at once: tools/kbench.py
+    // sweeps), but never so many that a block runs fewer than ~16 steps -- every block pays for its
+    // LDS tables and its statistics flush
+    long long want = (target_total * 256 / threads + ntiles - 1) / ntiles;
     if (tuning().blocks_per_tile > 0) want = tuning().blocks_per_tile;
-    long long cap = (work_items + threads - 1) / threads;
-    if (want > cap) want = cap;
+    long long cap = work_items / ((long long)threads * 16);
+    if (cap < 1) cap = 1;
+    if (want > cap && tuning().blocks_per_tile <= 0) want = cap;
+    const long long hard = (work_items + threads - 1) / threads;
+    if (want > hard) want = hard;
     if (want < 1) want = 1;
     if (want > 65535) want = 65535;
     return (int)want;
@@ -731,10 +736,10 @@ extern "C" int lars_d_fused(const lars_fused_args *a)
         dim3 grid(blocks_per_tile(a->npix / 4 + 1, a->ntiles, 512), (unsigned)a->ntiles);
         fused_v2_launch(mask, a->wb_table != nullptr, stats_mode, tuning().nt_stores != 0, grid, s, P);
     } else if (fast && a->dtype == LARS_U8) {
-        dim3 grid(blocks_per_tile(a->npix / 4 + 1, a->ntiles), (unsigned)a->ntiles);
+        dim3 grid(blocks_per_tile(a->npix / 4 + 1, a->ntiles, 256, 32768), (unsigned)a->ntiles);
         launch_fast<uint8_t>(mask, a->wb_table != nullptr, stats_mode, grid, s, P);
     } else if (fast && a->dtype == LARS_U16 && small_tile) {
-        dim3 grid(blocks_per_tile(a->npix / 4 + 1, a->ntiles), (unsigned)a->ntiles);
+        dim3 grid(blocks_per_tile(a->npix / 4 + 1, a->ntiles, 256, 32768), (unsigned)a->ntiles);
         launch_fast<uint16_t>(mask, a->wb_table != nullptr, stats_mode, grid, s, P);
     } else {
         dim3 grid(blocks_per_tile(a->npix, a->ntiles), (unsigned)a->ntiles);

@@ -78,12 +78,24 @@ __global__ __launch_bounds__(256) void k_probe_mix(const unsigned int *__restric
     }
 }
 
+// the NDVI-plane mix: 12 bytes read, 16 bytes written per lane and step
+__global__ __launch_bounds__(256) void k_probe_mix1(const unsigned int *__restrict__ src, pu32x4 *__restrict__ d0, long long nquads)
+{
+    const long long stride = (long long)gridDim.x * 256;
+    for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < nquads; i += stride) {
+        const unsigned int a = src[i * 3], b = src[i * 3 + 1], c = src[i * 3 + 2];
+        const pu32x4 v0 = {a, b, c, a ^ b};
+        d0[i] = v0;
+    }
+}
+
 }  // namespace lars
 
 using namespace lars;
 
 // kind: 0 read 16 B/lane, 1 read 12 B/lane, 2 copy 16 B/lane (bytes read + bytes written = 2*bytes), 3 write 16 B/lane,
-// 4 non-temporal write, 5 / 6 the fused kernel's mix (12 B read + 48 B written per lane; plain / non-temporal stores)
+// 4 non-temporal write, 5 / 6 the fused kernel's mix (12 B read + 48 B written per lane; plain / non-temporal stores),
+// 7 the NDVI-plane mix (12 B read + 16 B written per lane)
 extern "C" int lars_d_probe(int kind, int unroll, int blocks, const void *src, void *dst, int64_t bytes, void *stream)
 {
     ThreadCtx *c;
@@ -120,6 +132,9 @@ extern "C" int lars_d_probe(int kind, int unroll, int blocks, const void *src, v
             hipLaunchKernelGGL((k_probe_mix<false>), dim3(blocks), dim3(256), 0, s, p, d, d + nquads, d + 2 * nquads, nquads);
         else
             hipLaunchKernelGGL((k_probe_mix<true>), dim3(blocks), dim3(256), 0, s, p, d, d + nquads, d + 2 * nquads, nquads);
+    } else if (kind == 7) {
+        const long long nquads = bytes / 28;               // total traffic = bytes
+        hipLaunchKernelGGL(k_probe_mix1, dim3(blocks), dim3(256), 0, s, p, static_cast<pu32x4 *>(dst), nquads);
     } else {
         return fail(LARS_ERR_INVALID, "lars_d_probe: kind");
     }

@@ -15,7 +15,7 @@ def main():
     _ffi.call("lars_event_create", C.byref(a)); _ffi.call("lars_event_create", C.byref(b))
     res = {}
     for kind, name, mult in ((0, "read16", 1), (1, "read12", 1), (2, "copy16", 2), (3, "write16", 1), (4, "write16nt", 1),
-                             (5, "mix12r48w", 1), (6, "mix12r48w_nt", 1)):
+                             (5, "mix12r48w", 1), (6, "mix12r48w_nt", 1), (7, "mix12r16w", 1)):
         for unroll in ((1, 4) if kind < 2 else (1,)):
             for blocks in (2048, 8192, 16384, 65536, 262144):
                 ts = []

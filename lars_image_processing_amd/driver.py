@@ -97,3 +97,42 @@ def batch_process(input_dir, output_dir, process_wb=False, process_ndvi=False, p
             for k, v in pool.map(one, enumerate(files, 1)):
                 results[k] = v
     return results
+
+
+def export_zip(image_array, selected_indices, corrected_array=None, render="lut"):
+    """ZIP of the processed images of one upload (``download_processed_images``,
+    process-images.py:567-617): ``white_balanced.png`` + ``<INDEX>_visualization.png`` per index.
+
+    ``render="lut"`` writes the full-resolution per-pixel colormap image (one GPU pass for white
+    balance, every index and every colormap; no matplotlib figure), ``render="figure"`` the
+    reference's figure.  ``corrected_array`` (the cached white-balanced image the UI keeps,
+    process-images.py:1132) skips the white-balance step.
+    """
+    import io
+    import zipfile
+    from PIL import Image
+    indices = list(selected_indices)
+    if corrected_array is not None:
+        res = api.process_image(np.asarray(corrected_array), indices=indices, white_balance=False,
+                                want_arrays=(render == "figure"), want_rgba=(render == "lut"))
+        corrected = np.asarray(corrected_array)
+    else:
+        res = api.process_image(np.asarray(image_array), indices=indices, white_balance=True,
+                                want_arrays=(render == "figure"), want_rgba=(render == "lut"))
+        corrected = res["corrected"]
+    buf = io.BytesIO()
+    with zipfile.ZipFile(buf, "w", zipfile.ZIP_DEFLATED) as zf:
+        png = io.BytesIO()
+        Image.fromarray(corrected).save(png, format="PNG")
+        zf.writestr("white_balanced.png", png.getvalue())
+        for t in indices:
+            png = io.BytesIO()
+            if render == "lut":
+                Image.fromarray(res["indices"][t]["rgba"], "RGBA").save(png, format="PNG")
+            else:
+                import tempfile
+                with tempfile.NamedTemporaryFile(suffix=".png") as tmp:
+                    _figure_png(res["indices"][t]["index"], t, tmp.name)
+                    png.write(open(tmp.name, "rb").read())
+            zf.writestr(f"{t}_visualization.png", png.getvalue())
+    return buf.getvalue()

@@ -46,3 +46,26 @@ def test_batch_process_directory(tmp_path):
     res2 = driver.batch_process(src, tmp_path / "fig", process_wb=False, process_ndwi=True, render="figure", verbose=False)
     assert (tmp_path / "fig" / "NDWI" / "a_ndwi.png").stat().st_size > 1000
     assert not (tmp_path / "fig" / "white_balanced").exists() and "Water Coverage (%)" in res2["a.png"]["NDWI"]
+
+
+def test_export_zip(tmp_path):
+    import io
+    import zipfile
+    from PIL import Image
+    import lars_image_processing_amd as lars
+    from lars_image_processing_amd import driver
+    img = orc.synth_tile_u8(9, 2, 50, 70, profile="vegetation")
+    with warnings.catch_warnings():
+        warnings.simplefilter("ignore")
+        want_wb = orc.wb_app(img)
+    data = driver.export_zip(img, ["NDVI", "NDWI"])
+    with zipfile.ZipFile(io.BytesIO(data)) as zf:
+        assert sorted(zf.namelist()) == ["NDVI_visualization.png", "NDWI_visualization.png", "white_balanced.png"]
+        np.testing.assert_array_equal(np.array(Image.open(io.BytesIO(zf.read("white_balanced.png")))), want_wb)
+        got = np.array(Image.open(io.BytesIO(zf.read("NDWI_visualization.png"))))
+        np.testing.assert_array_equal(got, orc.colormap_closed_form(orc.index_app(want_wb, "NDWI"), lars.colormap_lut("RdYlBu")))
+    # with the cached white-balanced image, as the UI calls it
+    data2 = driver.export_zip(None, ["NDVI"], corrected_array=want_wb)
+    with zipfile.ZipFile(io.BytesIO(data2)) as zf:
+        got = np.array(Image.open(io.BytesIO(zf.read("NDVI_visualization.png"))))
+        np.testing.assert_array_equal(got, orc.colormap_closed_form(orc.index_app(want_wb, "NDVI"), lars.colormap_lut("RdYlGn")))

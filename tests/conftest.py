@@ -15,6 +15,12 @@ GOLDEN_DIR = os.path.join(ROOT, "tests", "golden")
 
 def pytest_configure(config):
     config.addinivalue_line("markers", "gpu: needs a real MI355X (gfx950) device")
+    # the shared library is git-ignored: build it when a fresh checkout has none (hipcc cross-compiles
+    # gfx950 without a GPU; on the GPU box the .so travels with the snapshot)
+    lib = os.path.join(ROOT, "lars_image_processing_amd", "liblars_hip.so")
+    if not os.path.exists(lib):
+        import subprocess
+        subprocess.check_call(["make", "-C", os.path.join(ROOT, "lars_image_processing_amd", "csrc"), "-j4"])
 
 
 @pytest.fixture(scope="session")

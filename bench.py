@@ -59,6 +59,7 @@ def parse():
     ap.add_argument("--profile", default="vegetation", choices=["uniform", "vegetation"])
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-tiles", type=int, default=8)
+    ap.add_argument("--cpu-workers", type=int, default=16, help="process pool of the multi-core CPU baseline leg")
     return ap.parse_args()
 
 
@@ -136,28 +137,46 @@ class Runner:
         return dt, timed, glob
 
 
-def cpu_baseline(args):
-    """The NumPy oracle (oracle/index_oracle.py == the reference's expressions) on a bounded sample."""
+def _cpu_tile_job(job):
+    """One tile through the NumPy oracle: white balance + 3 indices + 3 analyze_index (worker of cpu_baseline)."""
     import warnings
     from oracle import index_oracle as orc
-    n = max(1, args.cpu_tiles)
-    tiles = [orc.synth_tile_u8(1234, i, args.tile, args.tile, profile=args.profile) for i in range(n)]
+    tile, edge, profile = job
+    img = orc.synth_tile_u8(1234, tile, edge, edge, profile=profile)
     t0 = time.perf_counter()
     with warnings.catch_warnings():
         warnings.simplefilter("ignore")
-        for img in tiles:
-            wb = orc.wb_app(img)
-            for t in ("NDVI", "GNDVI", "NDWI"):
-                idx = orc.index_app(wb, t)
-                orc.stats_app(idx, t)
-    dt = time.perf_counter() - t0
-    pix = n * args.tile * args.tile
-    return {
-        "value": pix / dt / 1e6, "unit": "Mpix/s", "cores": 1, "kind": "port",
+        wb = orc.wb_app(img)
+        for t in ("NDVI", "GNDVI", "NDWI"):
+            orc.stats_app(orc.index_app(wb, t), t)
+    return time.perf_counter() - t0
+
+
+def cpu_baseline(args):
+    """The NumPy oracle (oracle/index_oracle.py == the reference's expressions) on a bounded sample:
+    one process / one core (how the reference runs), and a process pool over tiles on this GPU's
+    share of the host cores."""
+    n = max(1, args.cpu_tiles)
+    pix_tile = args.tile * args.tile
+    dt1 = sum(_cpu_tile_job((i, args.tile, args.profile)) for i in range(n))
+    out = {
+        "value": n * pix_tile / dt1 / 1e6, "unit": "Mpix/s", "cores": 1, "kind": "port",
         "sample": f"{n} tiles {args.tile}x{args.tile} uint8 ({args.profile}): fix_white_balance + 3x calculate_index "
-                  f"+ 3x analyze_index (incl. median), NumPy {np.__version__}, single process, {dt:.1f} s",
+                  f"+ 3x analyze_index (incl. median), NumPy {np.__version__}, single process, {dt1:.1f} s",
         "host_cpus": os.cpu_count(),
     }
+    workers = max(1, min(args.cpu_workers, os.cpu_count() or 1))
+    if workers > 1:
+        import multiprocessing as mp
+        jobs = [(i, args.tile, args.profile) for i in range(2 * workers)]
+        with mp.get_context("spawn").Pool(workers) as pool:
+            pool.map(_cpu_tile_job, jobs[:workers])              # warm the workers (imports, page faults)
+            t0 = time.perf_counter()
+            pool.map(_cpu_tile_job, jobs)
+            dtp = time.perf_counter() - t0
+        out["pool"] = {"value": len(jobs) * pix_tile / dtp / 1e6, "unit": "Mpix/s", "cores": workers,
+                       "sample": f"{len(jobs)} tiles over a pool of {workers} processes, {dtp:.1f} s"}
+    return out
 
 
 def device_probe(runner):

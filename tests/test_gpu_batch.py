@@ -321,3 +321,39 @@ def test_batch_medians_are_numpy_medians(lars):
     _, m = odd.process(medians=True, white_balance=False)
     assert m[1, 0] == float(np.median(orc.index_app(odd.host_tiles()[1], "NDVI")))
     b.free(); odd.free()
+
+
+def test_bad_arguments_fail_cleanly(lars):
+    """Every entry point validates its arguments and reports through lars_last_error (no crash, no launch)."""
+    import ctypes as C
+    from lars_image_processing_amd import _ffi
+    lib = _ffi.load()
+    b = lars.TileBatch.synthetic(2, 16, 16, seed=1)
+    b.compute_wb_tables()
+    a = b.fused_args(("NDVI",), True, None, False, None)
+    cases = []
+    bad = _ffi.FusedArgs.from_buffer_copy(a); bad.tiles = None; cases.append(bad)
+    bad = _ffi.FusedArgs.from_buffer_copy(a); bad.ntiles = 0; cases.append(bad)
+    bad = _ffi.FusedArgs.from_buffer_copy(a); bad.channels = 2; cases.append(bad)
+    bad = _ffi.FusedArgs.from_buffer_copy(a); bad.dtype = 7; cases.append(bad)
+    bad = _ffi.FusedArgs.from_buffer_copy(a); bad.index_mask = 8; cases.append(bad)
+    bad = _ffi.FusedArgs.from_buffer_copy(a); bad.flags = _ffi.F_STATS; cases.append(bad)          # stats == NULL
+    bad = _ffi.FusedArgs.from_buffer_copy(a); bad.index_mask = 0; cases.append(bad)                # nothing to do
+    bad = _ffi.FusedArgs.from_buffer_copy(a); bad.wb_table = None; bad.out_wb = b.tiles.ptr; cases.append(bad)
+    bad = _ffi.FusedArgs.from_buffer_copy(a); bad.out_rgba[0] = b.tiles.ptr; cases.append(bad)    # no LUT
+    for bad in cases:
+        assert lib.lars_d_fused(C.byref(bad)) == -1 and lib.lars_last_error()
+    assert lib.lars_d_channel_hist(None, 1, 16, 3, _ffi.U8, None, None) == -1
+    assert lib.lars_d_wb_table(None, 1, 16, _ffi.U8, None, None, 0, None) == -1
+    assert lib.lars_d_wb_prepare(C.c_void_p(b.tiles.ptr), 1, 16, 3, 9, C.c_void_p(b.table.ptr), None, 0, None) == -1
+    assert lib.lars_h_fix_white_balance(None, 4, 4, 3, _ffi.U8, 0, None, None) == -1
+    assert lib.lars_h_analyze_f32(None, 0, 0.2, 0, None, None) == -1
+    assert lib.lars_d_median_pair_f32(None, 10, None, None, None) == -1
+    assert lib.lars_set_tuning(b"no_such_knob", 1) == -1
+    assert lib.lars_set_device(99) == -1 and b"out of range" in lib.lars_last_error()
+    with pytest.raises(TypeError):
+        lars.fix_white_balance(np.zeros((4, 4, 3), np.float32))
+    # the library still works afterwards
+    rec = b.process(indices=("NDVI",))
+    assert int(rec[0, 0]["count"]) == 256
+    b.free()

@@ -217,6 +217,37 @@ __device__ inline unsigned int sample_entry(unsigned int word, int byte, unsigne
     return *reinterpret_cast<const unsigned int *>(s_tab + addr);
 }
 
+// Coverage counters live in scalar registers.  The compare mask goes through VCC inside ONE asm
+// statement (v_cmp -> s_bcnt1), so it never occupies an allocatable SGPR pair: with the
+// ballot/popcount form hipcc kept a dozen 64-bit masks alive per quad, ran out of SGPRs and spilled
+// them with v_writelane_b32 (4.5 extra VALU instructions per pixel in the three-index kernel).
+// Inactive lanes contribute zero bits; scalar instructions ignore EXEC.
+// LARS_COUNT_MODE (build-time, tools/kbench A/B): 0 scalar counters everywhere, 1 per-lane vector
+// counters everywhere (v_cmp + v_addc, no SALU), 2 NDVI on the vector pipe and GNDVI/NDWI on the scalar pipe.
+#ifndef LARS_COUNT_MODE
+#define LARS_COUNT_MODE 0
+#endif
+__device__ inline void vcount_gt(unsigned int &lane_counter, float x, float thr) { lane_counter += (x > thr) ? 1u : 0u; }
+__device__ inline void vcount_lt(unsigned int &lane_counter, float x, float thr) { lane_counter += (x < thr) ? 1u : 0u; }
+__device__ inline unsigned int wave_sum_u32(unsigned int v)
+{
+    for (int off = 32; off >= 1; off >>= 1) v += __shfl_xor(v, off);
+    return v;
+}
+
+__device__ inline void count_gt(unsigned int &counter, float x, float thr)      // counter += #lanes(x > thr)
+{
+    unsigned int c;
+    asm volatile("v_cmp_lt_f32 vcc, %1, %2\n\ts_bcnt1_i32_b64 %0, vcc" : "=s"(c) : "s"(thr), "v"(x) : "vcc", "scc");
+    counter += c;
+}
+__device__ inline void count_lt(unsigned int &counter, float x, float thr)      // counter += #lanes(x < thr)
+{
+    unsigned int c;
+    asm volatile("v_cmp_gt_f32 vcc, %1, %2\n\ts_bcnt1_i32_b64 %0, vcc" : "=s"(c) : "s"(thr), "v"(x) : "vcc", "scc");
+    counter += c;
+}
+
 template <int STATS>
 __device__ inline void push(WaveAcc &a, unsigned int &above, float x, float thr)
 {
@@ -231,7 +262,8 @@ __device__ inline void push(WaveAcc &a, unsigned int &above, float x, float thr)
     a.sum += xd;
     if (STATS >= 2) a.sumsq += xd * xd;
 #endif
-    above += (unsigned int)__popcll(__ballot(x > thr));              // wave-uniform scalar counter
+    if (LARS_COUNT_MODE == 0) count_gt(above, x, thr);               // wave-uniform scalar counter
+    else vcount_gt(above, x, thr);                                   // per-lane counter, folded at flush
 }
 
 __device__ inline void hist_add(unsigned int *s_hist, const HistCell<float> *s_edges, int index, float x, unsigned int lane32)
@@ -361,8 +393,13 @@ __global__ __launch_bounds__(512, 4) void k_fused_v2(FusedParams P)
                     acc_g.sum += xd;
                     if (STATS >= 2) acc_g.sumsq += xd * xd;
 #endif
-                    if (WANT_GNDVI) above_g += (unsigned int)__popcll(__ballot(x > 0.2f));
-                    if (WANT_NDWI) above_w += (unsigned int)__popcll(__ballot(x < 0.0f));   // -x > 0
+                    if (LARS_COUNT_MODE == 1) {
+                        if (WANT_GNDVI) vcount_gt(above_g, x, 0.2f);
+                        if (WANT_NDWI) vcount_lt(above_w, x, 0.0f);           // -x > 0
+                    } else {
+                        if (WANT_GNDVI) count_gt(above_g, x, 0.2f);
+                        if (WANT_NDWI) count_lt(above_w, x, 0.0f);
+                    }
                 }
                 if (STATS >= 2 && WANT_GNDVI) hist_add(s_hist, s_edges, 1, x, lane32);
                 if (WANT_NDWI) {
@@ -451,8 +488,13 @@ __global__ __launch_bounds__(512, 4) void k_fused_v2(FusedParams P)
                 const double xd = (double)x;
                 acc_g.sum += xd;
                 if (STATS >= 2) acc_g.sumsq += xd * xd;
-                if (WANT_GNDVI) above_g += (unsigned int)__popcll(__ballot(x > 0.2f));
-                if (WANT_NDWI) above_w += (unsigned int)__popcll(__ballot(x < 0.0f));
+                if (LARS_COUNT_MODE == 1) {
+                    if (WANT_GNDVI) vcount_gt(above_g, x, 0.2f);
+                    if (WANT_NDWI) vcount_lt(above_w, x, 0.0f);
+                } else {
+                    if (WANT_GNDVI) count_gt(above_g, x, 0.2f);
+                    if (WANT_NDWI) count_lt(above_w, x, 0.0f);
+                }
             }
             if (WANT_GNDVI) {
                 if (STATS >= 2) hist_add(s_hist, s_edges, 1, x, lane32);
@@ -469,7 +511,9 @@ __global__ __launch_bounds__(512, 4) void k_fused_v2(FusedParams P)
     }
 
     if (STATS >= 1) {
-        // wave fold (above_* are already wave totals)
+        // wave fold (scalar counters are already wave totals; per-lane ones are summed here)
+        if (LARS_COUNT_MODE != 0) above_v = wave_sum_u32(above_v);
+        if (LARS_COUNT_MODE == 1) { above_g = wave_sum_u32(above_g); above_w = wave_sum_u32(above_w); }
         for (int off = 32; off >= 1; off >>= 1) {
             if (WANT_NDVI) {
                 acc_v.mn = fminf(acc_v.mn, __shfl_xor(acc_v.mn, off)); acc_v.mx = fmaxf(acc_v.mx, __shfl_xor(acc_v.mx, off));

@@ -398,8 +398,11 @@ __global__ __launch_bounds__(256) void k_fused_u8c3(FusedParams P)
             for (int i = 0; i < 12; ++i) b[i] = t[i];
         }
         if (WB) {
+            // channels no requested index reads are only mapped when the white-balanced image is written
+            const bool need_r = (MASK & 1u) || owb, need_g = (MASK & 6u) || owb;
 #pragma unroll
-            for (int i = 0; i < 12; ++i) b[i] = wb_map(b[i], i % 3);
+            for (int i = 0; i < 12; ++i)
+                if (i % 3 == 2 || (i % 3 == 0 && need_r) || (i % 3 == 1 && need_g)) b[i] = wb_map(b[i], i % 3);
             if (owb) {
                 unsigned int *o = reinterpret_cast<unsigned int *>(owb + q * 12);
                 o[0] = b[0] | (b[1] << 8) | (b[2] << 16) | (b[3] << 24);

@@ -270,6 +270,12 @@ int lars_h_process_image(const void *img, int64_t h, int64_t w, int channels, in
 
 int lars_h_colormap_f32(const float *x, int64_t n, const uint8_t *lut_rgba, uint8_t *out_rgba);
 
+/* preprocess_large_image -- process-images.py:398-422: PIL.Image.resize((new_w, new_h), LANCZOS) of a
+ * uint8 image with 1, 3 or 4 (RGBA, premultiplied-alpha path) channels, bit-identical to Pillow's
+ * fixed-point resampler.  out is host [new_h][new_w][channels]. */
+int lars_h_resize_lanczos_u8(const uint8_t *img, int64_t h, int64_t w, int channels, int64_t new_h, int64_t new_w,
+                             uint8_t *out);
+
 /* ------------------------------------------------------------------ multi-GPU */
 /* One process per GPU.  RCCL (librccl.so) is loaded on first use.  unique_id is
  * LARS_COMM_ID_BYTES bytes produced by lars_comm_unique_id() on rank 0 and

@@ -16,6 +16,7 @@ from .api import (  # noqa: F401
     fix_white_balance,
     fix_white_balance_rgnir,
     index_histogram,
+    preprocess_large_image,
     process_image,
     timeseries_row,
 )

@@ -37,7 +37,7 @@ __all__ = [
     "fix_white_balance", "correct_white_balance", "fix_white_balance_rgnir",
     "calculate_index", "calculate_ndvi", "analyze_index", "analyze_index_statistics",
     "analyze_ndvi_statistics", "index_histogram", "colorize_index", "process_image",
-    "timeseries_row", "colormap_lut",
+    "timeseries_row", "colormap_lut", "preprocess_large_image",
 ]
 
 _CMAPS = None
@@ -75,6 +75,36 @@ def _as_image(img_array, what):
     if arr.shape[2] < 3:
         raise IndexError(f"index 2 is out of bounds for axis 2 with size {arr.shape[2]}")
     return np.ascontiguousarray(arr)
+
+
+# ---------------------------------------------------------------------------
+# down-scale in front of the path
+# ---------------------------------------------------------------------------
+def preprocess_large_image(img_array, max_dimension=1024):
+    """process-images.py:398-422: LANCZOS down-scale to ``max_dimension`` on the long edge.
+
+    ``None``/empty -> ``None``; an image that already fits is returned as is (the same object,
+    as upstream); otherwise Pillow's ``resize((new_w, new_h), LANCZOS)``, bit for bit, on the GPU
+    (uint8 images with 1, 3 or 4 channels; 4 = RGBA through premultiplied alpha, as Pillow does).
+    """
+    if img_array is None or np.size(img_array) == 0:
+        return None
+    h, w = img_array.shape[:2]
+    if max(h, w) <= max_dimension:
+        return img_array
+    if h > w:
+        new_h = max_dimension
+        new_w = int(w * (max_dimension / h))
+    else:
+        new_w = max_dimension
+        new_h = int(h * (max_dimension / w))
+    arr = np.ascontiguousarray(img_array)
+    if arr.dtype != np.uint8 or arr.ndim not in (2, 3) or (arr.ndim == 3 and arr.shape[2] not in (1, 3, 4)):
+        raise TypeError(f"preprocess_large_image: uint8 images with 1, 3 or 4 channels (got {arr.dtype}, shape {arr.shape})")
+    c = 1 if arr.ndim == 2 else arr.shape[2]
+    out = np.empty((new_h, new_w) if arr.ndim == 2 else (new_h, new_w, c), dtype=np.uint8)
+    _ffi.call("lars_h_resize_lanczos_u8", _ffi.ptr(arr), h, w, c, new_h, new_w, _ffi.ptr(out))
+    return out
 
 
 # ---------------------------------------------------------------------------

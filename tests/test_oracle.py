@@ -166,3 +166,32 @@ def test_synth_tile_is_deterministic_and_profiled():
     assert not np.array_equal(a, orc.synth_tile_u8(1234, 4, 16, 20))
     v = orc.synth_tile_u8(1234, 3, 16, 20, profile="vegetation")
     assert v[:, :, 0].max() <= 20 + 255 * 3 // 8 and v[:, :, 2].min() >= 60
+
+
+# ---------------------------------------------------------------- preprocess_large_image ---
+def _resize_cases():
+    import os
+    from conftest import GOLDEN_DIR
+    with np.load(os.path.join(GOLDEN_DIR, "resize_outputs.npz"), allow_pickle=False) as z:
+        return sorted({k.split("/")[0] for k in z.files})
+
+
+@pytest.fixture(scope="session")
+def resize_golden():
+    import os
+    from conftest import GOLDEN_DIR
+    with np.load(os.path.join(GOLDEN_DIR, "resize_outputs.npz"), allow_pickle=False) as z:
+        return {k: z[k] for k in z.files}
+
+
+@pytest.mark.parametrize("case", _resize_cases())
+def test_lanczos_restatement_matches_reference(resize_golden, golden_dicts, case):
+    from oracle import resize_oracle as ro
+    img = resize_golden[f"{case}/input"]
+    md = int(resize_golden[f"{case}/max_dimension"])
+    got = ro.preprocess_large_image(img, md)
+    want = resize_golden[f"{case}/output"]
+    assert got.dtype == np.uint8 and got.shape == want.shape
+    np.testing.assert_array_equal(got, want)
+    assert (got is img) == bool(resize_golden[f"{case}/same_object"])
+    assert golden_dicts["dicts"]["contract/resize_none"] == "None" and ro.preprocess_large_image(None) is None

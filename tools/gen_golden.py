@@ -177,6 +177,31 @@ def main():
         arrays[f"colormap/{cm_name}_lut"] = cm(np.arange(256), bytes=True)       # [256,4] uint8
         arrays[f"colormap/{cm_name}_probe_rgba"] = cm(Normalize(-1, 1)(probe), bytes=True)
 
+    # ---- preprocess_large_image (process-images.py:398-422): Pillow LANCZOS down-scale before the hot path
+    resize = {}
+    r = np.random.default_rng(31)
+    resize_cases = {
+        "rgb_150x110_to64": (r.integers(0, 256, (150, 110, 3), dtype=np.uint8), 64),
+        "rgb_110x150_to64": (r.integers(0, 256, (110, 150, 3), dtype=np.uint8), 64),
+        "rgb_97x301_to100": (r.integers(0, 256, (97, 301, 3), dtype=np.uint8), 100),
+        "rgb_513x40_to50": (r.integers(0, 256, (513, 40, 3), dtype=np.uint8), 50),
+        "rgb_smooth_200x160_to96": ((np.add.outer(np.arange(200), np.arange(160))[:, :, None] * np.array([1, 2, 3]) % 256).astype(np.uint8), 96),
+        "rgba_120x90_to64": (r.integers(0, 256, (120, 90, 4), dtype=np.uint8), 64),
+        "gray_90x140_to60": (r.integers(0, 256, (90, 140), dtype=np.uint8), 60),
+        "rgb_small_40x50_to64": (r.integers(0, 256, (40, 50, 3), dtype=np.uint8), 64),      # returned unchanged
+        "rgb_65x64_to64": (r.integers(0, 256, (65, 64, 3), dtype=np.uint8), 64),            # scale barely above 1
+    }
+    rgba_in = resize_cases["rgba_120x90_to64"][0]
+    rgba_in[:10, :, 3] = 0
+    rgba_in[10:30, :, 3] = 255
+    for name, (img, md) in resize_cases.items():
+        out = app.preprocess_large_image(img, max_dimension=md)
+        resize[f"{name}/input"] = img
+        resize[f"{name}/max_dimension"] = np.array(md)
+        resize[f"{name}/output"] = out
+        resize[f"{name}/same_object"] = np.array(out is img)
+    dicts["contract/resize_none"] = repr(app.preprocess_large_image(None))
+
     meta = {
         "numpy": np.__version__,
         "matplotlib": matplotlib.__version__,
@@ -187,6 +212,7 @@ def main():
     }
     os.makedirs(args.out, exist_ok=True)
     np.savez_compressed(os.path.join(args.out, "reference_outputs.npz"), **arrays)
+    np.savez_compressed(os.path.join(args.out, "resize_outputs.npz"), **resize)
     with open(os.path.join(args.out, "reference_dicts.json"), "w") as fh:
         json.dump({"meta": meta, "dicts": dicts}, fh, indent=1)   # insertion order kept: key order is contract
     total = sum(a.nbytes for a in arrays.values())

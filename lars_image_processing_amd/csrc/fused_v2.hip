@@ -248,7 +248,30 @@ __device__ inline void count_lt(unsigned int &counter, float x, float thr)      
     counter += c;
 }
 
-template <int STATS>
+// four samples at once: one asm statement per counter and quad (hipcc pads every asm statement that
+// touches VCC with an s_nop, and every scalar instruction costs a slot of the CU's single scalar pipe)
+__device__ inline void count4_gt(unsigned int &counter, const float (&x)[4], float thr)
+{
+    unsigned int c;
+    asm volatile("v_cmp_lt_f32 vcc, %1, %2\n\ts_bcnt1_i32_b64 %0, vcc\n\t"
+                 "v_cmp_lt_f32 vcc, %1, %3\n\ts_bcnt1_i32_b64 vcc_lo, vcc\n\ts_add_u32 %0, %0, vcc_lo\n\t"
+                 "v_cmp_lt_f32 vcc, %1, %4\n\ts_bcnt1_i32_b64 vcc_lo, vcc\n\ts_add_u32 %0, %0, vcc_lo\n\t"
+                 "v_cmp_lt_f32 vcc, %1, %5\n\ts_bcnt1_i32_b64 vcc_lo, vcc\n\ts_add_u32 %0, %0, vcc_lo"
+                 : "=&s"(c) : "s"(thr), "v"(x[0]), "v"(x[1]), "v"(x[2]), "v"(x[3]) : "vcc", "scc");
+    counter += c;
+}
+__device__ inline void count4_lt(unsigned int &counter, const float (&x)[4], float thr)
+{
+    unsigned int c;
+    asm volatile("v_cmp_gt_f32 vcc, %1, %2\n\ts_bcnt1_i32_b64 %0, vcc\n\t"
+                 "v_cmp_gt_f32 vcc, %1, %3\n\ts_bcnt1_i32_b64 vcc_lo, vcc\n\ts_add_u32 %0, %0, vcc_lo\n\t"
+                 "v_cmp_gt_f32 vcc, %1, %4\n\ts_bcnt1_i32_b64 vcc_lo, vcc\n\ts_add_u32 %0, %0, vcc_lo\n\t"
+                 "v_cmp_gt_f32 vcc, %1, %5\n\ts_bcnt1_i32_b64 vcc_lo, vcc\n\ts_add_u32 %0, %0, vcc_lo"
+                 : "=&s"(c) : "s"(thr), "v"(x[0]), "v"(x[1]), "v"(x[2]), "v"(x[3]) : "vcc", "scc");
+    counter += c;
+}
+
+template <int STATS, bool COUNT = true>
 __device__ inline void push(WaveAcc &a, unsigned int &above, float x, float thr)
 {
     a.mn = fminf(a.mn, x);
@@ -262,8 +285,10 @@ __device__ inline void push(WaveAcc &a, unsigned int &above, float x, float thr)
     a.sum += xd;
     if (STATS >= 2) a.sumsq += xd * xd;
 #endif
-    if (LARS_COUNT_MODE == 0) count_gt(above, x, thr);               // wave-uniform scalar counter
-    else vcount_gt(above, x, thr);                                   // per-lane counter, folded at flush
+    if (COUNT) {
+        if (LARS_COUNT_MODE == 0) count_gt(above, x, thr);           // wave-uniform scalar counter
+        else vcount_gt(above, x, thr);                               // per-lane counter, folded at flush
+    }
 }
 
 __device__ inline void hist_add(unsigned int *s_hist, const HistCell<float> *s_edges, int index, float x, unsigned int lane32)
@@ -376,7 +401,7 @@ __global__ __launch_bounds__(512, 4) void k_fused_v2(FusedParams P)
         for (int px = 0; px < 4; ++px) {
             if (WANT_NDVI) {
                 const float x = v0[px];
-                if (STATS >= 1) push<STATS>(acc_v, above_v, x, 0.2f);
+                if (STATS >= 1) push<STATS, LARS_COUNT_MODE != 0>(acc_v, above_v, x, 0.2f);
                 if (STATS >= 2) hist_add(s_hist, s_edges, 0, x, lane32);
             }
             if (NEED_G) {
@@ -396,9 +421,6 @@ __global__ __launch_bounds__(512, 4) void k_fused_v2(FusedParams P)
                     if (LARS_COUNT_MODE == 1) {
                         if (WANT_GNDVI) vcount_gt(above_g, x, 0.2f);
                         if (WANT_NDWI) vcount_lt(above_w, x, 0.0f);           // -x > 0
-                    } else {
-                        if (WANT_GNDVI) count_gt(above_g, x, 0.2f);
-                        if (WANT_NDWI) count_lt(above_w, x, 0.0f);
                     }
                 }
                 if (STATS >= 2 && WANT_GNDVI) hist_add(s_hist, s_edges, 1, x, lane32);
@@ -407,6 +429,14 @@ __global__ __launch_bounds__(512, 4) void k_fused_v2(FusedParams P)
                     if (STATS >= 2) hist_add(s_hist, s_edges, 2, v2[px], lane32);
                 }
             }
+        }
+        if (STATS >= 1 && LARS_COUNT_MODE == 0) {
+            if (WANT_NDVI) count4_gt(above_v, v0, 0.2f);
+            if (WANT_GNDVI) count4_gt(above_g, v1, 0.2f);
+            if (WANT_NDWI) count4_lt(above_w, v1, 0.0f);                   // -x > 0
+        } else if (STATS >= 1 && LARS_COUNT_MODE == 2) {
+            if (WANT_GNDVI) count4_gt(above_g, v1, 0.2f);
+            if (WANT_NDWI) count4_lt(above_w, v1, 0.0f);
         }
         if (WANT_NDVI && oi0) {
             store4<NT>(oi0 + q * 4, v0[0], v0[1], v0[2], v0[3]);

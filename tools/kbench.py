@@ -58,6 +58,7 @@ def main():
     ap.add_argument("--nt", default="0,1")
     ap.add_argument("--ntl", default="0", help="non-temporal loads: 0, 1 or 0,1")
     ap.add_argument("--bpt", default="0")
+    ap.add_argument("--prefetch", default="0", help="first-generation kernels: 0, 1 or 0,1")
     ap.add_argument("--wb", default="1")
     ap.add_argument("--profile", default="vegetation")
     args = ap.parse_args()
@@ -96,18 +97,19 @@ def main():
                     for bp in map(int, args.bpt.split(",")):
                         for wb in map(int, args.wb.split(",")):
                             for nl in map(int, args.ntl.split(",")):
-                                variants.append((m, impl, nt, bp, wb, nl))
+                                for pf in map(int, args.prefetch.split(",")):
+                                    variants.append((m, impl, nt, bp, wb, nl, pf))
         times = {v: [] for v in variants}
         for _ in range(args.rounds + 1):
             for v in variants:
-                m, impl, nt, bp, wb, nl = v
+                m, impl, nt, bp, wb, nl, pf = v
                 indices, write, hist, bpp = MODES[m]
                 outs = None
                 if write:
                     if indices not in outs_cache:
                         outs_cache[indices] = b.make_outputs(indices=indices, index=True, ring=args.ring)
                     outs = outs_cache[indices]
-                _ffi.set_tuning(fused_impl=impl, nt_stores=nt, blocks_per_tile=bp, nt_loads=nl)
+                _ffi.set_tuning(fused_impl=impl, nt_stores=nt, blocks_per_tile=bp, nt_loads=nl, prefetch=pf)
 
                 def run():
                     if outs is None:
@@ -118,10 +120,10 @@ def main():
                             b.run_fused(b.fused_args(indices, bool(wb), stats, hist, outs, None, start, cnt))
                 times[v].append(timer.time(run))
         for v, t in times.items():
-            m, impl, nt, bp, wb, nl = v
+            m, impl, nt, bp, wb, nl, pf = v
             med = float(np.median(t[1:]))
             bpp = MODES[m][3]
-            results[f"fused {m} impl={impl} nt={nt} ntl={nl} bpt={bp} wb={wb}"] = {
+            results[f"fused {m} impl={impl} nt={nt} ntl={nl} pf={pf} bpt={bp} wb={wb}"] = {
                 "ms": med, "min_ms": float(min(t[1:])), "GBs": npix * bpp / med / 1e6,
                 "frac_8TBs": npix * bpp / med / 1e6 / 8000.0, "Gpix_s": npix / med / 1e6}
     if "probe" in args.what:

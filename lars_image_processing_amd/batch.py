@@ -252,11 +252,14 @@ def summarize(record):
     """Global statistics of a merged record (SURVEY.md 8(e) semantics)."""
     count = int(record["count"])
     mean = float(record["sum"]) / count
-    var = max(float(record["sumsq"]) / count - mean * mean, 0.0)
+    sumsq = float(record["sumsq"])
+    # the fused kernel fills sumsq only with LARS_F_HIST (full statistics); without it std is unknown
+    have_sq = sumsq != 0.0 or (float(record["min"]) == 0.0 and float(record["max"]) == 0.0)
+    var = max(sumsq / count - mean * mean, 0.0)
     return {
         "count": count,
         "mean": mean,
-        "std": var ** 0.5,
+        "std": var ** 0.5 if have_sq else None,
         "min": float(record["min"]),
         "max": float(record["max"]),
         "coverage": int(record["above"]) / count * 100.0,

@@ -2,8 +2,9 @@
 outputs and against the oracle on seeded inputs.  Needs a real MI355X.
 
 Bars: uint8 outputs and index arrays BIT-EXACT; min / max / median / coverage /
-histogram exact; mean within 1e-6 relative (the reference's float32 pairwise
-sum is itself ~2.5e-7 from the exact mean).
+histogram exact; mean within 1e-6 of max(|mean|, mean|x|): the reference's float32
+pairwise sum carries an error proportional to sum|x| (~2.5e-7 relative to it,
+SURVEY.md 8a-3), ours is the exact sum of the float32 samples divided by N.
 """
 import warnings
 
@@ -34,11 +35,13 @@ def bits(a):
     return a.view({4: np.uint32, 8: np.uint64}[a.dtype.itemsize])
 
 
-def assert_stats_close(got, want):
+def assert_stats_close(got, want, samples=None):
+    """``samples``: the index array the statistics describe (sets the scale of the mean's tolerance)."""
     assert list(got.keys()) == list(want.keys())
+    scale = 1.0 if samples is None else float(np.mean(np.abs(np.asarray(samples, dtype=np.float64))))
     for key in want:
         if key.startswith("Mean") or key in ("Mean", "mean_ndvi"):
-            assert got[key] == pytest.approx(want[key], rel=MEAN_RTOL, abs=1e-9), key
+            assert abs(got[key] - want[key]) <= MEAN_RTOL * max(abs(want[key]), scale), key
         elif key in ("std_ndvi",):
             assert got[key] == pytest.approx(want[key], rel=1e-9, abs=1e-12), key
         else:
@@ -68,7 +71,7 @@ def test_index_bit_exact(lars, golden, case, kind, t):
 @pytest.mark.parametrize("t", TYPES)
 def test_analyze_index_matches_reference(lars, golden, golden_dicts, case, t):
     idx = golden[f"{case}/index_wb_{t}"]
-    assert_stats_close(lars.analyze_index(idx, t), golden_dicts["dicts"][f"{case}/stats_wb_{t}"])
+    assert_stats_close(lars.analyze_index(idx, t), golden_dicts["dicts"][f"{case}/stats_wb_{t}"], idx)
     np.testing.assert_array_equal(lars.index_histogram(idx), golden[f"{case}/hist50_wb_{t}"])
     row = lars.timeseries_row(idx, t, "2025-01-01")
     assert row["Date"] == "2025-01-01" and row["Median"] == golden_dicts["dicts"][f"{case}/stats_wb_{t}"][f"Median {t}"]
@@ -95,7 +98,7 @@ def test_script_variants_match_reference(lars, golden, golden_dicts, case, tmp_p
     nd = lars.calculate_ndvi(str(p), save_path=None, visualize=False)
     assert nd.dtype == np.float64
     np.testing.assert_array_equal(bits(nd), bits(golden[f"{case}/ndvi_f64"]))
-    assert_stats_close(lars.analyze_ndvi_statistics(nd), golden_dicts["dicts"][f"{case}/ndvi_stats"])
+    assert_stats_close(lars.analyze_ndvi_statistics(nd), golden_dicts["dicts"][f"{case}/ndvi_stats"], nd)
     np.testing.assert_array_equal(lars.index_histogram(nd), golden[f"{case}/ndvi_f64_hist50"])
 
 
@@ -113,7 +116,7 @@ def test_process_image_one_upload(lars, golden, golden_dicts, case):
     for t in TYPES:
         r = res["indices"][t]
         np.testing.assert_array_equal(bits(r["index"]), bits(golden[f"{case}/index_wb_{t}"]))
-        assert_stats_close(r["stats"], golden_dicts["dicts"][f"{case}/stats_wb_{t}"])
+        assert_stats_close(r["stats"], golden_dicts["dicts"][f"{case}/stats_wb_{t}"], golden[f"{case}/index_wb_{t}"])
         np.testing.assert_array_equal(r["hist"], golden[f"{case}/hist50_wb_{t}"])
         lut = lars.colormap_lut("RdYlBu" if t == "NDWI" else "RdYlGn")
         np.testing.assert_array_equal(r["rgba"], orc.colormap_closed_form(golden[f"{case}/index_wb_{t}"], lut))
@@ -132,7 +135,7 @@ def test_odd_shapes_against_oracle(lars, shape, profile):
     for t in TYPES:
         want = orc.index_app(want_wb, t)
         np.testing.assert_array_equal(bits(res["indices"][t]["index"]), bits(want))
-        assert_stats_close(res["indices"][t]["stats"], orc.stats_app(want, t))
+        assert_stats_close(res["indices"][t]["stats"], orc.stats_app(want, t), want)
         np.testing.assert_array_equal(res["indices"][t]["hist"], orc.hist50(want))
 
 
@@ -167,11 +170,11 @@ def test_median_and_stats_on_arbitrary_arrays(lars):
     for n in (1, 2, 3, 10, 1001, 4096, 100000):
         x = rng.uniform(-1, 1, n).astype(np.float32)
         x[rng.integers(0, n, max(1, n // 10))] = np.float32(0.25)       # ties
-        assert_stats_close(lars.analyze_index(x, "NDVI"), orc.stats_app(x, "NDVI"))
-        assert_stats_close(lars.analyze_index(x, "NDWI"), orc.stats_app(x, "NDWI"))
+        assert_stats_close(lars.analyze_index(x, "NDVI"), orc.stats_app(x, "NDVI"), x)
+        assert_stats_close(lars.analyze_index(x, "NDWI"), orc.stats_app(x, "NDWI"), x)
         np.testing.assert_array_equal(lars.index_histogram(x), orc.hist50(x))
         x64 = x.astype(np.float64) * 0.999
-        assert_stats_close(lars.analyze_ndvi_statistics(x64), orc.stats_ndvi(x64))
+        assert_stats_close(lars.analyze_ndvi_statistics(x64), orc.stats_ndvi(x64), x64)
     z = np.zeros((5, 5), np.float32)
     z[0, 0] = -0.0
     assert lars.analyze_index(z, "NDVI")["Median NDVI"] == 0.0

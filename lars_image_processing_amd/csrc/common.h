@@ -113,6 +113,13 @@ struct Tuning {
 Tuning &tuning();
 
 struct FusedParams;
+#ifndef LARS_V2_STATS_THREADS
+#define LARS_V2_STATS_THREADS 1024     // statistics-only second-generation kernels (tools/kbench.py A/B: 512 | 1024)
+#endif
+#ifndef LARS_V2_STATS_WAVES
+#define LARS_V2_STATS_WAVES 8          // waves per SIMD the statistics-only kernels are compiled for (64 VGPRs)
+#endif
+int fused_v2_threads(bool any_out);
 void fused_v2_launch(unsigned mask, bool wb, int stats, bool nt, dim3 grid, hipStream_t s, const FusedParams &P);
 void chan_hist_v2_launch(const uint8_t *tiles, long long npix, unsigned int *hist, dim3 grid, hipStream_t s);
 int quot_check_launch(unsigned int max_den, unsigned long long *mismatches_dev, unsigned int *first_bad_dev, hipStream_t s);

@@ -752,7 +752,7 @@ extern "C" int lars_d_fused(const lars_fused_args *a)
     // the second-generation kernels address a tile through a raw buffer descriptor with 32-bit offsets
     const bool small_tile = (long long)a->npix * 6 < (1ll << 30);
     if (fast && a->dtype == LARS_U8 && impl >= 2 && small_tile) {
-        dim3 grid(blocks_per_tile(a->npix / 4 + 1, a->ntiles, 512), (unsigned)a->ntiles);
+        dim3 grid(blocks_per_tile(a->npix / 4 + 1, a->ntiles, fused_v2_threads(any_out || mask == 0u)), (unsigned)a->ntiles);
         fused_v2_launch(mask, a->wb_table != nullptr, stats_mode, tuning().nt_stores != 0, grid, s, P);
     } else if (fast && a->dtype == LARS_U8) {
         dim3 grid(blocks_per_tile(a->npix / 4 + 1, a->ntiles, 256, 32768), (unsigned)a->ntiles);

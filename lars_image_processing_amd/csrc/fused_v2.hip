@@ -95,9 +95,8 @@ __global__ __launch_bounds__(256) void k_quot_check(unsigned int max_den, unsign
 // ---------------------------------------------------------------------------
 // LDS: [3 channels][256 bins][32 copies] u32 = 96 KiB; copy = lane % 32.
 __global__ __launch_bounds__(1024) void k_chan_hist_u8c3_v2(const uint8_t *__restrict__ tiles, long long npix,
-                                                            unsigned int *__restrict__ hist, int nt_loads)
+                                                            unsigned int *__restrict__ hist)
 {
-    const bool nt_ld = nt_loads != 0;
     __shared__ unsigned int s_h[3 * 256 * 32];             // 96 KiB
     const int tid = threadIdx.x;
     for (int i = tid; i < 3 * 256 * 32; i += 1024) s_h[i] = 0;
@@ -125,7 +124,7 @@ __global__ __launch_bounds__(1024) void k_chan_hist_u8c3_v2(const uint8_t *__res
         const unsigned int step_b = (unsigned int)step * 12u;
         u32x3 w[4];
 #pragma unroll
-        for (int k = 0; k < 4; ++k) w[k] = nt_ld ? __builtin_amdgcn_raw_buffer_load_b96(rsrc, voff, (unsigned)k * step_b, 2) : __builtin_amdgcn_raw_buffer_load_b96(rsrc, voff, (unsigned)k * step_b, 0);
+        for (int k = 0; k < 4; ++k) w[k] = __builtin_amdgcn_raw_buffer_load_b96(rsrc, voff, (unsigned)k * step_b, 0);
         long long it = 0;
         unsigned int soff = 4u * step_b;
         for (; it + 4 <= niter - 1; it += 4) {
@@ -133,7 +132,7 @@ __global__ __launch_bounds__(1024) void k_chan_hist_u8c3_v2(const uint8_t *__res
             for (int k = 0; k < 4; ++k) {
                 HQUAD(w[k].x, w[k].y, w[k].z)
                 __builtin_amdgcn_sched_barrier(0);
-                w[k] = nt_ld ? __builtin_amdgcn_raw_buffer_load_b96(rsrc, voff, soff + (unsigned)k * step_b, 2) : __builtin_amdgcn_raw_buffer_load_b96(rsrc, voff, soff + (unsigned)k * step_b, 0);
+                w[k] = __builtin_amdgcn_raw_buffer_load_b96(rsrc, voff, soff + (unsigned)k * step_b, 0);
                 __builtin_amdgcn_sched_barrier(0);
             }
             soff += 4u * step_b;
@@ -224,6 +223,8 @@ __device__ inline unsigned int sample_entry(unsigned int word, int byte, unsigne
 // Inactive lanes contribute zero bits; scalar instructions ignore EXEC.
 // LARS_COUNT_MODE (build-time, tools/kbench A/B): 0 scalar counters everywhere, 1 per-lane vector
 // counters everywhere (v_cmp + v_addc, no SALU), 2 NDVI on the vector pipe and GNDVI/NDWI on the scalar pipe.
+// (Also tried and dropped: per-lane float counters fed by a saturating packed fma, sat((x - thr) * 2^40) --
+// exact, no compare / SALU / VCC, but the same VALU time and 2 % slower at 8 waves per SIMD.)
 #ifndef LARS_COUNT_MODE
 #define LARS_COUNT_MODE 0
 #endif
@@ -297,15 +298,22 @@ __device__ inline void hist_add(unsigned int *s_hist, const HistCell<float> *s_e
     atomicAdd(&s_hist[(index * LARS_HIST_BINS + b) * V2_HIST_COPIES + (lane32 & (V2_HIST_COPIES - 1))], 1u);
 }
 
+// Block size: the 64 KiB table allows two blocks per CU.  A wave issues at most one vector instruction
+// per ~12 cycles (tools/issuebench.py), so the VALU-bound statistics-only variants want all 8 waves per
+// SIMD: 1024 threads per block.  With output planes the kernel needs more registers: 512.
+template <bool OUT> struct V2Block { static constexpr int threads = OUT ? 512 : LARS_V2_STATS_THREADS; };
+
 template <unsigned MASK, bool WB, int STATS, bool OUT, bool NT>
-__global__ __launch_bounds__(512, 4) void k_fused_v2(FusedParams P)
+__global__ __launch_bounds__(V2Block<OUT>::threads, OUT ? 4 : LARS_V2_STATS_WAVES) void k_fused_v2(FusedParams P)
 {
+    constexpr int NTHR = V2Block<OUT>::threads;
+    constexpr int NWAVES = NTHR / 64;
     __shared__ __attribute__((aligned(16))) char s_mem[(WB ? V2_TABLE_BYTES : 0) +
-                                                       (STATS >= 2 ? V2_HIST_WORDS * 4 + 66 * 8 : 0) + 8 * 16 * sizeof(double)];
+                                                       (STATS >= 2 ? V2_HIST_WORDS * 4 + 66 * 8 : 0) + NWAVES * 16 * sizeof(double)];
     char *s_tab = s_mem;                                                             // 64 KiB when WB
     unsigned int *s_hist = reinterpret_cast<unsigned int *>(s_mem + (WB ? V2_TABLE_BYTES : 0));
     HistCell<float> *s_edges = reinterpret_cast<HistCell<float> *>(s_hist + (STATS >= 2 ? V2_HIST_WORDS : 0));
-    double *s_red = reinterpret_cast<double *>(s_edges + (STATS >= 2 ? 66 : 0));     // [8 waves][16]
+    double *s_red = reinterpret_cast<double *>(s_edges + (STATS >= 2 ? 66 : 0));     // [NWAVES][16]
 
     constexpr bool NEED_R = (MASK & 1u) != 0;
     constexpr bool NEED_G = (MASK & 6u) != 0;
@@ -323,13 +331,13 @@ __global__ __launch_bounds__(512, 4) void k_fused_v2(FusedParams P)
         const uint8_t *t = P.wb_table + tile * 768;
         unsigned int *tab = reinterpret_cast<unsigned int *>(s_tab);
         // entry (v, copy) at dword v*64 + copy
-        for (int i = tid; i < 256 * 64; i += 512) {
+        for (int i = tid; i < 256 * 64; i += NTHR) {
             const int v = i >> 6;
             tab[i] = (unsigned)t[v] | ((unsigned)t[256 + v] << 8) | ((unsigned)t[512 + v] << 16);
         }
     }
     if (STATS >= 2) {
-        for (int i = tid; i < V2_HIST_WORDS; i += 512) s_hist[i] = 0;
+        for (int i = tid; i < V2_HIST_WORDS; i += NTHR) s_hist[i] = 0;
         hist_cells_init<float>(s_edges, tid);
     }
     if (WB || STATS >= 2) __syncthreads();
@@ -352,7 +360,7 @@ __global__ __launch_bounds__(512, 4) void k_fused_v2(FusedParams P)
     const unsigned int *lut2 = reinterpret_cast<const unsigned int *>(P.cmap_lut[2]);
 
     const long long nquads = npix >> 2;
-    const long long stride = (long long)gridDim.x * 512;
+    const long long stride = (long long)gridDim.x * NTHR;
 
     auto do_quad = [&](long long q, unsigned int w0, unsigned int w1, unsigned int w2) {
         // bytes: r0 g0 n0 r1 | g1 n1 r2 g2 | n2 r3 g3 n3
@@ -461,9 +469,8 @@ __global__ __launch_bounds__(512, 4) void k_fused_v2(FusedParams P)
     // Software pipeline: four 12-byte loads in flight per lane while the oldest quad is processed.
     // buffer_load with the tile as a raw buffer: the lane offset is fixed, the per-iteration offset
     // is a scalar (no vector address arithmetic), and loads past the end return zeros (no clamps).
-    const long long q0 = (long long)blockIdx.x * 512 + tid;
+    const long long q0 = (long long)blockIdx.x * NTHR + tid;
     const long long niter = (nquads + stride - 1) / stride;          // same for every lane of the grid
-    const bool nt_ld = (P.flags & 0x40000000u) != 0;
     if (niter > 0) {
         const __amdgpu_buffer_rsrc_t rsrc =
             __builtin_amdgcn_make_buffer_rsrc(const_cast<uint8_t *>(base), 0, (int)(nquads * 12), 0x00020000);
@@ -471,7 +478,7 @@ __global__ __launch_bounds__(512, 4) void k_fused_v2(FusedParams P)
         const unsigned int step_b = (unsigned int)stride * 12u;
         u32x3 w[4];
 #pragma unroll
-        for (int k = 0; k < 4; ++k) w[k] = nt_ld ? __builtin_amdgcn_raw_buffer_load_b96(rsrc, voff, (unsigned)k * step_b, 2) : __builtin_amdgcn_raw_buffer_load_b96(rsrc, voff, (unsigned)k * step_b, 0);
+        for (int k = 0; k < 4; ++k) w[k] = __builtin_amdgcn_raw_buffer_load_b96(rsrc, voff, (unsigned)k * step_b, 0);
         long long it = 0;
         unsigned int soff = 4u * step_b;
         // every lane's quad is in range while it < niter - 1
@@ -482,7 +489,7 @@ __global__ __launch_bounds__(512, 4) void k_fused_v2(FusedParams P)
                 // (no copies, no vmcnt(0) at the loop head) and has three quads of work to hide behind
                 do_quad(q0 + (it + k) * stride, w[k].x, w[k].y, w[k].z);
                 __builtin_amdgcn_sched_barrier(0);
-                w[k] = nt_ld ? __builtin_amdgcn_raw_buffer_load_b96(rsrc, voff, soff + (unsigned)k * step_b, 2) : __builtin_amdgcn_raw_buffer_load_b96(rsrc, voff, soff + (unsigned)k * step_b, 0);
+                w[k] = __builtin_amdgcn_raw_buffer_load_b96(rsrc, voff, soff + (unsigned)k * step_b, 0);
                 __builtin_amdgcn_sched_barrier(0);
             }
             soff += 4u * step_b;
@@ -567,14 +574,21 @@ __global__ __launch_bounds__(512, 4) void k_fused_v2(FusedParams P)
             row[9] = (double)above_g; row[10] = (double)above_w;
         }
         __syncthreads();
+        if (tid < 11) {
+            // column tid of the wave rows: sums (exact), minima (columns 2, 7), maxima (3, 8)
+            const bool is_min = tid == 2 || tid == 7, is_max = tid == 3 || tid == 8;
+            double t = s_red[tid];
+#pragma unroll 1
+            for (int w = 1; w < NWAVES; ++w) {
+                const double o = s_red[w * 16 + tid];
+                t = is_min ? fmin(t, o) : is_max ? fmax(t, o) : t + o;
+            }
+            s_red[tid] = t;
+        }
+        __syncthreads();
         if (tid == 0) {
             double t[11];
             for (int j = 0; j < 11; ++j) t[j] = s_red[j];
-            for (int w = 1; w < 8; ++w) {
-                const double *o = s_red + w * 16;
-                t[0] += o[0]; t[1] += o[1]; t[2] = fmin(t[2], o[2]); t[3] = fmax(t[3], o[3]); t[4] += o[4];
-                t[5] += o[5]; t[6] += o[6]; t[7] = fmin(t[7], o[7]); t[8] = fmax(t[8], o[8]); t[9] += o[9]; t[10] += o[10];
-            }
             StatsAccView *rec = reinterpret_cast<StatsAccView *>(P.stats + tile * 3);
             if (WANT_NDVI) {
                 atomicAdd(&rec[0].sum_fx, (unsigned long long)__double2ll_rn(t[0] * LARS_FX_SCALE));
@@ -630,7 +644,7 @@ namespace lars {
 template <unsigned MASK, bool WB, int STATS>
 static void v2_launch_out(bool out, bool nt, dim3 grid, hipStream_t s, const FusedParams &P)
 {
-    if (!out) hipLaunchKernelGGL((k_fused_v2<MASK, WB, STATS, false, false>), grid, dim3(512), 0, s, P);
+    if (!out) hipLaunchKernelGGL((k_fused_v2<MASK, WB, STATS, false, false>), grid, dim3(V2Block<false>::threads), 0, s, P);
     else if (nt) hipLaunchKernelGGL((k_fused_v2<MASK, WB, STATS, true, true>), grid, dim3(512), 0, s, P);
     else hipLaunchKernelGGL((k_fused_v2<MASK, WB, STATS, true, false>), grid, dim3(512), 0, s, P);
 }
@@ -648,6 +662,8 @@ static void v2_launch_wb(bool wb, int stats, bool out, bool nt, dim3 grid, hipSt
     else v2_launch_stats<MASK, false>(stats, out, nt, grid, s, P);
 }
 
+int fused_v2_threads(bool any_out) { return any_out ? V2Block<true>::threads : V2Block<false>::threads; }
+
 void fused_v2_launch(unsigned mask, bool wb, int stats, bool nt, dim3 grid, hipStream_t s, const FusedParams &P)
 {
     const bool out = P.out_wb || P.out_index[0] || P.out_index[1] || P.out_index[2] || P.out_rgba[0] || P.out_rgba[1] ||
@@ -663,7 +679,7 @@ void fused_v2_launch(unsigned mask, bool wb, int stats, bool nt, dim3 grid, hipS
 
 void chan_hist_v2_launch(const uint8_t *tiles, long long npix, unsigned int *hist, dim3 grid, hipStream_t s)
 {
-    hipLaunchKernelGGL(k_chan_hist_u8c3_v2, grid, dim3(1024), 0, s, tiles, npix, hist, tuning().nt_loads);
+    hipLaunchKernelGGL(k_chan_hist_u8c3_v2, grid, dim3(1024), 0, s, tiles, npix, hist);
 }
 
 int quot_check_launch(unsigned int max_den, unsigned long long *mismatches_dev, unsigned int *first_bad_dev, hipStream_t s)

@@ -89,13 +89,121 @@ __global__ __launch_bounds__(256) void k_probe_mix1(const unsigned int *__restri
     }
 }
 
+// ---------------------------------------------------------------------------
+// instruction-issue probes: 16 independent chains of ONE instruction per loop
+// trip, every lane of every wave.  tools/probe.py turns the time into cycles
+// per wave64 instruction per SIMD (what the hot loops' VALU budget is made of).
+// ---------------------------------------------------------------------------
+typedef float pf32x2 __attribute__((ext_vector_type(2)));
+
+template <int OP>
+__global__ __launch_bounds__(256) void k_probe_issue(int iters, unsigned int *__restrict__ sink)
+{
+    __shared__ unsigned int s_lds[64 * 64];
+    float a[16];
+    pf32x2 p[16];
+    double d[16];
+    unsigned int u[16];
+    unsigned int cnt = 0;
+#pragma unroll
+    for (int j = 0; j < 16; ++j) {
+        a[j] = 1.0f + (float)((threadIdx.x + j) & 7) * 0.125f;
+        p[j] = (pf32x2){a[j], 0.5f * a[j]};
+        d[j] = (double)a[j];
+        u[j] = threadIdx.x * 2654435761u + j;
+    }
+    if (OP == 10) {
+        // conflict-free pointer chase: row r, lane column l -> byte address of (r + 1, l)
+        for (int i = threadIdx.x; i < 64 * 64; i += 256) s_lds[i] = ((((i >> 6) + 1) & 63) << 8) | ((i & 63) << 2);
+#pragma unroll
+        for (int j = 0; j < 16; ++j) u[j] = (j << 8) | ((threadIdx.x & 63u) << 2);
+        __syncthreads();
+    }
+    const float one = 1.0f, thr = 0.2f;
+    const unsigned int lane_off4 = (threadIdx.x & 63u) << 2;
+    for (int it = 0; it < iters; ++it) {
+#pragma unroll
+        for (int j = 0; j < 16; ++j) {
+            if (OP == 0) asm volatile("v_add_f32 %0, %0, %1" : "+v"(a[j]) : "v"(one));
+            else if (OP == 1) asm volatile("v_pk_fma_f32 %0, %0, %1, %0" : "+v"(p[j]) : "v"(p[(j + 1) & 15]));
+            else if (OP == 2) asm volatile("v_rcp_f32 %0, %0" : "+v"(a[j]));
+            else if (OP == 3) asm volatile("v_add_f64 %0, %0, %1" : "+v"(d[j]) : "v"(d[(j + 1) & 15]));
+            else if (OP == 4) asm volatile("v_cvt_f64_f32 %0, %1" : "=v"(d[j]) : "v"(a[j]));
+            else if (OP == 5) asm volatile("v_perm_b32 %0, %0, %1, %2" : "+v"(u[j]) : "v"(lane_off4), "s"(0x0c0c0500u));
+            else if (OP == 6) {
+                unsigned int c;
+                asm volatile("v_cmp_lt_f32 vcc, %1, %2\n\ts_bcnt1_i32_b64 %0, vcc" : "=s"(c) : "s"(thr), "v"(a[j]) : "vcc", "scc");
+                cnt += c;
+            }
+            else if (OP == 7) asm volatile("v_min3_f32 %0, %0, %1, %2" : "+v"(a[j]) : "v"(a[(j + 1) & 15]), "v"(a[(j + 2) & 15]));
+            else if (OP == 8) asm volatile("v_cvt_f32_ubyte0 %0, %1" : "=v"(a[j]) : "v"(u[j]));
+            else if (OP == 9) asm volatile("v_fma_mix_f32 %0, %0, %1, %0" : "+v"(a[j]) : "v"(one));
+            else if (OP == 10) {
+                asm volatile("ds_read_b32 %0, %0" : "+v"(u[j]));
+                if (j == 15) asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+            }
+            else if (OP == 11) asm volatile("v_cmp_lt_f32 vcc, %0, %1" : : "s"(thr), "v"(a[j]) : "vcc");
+            else if (OP == 12) asm volatile("v_pk_add_f32 %0, %0, %1" : "+v"(p[j]) : "v"(p[(j + 1) & 15]));
+            else if (OP == 13) asm volatile("v_pk_mul_f32 %0, %0, %1" : "+v"(p[j]) : "v"(p[(j + 1) & 15]));
+            else if (OP == 14) asm volatile("v_fma_f32 %0, %0, %1, %0" : "+v"(a[j]) : "v"(one));
+            else if (OP == 15) asm volatile("v_fma_f64 %0, %0, %1, %0" : "+v"(d[j]) : "v"(d[(j + 1) & 15]));
+            else if (OP == 16) asm volatile("v_max_f32 %0, %0, %1" : "+v"(a[j]) : "v"(a[(j + 1) & 15]));
+            else if (OP == 17) asm volatile("v_addc_co_u32 %0, vcc, 0, %0, vcc" : "+v"(u[j]) : : "vcc");
+            else if (OP == 18) asm volatile("v_dot4_u32_u8 %0, %1, %2, %0" : "+v"(u[j]) : "v"(u[(j + 1) & 15]), "v"(lane_off4));
+            else if (OP == 19) asm volatile("v_add_u32 %0, %0, %1" : "+v"(u[j]) : "v"(lane_off4));
+            else if (OP == 20) asm volatile("v_add_f32 %0, %0, %1" : "+v"(a[j]) : "v"(a[(j + 1) & 15]));
+            else if (OP == 21) asm volatile("v_max_f32 %0, %0, %1" : "+v"(a[j]) : "v"(one));
+            else if (OP == 22) asm volatile("v_mul_f32 %0, %0, %1" : "+v"(a[j]) : "v"(one));
+            else if (OP == 23) asm volatile("v_cvt_f32_ubyte0 %0, %0" : "+v"(u[j]));
+            else if (OP == 24) asm volatile("v_mov_b32 %0, %1" : "=v"(u[j]) : "v"(lane_off4));
+            else if (OP == 25) asm volatile("v_add_f32 %0, %1, %2" : "=v"(a[j]) : "v"(a[(j + 1) & 15]), "v"(a[(j + 2) & 15]));
+            else if (OP == 26) asm volatile("v_fma_f32 %0, %0, %1, %2" : "+v"(a[j]) : "v"(a[(j + 1) & 15]), "v"(a[(j + 2) & 15]));
+            else if (OP == 27) asm volatile("v_pk_add_f32 %0, %0, %1" : "+v"(p[j]) : "v"(p[0]));
+            else if (OP == 28) asm volatile("v_add_f64 %0, %0, %1" : "+v"(d[j]) : "v"(d[0]));
+            else if (OP == 30) asm volatile("v_and_or_b32 %0, %0, %1, %2" : "+v"(u[j]) : "s"(0x7F80u), "v"(lane_off4));
+            else if (OP == 31) asm volatile("v_lshl_or_b32 %0, %0, 7, %1" : "+v"(u[j]) : "v"(lane_off4));
+            else if (OP == 32) asm volatile("v_bfe_u32 %0, %0, 8, 8" : "+v"(u[j]));
+            else if (OP == 33) asm volatile("v_lshrrev_b32 %0, 1, %0" : "+v"(u[j]));
+            else if (OP == 34) asm volatile("v_and_b32 %0, %1, %0" : "+v"(u[j]) : "s"(0x7F80u));
+            else if (OP == 35) asm volatile("v_lshlrev_b32_sdwa %0, %1, %0 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:DWORD src1_sel:BYTE_1" : "+v"(u[j]) : "v"(7u));
+            else if (OP == 36) asm volatile("v_lshl_add_u32 %0, %0, 7, %1" : "+v"(u[j]) : "v"(lane_off4));
+            else if (OP == 37) asm volatile("v_pk_fma_f32 %0, %0, %1, %1 clamp" : "+v"(p[j]) : "v"(p[(j + 1) & 15]));
+            else if (OP == 38) asm volatile("v_fma_f32 %0, %0, %1, %1 clamp" : "+v"(a[j]) : "v"(one));
+            else if (OP == 39) asm volatile("v_or_b32 %0, %0, %1" : "+v"(u[j]) : "v"(lane_off4));
+            else if (OP == 29) asm volatile("v_perm_b32 %0, %0, %0, %1" : "+v"(u[j]) : "s"(0x0c0c0500u));
+        }
+    }
+    float fa = 0; double fd = 0; unsigned int fu = cnt;
+#pragma unroll
+    for (int j = 0; j < 16; ++j) { fa += a[j] + p[j].x + p[j].y; fd += d[j]; fu ^= u[j]; }
+    if (fa == 123.456f && fd == 654.321 && fu == 77u) sink[0] = fu;
+}
+
+// shader clock against the 100 MHz constant-rate counter: out[0] = shader cycles, out[1] = 100 MHz ticks
+__global__ void k_probe_clock(unsigned long long *out, int spin)
+{
+    const unsigned long long c0 = __builtin_readcyclecounter();
+    const unsigned long long t0 = wall_clock64();
+    float x = 1.0f;
+    for (int i = 0; i < spin; ++i) asm volatile("v_add_f32 %0, %0, %0" : "+v"(x));
+    const unsigned long long c1 = __builtin_readcyclecounter();
+    const unsigned long long t1 = wall_clock64();
+    if (threadIdx.x == 0 && blockIdx.x == 0) { out[0] = c1 - c0; out[1] = t1 - t0; out[2] = (unsigned long long)(x != 0.5f); }
+}
+
 }  // namespace lars
 
 using namespace lars;
 
+template <int OP>
+static void issue_launch(int iters, int blocks, unsigned int *sink, hipStream_t s)
+{
+    hipLaunchKernelGGL((k_probe_issue<OP>), dim3(blocks), dim3(256), 0, s, iters, sink);
+}
+
 // kind: 0 read 16 B/lane, 1 read 12 B/lane, 2 copy 16 B/lane (bytes read + bytes written = 2*bytes), 3 write 16 B/lane,
 // 4 non-temporal write, 5 / 6 the fused kernel's mix (12 B read + 48 B written per lane; plain / non-temporal stores),
-// 7 the NDVI-plane mix (12 B read + 16 B written per lane)
+// 7 the NDVI-plane mix (12 B read + 16 B written per lane); 100 + op: instruction-issue probe (unroll = loop trips)
 extern "C" int lars_d_probe(int kind, int unroll, int blocks, const void *src, void *dst, int64_t bytes, void *stream)
 {
     ThreadCtx *c;
@@ -135,6 +243,21 @@ extern "C" int lars_d_probe(int kind, int unroll, int blocks, const void *src, v
     } else if (kind == 7) {
         const long long nquads = bytes / 28;               // total traffic = bytes
         hipLaunchKernelGGL(k_probe_mix1, dim3(blocks), dim3(256), 0, s, p, static_cast<pu32x4 *>(dst), nquads);
+    } else if (kind == 99) {
+        // shader clock: dst receives {shader cycles, 100 MHz ticks}; unroll = spin count; runs beside `blocks` busy blocks
+        hipLaunchKernelGGL(k_probe_clock, dim3(blocks), dim3(256), 0, s, static_cast<unsigned long long *>(dst), unroll);
+    } else if (kind >= 100 && kind < 140) {
+        // instruction-issue probe: unroll = loop trips (16 instructions each), blocks of 4 waves
+        typedef void (*fn_t)(int, int, unsigned int *, hipStream_t);
+        static const fn_t table[40] = {issue_launch<0>, issue_launch<1>, issue_launch<2>, issue_launch<3>, issue_launch<4>,
+                                       issue_launch<5>, issue_launch<6>, issue_launch<7>, issue_launch<8>, issue_launch<9>,
+                                       issue_launch<10>, issue_launch<11>, issue_launch<12>, issue_launch<13>, issue_launch<14>,
+                                       issue_launch<15>, issue_launch<16>, issue_launch<17>, issue_launch<18>, issue_launch<19>,
+                                       issue_launch<20>, issue_launch<21>, issue_launch<22>, issue_launch<23>, issue_launch<24>,
+                                       issue_launch<25>, issue_launch<26>, issue_launch<27>, issue_launch<28>, issue_launch<29>,
+                                       issue_launch<30>, issue_launch<31>, issue_launch<32>, issue_launch<33>, issue_launch<34>,
+                                       issue_launch<35>, issue_launch<36>, issue_launch<37>, issue_launch<38>, issue_launch<39>};
+        table[kind - 100](unroll, blocks, sink, s);
     } else {
         return fail(LARS_ERR_INVALID, "lars_d_probe: kind");
     }

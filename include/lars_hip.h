@@ -207,6 +207,28 @@ int lars_d_median_pair_batch_f32(const float *x, int64_t n, int64_t items, int64
 int lars_d_colormap_f32(const float *x, int64_t n, const uint8_t *lut_rgba, uint8_t *out_rgba,
                         void *stream);
 
+/* ---- registration and change detection ---- */
+/* skimage.color.rgb2gray of a uint8 [npix][3] image (process-images.py:538-546) into the real parts of a
+ * complex128 buffer [npix][2] (imaginary parts 0); channels == 1: the sample value itself. */
+int lars_d_gray_c128(const uint8_t *img, int64_t npix, int channels, double *out_c128, void *stream);
+/* skimage.registration.phase_cross_correlation(fixed, moving) with its defaults (process-images.py:549):
+ * FFT cross-power spectrum / max(|.|, 100 eps) -> inverse FFT -> argmax |.| -> signed shift.  Both
+ * [h][w] complex128 buffers are overwritten.  shift_dev receives {dy, dx}; scratch holds
+ * lars_phase_scratch_bytes().  The FFTs run in rocFFT via libhipfft.so, loaded on first use. */
+size_t lars_phase_scratch_bytes(void);
+int lars_d_phase_correlation(double *fixed_c128, double *moving_c128, int64_t h, int64_t w, int64_t *shift_dev,
+                             void *scratch, void *stream);
+/* scipy.ndimage.shift(img, (dy, dx, 0), order=1, mode='reflect') for the integer shift in shift_dev
+ * (process-images.py:557); out must not alias img. */
+int lars_d_shift_reflect_u8(const uint8_t *img, int64_t h, int64_t w, int channels, const int64_t *shift_dev,
+                            uint8_t *out, void *stream);
+/* diff = late - early (process-images.py:923) */
+int lars_d_diff_f32(const float *early, const float *late, int64_t n, float *out_diff, void *stream);
+/* RGBA8 of cmap(Normalize(vmin, vmax)(x), bytes=True): the per-pixel mapping of
+ * imshow(x, cmap, vmin, vmax) -- e.g. the change map's bwr, -0.5, 0.5 (process-images.py:956). */
+int lars_d_colormap_norm_f32(const float *x, int64_t n, float vmin, float vmax, const uint8_t *lut_rgba,
+                             uint8_t *out_rgba, void *stream);
+
 /* Synthetic RGNir tiles generated in HBM (bench / tests): counter hash of
  * (seed, tile, word); profile 0 = uniform bytes, 1 = vegetation-like squeeze. */
 int lars_d_synth_u8(uint8_t *tiles, int64_t ntiles, int64_t first_tile, int64_t npix, int channels,
@@ -275,6 +297,21 @@ int lars_h_colormap_f32(const float *x, int64_t n, const uint8_t *lut_rgba, uint
  * fixed-point resampler.  out is host [new_h][new_w][channels]. */
 int lars_h_resize_lanczos_u8(const uint8_t *img, int64_t h, int64_t w, int channels, int64_t new_h, int64_t new_w,
                              uint8_t *out);
+
+/* align_images -- process-images.py:515-565 for two uint8 images of the same shape ([h][w][3] or [h][w]):
+ * out_aligned = moving registered onto fixed, shift = {dy, dx} (what phase_cross_correlation returns). */
+int lars_h_align_images(const uint8_t *fixed, const uint8_t *moving, int64_t h, int64_t w, int channels,
+                        uint8_t *out_aligned, double shift[2]);
+/* create_change_detection_visualization's arithmetic -- process-images.py:885-923 and :956 -- in one upload:
+ * optional white balance of either image, optional registration of the late image, the index of both,
+ * diff = late - early and its colormap.  Any output pointer may be NULL. */
+int lars_h_change_detection(const uint8_t *early, const uint8_t *late, int64_t h, int64_t w, int channels,
+                            int wb_early, int wb_late, int align, int index_id,
+                            float *out_early, float *out_late, float *out_diff,
+                            uint8_t *out_rgba_diff, const uint8_t *lut_rgba, float vmin, float vmax,
+                            uint8_t *out_aligned_late, double shift[2]);
+int lars_h_colormap_norm_f32(const float *x, int64_t n, float vmin, float vmax, const uint8_t *lut_rgba,
+                             uint8_t *out_rgba);
 
 /* ------------------------------------------------------------------ multi-GPU */
 /* One process per GPU.  RCCL (librccl.so) is loaded on first use.  unique_id is

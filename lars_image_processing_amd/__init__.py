@@ -5,19 +5,26 @@ below keep the reference's signatures and run on hand-written HIP kernels
 (gfx950) behind a C ABI (include/lars_hip.h).  No PyTorch, no NumPy fallback.
 """
 from .api import (  # noqa: F401
+    align_images,
     analyze_index,
     analyze_index_statistics,
     analyze_ndvi_statistics,
     calculate_index,
+    calculate_index_statistics_by_timeframe,
     calculate_ndvi,
+    change_detection,
+    colorize_difference,
     colorize_index,
     colormap_lut,
     correct_white_balance,
+    create_change_detection_visualization,
+    create_time_series_plot,
     fix_white_balance,
     fix_white_balance_rgnir,
     index_histogram,
     preprocess_large_image,
     process_image,
+    time_series_points,
     timeseries_row,
 )
 from .batch import TileBatch, local_fold, merge_records, shard_range, summarize, timeseries_rows  # noqa: F401

@@ -116,6 +116,15 @@ SIGNATURES = {
     "lars_h_process_image": (_I, [_P, _I64, _I64, _I, _I, _I, _U32, _I, _P, C.POINTER(_P * 3), _P, _P,
                                   C.POINTER(_P * 3), C.POINTER(_P * 3)]),
     "lars_h_colormap_f32": (_I, [_P, _I64, _P, _P]),
+    "lars_h_colormap_norm_f32": (_I, [_P, _I64, _F, _F, _P, _P]),
+    "lars_h_align_images": (_I, [_P, _P, _I64, _I64, _I, _P, _P]),
+    "lars_h_change_detection": (_I, [_P, _P, _I64, _I64, _I, _I, _I, _I, _I, _P, _P, _P, _P, _P, _F, _F, _P, _P]),
+    "lars_d_gray_c128": (_I, [_P, _I64, _I, _P, _P]),
+    "lars_phase_scratch_bytes": (_SZ, []),
+    "lars_d_phase_correlation": (_I, [_P, _P, _I64, _I64, _P, _P, _P]),
+    "lars_d_shift_reflect_u8": (_I, [_P, _I64, _I64, _I, _P, _P, _P]),
+    "lars_d_diff_f32": (_I, [_P, _P, _I64, _P, _P]),
+    "lars_d_colormap_norm_f32": (_I, [_P, _I64, _F, _F, _P, _P, _P]),
     "lars_h_resize_lanczos_u8": (_I, [_P, _I64, _I64, _I, _I64, _I64, _P]),
     "lars_comm_unique_id": (_I, [_P]),
     "lars_comm_init": (_I, [C.POINTER(_P), _I, _I, _P]),

@@ -15,6 +15,11 @@ this module                     reference
 ``calculate_ndvi(path, ...)``   process-ndvi.py:5      (float64)
 ``analyze_index(idx, t)``       process-images.py:492
 ``analyze_ndvi_statistics``     process-ndvi.py:50
+``preprocess_large_image``      process-images.py:398  (Pillow LANCZOS down-scale)
+``align_images``                process-images.py:515  (phase correlation + shift)
+``calculate_index_statistics_by_timeframe``  process-images.py:619 (pandas table)
+``create_time_series_plot``     process-images.py:801  (figure; statistics from the GPU)
+``create_change_detection_visualization``    process-images.py:885 (figure; arrays from the GPU)
 ==============================  ============================================
 
 ``correct_white_balance`` and ``analyze_index_statistics`` are aliases (the
@@ -37,7 +42,9 @@ __all__ = [
     "fix_white_balance", "correct_white_balance", "fix_white_balance_rgnir",
     "calculate_index", "calculate_ndvi", "analyze_index", "analyze_index_statistics",
     "analyze_ndvi_statistics", "index_histogram", "colorize_index", "process_image",
-    "timeseries_row", "colormap_lut", "preprocess_large_image",
+    "timeseries_row", "colormap_lut", "preprocess_large_image", "align_images", "change_detection",
+    "colorize_difference", "calculate_index_statistics_by_timeframe", "time_series_points",
+    "create_time_series_plot", "create_change_detection_visualization",
 ]
 
 _CMAPS = None
@@ -384,3 +391,218 @@ def process_image(img_array, indices=INDEX_NAMES, white_balance=True, want_array
             },
         }
     return result
+
+
+# ---------------------------------------------------------------------------
+# registration, change detection, time series
+# ---------------------------------------------------------------------------
+_ALIGN_MAX_DIM = 1024                                      # process-images.py:530
+
+
+def align_images(fixed_img, moving_img):
+    """process-images.py:515-565: register ``moving_img`` onto ``fixed_img`` by phase correlation.
+
+    Returns ``(aligned_img, shift)`` like upstream: ``shift`` is what
+    ``skimage.registration.phase_cross_correlation`` returns (``[dy, dx]``, with a trailing 0
+    for the channel axis of a colour image) and ``aligned_img`` is
+    ``scipy.ndimage.shift(moving_img, shift, order=1, mode='reflect')``.  Images larger than 1024
+    on a side are down-scaled first (both, independently, as upstream -- the aligned image then has
+    the down-scaled size).  ``None`` in -> ``(moving_img, array([0, 0]))``.
+    """
+    if fixed_img is None or moving_img is None:
+        return moving_img, np.array([0, 0])
+    fixed_img, moving_img = np.asarray(fixed_img), np.asarray(moving_img)
+    if fixed_img.shape[0] > _ALIGN_MAX_DIM or fixed_img.shape[1] > _ALIGN_MAX_DIM:
+        fixed_img = preprocess_large_image(fixed_img, _ALIGN_MAX_DIM)
+    if moving_img.shape[0] > _ALIGN_MAX_DIM or moving_img.shape[1] > _ALIGN_MAX_DIM:
+        moving_img = preprocess_large_image(moving_img, _ALIGN_MAX_DIM)
+    for name, a in (("fixed_img", fixed_img), ("moving_img", moving_img)):
+        if a.dtype != np.uint8:
+            raise TypeError(f"align_images: {name} must be uint8 (got {a.dtype})")
+        if a.ndim == 3 and a.shape[2] != 3:
+            # skimage.color.rgb2gray's own complaint
+            raise ValueError(f"the input array must have size 3 along `channel_axis`, got {a.shape}")
+        if a.ndim not in (2, 3):
+            raise ValueError(f"align_images: {name} must be [H, W] or [H, W, 3] (got shape {a.shape})")
+    if fixed_img.shape != moving_img.shape:
+        raise ValueError("images must be same shape")      # phase_cross_correlation's own complaint
+    fixed_c, moving_c = np.ascontiguousarray(fixed_img), np.ascontiguousarray(moving_img)
+    h, w = moving_c.shape[:2]
+    channels = 1 if moving_c.ndim == 2 else 3
+    aligned = np.empty_like(moving_c)
+    shift = np.zeros(2, dtype=np.float64)
+    _ffi.call("lars_h_align_images", _ffi.ptr(fixed_c), _ffi.ptr(moving_c), h, w, channels, _ffi.ptr(aligned), _ffi.ptr(shift))
+    if moving_c.ndim == 3:
+        shift = np.append(shift, 0)                         # process-images.py:552-554
+    return aligned, shift
+
+
+def colorize_difference(diff, vmin=-0.5, vmax=0.5, cmap="bwr"):
+    """Per-pixel RGBA8 of ``imshow(diff, cmap='bwr', vmin=-0.5, vmax=0.5)`` (process-images.py:956)."""
+    arr = np.ascontiguousarray(diff, dtype=np.float32)
+    out = np.empty(arr.shape + (4,), dtype=np.uint8)
+    _ffi.call("lars_h_colormap_norm_f32", _ffi.ptr(arr.reshape(-1)), arr.size, float(vmin), float(vmax),
+              _ffi.ptr(colormap_lut(cmap)), _ffi.ptr(out))
+    return out
+
+
+def change_detection(early, late, index_type, early_corrected=None, late_corrected=None, align=True, want_rgba=False):
+    """The arithmetic of ``create_change_detection_visualization`` (process-images.py:885-923, :956).
+
+    ``early`` / ``late`` are the raw uint8 images, ``*_corrected`` the cached white-balanced arrays
+    the UI keeps (process-images.py:894-902); whichever is missing is computed.  One upload: white
+    balance, registration of the late image, both indices, ``diff = late_index - early_index`` and
+    (``want_rgba``) the per-pixel ``bwr`` map of the difference.  Returns a dict with
+    ``early_index``, ``late_index``, ``diff``, ``aligned_late``, ``shift`` and ``diff_rgba``.
+    """
+    if index_type not in INDEX_IDS:
+        raise ValueError(f"Unknown index type: {index_type}")
+    e_src = early_corrected if early_corrected is not None else early
+    l_src = late_corrected if late_corrected is not None else late
+    if e_src is None or l_src is None:
+        return None
+    e_arr, l_arr = _as_image(e_src, "change_detection"), _as_image(l_src, "change_detection")
+    wb_e, wb_l = early_corrected is None, late_corrected is None
+    fused = (e_arr.dtype == np.uint8 and l_arr.dtype == np.uint8 and e_arr.shape == l_arr.shape
+             and (not align or (e_arr.shape[2] == 3 and max(e_arr.shape[:2]) <= _ALIGN_MAX_DIM)))
+    if not fused:
+        # sizes the one-upload entry point does not cover: the same steps, one call each
+        e_c = fix_white_balance(e_arr) if wb_e else e_arr
+        l_c = fix_white_balance(l_arr) if wb_l else l_arr
+        aligned, shift = align_images(e_c, l_c) if align else (l_c, np.zeros(3))
+        e_idx, l_idx = calculate_index(e_c, index_type), calculate_index(aligned, index_type)
+        diff = l_idx - e_idx                               # raises like upstream when the shapes differ (:923)
+        return {"early_index": e_idx, "late_index": l_idx, "diff": diff, "aligned_late": aligned, "shift": shift,
+                "diff_rgba": colorize_difference(diff) if want_rgba else None}
+    h, w, c = e_arr.shape
+    e_idx, l_idx, diff = (np.empty((h, w), dtype=np.float32) for _ in range(3))
+    aligned = np.empty((h, w, c), dtype=np.uint8)
+    rgba = np.empty((h, w, 4), dtype=np.uint8) if want_rgba else None
+    shift = np.zeros(2, dtype=np.float64)
+    _ffi.call("lars_h_change_detection", _ffi.ptr(e_arr), _ffi.ptr(l_arr), h, w, c, int(wb_e), int(wb_l), int(bool(align)),
+              INDEX_IDS[index_type], _ffi.ptr(e_idx), _ffi.ptr(l_idx), _ffi.ptr(diff), _ffi.ptr(rgba),
+              _ffi.ptr(colormap_lut("bwr")) if want_rgba else None, -0.5, 0.5, _ffi.ptr(aligned), _ffi.ptr(shift))
+    return {"early_index": e_idx, "late_index": l_idx, "diff": diff, "aligned_late": aligned,
+            "shift": np.append(shift, 0), "diff_rgba": rgba}
+
+
+def _corrected_of(img_data):
+    """The cached white-balanced array of an ``image_data`` dict, or ``None`` (process-images.py:636-641)."""
+    if "corrected_array" in img_data and img_data["corrected_array"] is not None:
+        return img_data["corrected_array"]
+    return None
+
+
+def _timeframe_records(image_data_list, index_type, want_median):
+    """[(date, Stats, median)] of every image of a series: one upload per image, nothing but the
+    statistics comes back."""
+    if index_type not in INDEX_IDS:
+        raise ValueError(f"Unknown index type: {index_type}")
+    k = INDEX_IDS[index_type]
+    _, threshold = _coverage_rule(index_type)
+    out = []
+    for img_data in image_data_list:
+        date = img_data["metadata"]["upload_date"]
+        corrected = _corrected_of(img_data)
+        src = corrected if corrected is not None else img_data["array"]
+        if src is None or np.size(src) == 0:
+            continue                                        # calculate_index -> None -> the row is skipped (:649)
+        arr = _as_image(src, "time series")
+        code = _ffi.dtype_code(arr.dtype)
+        if code is None:
+            raise TypeError(f"time series: unsupported sample type {arr.dtype}")
+        h, w, c = arr.shape
+        stats = (Stats * 3)()
+        med = np.zeros((3, 2), dtype=np.float32)
+        _ffi.call("lars_h_process_image", _ffi.ptr(arr), h, w, c, code, int(corrected is None), 1 << k, 0, None, None,
+                  C.byref(stats), _ffi.ptr(med) if want_median else None, None, None)
+        median = float(np.float32(np.float32(med[k, 0] + med[k, 1]) / 2)) if want_median else None
+        out.append((date, stats[k], median))
+    return out
+
+
+def calculate_index_statistics_by_timeframe(image_data_list, index_type):
+    """process-images.py:619-667: pandas DataFrame, one row per image, the upstream columns."""
+    import pandas as pd
+    feature_name, _ = _coverage_rule(index_type)
+    results = []
+    for date, st, median in _timeframe_records(image_data_list, index_type, want_median=True):
+        results.append({"Date": date, "Mean": st.sum / st.count, "Median": median, "Min": st.min, "Max": st.max,
+                        f"{feature_name} Coverage (%)": st.above / st.count * 100})
+    return pd.DataFrame(results)
+
+
+def time_series_points(image_data_list, index_type):
+    """The numbers ``create_time_series_plot`` draws (process-images.py:814-832): dates, means, maxima, minima."""
+    recs = _timeframe_records(image_data_list, index_type, want_median=False)
+    return ([d for d, _, _ in recs], [st.sum / st.count for _, st, _ in recs], [st.max for _, st, _ in recs],
+            [st.min for _, st, _ in recs])
+
+
+def create_time_series_plot(image_data_list, index_type):
+    """process-images.py:801-883: the error-bar figure as a PIL image (matplotlib plumbing as upstream)."""
+    if not image_data_list or len(image_data_list) < 2:
+        return None
+    import io
+    from matplotlib.backends.backend_agg import FigureCanvasAgg as FigureCanvas
+    from matplotlib.figure import Figure
+    from PIL import Image
+    dates, mean_values, max_values, min_values = time_series_points(image_data_list, index_type)
+    fig = Figure(figsize=(10, 6), dpi=100)
+    canvas = FigureCanvas(fig)
+    ax = fig.add_subplot(111)
+    ax.errorbar(dates, mean_values,
+                yerr=[np.array(mean_values) - np.array(min_values), np.array(max_values) - np.array(mean_values)],
+                fmt="o-", capsize=5, label=f"Mean {index_type}")
+    feature_name, threshold = _coverage_rule(index_type)
+    ax.axhline(y=threshold, color="r", linestyle="--", label=f"{feature_name} Threshold")
+    ax.set_title(f"{index_type} Time Series")
+    ax.set_xlabel("Date")
+    ax.set_ylabel(f"{index_type} Value")
+    ax.grid(True, alpha=0.3)
+    ax.legend()
+    fig.autofmt_xdate()
+    buf = io.BytesIO()
+    canvas.print_figure(buf, format="png", bbox_inches="tight", dpi=100)
+    buf.seek(0)
+    img = Image.open(buf)
+    img_copy = img.copy()
+    buf.close()
+    img.close()
+    return img_copy
+
+
+def create_change_detection_visualization(image_pair, index_type):
+    """process-images.py:885-989: early | late | change figure as a PIL image (arrays from the GPU)."""
+    if not image_pair or len(image_pair) != 2:
+        return None
+    early_img_data, late_img_data = image_pair
+    res = change_detection(early_img_data.get("array"), late_img_data.get("array"), index_type,
+                           early_corrected=_corrected_of(early_img_data), late_corrected=_corrected_of(late_img_data))
+    if res is None:
+        return None
+    import io
+    from matplotlib.backends.backend_agg import FigureCanvasAgg as FigureCanvas
+    from matplotlib.figure import Figure
+    from PIL import Image
+    fig = Figure(figsize=(15, 5), dpi=100)
+    canvas = FigureCanvas(fig)
+    cmap = _colormap_for(index_type)
+    panels = ((res["early_index"], f"Early: {early_img_data['metadata']['upload_date'].strftime('%Y-%m-%d')}", cmap, -1, 1, index_type),
+              (res["late_index"], f"Late: {late_img_data['metadata']['upload_date'].strftime('%Y-%m-%d')}", cmap, -1, 1, index_type),
+              (res["diff"], f"Change in {index_type}", "bwr", -0.5, 0.5, f"\u0394{index_type}"))
+    for k, (arr, title, cm, lo, hi, label) in enumerate(panels, 1):
+        ax = fig.add_subplot(1, 3, k)
+        im = ax.imshow(arr, cmap=cm, vmin=lo, vmax=hi)
+        ax.set_title(title)
+        fig.colorbar(im, ax=ax, label=label)
+        ax.axis("off")
+    fig.tight_layout()
+    buf = io.BytesIO()
+    canvas.print_figure(buf, format="png", bbox_inches="tight", dpi=100)
+    buf.seek(0)
+    img = Image.open(buf)
+    img_copy = img.copy()
+    buf.close()
+    img.close()
+    return img_copy

@@ -99,6 +99,7 @@ __host__ __device__ inline double hist_edge_f64(int i) {
 
 // launch geometry helpers (host)
 int launch_check(const char *what);
+void align_release();                            // drops the calling thread's cached FFT plan (lars_shutdown)
 
 // tuning knobs (lars_set_tuning)
 struct Tuning {

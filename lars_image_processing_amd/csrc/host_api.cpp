@@ -299,4 +299,148 @@ int lars_h_colormap_f32(const float *x, int64_t n, const uint8_t *lut_rgba, uint
     return LARS_OK;
 }
 
+int lars_h_colormap_norm_f32(const float *x, int64_t n, float vmin, float vmax, const uint8_t *lut_rgba, uint8_t *out_rgba)
+{
+    ThreadCtx *c;
+    LARS_TRY(ensure_ctx(&c));
+    if (!x || !lut_rgba || !out_rgba || n <= 0) return fail(LARS_ERR_INVALID, "lars_h_colormap_norm_f32: bad arguments");
+    Carver cv(nullptr);
+    cv.take<float>(n); cv.take<uint8_t>(1024); cv.take<uint8_t>((size_t)n * 4);
+    LARS_TRY(ws_reserve(c, cv.off + 256));
+    Carver d(c->ws);
+    float *dx = d.take<float>(n);
+    uint8_t *dl = d.take<uint8_t>(1024);
+    uint8_t *dout = d.take<uint8_t>((size_t)n * 4);
+    hipStream_t s = c->stream;
+    LARS_HIP_TRY(hipMemcpyAsync(dx, x, (size_t)n * 4, hipMemcpyHostToDevice, s));
+    LARS_HIP_TRY(hipMemcpyAsync(dl, lut_rgba, 1024, hipMemcpyHostToDevice, s));
+    LARS_TRY(lars_d_colormap_norm_f32(dx, n, vmin, vmax, dl, dout, s));
+    LARS_HIP_TRY(hipMemcpyAsync(out_rgba, dout, (size_t)n * 4, hipMemcpyDeviceToHost, s));
+    LARS_HIP_TRY(hipStreamSynchronize(s));
+    return LARS_OK;
+}
+
+// device-side registration of `moving` (device, uint8 [h][w][channels]) to `fixed`: estimate + apply
+static int align_on_device(ThreadCtx *c, const uint8_t *d_fixed, const uint8_t *d_moving, int64_t h, int64_t w, int channels,
+                           double *d_fa, double *d_fb, void *d_scratch, int64_t *d_shift, uint8_t *d_aligned, hipStream_t s)
+{
+    const int64_t npix = h * w;
+    LARS_TRY(lars_d_gray_c128(d_fixed, npix, channels, d_fa, s));
+    LARS_TRY(lars_d_gray_c128(d_moving, npix, channels, d_fb, s));
+    LARS_TRY(lars_d_phase_correlation(d_fa, d_fb, h, w, d_shift, d_scratch, s));
+    LARS_TRY(lars_d_shift_reflect_u8(d_moving, h, w, channels, d_shift, d_aligned, s));
+    return LARS_OK;
+}
+
+int lars_h_align_images(const uint8_t *fixed, const uint8_t *moving, int64_t h, int64_t w, int channels, uint8_t *out_aligned,
+                        double shift[2])
+{
+    ThreadCtx *c;
+    LARS_TRY(ensure_ctx(&c));
+    if (!fixed || !moving || !out_aligned || h <= 0 || w <= 0 || (channels != 1 && channels != 3))
+        return fail(LARS_ERR_INVALID, "lars_h_align_images: two uint8 [h][w][3] (or [h][w]) images of the same shape are required");
+    const size_t npix = (size_t)h * w, nbytes = npix * channels;
+    Carver cv(nullptr);
+    cv.take<uint8_t>(nbytes); cv.take<uint8_t>(nbytes); cv.take<uint8_t>(nbytes);
+    cv.take<double>(npix * 2); cv.take<double>(npix * 2); cv.take<char>(lars_phase_scratch_bytes()); cv.take<int64_t>(2);
+    LARS_TRY(ws_reserve(c, cv.off + 256));
+    Carver d(c->ws);
+    uint8_t *df = d.take<uint8_t>(nbytes), *dm = d.take<uint8_t>(nbytes), *da = d.take<uint8_t>(nbytes);
+    double *fa = d.take<double>(npix * 2), *fb = d.take<double>(npix * 2);
+    char *sc = d.take<char>(lars_phase_scratch_bytes());
+    int64_t *dshift = d.take<int64_t>(2);
+    hipStream_t s = c->stream;
+    LARS_HIP_TRY(hipMemcpyAsync(df, fixed, nbytes, hipMemcpyHostToDevice, s));
+    LARS_HIP_TRY(hipMemcpyAsync(dm, moving, nbytes, hipMemcpyHostToDevice, s));
+    LARS_TRY(align_on_device(c, df, dm, h, w, channels, fa, fb, sc, dshift, da, s));
+    int64_t hs[2] = {0, 0};
+    LARS_HIP_TRY(hipMemcpyAsync(out_aligned, da, nbytes, hipMemcpyDeviceToHost, s));
+    LARS_HIP_TRY(hipMemcpyAsync(hs, dshift, sizeof hs, hipMemcpyDeviceToHost, s));
+    LARS_HIP_TRY(hipStreamSynchronize(s));
+    if (shift) { shift[0] = (double)hs[0]; shift[1] = (double)hs[1]; }
+    return LARS_OK;
+}
+
+int lars_h_change_detection(const uint8_t *early, const uint8_t *late, int64_t h, int64_t w, int channels, int wb_early,
+                            int wb_late, int align, int index_id, float *out_early, float *out_late, float *out_diff,
+                            uint8_t *out_rgba_diff, const uint8_t *lut_rgba, float vmin, float vmax,
+                            uint8_t *out_aligned_late, double shift[2])
+{
+    ThreadCtx *c;
+    LARS_TRY(ensure_ctx(&c));
+    if (!early || !late || h <= 0 || w <= 0 || channels < 3)
+        return fail(LARS_ERR_INVALID, "lars_h_change_detection: two uint8 [h][w][>=3] images of the same shape are required");
+    if (index_id < 0 || index_id > 2) return fail(LARS_ERR_INVALID, "lars_h_change_detection: index_id");
+    if (align && channels != 3) return fail(LARS_ERR_INVALID, "lars_h_change_detection: registration needs 3-channel images (rgb2gray)");
+    if (out_rgba_diff && !lut_rgba) return fail(LARS_ERR_INVALID, "lars_h_change_detection: out_rgba_diff needs lut_rgba");
+    const size_t npix = (size_t)h * w, nbytes = npix * channels;
+    const size_t tbytes = lars_wb_table_bytes(LARS_U8);
+    Carver cv(nullptr);
+    for (int pass = 0; pass < 2; ++pass) {
+        // pass 0 sizes the workspace, pass 1 carves it
+        if (pass == 1) { LARS_TRY(ws_reserve(c, cv.off + 256)); cv = Carver(c->ws); }
+        Carver &d = cv;
+        uint8_t *d_e = d.take<uint8_t>(nbytes), *d_l = d.take<uint8_t>(nbytes);
+        uint8_t *d_ewb = d.take<uint8_t>(nbytes), *d_lwb = d.take<uint8_t>(nbytes), *d_al = d.take<uint8_t>(nbytes);
+        uint8_t *d_tab = d.take<uint8_t>(tbytes);
+        double *d_pct = d.take<double>(6);
+        double *fa = d.take<double>(align ? npix * 2 : 1), *fb = d.take<double>(align ? npix * 2 : 1);
+        char *sc = d.take<char>(lars_phase_scratch_bytes());
+        int64_t *d_shift = d.take<int64_t>(2);
+        float *d_ie = d.take<float>(npix), *d_il = d.take<float>(npix), *d_df = d.take<float>(npix);
+        uint8_t *d_rgba = d.take<uint8_t>(out_rgba_diff ? npix * 4 : 1), *d_lut = d.take<uint8_t>(1024);
+        if (pass == 0) continue;
+
+        hipStream_t s = c->stream;
+        LARS_HIP_TRY(hipMemcpyAsync(d_e, early, nbytes, hipMemcpyHostToDevice, s));
+        LARS_HIP_TRY(hipMemcpyAsync(d_l, late, nbytes, hipMemcpyHostToDevice, s));
+        LARS_HIP_TRY(hipMemsetAsync(d_shift, 0, 2 * sizeof(int64_t), s));
+        // white balance where the caller holds no cached corrected array (process-images.py:894-902)
+        const uint8_t *src[2] = {d_e, d_l};
+        uint8_t *wb_out[2] = {d_ewb, d_lwb};
+        const int want_wb[2] = {wb_early, wb_late};
+        for (int k = 0; k < 2; ++k) {
+            if (!want_wb[k]) continue;
+            LARS_TRY(lars_d_wb_prepare(src[k], 1, (int64_t)npix, channels, LARS_U8, d_tab, d_pct, 0, s));
+            lars_fused_args a;
+            memset(&a, 0, sizeof a);
+            a.tiles = src[k]; a.ntiles = 1; a.npix = (int64_t)npix; a.channels = channels; a.dtype = LARS_U8;
+            a.wb_table = d_tab; a.out_wb = wb_out[k]; a.stream = s;
+            LARS_TRY(lars_d_fused(&a));
+            src[k] = wb_out[k];
+        }
+        // registration of the late image onto the early one (:905-908)
+        const uint8_t *late_final = src[1];
+        if (align) {
+            LARS_TRY(align_on_device(c, src[0], src[1], h, w, channels, fa, fb, sc, d_shift, d_al, s));
+            late_final = d_al;
+        }
+        // indices (:911-919), difference (:923) and its colour map (:956)
+        const uint8_t *imgs[2] = {src[0], late_final};
+        float *idx[2] = {d_ie, d_il};
+        for (int k = 0; k < 2; ++k) {
+            lars_fused_args a;
+            memset(&a, 0, sizeof a);
+            a.tiles = imgs[k]; a.ntiles = 1; a.npix = (int64_t)npix; a.channels = channels; a.dtype = LARS_U8;
+            a.index_mask = 1u << index_id; a.out_index[index_id] = idx[k]; a.stream = s;
+            LARS_TRY(lars_d_fused(&a));
+        }
+        LARS_TRY(lars_d_diff_f32(d_ie, d_il, (int64_t)npix, d_df, s));
+        if (out_rgba_diff) {
+            LARS_HIP_TRY(hipMemcpyAsync(d_lut, lut_rgba, 1024, hipMemcpyHostToDevice, s));
+            LARS_TRY(lars_d_colormap_norm_f32(d_df, (int64_t)npix, vmin, vmax, d_lut, d_rgba, s));
+            LARS_HIP_TRY(hipMemcpyAsync(out_rgba_diff, d_rgba, npix * 4, hipMemcpyDeviceToHost, s));
+        }
+        int64_t hs[2] = {0, 0};
+        if (out_early) LARS_HIP_TRY(hipMemcpyAsync(out_early, d_ie, npix * 4, hipMemcpyDeviceToHost, s));
+        if (out_late) LARS_HIP_TRY(hipMemcpyAsync(out_late, d_il, npix * 4, hipMemcpyDeviceToHost, s));
+        if (out_diff) LARS_HIP_TRY(hipMemcpyAsync(out_diff, d_df, npix * 4, hipMemcpyDeviceToHost, s));
+        if (out_aligned_late) LARS_HIP_TRY(hipMemcpyAsync(out_aligned_late, late_final, nbytes, hipMemcpyDeviceToHost, s));
+        LARS_HIP_TRY(hipMemcpyAsync(hs, d_shift, sizeof hs, hipMemcpyDeviceToHost, s));
+        LARS_HIP_TRY(hipStreamSynchronize(s));
+        if (shift) { shift[0] = (double)hs[0]; shift[1] = (double)hs[1]; }
+    }
+    return LARS_OK;
+}
+
 }  // extern "C"

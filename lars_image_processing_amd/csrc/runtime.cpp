@@ -209,6 +209,7 @@ int lars_shutdown(void)
     ThreadCtx *c = &g_ctx;
     if (c->device < 0) return LARS_OK;
     hipSetDevice(c->device);
+    align_release();
     if (c->stream) { hipStreamSynchronize(c->stream); hipStreamDestroy(c->stream); c->stream = nullptr; }
     if (c->ws) { hipFree(c->ws); c->ws = nullptr; c->ws_bytes = 0; }
     if (c->scratch) { hipFree(c->scratch); c->scratch = nullptr; c->scratch_bytes = 0; }

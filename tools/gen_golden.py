@@ -176,6 +176,17 @@ def main():
         cm = matplotlib.colormaps[cm_name]
         arrays[f"colormap/{cm_name}_lut"] = cm(np.arange(256), bytes=True)       # [256,4] uint8
         arrays[f"colormap/{cm_name}_probe_rgba"] = cm(Normalize(-1, 1)(probe), bytes=True)
+    # change map: imshow(diff, cmap='bwr', vmin=-0.5, vmax=0.5) (process-images.py:956); diff = late - early in [-2, 2]
+    dprobe = np.concatenate([
+        np.random.default_rng(12).uniform(-2, 2, 4096).astype(np.float32),
+        np.random.default_rng(13).uniform(-0.5, 0.5, 4096).astype(np.float32),
+        np.linspace(-0.5, 0.5, 1025, dtype=np.float32),
+        np.array([-2.0, -0.5, -0.0, 0.0, 0.5, 2.0, np.nextafter(np.float32(0.5), np.float32(0)),
+                  np.nextafter(np.float32(0.5), np.float32(1)), np.nextafter(np.float32(-0.5), np.float32(0)),
+                  np.nextafter(np.float32(-0.5), np.float32(-1))], dtype=np.float32),
+    ])
+    arrays["colormap/diff_probe"] = dprobe
+    arrays["colormap/bwr_diff_probe_rgba"] = matplotlib.colormaps["bwr"](Normalize(-0.5, 0.5)(dprobe), bytes=True)
 
     # ---- preprocess_large_image (process-images.py:398-422): Pillow LANCZOS down-scale before the hot path
     resize = {}

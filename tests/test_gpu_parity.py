@@ -139,6 +139,23 @@ def test_odd_shapes_against_oracle(lars, shape, profile):
         np.testing.assert_array_equal(res["indices"][t]["hist"], orc.hist50(want))
 
 
+def test_large_odd_shaped_image(lars):
+    """35 Mpix, neither dimension a multiple of anything: many blocks per image, ragged rows, the npix % 4 tail."""
+    rng = np.random.default_rng(77)
+    img = rng.integers(0, 256, (5001, 7001, 3), dtype=np.uint8)
+    img[:, :, 2] = np.clip(img[:, :, 2].astype(np.int32) // 2 + 100, 0, 255).astype(np.uint8)
+    res = lars.process_image(img, want_hist=True)
+    with warnings.catch_warnings():
+        warnings.simplefilter("ignore")
+        wb = orc.wb_closed_form(img)                       # == wb_app (test_oracle.py), 10x faster at this size
+    np.testing.assert_array_equal(res["corrected"], wb)
+    for t in TYPES:
+        want = orc.index_app(wb, t)
+        np.testing.assert_array_equal(bits(res["indices"][t]["index"]), bits(want))
+        assert_stats_close(res["indices"][t]["stats"], orc.stats_app(want, t), want)
+        np.testing.assert_array_equal(res["indices"][t]["hist"], orc.hist50(want))
+
+
 def test_rgba_and_uint16_inputs(lars):
     rng = np.random.default_rng(17)
     rgba = rng.integers(0, 256, (37, 41, 4), dtype=np.uint8)

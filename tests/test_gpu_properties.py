@@ -53,7 +53,8 @@ def test_analyze_index_on_arbitrary_float32(x, t):
     got, want = lars.analyze_index(x, t), orc.stats_app(x, t)
     for key, val in want.items():
         if key.startswith("Mean"):
-            assert abs(got[key] - val) <= 1e-6 * max(abs(val), float(np.mean(np.abs(x))))
+            # + the float32 subnormal range: hypothesis feeds denormals, whose float32 mean has no relative accuracy
+            assert abs(got[key] - val) <= 1e-6 * max(abs(val), float(np.mean(np.abs(x)))) + 1e-36
         else:
             assert got[key] == val, key
     np.testing.assert_array_equal(lars.index_histogram(x), orc.hist50(x))

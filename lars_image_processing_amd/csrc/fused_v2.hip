@@ -180,8 +180,10 @@ struct WaveAcc {
 
 // LDS layout (dynamic): [WB table 64 KiB][hist 3*50*32 u32][edges 51 f32][reduce scratch]
 #define V2_TABLE_BYTES 65536
-#define V2_HIST_COPIES 4     // lane-private copies of each index histogram (keeps two blocks per CU)
-#define V2_HIST_WORDS (3 * LARS_HIST_BINS * V2_HIST_COPIES)
+#define V2_HIST_COPIES 16    // copies of each index histogram, copy = lane % 16 (two blocks per CU still fit)
+#define V2_HIST_SHIFT 6      // log2(V2_HIST_COPIES * 4): bytes between consecutive bins
+#define V2_HIST_ROWS 51      // bins 0..50; 50 (x == 1.0, the closed right edge) folds into 49 at the flush
+#define V2_HIST_WORDS (3 * V2_HIST_ROWS * V2_HIST_COPIES)
 
 // byte k of a dword -> float in one VALU instruction.  Kept opaque (asm) so that hipcc does not
 // turn "float(a) +/- float(b)" into integer SDWA adds plus conversions (5 instructions per pixel
@@ -292,10 +294,30 @@ __device__ inline void push(WaveAcc &a, unsigned int &above, float x, float thr)
     }
 }
 
-__device__ inline void hist_add(unsigned int *s_hist, const HistCell<float> *s_edges, int index, float x, unsigned int lane32)
+// Histogram bin of an index value of a uint8 tile without looking at the edges.  x = (a-b)/(a+b)
+// with bytes a, b, so the exact position T = 25 x + 25 = 50 a / (a + b) is either an integer or at
+// least 1/510 away from one, while t = fma(x, 25, 25.5001) carries an error below 4e-6: adding 2^23
+// rounds t to nearest and leaves floor(T) + 1 in the low mantissa bits.  On an exact hit the float32
+// quotient is >= the float32 edge for every edge of numpy's linspace (checked for all 51 edges and,
+// exhaustively over the 65536 byte pairs, by tests/test_properties_cpu.py), so floor(T) is numpy's bin.
+// One packed fma + one packed add per pixel pair, one v_lshl_add_u32 per pixel, no LDS lookup.
+// sign = -1 bins -x (NDWI from the GNDVI quotient).  `base` is the lane's byte address of copy
+// lane % 16 of the index's bin 0, minus the constant part of the shifted float bits.
+#define V2_HIST_MAGIC_C 25.5001f
+#define V2_HIST_MAGIC_BITS 0x4B000001u                   /* float bits of 2^23 + 1: "bin 0" */
+__device__ inline f32x2 hist_pos2(f32x2 x, float sign)
 {
-    const int b = hist_bin_f32(x, s_edges);
-    atomicAdd(&s_hist[(index * LARS_HIST_BINS + b) * V2_HIST_COPIES + (lane32 & (V2_HIST_COPIES - 1))], 1u);
+    const f32x2 k = {25.0f * sign, 25.0f * sign}, c = {V2_HIST_MAGIC_C, V2_HIST_MAGIC_C}, big = {8388608.0f, 8388608.0f};
+    return __builtin_elementwise_fma(x, k, c) + big;
+}
+__device__ inline void hist_add_pos(float pos, unsigned int base)
+{
+    const unsigned int addr = (__builtin_bit_cast(unsigned int, pos) << V2_HIST_SHIFT) + base;
+    asm volatile("ds_add_u32 %0, %1" : : "v"(addr), "v"(1u) : "memory");
+}
+__device__ inline void hist_add(float x, float sign, unsigned int base)
+{
+    hist_add_pos(__builtin_fmaf(x, 25.0f * sign, V2_HIST_MAGIC_C) + 8388608.0f, base);
 }
 
 // Block size: the 64 KiB table allows two blocks per CU.  A wave issues at most one vector instruction
@@ -309,11 +331,10 @@ __global__ __launch_bounds__(V2Block<OUT>::threads, OUT ? 4 : LARS_V2_STATS_WAVE
     constexpr int NTHR = V2Block<OUT>::threads;
     constexpr int NWAVES = NTHR / 64;
     __shared__ __attribute__((aligned(16))) char s_mem[(WB ? V2_TABLE_BYTES : 0) +
-                                                       (STATS >= 2 ? V2_HIST_WORDS * 4 + 66 * 8 : 0) + NWAVES * 16 * sizeof(double)];
+                                                       (STATS >= 2 ? V2_HIST_WORDS * 4 : 0) + NWAVES * 16 * sizeof(double)];
     char *s_tab = s_mem;                                                             // 64 KiB when WB
     unsigned int *s_hist = reinterpret_cast<unsigned int *>(s_mem + (WB ? V2_TABLE_BYTES : 0));
-    HistCell<float> *s_edges = reinterpret_cast<HistCell<float> *>(s_hist + (STATS >= 2 ? V2_HIST_WORDS : 0));
-    double *s_red = reinterpret_cast<double *>(s_edges + (STATS >= 2 ? 66 : 0));     // [NWAVES][16]
+    double *s_red = reinterpret_cast<double *>(s_hist + (STATS >= 2 ? V2_HIST_WORDS : 0));     // [NWAVES][16]
 
     constexpr bool NEED_R = (MASK & 1u) != 0;
     constexpr bool NEED_G = (MASK & 6u) != 0;
@@ -321,8 +342,12 @@ __global__ __launch_bounds__(V2Block<OUT>::threads, OUT ? 4 : LARS_V2_STATS_WAVE
 
     const int tid = threadIdx.x;
     const unsigned int lane = tid & 63;
+    // byte address (LDS offset) of this lane's copy of bin 0 of index k, less the shifted bits of "bin 0"
+    typedef __attribute__((address_space(3))) unsigned int lds_u32;
+    const unsigned int hist_lds = STATS >= 2 ? (unsigned int)(unsigned long long)(lds_u32 *)s_hist : 0u;
+    const unsigned int hb0 = hist_lds + (((unsigned)tid & (V2_HIST_COPIES - 1)) << 2) - (V2_HIST_MAGIC_BITS << V2_HIST_SHIFT);
+    const unsigned int hb1 = hb0 + V2_HIST_ROWS * V2_HIST_COPIES * 4, hb2 = hb1 + V2_HIST_ROWS * V2_HIST_COPIES * 4;
     const unsigned int lane_off4 = lane << 2;
-    const unsigned int lane32 = lane & 31;
     const long long tile = blockIdx.y;
     const long long npix = P.npix;
     const uint8_t *base = static_cast<const uint8_t *>(P.tiles) + tile * npix * 3;
@@ -338,7 +363,6 @@ __global__ __launch_bounds__(V2Block<OUT>::threads, OUT ? 4 : LARS_V2_STATS_WAVE
     }
     if (STATS >= 2) {
         for (int i = tid; i < V2_HIST_WORDS; i += NTHR) s_hist[i] = 0;
-        hist_cells_init<float>(s_edges, tid);
     }
     if (WB || STATS >= 2) __syncthreads();
 
@@ -398,11 +422,23 @@ __global__ __launch_bounds__(V2Block<OUT>::threads, OUT ? 4 : LARS_V2_STATS_WAVE
                 const f32x2 R = {fr[2 * h], fr[2 * h + 1]};
                 const f32x2 x = exact_quot2(N - R, Ne + R);
                 v0[2 * h] = x.x; v0[2 * h + 1] = x.y;
+                if (STATS >= 2) {
+                    const f32x2 p = hist_pos2(x, 1.0f);
+                    hist_add_pos(p.x, hb0); hist_add_pos(p.y, hb0);
+                }
             }
             if (NEED_G) {
                 const f32x2 G = {fg[2 * h], fg[2 * h + 1]};
                 const f32x2 x = exact_quot2(N - G, Ne + G);
                 v1[2 * h] = x.x; v1[2 * h + 1] = x.y;
+                if (STATS >= 2 && WANT_GNDVI) {
+                    const f32x2 p = hist_pos2(x, 1.0f);
+                    hist_add_pos(p.x, hb1); hist_add_pos(p.y, hb1);
+                }
+                if (STATS >= 2 && WANT_NDWI) {
+                    const f32x2 p = hist_pos2(x, -1.0f);
+                    hist_add_pos(p.x, hb2); hist_add_pos(p.y, hb2);
+                }
             }
         }
 #pragma unroll
@@ -410,7 +446,6 @@ __global__ __launch_bounds__(V2Block<OUT>::threads, OUT ? 4 : LARS_V2_STATS_WAVE
             if (WANT_NDVI) {
                 const float x = v0[px];
                 if (STATS >= 1) push<STATS, LARS_COUNT_MODE != 0>(acc_v, above_v, x, 0.2f);
-                if (STATS >= 2) hist_add(s_hist, s_edges, 0, x, lane32);
             }
             if (NEED_G) {
                 const float x = v1[px];
@@ -431,10 +466,8 @@ __global__ __launch_bounds__(V2Block<OUT>::threads, OUT ? 4 : LARS_V2_STATS_WAVE
                         if (WANT_NDWI) vcount_lt(above_w, x, 0.0f);           // -x > 0
                     }
                 }
-                if (STATS >= 2 && WANT_GNDVI) hist_add(s_hist, s_edges, 1, x, lane32);
                 if (WANT_NDWI) {
                     v2[px] = 0.0f - x;                     // +0.0 where the quotient is zero
-                    if (STATS >= 2) hist_add(s_hist, s_edges, 2, v2[px], lane32);
                 }
             }
         }
@@ -514,7 +547,7 @@ __global__ __launch_bounds__(V2Block<OUT>::threads, OUT ? 4 : LARS_V2_STATS_WAVE
         if (WANT_NDVI) {
             const float x = norm_diff_fast(fn, fr);
             if (STATS >= 1) push<STATS>(acc_v, above_v, x, 0.2f);
-            if (STATS >= 2) hist_add(s_hist, s_edges, 0, x, lane32);
+            if (STATS >= 2) hist_add(x, 1.0f, hb0);
             if (oi0) oi0[i] = x;
             if (oc0) reinterpret_cast<unsigned int *>(oc0)[i] = lut0[cmap_index(x)];
         }
@@ -534,19 +567,21 @@ __global__ __launch_bounds__(V2Block<OUT>::threads, OUT ? 4 : LARS_V2_STATS_WAVE
                 }
             }
             if (WANT_GNDVI) {
-                if (STATS >= 2) hist_add(s_hist, s_edges, 1, x, lane32);
+                if (STATS >= 2) hist_add(x, 1.0f, hb1);
                 if (oi1) oi1[i] = x;
                 if (oc1) reinterpret_cast<unsigned int *>(oc1)[i] = lut1[cmap_index(x)];
             }
             if (WANT_NDWI) {
                 const float w = 0.0f - x;
-                if (STATS >= 2) hist_add(s_hist, s_edges, 2, w, lane32);
+                if (STATS >= 2) hist_add(x, -1.0f, hb2);
                 if (oi2) oi2[i] = w;
                 if (oc2) reinterpret_cast<unsigned int *>(oc2)[i] = lut2[cmap_index(w)];
             }
         }
     }
 
+    // the histogram atomics are inline asm: the compiler does not count them, wait for them by hand
+    if (STATS >= 2) asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
     if (STATS >= 1) {
         // wave fold (scalar counters are already wave totals; per-lane ones are summed here)
         if (LARS_COUNT_MODE != 0) above_v = wave_sum_u32(above_v);
@@ -621,10 +656,13 @@ __global__ __launch_bounds__(V2Block<OUT>::threads, OUT ? 4 : LARS_V2_STATS_WAVE
             if (tid < 3 * LARS_HIST_BINS) {
                 const int k = tid / LARS_HIST_BINS;
                 if (MASK & (1u << k)) {
-                    const unsigned int *rowh = s_hist + tid * V2_HIST_COPIES;
+                    const int b = tid - k * LARS_HIST_BINS;
+                    const unsigned int *rowh = s_hist + (k * V2_HIST_ROWS + b) * V2_HIST_COPIES;
                     unsigned int v = 0;
-                    for (int j = 0; j < V2_HIST_COPIES; ++j) v += rowh[j];
-                    if (v) atomicAdd(&rec[k].hist[tid - k * LARS_HIST_BINS], (unsigned long long)v);
+                    // row 50 holds x == 1.0: numpy's last bin is closed on the right
+                    const int nwords = (b == LARS_HIST_BINS - 1) ? 2 * V2_HIST_COPIES : V2_HIST_COPIES;
+                    for (int j = 0; j < nwords; ++j) v += rowh[j];
+                    if (v) atomicAdd(&rec[k].hist[b], (unsigned long long)v);
                 }
             }
         }

@@ -54,3 +54,23 @@ def test_merge_of_partials_is_statistics_of_the_union(tiles, t):
     _, thr = orc.coverage_rule(t)
     assert merged["coverage"] == np.count_nonzero(union > np.float32(thr)) / union.size * 100.0
     np.testing.assert_array_equal(merged["hist"], orc.hist50(union))
+
+
+def test_histogram_bin_from_the_quotient_position():
+    """The statistics kernels bin an index value of a uint8 tile as floor(fma(x, 25, 25.5001) + 2^23) - 1
+    instead of searching numpy's edges (csrc/fused_v2.hip): exhaustive over the 65536 byte pairs, both signs."""
+    edges = orc.hist50_edges(np.float32)
+    for i in range(51):                                    # an exact hit compares >= its float32 edge
+        assert np.float32(i - 25) / np.float32(25) >= edges[i]
+    a, b = np.meshgrid(np.arange(256, dtype=np.float32), np.arange(256, dtype=np.float32), indexing="ij")
+    q = orc.index_closed_form(a.ravel(), b.ravel())
+    c = np.float32(25.5001)
+    for sign in (1.0, -1.0):
+        x = q if sign > 0 else (np.float32(0) - q).astype(np.float32)
+        want = np.searchsorted(edges, x, side="right") - 1
+        want[x == edges[-1]] = 49
+        assert np.array_equal(np.bincount(want, minlength=50), np.histogram(x, bins=50, range=(-1, 1))[0])
+        t = (q.astype(np.float64) * (25.0 * sign) + float(c)).astype(np.float32)          # one rounding, like fma
+        u = (t + np.float32(8388608.0)).astype(np.float32)
+        got = np.minimum((u.view(np.uint32) & 0x7FFFFF).astype(np.int64) - 1, 49)
+        np.testing.assert_array_equal(got, want)

@@ -254,6 +254,15 @@ def main():
                 "fused_frac_of_8TBs": npix_rank * MODES[m][3] / (f_ms * 1e-3) / 1e9 / HBM_PEAK_GBS,
             }
 
+    # exact global medians (all tiles of all ranks) by radix select on recomputed values: informational, untimed region
+    medians, median_ms = None, None
+    if args.all_modes:
+        _ffi.call("lars_synchronize", None)
+        comm.barrier()
+        t0 = time.perf_counter()
+        medians = runner.batch.global_medians(indices, white_balance=True, comm=comm)
+        median_ms = (time.perf_counter() - t0) * 1e3
+
     probe = device_probe(runner) if (args.probe and rank == 0) else None
     if rank == 0:
         cpu = None if args.no_cpu_baseline or world > 1 else cpu_baseline(args)
@@ -283,6 +292,10 @@ def main():
             "cpu_baseline": cpu,
             "global_stats": {t: {k: v for k, v in s.items() if k != "hist"} for t, s in g.items()},
         }
+        if medians is not None:
+            for t in indices:
+                line["global_stats"][t]["median"] = medians[t]
+            line["global_median_ms"] = median_ms
         if extra:
             line["modes"] = extra
         if probe:

@@ -202,6 +202,17 @@ int lars_d_median_pair_f64(const double *x, int64_t n, double *out_dev, void *sc
 int lars_d_median_pair_batch_f32(const float *x, int64_t n, int64_t items, int64_t stride, float *out_dev,
                                  void *scratch, void *stream);
 
+/* One radix-select pass over the index values of a batch WITHOUT the planes in memory (exact batch /
+ * global medians): the NDVI and GNDVI quotients of every pixel are recomputed from the
+ * uint8 tiles and the digit [shift, shift + bits) of their order-preserving keys (x >= 0: bits | 2^31,
+ * x < 0: ~bits) is counted for the values whose key matches prefix[stream * 2 + track] above the digit
+ * (shift + bits == 32: all values; then track = lane parity, add the two tracks).  hist is
+ * uint64[2 streams][2 tracks][2048], accumulated with atomics (zero it first).  NDWI = -GNDVI shares
+ * GNDVI's order statistics. */
+int lars_d_quotient_digit_hist(const void *tiles, int64_t ntiles, int64_t npix, int channels, int dtype,
+                               const uint8_t *wb_table, int shift, int bits, const uint32_t prefix[4],
+                               uint64_t *hist, void *stream);
+
 /* float32 index -> RGBA8: LUT[min(int((x + 1f) * 128f), 255)], the per-pixel
  * mapping of imshow(cmap, vmin=-1, vmax=1) (process-images.py:695). */
 int lars_d_colormap_f32(const float *x, int64_t n, const uint8_t *lut_rgba, uint8_t *out_rgba,

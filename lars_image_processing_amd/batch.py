@@ -197,6 +197,34 @@ class TileBatch:
             if b is not None:
                 b.free()
 
+    # -- exact medians of the whole batch (all tiles, all ranks) ------------
+    def digit_histogram(self, shift, bits, prefix, white_balance=True, stream=None):
+        """One radix-select pass (``lars_d_quotient_digit_hist``): uint64[2 streams][2 tracks][2048]."""
+        if self.code != _ffi.U8 or self.channels != 3:
+            raise TypeError("exact batch medians need uint8 tiles with 3 channels")
+        if white_balance and self.table is None:
+            raise RuntimeError("compute_wb_tables() first")
+        if getattr(self, "_selq", None) is None:
+            self._selq = DeviceBuffer(2 * 2 * SELECT_BINS * 8)
+        self._selq.zero()
+        pre = np.ascontiguousarray(prefix, dtype=np.uint32).reshape(4)
+        _ffi.call("lars_d_quotient_digit_hist", C.c_void_p(self.tiles.ptr), self.ntiles, self.npix, self.channels, self.code,
+                  C.c_void_p(self.table.ptr) if white_balance else None, int(shift), int(bits), _ffi.ptr(pre),
+                  C.c_void_p(self._selq.ptr), stream)
+        _ffi.call("lars_synchronize", stream)
+        return self._selq.download(np.uint64, (2, 2, SELECT_BINS))
+
+    def global_medians(self, indices=INDEX_NAMES, white_balance=True, comm=None, recompute_tables=False):
+        """``np.median`` of each index over ALL pixels of ALL tiles of ALL ranks, exactly, without writing a plane:
+        three radix-select passes (11 + 11 + 10 key bits) that recompute the index values from the tiles
+        (3 bytes per pixel and pass) and one small all-reduce per pass."""
+        if white_balance and (recompute_tables or self.table is None):
+            self.compute_wb_tables()
+        n_local = self.ntiles * self.npix
+        keys = select_order_statistics(lambda shift, bits, prefix: self.digit_histogram(shift, bits, prefix, white_balance),
+                                       n_local, comm)
+        return medians_from_keys(keys, indices)
+
 
 class BatchOutputs:
     """Device output planes of a batch (optionally a ring of ``slots`` tiles)."""
@@ -295,3 +323,60 @@ def timeseries_rows(records, medians, index_type, dates=None):
             f"{feature} Coverage (%)": int(r["above"]) / count * 100,
         })
     return rows
+
+
+# ---------------------------------------------------------------------------
+# exact order statistics across tiles and ranks (radix select on recomputed values)
+# ---------------------------------------------------------------------------
+SELECT_BINS = 2048
+SELECT_PASSES = ((21, 11), (10, 11), (0, 10))              # (shift, bits) of the order-preserving 32-bit key
+
+
+def key_to_float32(key):
+    """Inverse of the kernels' order-preserving key (x >= 0: bits | 2^31; x < 0: ~bits)."""
+    key = np.uint32(key)
+    bits = (key & np.uint32(0x7FFFFFFF)) if (key & np.uint32(0x80000000)) else ~key
+    return np.array([bits], dtype=np.uint32).view(np.float32)[0]
+
+
+def select_order_statistics(pass_fn, n_local, comm=None):
+    """Keys of the two middle order statistics (ranks (N-1)//2 and N//2) of two value streams.
+
+    ``pass_fn(shift, bits, prefix[4]) -> uint64[2][2][SELECT_BINS]`` counts, on this rank, the digit
+    ``[shift, shift+bits)`` of the keys matching ``prefix[stream*2+track]`` above the digit (first pass: all
+    values, split over the two tracks).  Histograms are summed over ranks through ``comm.allreduce_f64``
+    (counts < 2^53 are exact in float64), every rank then picks the same digits.  Returns uint32[2][2].
+    """
+    tot = np.array([float(n_local)])
+    n_total = int((comm.allreduce_f64(tot, "sum") if comm is not None else tot)[0])
+    ranks = np.array([[(n_total - 1) // 2, n_total // 2]] * 2, dtype=np.int64)     # [stream][track]
+    prefix = np.zeros((2, 2), dtype=np.uint32)
+    for shift, bits in SELECT_PASSES:
+        local = np.asarray(pass_fn(shift, bits, prefix.reshape(4)), dtype=np.uint64).reshape(2, 2, SELECT_BINS)
+        hist = local.astype(np.float64).reshape(-1)
+        if comm is not None:
+            hist = comm.allreduce_f64(hist, "sum")
+        hist = np.asarray(hist).reshape(2, 2, SELECT_BINS).astype(np.int64)
+        if shift + bits == 32:
+            hist[:, 0] += hist[:, 1]                        # first pass: the two tracks are two copies
+            hist[:, 1] = hist[:, 0]
+        for s in range(2):
+            for t in range(2):
+                cum = np.cumsum(hist[s, t][: 1 << bits])
+                d = int(np.searchsorted(cum, ranks[s, t], side="right"))
+                if d >= (1 << bits):
+                    raise RuntimeError("radix select: rank beyond the histogram mass (inconsistent passes)")
+                ranks[s, t] -= int(cum[d - 1]) if d else 0
+                prefix[s, t] |= np.uint32(d << shift)
+    return prefix
+
+
+def medians_from_keys(keys, indices=INDEX_NAMES):
+    """np.median semantics (mean of the two middle values in float32); NDWI = -GNDVI shares GNDVI's statistics."""
+    out = {}
+    for t in indices:
+        s = 0 if t == "NDVI" else 1
+        a, b = key_to_float32(keys[s, 0]), key_to_float32(keys[s, 1])
+        m = np.float32(np.float32(a + b) / np.float32(2))
+        out[t] = float(np.float32(0) - m) if t == "NDWI" else float(m)
+    return out

@@ -669,6 +669,102 @@ __global__ __launch_bounds__(V2Block<OUT>::threads, OUT ? 4 : LARS_V2_STATS_WAVE
     }
 }
 
+
+// ---------------------------------------------------------------------------
+// Exact medians of a whole batch without materialising the index planes (global
+// statistics over all tiles of all ranks).  One radix-select pass: the index values are recomputed
+// from the tiles (3 bytes per pixel) and the digit [shift, shift + bits) of their order-preserving
+// keys is histogrammed for the values that match the already decided key prefix.  Two streams
+// (NDVI, GNDVI; NDWI = -GNDVI shares GNDVI's order statistics) x two tracks (the ranks (N-1)/2
+// and N/2, whose prefixes may part ways).  The host sums the histograms over ranks (one small RCCL
+// all-reduce), picks the digits and runs the next pass: 11 + 11 + 10 bits.
+// ---------------------------------------------------------------------------
+#define SELQ_BINS 2048
+struct SelQParams {
+    const uint8_t *tiles;
+    const uint8_t *wb_table;
+    long long npix;
+    int shift, bits, hi;                  // digit position; hi = shift + bits (32: nothing decided yet)
+    unsigned int prefix[2][2];            // [stream][track]
+    unsigned long long *hist;             // [2][2][SELQ_BINS], accumulated with atomics
+};
+
+template <bool WB>
+__global__ __launch_bounds__(1024) void k_selq_pass(SelQParams P)
+{
+    __shared__ __attribute__((aligned(16))) char s_tab[WB ? V2_TABLE_BYTES : 16];
+    __shared__ unsigned int s_h[4 * SELQ_BINS];
+    const int tid = threadIdx.x;
+    const unsigned int lane_off4 = (tid & 63u) << 2;
+    const long long tile = blockIdx.y;
+    const long long npix = P.npix;
+    const uint8_t *base = P.tiles + tile * npix * 3;
+    if (WB) {
+        const uint8_t *t = P.wb_table + tile * 768;
+        unsigned int *tab = reinterpret_cast<unsigned int *>(s_tab);
+        for (int i = tid; i < 256 * 64; i += 1024) {
+            const int v = i >> 6;
+            tab[i] = (unsigned)t[v] | ((unsigned)t[256 + v] << 8) | ((unsigned)t[512 + v] << 16);
+        }
+    }
+    for (int i = tid; i < 4 * SELQ_BINS; i += 1024) s_h[i] = 0;
+    __syncthreads();
+
+    const int shift = P.shift, hi = P.hi;
+    const unsigned int dmask = (1u << P.bits) - 1u;
+    const bool top = hi >= 32;
+    const unsigned int pa0 = top ? 0u : P.prefix[0][0] >> hi, pa1 = top ? 0u : P.prefix[0][1] >> hi;
+    const unsigned int pb0 = top ? 0u : P.prefix[1][0] >> hi, pb1 = top ? 0u : P.prefix[1][1] >> hi;
+    const unsigned int my_track = tid & 1u;                 // first pass: the two tracks are two copies
+    auto push = [&](int stream, float x, unsigned int p0, unsigned int p1) {
+        const unsigned int key = f32_key(x);
+        const unsigned int d = (key >> shift) & dmask;
+        if (top) {
+            atomicAdd(&s_h[(stream * 2 + my_track) * SELQ_BINS + d], 1u);
+        } else {
+            const unsigned int up = key >> hi;
+            if (up == p0) atomicAdd(&s_h[(stream * 2 + 0) * SELQ_BINS + d], 1u);
+            if (up == p1) atomicAdd(&s_h[(stream * 2 + 1) * SELQ_BINS + d], 1u);
+        }
+    };
+    const long long nquads = npix >> 2;
+    const long long stride = (long long)gridDim.x * 1024;
+    for (long long q = (long long)blockIdx.x * 1024 + tid; q < nquads; q += stride) {
+        const unsigned int *p = reinterpret_cast<const unsigned int *>(base) + q * 3;
+        const unsigned int w0 = p[0], w1 = p[1], w2 = p[2];
+        const unsigned int wr[4] = {w0, w0, w1, w2}, wg[4] = {w0, w1, w1, w2}, wn[4] = {w0, w1, w2, w2};
+        constexpr int br[4] = {0, 3, 2, 1}, bg[4] = {1, 0, 3, 2}, bn[4] = {2, 1, 0, 3};
+        float fn[4], fr[4], fg[4];
+#pragma unroll
+        for (int px = 0; px < 4; ++px) {
+            fn[px] = sample<WB>(wn[px], bn[px], 2, lane_off4, s_tab);
+            fr[px] = sample<WB>(wr[px], br[px], 0, lane_off4, s_tab);
+            fg[px] = sample<WB>(wg[px], bg[px], 1, lane_off4, s_tab);
+        }
+#pragma unroll
+        for (int h = 0; h < 2; ++h) {
+            const f32x2 N = {fn[2 * h], fn[2 * h + 1]}, R = {fr[2 * h], fr[2 * h + 1]}, G = {fg[2 * h], fg[2 * h + 1]};
+            const f32x2 Ne = N + (f32x2){LARS_DEN_EPS, LARS_DEN_EPS};
+            const f32x2 v = exact_quot2(N - R, Ne + R), g = exact_quot2(N - G, Ne + G);
+            push(0, v.x, pa0, pa1); push(0, v.y, pa0, pa1);
+            push(1, g.x, pb0, pb1); push(1, g.y, pb0, pb1);
+        }
+    }
+    if (blockIdx.x == 0 && tid < (int)(npix & 3)) {
+        const long long i = nquads * 4 + tid;
+        unsigned int r = base[i * 3], g = base[i * 3 + 1], n = base[i * 3 + 2];
+        if (WB) {
+            const unsigned int *tab = reinterpret_cast<const unsigned int *>(s_tab);
+            r = tab[r * 64] & 0xFFu; g = (tab[g * 64] >> 8) & 0xFFu; n = (tab[n * 64] >> 16) & 0xFFu;
+        }
+        push(0, norm_diff_fast((float)n, (float)r), pa0, pa1);
+        push(1, norm_diff_fast((float)n, (float)g), pb0, pb1);
+    }
+    __syncthreads();
+    for (int i = tid; i < 4 * SELQ_BINS; i += 1024)
+        if (s_h[i]) atomicAdd(&P.hist[i], (unsigned long long)s_h[i]);
+}
+
 }  // namespace lars
 
 // ===========================================================================
@@ -718,6 +814,23 @@ void fused_v2_launch(unsigned mask, bool wb, int stats, bool nt, dim3 grid, hipS
 void chan_hist_v2_launch(const uint8_t *tiles, long long npix, unsigned int *hist, dim3 grid, hipStream_t s)
 {
     hipLaunchKernelGGL(k_chan_hist_u8c3_v2, grid, dim3(1024), 0, s, tiles, npix, hist);
+}
+
+int selq_pass_launch(const uint8_t *tiles, const uint8_t *wb_table, long long ntiles, long long npix, int shift, int bits,
+                     const unsigned int prefix[4], unsigned long long *hist, hipStream_t s)
+{
+    SelQParams P;
+    P.tiles = tiles; P.wb_table = wb_table; P.npix = npix; P.shift = shift; P.bits = bits; P.hi = shift + bits;
+    P.prefix[0][0] = prefix[0]; P.prefix[0][1] = prefix[1]; P.prefix[1][0] = prefix[2]; P.prefix[1][1] = prefix[3];
+    P.hist = hist;
+    long long bpt = (2048 + ntiles - 1) / ntiles;                  // ~2048 workgroups per launch
+    const long long cap = (npix / 4 + 1024 * 8 - 1) / (1024 * 8);  // at least ~8 steps per block (64 KiB table each)
+    if (bpt > cap) bpt = cap;
+    if (bpt < 1) bpt = 1;
+    dim3 grid((unsigned)bpt, (unsigned)ntiles);
+    if (wb_table) hipLaunchKernelGGL((k_selq_pass<true>), grid, dim3(1024), 0, s, P);
+    else hipLaunchKernelGGL((k_selq_pass<false>), grid, dim3(1024), 0, s, P);
+    return launch_check("k_selq_pass");
 }
 
 int quot_check_launch(unsigned int max_den, unsigned long long *mismatches_dev, unsigned int *first_bad_dev, hipStream_t s)

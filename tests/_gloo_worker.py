@@ -41,8 +41,38 @@ class GlooComm:
         per_rank = [g.numpy().view(_ffi.STATS_DTYPE) for g in gathered]
         return dist.fold_gathered(per_rank)                   # the fold csrc/comm.cpp applies
 
+    def allreduce_f64(self, values, op="sum"):
+        t = torch.from_numpy(np.ascontiguousarray(values, dtype=np.float64).reshape(-1).copy())
+        td.all_reduce(t, op={"sum": td.ReduceOp.SUM, "max": td.ReduceOp.MAX, "min": td.ReduceOp.MIN}[op])
+        return t.numpy()
+
     def barrier(self):
         td.barrier()
+
+
+def f32_key(x):
+    b = np.ascontiguousarray(x, dtype=np.float32).view(np.uint32)
+    return np.where(b >> 31, ~b, b | np.uint32(0x80000000)).astype(np.uint32)
+
+
+def digit_pass_on_planes(planes):
+    """NumPy stand-in for lars_d_quotient_digit_hist over this rank's index planes [NDVI values, GNDVI values]."""
+    keys = [f32_key(p) for p in planes]
+
+    def pass_fn(shift, bits, prefix):
+        out = np.zeros((2, 2, batch.SELECT_BINS), dtype=np.uint64)
+        hi = shift + bits
+        for s in range(2):
+            k = keys[s]
+            d = (k >> np.uint32(shift)) & np.uint32((1 << bits) - 1)
+            for t in range(2):
+                if hi >= 32:
+                    sel = (np.arange(k.size) & 1) == t
+                else:
+                    sel = (k >> np.uint32(hi)) == (np.uint32(prefix[s * 2 + t]) >> np.uint32(hi))
+                out[s, t] = np.bincount(d[sel], minlength=batch.SELECT_BINS)[:batch.SELECT_BINS]
+        return out
+    return pass_fn
 
 
 def tile_records(tile_ids, h, w):
@@ -92,6 +122,23 @@ def main():
         assert np.array_equal(g["hist"], s["hist"])
         assert abs(g["mean"] - s["mean"]) <= 1e-15
         summary[name] = {"mean": g["mean"], "coverage": g["coverage"]}
+    # 4. exact global medians: radix-select passes, histograms summed over ranks
+    def planes_of(tile_ids):
+        out = {name: [np.zeros(0, np.float32)] for name in TYPES}
+        for t in tile_ids:
+            with warnings.catch_warnings():
+                warnings.simplefilter("ignore")
+                wb = orc.wb_app(orc.synth_tile_u8(77, t, h, w, profile="vegetation"))
+            for name in TYPES:
+                out[name].append(orc.index_app(wb, name).ravel())
+        return {name: np.concatenate(v) for name, v in out.items()}
+    mine_planes, all_planes = planes_of(range(lo, hi)), planes_of(range(ntiles))
+    keys = batch.select_order_statistics(digit_pass_on_planes([mine_planes["NDVI"], mine_planes["GNDVI"]]),
+                                         mine_planes["NDVI"].size, comm)
+    medians = batch.medians_from_keys(keys)
+    for name in TYPES:
+        assert medians[name] == float(np.median(all_planes[name])), name
+        summary[name]["median"] = medians[name]
     blob = torch.from_numpy(glob.view(np.uint8).copy())
     ref = blob.clone()
     td.broadcast(ref, src=0)

@@ -360,3 +360,30 @@ def test_bad_arguments_fail_cleanly(lars):
     rec = b.process(indices=("NDVI",))
     assert int(rec[0, 0]["count"]) == 256
     b.free()
+
+
+@pytest.mark.parametrize("white_balance", [True, False])
+@pytest.mark.parametrize("shape,ntiles", [((64, 96), 5), ((63, 65), 1), ((128, 128), 2)])
+def test_global_medians_without_planes(shape, ntiles, white_balance):
+    """np.median over all pixels of all tiles, from three radix-select passes that recompute the index values."""
+    import warnings
+    import lars_image_processing_amd as lars
+    from oracle import index_oracle as orc
+    tiles = np.stack([orc.synth_tile_u8(5, t, shape[0], shape[1], profile="vegetation" if t % 2 else "uniform")
+                      for t in range(ntiles)])
+    b = lars.TileBatch.from_host(tiles)
+    got = b.global_medians(white_balance=white_balance)
+    planes = {t: [] for t in ("NDVI", "GNDVI", "NDWI")}
+    for img in tiles:
+        with warnings.catch_warnings():
+            warnings.simplefilter("ignore")
+            src = orc.wb_app(img) if white_balance else img
+        for t in planes:
+            planes[t].append(orc.index_app(src, t).ravel())
+    for t in planes:
+        assert got[t] == float(np.median(np.concatenate(planes[t]))), t
+    # one index only, and agreement with the per-tile medians of the plane-writing route for a single tile
+    if ntiles == 1:
+        rec, med = b.process(white_balance=white_balance, medians=True)
+        for k, t in enumerate(("NDVI", "GNDVI", "NDWI")):
+            assert float(med[0, k]) == got[t]

@@ -213,6 +213,14 @@ int lars_d_quotient_digit_hist(const void *tiles, int64_t ntiles, int64_t npix, 
                                const uint8_t *wb_table, int shift, int bits, const uint32_t prefix[4],
                                uint64_t *hist, void *stream);
 
+/* np.median of the NDVI and GNDVI planes of EVERY tile without writing a plane: the same three passes with
+ * per-tile histograms and the digit picks on the device (no host round trip).  out_pairs is float[ntiles][2
+ * streams: NDVI, GNDVI][2]: the two middle order statistics (median = their float32 mean; NDWI's median is
+ * -GNDVI's).  scratch holds lars_quotient_median_scratch_bytes(ntiles). */
+size_t lars_quotient_median_scratch_bytes(int64_t ntiles);
+int lars_d_quotient_median_pairs(const void *tiles, int64_t ntiles, int64_t npix, int channels, int dtype,
+                                 const uint8_t *wb_table, float *out_pairs, void *scratch, void *stream);
+
 /* float32 index -> RGBA8: LUT[min(int((x + 1f) * 128f), 255)], the per-pixel
  * mapping of imshow(cmap, vmin=-1, vmax=1) (process-images.py:695). */
 int lars_d_colormap_f32(const float *x, int64_t n, const uint8_t *lut_rgba, uint8_t *out_rgba,

@@ -158,6 +158,13 @@ class TileBatch:
             self.compute_wb_tables(stream)
         stats = self.new_stats()
         stats.zero()
+        if medians and outputs is None and self.code == _ffi.U8 and self.channels == 3 and (self.ntiles == 1 or self.npix % 4 == 0):
+            # nothing to write: statistics in one pass, medians by three recompute-and-select passes (3 B per pixel each)
+            self.run_fused(self.fused_args(indices, white_balance, stats, hist, None, stream))
+            med = self.tile_medians(indices, white_balance, stream)
+            rec = stats.download(STATS_DTYPE, (self.ntiles, 3))
+            stats.free()
+            return rec, med
         own_outputs = None
         if medians and (outputs is None or any(outputs.index[INDEX_IDS[t]] is None for t in indices)):
             own_outputs = outputs = self.make_outputs(indices=indices, index=True, ring=min(self.ntiles, 16))
@@ -196,6 +203,26 @@ class TileBatch:
         for b in (self.tiles, self.hist, self.table, self.percentiles):
             if b is not None:
                 b.free()
+
+    def tile_medians(self, indices=INDEX_NAMES, white_balance=True, stream=None):
+        """float64[ntiles, 3]: np.median of every tile's index planes, none of which is written
+        (``lars_d_quotient_median_pairs``: per-tile radix select on recomputed values, all on the device)."""
+        if white_balance and self.table is None:
+            raise RuntimeError("compute_wb_tables() first")
+        pairs_dev = DeviceBuffer(self.ntiles * 4 * 4)
+        scratch = DeviceBuffer(int(_ffi.load().lars_quotient_median_scratch_bytes(self.ntiles)))
+        _ffi.call("lars_d_quotient_median_pairs", C.c_void_p(self.tiles.ptr), self.ntiles, self.npix, self.channels, self.code,
+                  C.c_void_p(self.table.ptr) if white_balance else None, C.c_void_p(pairs_dev.ptr), C.c_void_p(scratch.ptr), stream)
+        _ffi.call("lars_synchronize", stream)
+        pairs = pairs_dev.download(np.float32, (self.ntiles, 2, 2))
+        pairs_dev.free()
+        scratch.free()
+        mid = ((pairs[:, :, 0] + pairs[:, :, 1]) / np.float32(2)).astype(np.float32)          # float32 mean of the middles
+        med = np.full((self.ntiles, 3), np.nan, dtype=np.float64)
+        for t in indices:
+            k = INDEX_IDS[t]
+            med[:, k] = mid[:, 0] if t == "NDVI" else (mid[:, 1] if t == "GNDVI" else np.float32(0) - mid[:, 1])
+        return med
 
     # -- exact medians of the whole batch (all tiles, all ranks) ------------
     def digit_histogram(self, shift, bits, prefix, white_balance=True, stream=None):

@@ -125,6 +125,9 @@ void fused_v2_launch(unsigned mask, bool wb, int stats, bool nt, dim3 grid, hipS
 void chan_hist_v2_launch(const uint8_t *tiles, long long npix, unsigned int *hist, dim3 grid, hipStream_t s);
 int selq_pass_launch(const uint8_t *tiles, const uint8_t *wb_table, long long ntiles, long long npix, int shift, int bits,
                      const unsigned int prefix[4], unsigned long long *hist, hipStream_t s);
+size_t selq_tile_scratch_bytes(long long ntiles);
+int selq_tile_medians_launch(const uint8_t *tiles, const uint8_t *wb_table, long long ntiles, long long npix, float *out_pairs,
+                             void *scratch, hipStream_t s);
 int quot_check_launch(unsigned int max_den, unsigned long long *mismatches_dev, unsigned int *first_bad_dev, hipStream_t s);
 
 }  // namespace lars

@@ -801,3 +801,19 @@ extern "C" int lars_d_quotient_digit_hist(const void *tiles, int64_t ntiles, int
     return selq_pass_launch(static_cast<const uint8_t *>(tiles), wb_table, ntiles, npix, shift, bits, prefix,
                             reinterpret_cast<unsigned long long *>(hist), pick_stream(c, stream));
 }
+
+extern "C" size_t lars_quotient_median_scratch_bytes(int64_t ntiles) { return selq_tile_scratch_bytes(ntiles > 0 ? ntiles : 1); }
+
+extern "C" int lars_d_quotient_median_pairs(const void *tiles, int64_t ntiles, int64_t npix, int channels, int dtype,
+                                            const uint8_t *wb_table, float *out_pairs, void *scratch, void *stream)
+{
+    ThreadCtx *c;
+    LARS_TRY(ensure_ctx(&c));
+    if (!tiles || !out_pairs || !scratch || ntiles <= 0 || npix <= 0)
+        return fail(LARS_ERR_INVALID, "lars_d_quotient_median_pairs: bad arguments");
+    if (dtype != LARS_U8 || channels != 3 || (reinterpret_cast<uintptr_t>(tiles) & 3) || (ntiles > 1 && (npix & 3)))
+        return fail(LARS_ERR_INVALID, "lars_d_quotient_median_pairs: uint8 [ntiles][npix][3] tiles on 4-byte boundaries are required");
+    if (ntiles > 65535 || npix >= (1ll << 32)) return fail(LARS_ERR_INVALID, "lars_d_quotient_median_pairs: at most 65535 tiles of < 2^32 pixels");
+    return selq_tile_medians_launch(static_cast<const uint8_t *>(tiles), wb_table, ntiles, npix, out_pairs, scratch,
+                                    pick_stream(c, stream));
+}

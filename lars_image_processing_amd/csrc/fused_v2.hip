@@ -21,6 +21,8 @@
 //     256-bin histogram (96 KiB of LDS) so ds_add_u32 never conflicts.
 //
 // Reference semantics: see fused.hip.  Built with -ffp-contract=off.
+#include <string.h>
+
 #include "common.h"
 #include "device_common.h"
 
@@ -687,9 +689,16 @@ struct SelQParams {
     int shift, bits, hi;                  // digit position; hi = shift + bits (32: nothing decided yet)
     unsigned int prefix[2][2];            // [stream][track]
     unsigned long long *hist;             // [2][2][SELQ_BINS], accumulated with atomics
+    // per-tile selection (medians of every tile of a batch, all on the device): state and 32-bit histograms per tile
+    struct SelQTile *state;
+    unsigned int *hist32;                 // [ntiles][2][2][SELQ_BINS]
+};
+struct SelQTile {
+    unsigned int prefix[4];               // [stream * 2 + track]
+    unsigned int rank[4];                 // rank still to find inside the prefix
 };
 
-template <bool WB>
+template <bool WB, bool PER_TILE>
 __global__ __launch_bounds__(1024) void k_selq_pass(SelQParams P)
 {
     __shared__ __attribute__((aligned(16))) char s_tab[WB ? V2_TABLE_BYTES : 16];
@@ -713,8 +722,9 @@ __global__ __launch_bounds__(1024) void k_selq_pass(SelQParams P)
     const int shift = P.shift, hi = P.hi;
     const unsigned int dmask = (1u << P.bits) - 1u;
     const bool top = hi >= 32;
-    const unsigned int pa0 = top ? 0u : P.prefix[0][0] >> hi, pa1 = top ? 0u : P.prefix[0][1] >> hi;
-    const unsigned int pb0 = top ? 0u : P.prefix[1][0] >> hi, pb1 = top ? 0u : P.prefix[1][1] >> hi;
+    const unsigned int *pre = PER_TILE ? P.state[tile].prefix : &P.prefix[0][0];
+    const unsigned int pa0 = top ? 0u : pre[0] >> hi, pa1 = top ? 0u : pre[1] >> hi;
+    const unsigned int pb0 = top ? 0u : pre[2] >> hi, pb1 = top ? 0u : pre[3] >> hi;
     const unsigned int my_track = tid & 1u;                 // first pass: the two tracks are two copies
     auto push = [&](int stream, float x, unsigned int p0, unsigned int p1) {
         const unsigned int key = f32_key(x);
@@ -761,8 +771,65 @@ __global__ __launch_bounds__(1024) void k_selq_pass(SelQParams P)
         push(1, norm_diff_fast((float)n, (float)g), pb0, pb1);
     }
     __syncthreads();
-    for (int i = tid; i < 4 * SELQ_BINS; i += 1024)
-        if (s_h[i]) atomicAdd(&P.hist[i], (unsigned long long)s_h[i]);
+    if (PER_TILE) {
+        unsigned int *h = P.hist32 + tile * (4 * SELQ_BINS);
+        for (int i = tid; i < 4 * SELQ_BINS; i += 1024)
+            if (s_h[i]) atomicAdd(&h[i], s_h[i]);
+    } else {
+        for (int i = tid; i < 4 * SELQ_BINS; i += 1024)
+            if (s_h[i]) atomicAdd(&P.hist[i], (unsigned long long)s_h[i]);
+    }
+}
+
+__global__ void k_selq_init(SelQTile *state, long long ntiles, long long npix)
+{
+    const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < ntiles) {
+        SelQTile t;
+        for (int c = 0; c < 4; ++c) { t.prefix[c] = 0u; t.rank[c] = (unsigned int)((c & 1) ? npix / 2 : (npix - 1) / 2); }
+        state[i] = t;
+    }
+}
+
+// one block per tile, one wave per (stream, track): find the digit whose cumulative count covers the rank
+__global__ __launch_bounds__(256) void k_selq_pick(SelQTile *state, unsigned int *hist32, int shift, int first)
+{
+    const long long tile = blockIdx.x;
+    unsigned int *h = hist32 + tile * (4 * SELQ_BINS);
+    const int combo = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    const unsigned int *mine = h + combo * SELQ_BINS;
+    const unsigned int *twin = h + (combo ^ 1) * SELQ_BINS;        // first pass: the two tracks are two copies
+    unsigned int c[32], local = 0;
+#pragma unroll
+    for (int j = 0; j < 32; ++j) {
+        c[j] = mine[lane * 32 + j] + (first ? twin[lane * 32 + j] : 0u);
+        local += c[j];
+    }
+    unsigned int incl = local;
+    for (int off = 1; off < 64; off <<= 1) {
+        const unsigned int o = __shfl_up(incl, off);
+        if (lane >= off) incl += o;
+    }
+    const unsigned int rank = state[tile].rank[combo];
+    unsigned int cum = incl - local;
+    if (rank >= cum && rank < incl) {                       // exactly one lane (the total is the tile's pixel count)
+        int d = 0;
+#pragma unroll
+        for (int j = 0; j < 32; ++j) {
+            if (rank >= cum + c[j]) { cum += c[j]; d = j + 1; }
+            else break;
+        }
+        state[tile].prefix[combo] |= (unsigned int)(lane * 32 + d) << shift;
+        state[tile].rank[combo] = rank - cum;
+    }
+    __syncthreads();
+    for (int i = threadIdx.x; i < 4 * SELQ_BINS; i += 256) h[i] = 0u;
+}
+
+__global__ void k_selq_finish(const SelQTile *state, long long ntiles, float *out)
+{
+    const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < ntiles * 4) out[i] = key_f32(state[i >> 2].prefix[i & 3]);
 }
 
 }  // namespace lars
@@ -822,15 +889,49 @@ int selq_pass_launch(const uint8_t *tiles, const uint8_t *wb_table, long long nt
     SelQParams P;
     P.tiles = tiles; P.wb_table = wb_table; P.npix = npix; P.shift = shift; P.bits = bits; P.hi = shift + bits;
     P.prefix[0][0] = prefix[0]; P.prefix[0][1] = prefix[1]; P.prefix[1][0] = prefix[2]; P.prefix[1][1] = prefix[3];
-    P.hist = hist;
+    P.hist = hist; P.state = nullptr; P.hist32 = nullptr;
     long long bpt = (2048 + ntiles - 1) / ntiles;                  // ~2048 workgroups per launch
     const long long cap = (npix / 4 + 1024 * 8 - 1) / (1024 * 8);  // at least ~8 steps per block (64 KiB table each)
     if (bpt > cap) bpt = cap;
     if (bpt < 1) bpt = 1;
     dim3 grid((unsigned)bpt, (unsigned)ntiles);
-    if (wb_table) hipLaunchKernelGGL((k_selq_pass<true>), grid, dim3(1024), 0, s, P);
-    else hipLaunchKernelGGL((k_selq_pass<false>), grid, dim3(1024), 0, s, P);
+    if (wb_table) hipLaunchKernelGGL((k_selq_pass<true, false>), grid, dim3(1024), 0, s, P);
+    else hipLaunchKernelGGL((k_selq_pass<false, false>), grid, dim3(1024), 0, s, P);
     return launch_check("k_selq_pass");
+}
+
+size_t selq_tile_scratch_bytes(long long ntiles)
+{
+    return (size_t)ntiles * (sizeof(SelQTile) + 4 * SELQ_BINS * sizeof(unsigned int)) + 256;
+}
+
+// medians of every tile: three passes + picks, no host round trip
+int selq_tile_medians_launch(const uint8_t *tiles, const uint8_t *wb_table, long long ntiles, long long npix, float *out_pairs,
+                             void *scratch, hipStream_t s)
+{
+    SelQTile *state = static_cast<SelQTile *>(scratch);
+    unsigned int *hist32 = reinterpret_cast<unsigned int *>(static_cast<char *>(scratch) + (((size_t)ntiles * sizeof(SelQTile) + 255) & ~(size_t)255));
+    hipLaunchKernelGGL(k_selq_init, dim3((unsigned)((ntiles + 255) / 256)), dim3(256), 0, s, state, ntiles, npix);
+    if (hipMemsetAsync(hist32, 0, (size_t)ntiles * 4 * SELQ_BINS * sizeof(unsigned int), s) != hipSuccess)
+        return fail(LARS_ERR_HIP, "hipMemsetAsync failed (tile median scratch)");
+    long long bpt = (2048 + ntiles - 1) / ntiles;
+    const long long cap = (npix / 4 + 1024 * 8 - 1) / (1024 * 8);
+    if (bpt > cap) bpt = cap;
+    if (bpt < 1) bpt = 1;
+    dim3 grid((unsigned)bpt, (unsigned)ntiles);
+    const int passes[3][2] = {{21, 11}, {10, 11}, {0, 10}};
+    for (int p = 0; p < 3; ++p) {
+        SelQParams P;
+        memset(&P, 0, sizeof P);
+        P.tiles = tiles; P.wb_table = wb_table; P.npix = npix;
+        P.shift = passes[p][0]; P.bits = passes[p][1]; P.hi = P.shift + P.bits;
+        P.state = state; P.hist32 = hist32;
+        if (wb_table) hipLaunchKernelGGL((k_selq_pass<true, true>), grid, dim3(1024), 0, s, P);
+        else hipLaunchKernelGGL((k_selq_pass<false, true>), grid, dim3(1024), 0, s, P);
+        hipLaunchKernelGGL(k_selq_pick, dim3((unsigned)ntiles), dim3(256), 0, s, state, hist32, P.shift, p == 0 ? 1 : 0);
+    }
+    hipLaunchKernelGGL(k_selq_finish, dim3((unsigned)((ntiles * 4 + 255) / 256)), dim3(256), 0, s, state, ntiles, out_pairs);
+    return launch_check("selq_tile_medians");
 }
 
 int quot_check_launch(unsigned int max_den, unsigned long long *mismatches_dev, unsigned int *first_bad_dev, hipStream_t s)

@@ -318,6 +318,20 @@ def test_batch_medians_are_numpy_medians(lars):
             assert abs(rows[7][key] - val) <= 1e-6 * max(abs(val), 0.1), key
         else:
             assert rows[7][key] == val, key
+    # the plane-writing route (batched select over stored planes) must agree with the recompute-and-select route
+    outs = b.make_outputs(index=True, ring=8)
+    rec_o, med_o = b.process(medians=True, outputs=outs)
+    np.testing.assert_array_equal(med_o, med)
+    outs.free()
+    big = lars.TileBatch.synthetic(3, 512, 384, seed=3, profile="uniform")         # several workgroups per tile
+    _, med_b = big.process(medians=True)
+    for i in range(3):
+        with warnings.catch_warnings():
+            warnings.simplefilter("ignore")
+            wb = orc.wb_app(big.host_tiles(i, 1)[0])
+        for k, t in enumerate(TYPES):
+            assert med_b[i, k] == float(np.median(orc.index_app(wb, t))), (i, t)
+    big.free()
     rec2, med2 = b.process(indices=("NDWI",), medians=True, white_balance=False)
     assert np.isnan(med2[:, 0]).all() and med2[3, 2] == float(np.median(orc.index_app(tiles[3], "NDWI")))
     odd = lars.TileBatch.synthetic(2, 5, 7, seed=1)                                # odd sample count: single middle element

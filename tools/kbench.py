@@ -126,6 +126,19 @@ def main():
             results[f"fused {m} impl={impl} nt={nt} ntl={nl} pf={pf} bpt={bp} wb={wb}"] = {
                 "ms": med, "min_ms": float(min(t[1:])), "GBs": npix * bpp / med / 1e6,
                 "frac_8TBs": npix * bpp / med / 1e6 / 8000.0, "Gpix_s": npix / med / 1e6}
+    if "medians" in args.what:
+        # time-series table of the whole batch (statistics + median per tile): recompute-and-select vs stored planes
+        import time
+        outs = b.make_outputs(index=True, ring=min(args.ring, 16))
+        for name, kw in (("medians recompute+select (no planes)", {}), ("medians over stored planes (ring)", {"outputs": outs})):
+            ts = []
+            for _ in range(3):
+                _ffi.call("lars_synchronize", None)
+                t0 = time.perf_counter()
+                b.process(medians=True, recompute_tables=False, **kw)
+                ts.append((time.perf_counter() - t0) * 1e3)
+            results[name] = {"ms": float(np.median(ts[1:])), "min_ms": float(min(ts[1:])), "Gpix_s": npix / float(np.median(ts[1:])) / 1e6}
+        outs.free()
     if "probe" in args.what:
         nbytes = args.tiles * b.tile_bytes
         nbytes -= nbytes % 960

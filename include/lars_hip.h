@@ -206,7 +206,8 @@ int lars_d_median_pair_batch_f32(const float *x, int64_t n, int64_t items, int64
  * global medians): the NDVI and GNDVI quotients of every pixel are recomputed from the
  * uint8 tiles and the digit [shift, shift + bits) of their order-preserving keys (x >= 0: bits | 2^31,
  * x < 0: ~bits) is counted for the values whose key matches prefix[stream * 2 + track] above the digit
- * (shift + bits == 32: all values; then track = lane parity, add the two tracks).  hist is
+ * (shift + bits == 32: all values; then track = lane parity, add the two tracks; later passes count a prefix
+ * shared by both tracks of a stream once, under track 0).  hist is
  * uint64[2 streams][2 tracks][2048], accumulated with atomics (zero it first).  NDWI = -GNDVI shares
  * GNDVI's order statistics. */
 int lars_d_quotient_digit_hist(const void *tiles, int64_t ntiles, int64_t npix, int channels, int dtype,

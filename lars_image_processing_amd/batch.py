@@ -387,6 +387,10 @@ def select_order_statistics(pass_fn, n_local, comm=None):
         if shift + bits == 32:
             hist[:, 0] += hist[:, 1]                        # first pass: the two tracks are two copies
             hist[:, 1] = hist[:, 0]
+        else:
+            for s in range(2):                              # a shared prefix is counted once, under track 0
+                if prefix[s, 0] == prefix[s, 1]:
+                    hist[s, 1] = hist[s, 0]
         for s in range(2):
             for t in range(2):
                 cum = np.cumsum(hist[s, t][: 1 << bits])

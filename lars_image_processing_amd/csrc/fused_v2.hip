@@ -23,6 +23,8 @@
 // Reference semantics: see fused.hip.  Built with -ffp-contract=off.
 #include <string.h>
 
+#include <type_traits>
+
 #include "common.h"
 #include "device_common.h"
 
@@ -672,6 +674,41 @@ __global__ __launch_bounds__(V2Block<OUT>::threads, OUT ? 4 : LARS_V2_STATS_WAVE
 }
 
 
+// The fused kernel's load pipeline as a reusable loop: four 12-byte buffer loads in flight per lane, slot k is
+// consumed and refilled in place.  f(q, w0, w1, w2) sees every quad of the tile exactly once.
+template <int NTHR, typename F>
+__device__ inline void for_each_quad_ring(const uint8_t *base, long long nquads, F &&f)
+{
+    const long long stride = (long long)gridDim.x * NTHR;
+    const long long q0 = (long long)blockIdx.x * NTHR + threadIdx.x;
+    const long long niter = (nquads + stride - 1) / stride;          // same for every lane of the grid
+    if (niter <= 0) return;
+    const __amdgpu_buffer_rsrc_t rsrc =
+        __builtin_amdgcn_make_buffer_rsrc(const_cast<uint8_t *>(base), 0, (int)(nquads * 12), 0x00020000);
+    const unsigned int voff = (unsigned int)q0 * 12u;
+    const unsigned int step_b = (unsigned int)stride * 12u;
+    u32x3 w[4];
+#pragma unroll
+    for (int k = 0; k < 4; ++k) w[k] = __builtin_amdgcn_raw_buffer_load_b96(rsrc, voff, (unsigned)k * step_b, 0);
+    long long it = 0;
+    unsigned int soff = 4u * step_b;
+    for (; it + 4 <= niter - 1; it += 4) {
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            f(q0 + (it + k) * stride, w[k].x, w[k].y, w[k].z);
+            __builtin_amdgcn_sched_barrier(0);
+            w[k] = __builtin_amdgcn_raw_buffer_load_b96(rsrc, voff, soff + (unsigned)k * step_b, 0);
+            __builtin_amdgcn_sched_barrier(0);
+        }
+        soff += 4u * step_b;
+    }
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+        const long long qq = q0 + (it + k) * stride;
+        if (it + k < niter && qq < nquads) f(qq, w[k].x, w[k].y, w[k].z);
+    }
+}
+
 // ---------------------------------------------------------------------------
 // Exact medians of a whole batch without materialising the index planes (global
 // statistics over all tiles of all ranks).  One radix-select pass: the index values are recomputed
@@ -682,6 +719,7 @@ __global__ __launch_bounds__(V2Block<OUT>::threads, OUT ? 4 : LARS_V2_STATS_WAVE
 // all-reduce), picks the digits and runs the next pass: 11 + 11 + 10 bits.
 // ---------------------------------------------------------------------------
 #define SELQ_BINS 2048
+#define SELQ_ROW (SELQ_BINS + 64)
 struct SelQParams {
     const uint8_t *tiles;
     const uint8_t *wb_table;
@@ -702,7 +740,7 @@ template <bool WB, bool PER_TILE>
 __global__ __launch_bounds__(1024) void k_selq_pass(SelQParams P)
 {
     __shared__ __attribute__((aligned(16))) char s_tab[WB ? V2_TABLE_BYTES : 16];
-    __shared__ unsigned int s_h[4 * SELQ_BINS];
+    __shared__ unsigned int s_h[4 * SELQ_ROW];             // per (stream, track): 2048 bins + one dummy word per lane
     const int tid = threadIdx.x;
     const unsigned int lane_off4 = (tid & 63u) << 2;
     const long long tile = blockIdx.y;
@@ -716,68 +754,95 @@ __global__ __launch_bounds__(1024) void k_selq_pass(SelQParams P)
             tab[i] = (unsigned)t[v] | ((unsigned)t[256 + v] << 8) | ((unsigned)t[512 + v] << 16);
         }
     }
-    for (int i = tid; i < 4 * SELQ_BINS; i += 1024) s_h[i] = 0;
+    for (int i = tid; i < 4 * SELQ_ROW; i += 1024) s_h[i] = 0;
     __syncthreads();
 
     const int shift = P.shift, hi = P.hi;
-    const unsigned int dmask = (1u << P.bits) - 1u;
     const bool top = hi >= 32;
     const unsigned int *pre = PER_TILE ? P.state[tile].prefix : &P.prefix[0][0];
     const unsigned int pa0 = top ? 0u : pre[0] >> hi, pa1 = top ? 0u : pre[1] >> hi;
     const unsigned int pb0 = top ? 0u : pre[2] >> hi, pb1 = top ? 0u : pre[3] >> hi;
     const unsigned int my_track = tid & 1u;                 // first pass: the two tracks are two copies
-    auto push = [&](int stream, float x, unsigned int p0, unsigned int p1) {
-        const unsigned int key = f32_key(x);
-        const unsigned int d = (key >> shift) & dmask;
-        if (top) {
-            atomicAdd(&s_h[(stream * 2 + my_track) * SELQ_BINS + d], 1u);
-        } else {
-            const unsigned int up = key >> hi;
-            if (up == p0) atomicAdd(&s_h[(stream * 2 + 0) * SELQ_BINS + d], 1u);
-            if (up == p1) atomicAdd(&s_h[(stream * 2 + 1) * SELQ_BINS + d], 1u);
+    const long long nquads = npix >> 2;
+    const unsigned int sign_bit = 0x80000000u;
+    const unsigned int dummy_idx = SELQ_BINS + (tid & 63u); // a value outside the prefix adds to its lane's dummy word
+
+    // The loop is compiled three times and chosen by ONE uniform branch (the conditions never change inside a
+    // block): MODE 0 first pass (every value counts, track = lane parity), MODE 1 both streams' two ranks still
+    // share their prefix (counted once, under track 0), MODE 2 general.  No divergence in any of them: with
+    // q = key >> shift, a value lies under the prefix exactly when d = q - (prefix >> shift with the digit cleared)
+    // is below 2^bits (unsigned), and d is then its digit -- so the histogram index is min(d, dummy) and every value
+    // adds somewhere (a 10-bit pass may also touch bins 1024..2047 of its row: nobody reads them).  Per value: 3
+    // simple ops for the key, shift, subtract, min, address.
+    auto run = [&](auto mode_tag) {
+        constexpr int MODE = decltype(mode_tag)::value;
+        const unsigned int base_a0 = (pa0 << P.bits), base_a1 = (pa1 << P.bits), base_b0 = (pb0 << P.bits), base_b1 = (pb1 << P.bits);
+        auto push_n = [&](int stream, const float *x, int nval, unsigned int b0, unsigned int b1) {
+            for (int j = 0; j < nval; ++j) {
+                const unsigned int bits_j = __builtin_bit_cast(unsigned int, x[j]);
+                unsigned int key;
+                // order-preserving key: x >= 0 -> bits | 2^31, x < 0 -> ~bits
+                asm("v_ashrrev_i32 %0, 31, %1\n\tv_or_b32 %0, %2, %0\n\tv_xor_b32 %0, %0, %1" : "=&v"(key) : "v"(bits_j), "v"(sign_bit));
+                const unsigned int q = key >> shift;
+                if (MODE == 0) {
+                    atomicAdd(&s_h[(stream * 2 + my_track) * SELQ_ROW + q], 1u);
+                } else {
+                    const unsigned int d0 = q - b0;
+                    atomicAdd(&s_h[(stream * 2 + 0) * SELQ_ROW + (d0 < dummy_idx ? d0 : dummy_idx)], 1u);
+                    if (MODE == 2) {
+                        const unsigned int d1 = q - b1;
+                        atomicAdd(&s_h[(stream * 2 + 1) * SELQ_ROW + (d1 < dummy_idx ? d1 : dummy_idx)], 1u);
+                    }
+                }
+            }
+        };
+        for_each_quad_ring<1024>(base, nquads, [&](long long, unsigned int w0, unsigned int w1, unsigned int w2) {
+            const unsigned int wr[4] = {w0, w0, w1, w2}, wg[4] = {w0, w1, w1, w2}, wn[4] = {w0, w1, w2, w2};
+            constexpr int br[4] = {0, 3, 2, 1}, bg[4] = {1, 0, 3, 2}, bn[4] = {2, 1, 0, 3};
+            float fn[4], fr[4], fg[4], qv[4], qg[4];
+#pragma unroll
+            for (int px = 0; px < 4; ++px) {
+                fn[px] = sample<WB>(wn[px], bn[px], 2, lane_off4, s_tab);
+                fr[px] = sample<WB>(wr[px], br[px], 0, lane_off4, s_tab);
+                fg[px] = sample<WB>(wg[px], bg[px], 1, lane_off4, s_tab);
+            }
+#pragma unroll
+            for (int h = 0; h < 2; ++h) {
+                const f32x2 N = {fn[2 * h], fn[2 * h + 1]}, R = {fr[2 * h], fr[2 * h + 1]}, G = {fg[2 * h], fg[2 * h + 1]};
+                const f32x2 Ne = N + (f32x2){LARS_DEN_EPS, LARS_DEN_EPS};
+                const f32x2 v = exact_quot2(N - R, Ne + R), g = exact_quot2(N - G, Ne + G);
+                qv[2 * h] = v.x; qv[2 * h + 1] = v.y; qg[2 * h] = g.x; qg[2 * h + 1] = g.y;
+            }
+            push_n(0, qv, 4, base_a0, base_a1);
+            push_n(1, qg, 4, base_b0, base_b1);
+        });
+        if (blockIdx.x == 0 && tid < (int)(npix & 3)) {
+            const long long i = nquads * 4 + tid;
+            unsigned int r = base[i * 3], g = base[i * 3 + 1], n = base[i * 3 + 2];
+            if (WB) {
+                const unsigned int *tab = reinterpret_cast<const unsigned int *>(s_tab);
+                r = tab[r * 64] & 0xFFu; g = (tab[g * 64] >> 8) & 0xFFu; n = (tab[n * 64] >> 16) & 0xFFu;
+            }
+            const float tv = norm_diff_fast((float)n, (float)r), tg = norm_diff_fast((float)n, (float)g);
+            push_n(0, &tv, 1, base_a0, base_a1);
+            push_n(1, &tg, 1, base_b0, base_b1);
         }
     };
-    const long long nquads = npix >> 2;
-    const long long stride = (long long)gridDim.x * 1024;
-    for (long long q = (long long)blockIdx.x * 1024 + tid; q < nquads; q += stride) {
-        const unsigned int *p = reinterpret_cast<const unsigned int *>(base) + q * 3;
-        const unsigned int w0 = p[0], w1 = p[1], w2 = p[2];
-        const unsigned int wr[4] = {w0, w0, w1, w2}, wg[4] = {w0, w1, w1, w2}, wn[4] = {w0, w1, w2, w2};
-        constexpr int br[4] = {0, 3, 2, 1}, bg[4] = {1, 0, 3, 2}, bn[4] = {2, 1, 0, 3};
-        float fn[4], fr[4], fg[4];
-#pragma unroll
-        for (int px = 0; px < 4; ++px) {
-            fn[px] = sample<WB>(wn[px], bn[px], 2, lane_off4, s_tab);
-            fr[px] = sample<WB>(wr[px], br[px], 0, lane_off4, s_tab);
-            fg[px] = sample<WB>(wg[px], bg[px], 1, lane_off4, s_tab);
-        }
-#pragma unroll
-        for (int h = 0; h < 2; ++h) {
-            const f32x2 N = {fn[2 * h], fn[2 * h + 1]}, R = {fr[2 * h], fr[2 * h + 1]}, G = {fg[2 * h], fg[2 * h + 1]};
-            const f32x2 Ne = N + (f32x2){LARS_DEN_EPS, LARS_DEN_EPS};
-            const f32x2 v = exact_quot2(N - R, Ne + R), g = exact_quot2(N - G, Ne + G);
-            push(0, v.x, pa0, pa1); push(0, v.y, pa0, pa1);
-            push(1, g.x, pb0, pb1); push(1, g.y, pb0, pb1);
-        }
-    }
-    if (blockIdx.x == 0 && tid < (int)(npix & 3)) {
-        const long long i = nquads * 4 + tid;
-        unsigned int r = base[i * 3], g = base[i * 3 + 1], n = base[i * 3 + 2];
-        if (WB) {
-            const unsigned int *tab = reinterpret_cast<const unsigned int *>(s_tab);
-            r = tab[r * 64] & 0xFFu; g = (tab[g * 64] >> 8) & 0xFFu; n = (tab[n * 64] >> 16) & 0xFFu;
-        }
-        push(0, norm_diff_fast((float)n, (float)r), pa0, pa1);
-        push(1, norm_diff_fast((float)n, (float)g), pb0, pb1);
-    }
+    if (top) run(std::integral_constant<int, 0>{});
+    else if (pa0 == pa1 && pb0 == pb1) run(std::integral_constant<int, 1>{});
+    else run(std::integral_constant<int, 2>{});
     __syncthreads();
     if (PER_TILE) {
         unsigned int *h = P.hist32 + tile * (4 * SELQ_BINS);
-        for (int i = tid; i < 4 * SELQ_BINS; i += 1024)
-            if (s_h[i]) atomicAdd(&h[i], s_h[i]);
+        for (int i = tid; i < 4 * SELQ_BINS; i += 1024) {
+            const unsigned int v = s_h[(i >> 11) * SELQ_ROW + (i & (SELQ_BINS - 1))];
+            if (v) atomicAdd(&h[i], v);
+        }
     } else {
-        for (int i = tid; i < 4 * SELQ_BINS; i += 1024)
-            if (s_h[i]) atomicAdd(&P.hist[i], (unsigned long long)s_h[i]);
+        for (int i = tid; i < 4 * SELQ_BINS; i += 1024) {
+            const unsigned int v = s_h[(i >> 11) * SELQ_ROW + (i & (SELQ_BINS - 1))];
+            if (v) atomicAdd(&P.hist[i], (unsigned long long)v);
+        }
     }
 }
 
@@ -797,7 +862,10 @@ __global__ __launch_bounds__(256) void k_selq_pick(SelQTile *state, unsigned int
     const long long tile = blockIdx.x;
     unsigned int *h = hist32 + tile * (4 * SELQ_BINS);
     const int combo = threadIdx.x >> 6, lane = threadIdx.x & 63;
-    const unsigned int *mine = h + combo * SELQ_BINS;
+    // the pass counted a shared prefix once, under track 0 (decided before this kernel changes any prefix)
+    const bool shared = !first && state[tile].prefix[combo & 2] == state[tile].prefix[combo | 1];
+    __syncthreads();
+    const unsigned int *mine = h + (shared ? (combo & 2) : combo) * SELQ_BINS;
     const unsigned int *twin = h + (combo ^ 1) * SELQ_BINS;        // first pass: the two tracks are two copies
     unsigned int c[32], local = 0;
 #pragma unroll

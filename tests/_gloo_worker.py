@@ -68,6 +68,8 @@ def digit_pass_on_planes(planes):
             for t in range(2):
                 if hi >= 32:
                     sel = (np.arange(k.size) & 1) == t
+                elif t == 1 and prefix[s * 2] == prefix[s * 2 + 1]:
+                    continue                                 # shared prefix: counted once, under track 0 (as the kernel does)
                 else:
                     sel = (k >> np.uint32(hi)) == (np.uint32(prefix[s * 2 + t]) >> np.uint32(hi))
                 out[s, t] = np.bincount(d[sel], minlength=batch.SELECT_BINS)[:batch.SELECT_BINS]

@@ -1,0 +1,56 @@
+#!/usr/bin/env python3
+"""profiles/<round>_* from what tools/profile_round.sh left under gpurun_out/prof_<round>/ (run in the container)."""
+import glob
+import json
+import os
+import re
+import shutil
+import subprocess
+import sys
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def read(rnd, counter):
+    out, name = {}, None
+    for line in open(f"{ROOT}/profiles/{rnd}_pmc_{counter}.txt"):
+        if not line.startswith(" "):
+            name = line.split(" grid=")[0].strip()
+        else:
+            m = re.search(r"mean=\s*([\d.]+)", line)
+            if m:
+                out[name] = float(m.group(1))
+    return out
+
+
+def main():
+    rnd = sys.argv[1] if len(sys.argv) > 1 else "r01"
+    src = f"{ROOT}/gpurun_out/prof_{rnd}"
+    for c in ("FETCH_SIZE", "WRITE_SIZE"):
+        with open(f"{ROOT}/profiles/{rnd}_pmc_{c}.txt", "w") as fh:
+            subprocess.run([sys.executable, f"{ROOT}/tools/pmc_summary.py", f"{src}/pmc_{c}", "k_"], stdout=fh, check=True)
+    stats = sorted(glob.glob(f"{src}/trace/**/*kernel_stats.csv", recursive=True))[0]
+    shutil.copy(stats, f"{ROOT}/profiles/{rnd}_bench_kernel_stats.csv")
+    shutil.copy(f"{src}/bench_under_rocprof.json", f"{ROOT}/profiles/{rnd}_bench_under_rocprof.json")
+    f, w = read(rnd, "FETCH_SIZE"), read(rnd, "WRITE_SIZE")
+    px64, px256 = 64 * 4096 * 4096, 256 * 4096 * 4096
+    rows = {
+        "wb3idx_out_stats": ("k_fused_u8c3<unsigned char, 7u, true, 1>", px64),
+        "wb3idx_out_stats_hist": ("k_fused_u8c3<unsigned char, 7u, true, 2>", px64),
+        "wb_ndvi_out_stats": ("k_fused_u8c3<unsigned char, 1u, true, 1>", px64),
+        "wb3idx_stats_only": ("k_fused_v2<7u, true, 1, false, false>", px256),
+        "wb_ndvi_stats_only": ("k_fused_v2<1u, true, 1, false, false>", px256),
+        "channel_hist": ("k_chan_hist_u8c3_v2", px256),
+    }
+    t = {"_comment": "HBM bytes per pixel from rocprofv3 PMC (separate --pmc FETCH_SIZE / --pmc WRITE_SIZE passes): "
+                     "(2*FETCH_SIZE + WRITE_SIZE)*1024 / pixels per launch; FETCH_SIZE doubled as MI355X_MICROARCH.md "
+                     "(HBM) prescribes for wide coalesced streaming reads on gfx950."}
+    for mode, (kernel, px) in rows.items():
+        if kernel in f and kernel in w:
+            t[mode] = {"bytes_per_pixel": (2 * f[kernel] + w[kernel]) * 1024 / px, "kernel": kernel}
+    json.dump(t, open(f"{ROOT}/profiles/traffic.json", "w"), indent=1)
+    print({k: round(v["bytes_per_pixel"], 4) for k, v in t.items() if k != "_comment"})
+
+
+if __name__ == "__main__":
+    main()

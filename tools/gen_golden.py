@@ -15,7 +15,6 @@ them, plus the library versions they were produced under.
 from __future__ import annotations
 
 import argparse
-import io
 import json
 import os
 import sys

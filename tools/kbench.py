@@ -8,7 +8,6 @@ from __future__ import annotations
 
 import argparse
 import ctypes as C
-import itertools
 import json
 import os
 import sys

@@ -117,6 +117,7 @@ int         lars_memcpy_d2d(void *dst_dev, const void *src_dev, size_t bytes, vo
 int         lars_stream_create(void **stream);
 int         lars_stream_destroy(void *stream);
 int         lars_synchronize(void *stream);         /* NULL = calling thread's library stream */
+int         lars_mem_info(size_t *free_bytes, size_t *total_bytes);   /* hipMemGetInfo of the bound device */
 int         lars_shutdown(void);                    /* frees the calling thread's workspace */
 /* HIP events on a given stream (bench.py times kernels with these) */
 int         lars_event_create(void **event);

@@ -83,6 +83,7 @@ SIGNATURES = {
     "lars_stream_destroy": (_I, [_P]),
     "lars_synchronize": (_I, [_P]),
     "lars_shutdown": (_I, []),
+    "lars_mem_info": (_I, [C.POINTER(_SZ), C.POINTER(_SZ)]),
     "lars_event_create": (_I, [C.POINTER(_P)]),
     "lars_event_destroy": (_I, [_P]),
     "lars_event_record": (_I, [_P, _P]),

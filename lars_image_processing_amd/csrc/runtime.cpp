@@ -13,6 +13,24 @@ namespace lars {
 static thread_local std::string g_last_error;
 static thread_local ThreadCtx g_ctx;
 
+// A thread that used the library gives its stream, workspaces and FFT plan back when it ends (Streamlit sessions
+// are threads that come and go).  Thread-local destructors of the main thread run before any atexit handler, so
+// the HIP runtime is still alive then.
+static void release_ctx(ThreadCtx *c)
+{
+    if (c->device < 0) return;
+    if (hipSetDevice(c->device) != hipSuccess) { c->device = -1; return; }
+    align_release();
+    if (c->stream) { hipStreamSynchronize(c->stream); hipStreamDestroy(c->stream); c->stream = nullptr; }
+    if (c->ws) { hipFree(c->ws); c->ws = nullptr; c->ws_bytes = 0; }
+    if (c->scratch) { hipFree(c->scratch); c->scratch = nullptr; c->scratch_bytes = 0; }
+    c->device = -1;
+}
+struct CtxGuard {
+    ~CtxGuard() { release_ctx(&g_ctx); }
+};
+static thread_local CtxGuard g_ctx_guard;
+
 void set_error(const char *fmt, ...)
 {
     char buf[1024];
@@ -53,6 +71,7 @@ static int bind_device(ThreadCtx *c, int ordinal)
     if (c->scratch) { hipFree(c->scratch); c->scratch = nullptr; c->scratch_bytes = 0; }
     LARS_HIP_TRY(hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking));
     c->device = ordinal;
+    (void)&g_ctx_guard;                                   // odr-use: constructs this thread's guard
     return LARS_OK;
 }
 
@@ -206,14 +225,18 @@ int lars_synchronize(void *stream)
 }
 int lars_shutdown(void)
 {
-    ThreadCtx *c = &g_ctx;
-    if (c->device < 0) return LARS_OK;
-    hipSetDevice(c->device);
-    align_release();
-    if (c->stream) { hipStreamSynchronize(c->stream); hipStreamDestroy(c->stream); c->stream = nullptr; }
-    if (c->ws) { hipFree(c->ws); c->ws = nullptr; c->ws_bytes = 0; }
-    if (c->scratch) { hipFree(c->scratch); c->scratch = nullptr; c->scratch_bytes = 0; }
-    c->device = -1;
+    release_ctx(&g_ctx);
+    return LARS_OK;
+}
+
+int lars_mem_info(size_t *free_bytes, size_t *total_bytes)
+{
+    ThreadCtx *c;
+    LARS_TRY(ensure_ctx(&c));
+    size_t f = 0, t = 0;
+    LARS_HIP_TRY(hipMemGetInfo(&f, &t));
+    if (free_bytes) *free_bytes = f;
+    if (total_bytes) *total_bytes = t;
     return LARS_OK;
 }
 

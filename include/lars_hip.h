@@ -205,16 +205,16 @@ int lars_d_median_pair_batch_f32(const float *x, int64_t n, int64_t items, int64
 
 /* One radix-select pass over the index values of a batch WITHOUT the planes in memory (exact batch /
  * global medians): the NDVI and GNDVI quotients of every pixel are recomputed from the
- * uint8 tiles and the digit [shift, shift + bits) of their order-preserving keys (x >= 0: bits | 2^31,
- * x < 0: ~bits) is counted for the values whose key matches prefix[stream * 2 + track] above the digit
- * (shift + bits == 32: all values; then track = lane parity, add the two tracks; later passes count a prefix
- * shared by both tracks of a stream once, under track 0).  hist is
+ * uint8 tiles.  first != 0: each value is counted in one of 2048 linear buckets of [-1, 1]
+ * (bucket = low 23 bits of float32(fma(x, 1023.5, 1023.5) + 2^23); track = lane parity, add the two
+ * tracks).  Otherwise, per stream s and track t, the value's order-preserving key (x >= 0: bits | 2^31,
+ * x < 0: ~bits) is counted in bin (key - bias[2s+t]) >> shift[2s+t] when that is below 2048; a
+ * (bias, shift) shared by both tracks of a stream is counted once, under track 0.  hist is
  * uint64[2 streams][2 tracks][2048], accumulated with atomics (zero it first).  NDWI = -GNDVI shares
  * GNDVI's order statistics. */
 int lars_d_quotient_digit_hist(const void *tiles, int64_t ntiles, int64_t npix, int channels, int dtype,
-                               const uint8_t *wb_table, int shift, int bits, const uint32_t prefix[4],
+                               const uint8_t *wb_table, int first, const uint32_t bias[4], const uint32_t shift[4],
                                uint64_t *hist, void *stream);
-
 /* np.median of the NDVI and GNDVI planes of EVERY tile without writing a plane: the same three passes with
  * per-tile histograms and the digit picks on the device (no host round trip).  out_pairs is float[ntiles][2
  * streams: NDVI, GNDVI][2]: the two middle order statistics (median = their float32 mean; NDWI's median is

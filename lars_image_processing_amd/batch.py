@@ -225,7 +225,7 @@ class TileBatch:
         return med
 
     # -- exact medians of the whole batch (all tiles, all ranks) ------------
-    def digit_histogram(self, shift, bits, prefix, white_balance=True, stream=None):
+    def digit_histogram(self, first, bias, shift, white_balance=True, stream=None):
         """One radix-select pass (``lars_d_quotient_digit_hist``): uint64[2 streams][2 tracks][2048]."""
         if self.code != _ffi.U8 or self.channels != 3:
             raise TypeError("exact batch medians need uint8 tiles with 3 channels")
@@ -234,22 +234,24 @@ class TileBatch:
         if getattr(self, "_selq", None) is None:
             self._selq = DeviceBuffer(2 * 2 * SELECT_BINS * 8)
         self._selq.zero()
-        pre = np.ascontiguousarray(prefix, dtype=np.uint32).reshape(4)
+        b = np.ascontiguousarray(bias, dtype=np.uint32).reshape(4)
+        sh = np.ascontiguousarray(shift, dtype=np.uint32).reshape(4)
         _ffi.call("lars_d_quotient_digit_hist", C.c_void_p(self.tiles.ptr), self.ntiles, self.npix, self.channels, self.code,
-                  C.c_void_p(self.table.ptr) if white_balance else None, int(shift), int(bits), _ffi.ptr(pre),
+                  C.c_void_p(self.table.ptr) if white_balance else None, int(bool(first)), _ffi.ptr(b), _ffi.ptr(sh),
                   C.c_void_p(self._selq.ptr), stream)
         _ffi.call("lars_synchronize", stream)
         return self._selq.download(np.uint64, (2, 2, SELECT_BINS))
 
     def global_medians(self, indices=INDEX_NAMES, white_balance=True, comm=None, recompute_tables=False):
         """``np.median`` of each index over ALL pixels of ALL tiles of ALL ranks, exactly, without writing a plane:
-        three radix-select passes (11 + 11 + 10 key bits) that recompute the index values from the tiles
-        (3 bytes per pixel and pass) and one small all-reduce per pass."""
+        three radix-select passes (2048 linear buckets, then two 11-bit digits of the key range of the chosen bucket)
+        that recompute the index values from the tiles (3 bytes per pixel and pass) and one small all-reduce per pass
+        (SURVEY.md 8(e))."""
         if white_balance and (recompute_tables or self.table is None):
             self.compute_wb_tables()
         n_local = self.ntiles * self.npix
-        keys = select_order_statistics(lambda shift, bits, prefix: self.digit_histogram(shift, bits, prefix, white_balance),
-                                       n_local, comm)
+        keys = select_order_statistics(lambda first, bias, shift: self.digit_histogram(first, bias, shift, white_balance),
+                                       n_local, comm, min_abs=1.0 / 510.0)
         return medians_from_keys(keys, indices)
 
 
@@ -356,7 +358,7 @@ def timeseries_rows(records, medians, index_type, dates=None):
 # exact order statistics across tiles and ranks (radix select on recomputed values)
 # ---------------------------------------------------------------------------
 SELECT_BINS = 2048
-SELECT_PASSES = ((21, 11), (10, 11), (0, 10))              # (shift, bits) of the order-preserving 32-bit key
+KEY_MINUS1, KEY_PLUS1, KEY_ZERO = 0x407FFFFF, 0xBF800000, 0x80000000     # order-preserving keys of -1.0, +1.0, +0.0
 
 
 def key_to_float32(key):
@@ -366,40 +368,83 @@ def key_to_float32(key):
     return np.array([bits], dtype=np.uint32).view(np.float32)[0]
 
 
-def select_order_statistics(pass_fn, n_local, comm=None):
-    """Keys of the two middle order statistics (ranks (N-1)//2 and N//2) of two value streams.
+def float32_to_key(x):
+    bits = int(np.array([x], dtype=np.float32).view(np.uint32)[0])
+    return (~bits & 0xFFFFFFFF) if bits >> 31 else (bits | 0x80000000)
 
-    ``pass_fn(shift, bits, prefix[4]) -> uint64[2][2][SELECT_BINS]`` counts, on this rank, the digit
-    ``[shift, shift+bits)`` of the keys matching ``prefix[stream*2+track]`` above the digit (first pass: all
-    values, split over the two tracks).  Histograms are summed over ranks through ``comm.allreduce_f64``
-    (counts < 2^53 are exact in float64), every rank then picks the same digits.  Returns uint32[2][2].
+
+def select_bucket(x):
+    """First-level bucket of x in [-1, 1], the kernels' ``selq_bucket``: the low 23 bits of
+    float32(fma(x, 1023.5, 1023.5) + 2^23).  (The float64 product and sum are exact, so one rounding = the fma.)"""
+    t = np.float32(np.float64(np.float32(x)) * 1023.5 + 1023.5)
+    u = np.float32(t + np.float32(8388608.0))
+    return int(np.array([u], dtype=np.float32).view(np.uint32)[0] & 0x7FFFFF)
+
+
+def bucket_lower_key(b):
+    """Smallest key in [key(-1), key(+1) + 1] whose bucket is >= b (the bucket function is monotone in x)."""
+    lo, hi = KEY_MINUS1, KEY_PLUS1 + 1
+    while lo < hi:
+        mid = (lo + hi) // 2
+        if select_bucket(key_to_float32(mid)) >= b:
+            hi = mid
+        else:
+            lo = mid + 1
+    return lo
+
+
+def select_order_statistics(pass_fn, n_local, comm=None, min_abs=0.0, max_passes=6):
+    """Keys of the two middle order statistics (ranks (N-1)//2 and N//2) of two value streams in [-1, 1].
+
+    ``pass_fn(first, bias[4], shift[4]) -> uint64[2][2][SELECT_BINS]`` counts on this rank: first pass, the
+    linear bucket of every value (split over the two tracks); later passes, bin ``(key - bias) >> shift`` of the
+    keys inside the chosen range (a (bias, shift) shared by both tracks of a stream once, under track 0).
+    Histograms are summed over ranks through ``comm.allreduce_f64`` (counts < 2^53 are exact in float64), every
+    rank then picks the same bins.  ``min_abs``: the values are 0 or at least that large in magnitude (uint8
+    quotients: 1/510), which cuts the bucket around zero down to the key of +0.0.  Returns uint32[2][2].
     """
     tot = np.array([float(n_local)])
     n_total = int((comm.allreduce_f64(tot, "sum") if comm is not None else tot)[0])
     ranks = np.array([[(n_total - 1) // 2, n_total // 2]] * 2, dtype=np.int64)     # [stream][track]
-    prefix = np.zeros((2, 2), dtype=np.uint32)
-    for shift, bits in SELECT_PASSES:
-        local = np.asarray(pass_fn(shift, bits, prefix.reshape(4)), dtype=np.uint64).reshape(2, 2, SELECT_BINS)
+    bias = np.zeros((2, 2), dtype=np.uint32)
+    shift = np.zeros((2, 2), dtype=np.uint32)
+    first = True
+    for _ in range(max_passes):
+        local = np.asarray(pass_fn(first, bias.reshape(4), shift.reshape(4)), dtype=np.uint64).reshape(2, 2, SELECT_BINS)
         hist = local.astype(np.float64).reshape(-1)
         if comm is not None:
             hist = comm.allreduce_f64(hist, "sum")
         hist = np.asarray(hist).reshape(2, 2, SELECT_BINS).astype(np.int64)
-        if shift + bits == 32:
-            hist[:, 0] += hist[:, 1]                        # first pass: the two tracks are two copies
+        if first:
+            hist[:, 0] += hist[:, 1]                        # bucket pass: the two tracks are two copies
             hist[:, 1] = hist[:, 0]
         else:
-            for s in range(2):                              # a shared prefix is counted once, under track 0
-                if prefix[s, 0] == prefix[s, 1]:
+            for s in range(2):                              # a shared (bias, shift) is counted once, under track 0
+                if bias[s, 0] == bias[s, 1] and shift[s, 0] == shift[s, 1]:
                     hist[s, 1] = hist[s, 0]
+        last = not first and not shift.any()
         for s in range(2):
             for t in range(2):
-                cum = np.cumsum(hist[s, t][: 1 << bits])
+                cum = np.cumsum(hist[s, t])
                 d = int(np.searchsorted(cum, ranks[s, t], side="right"))
-                if d >= (1 << bits):
+                if d >= SELECT_BINS:
                     raise RuntimeError("radix select: rank beyond the histogram mass (inconsistent passes)")
                 ranks[s, t] -= int(cum[d - 1]) if d else 0
-                prefix[s, t] |= np.uint32(d << shift)
-    return prefix
+                if first:
+                    lo = bucket_lower_key(d)
+                    hi = KEY_PLUS1 + 1 if d >= SELECT_BINS - 1 else bucket_lower_key(d + 1)
+                    if min_abs > 0 and lo <= KEY_ZERO < hi and float32_to_key(-min_abs) < lo and hi <= float32_to_key(min_abs):
+                        lo, hi = KEY_ZERO, KEY_ZERO + 1     # only +0.0 lives there
+                    span = hi - lo - 1
+                    bias[s, t] = lo
+                    shift[s, t] = 0 if span < SELECT_BINS else span.bit_length() - 11
+                else:
+                    bias[s, t] = np.uint32(int(bias[s, t]) + (d << int(shift[s, t])))
+                    shift[s, t] = max(int(shift[s, t]) - 11, 0)
+        if last:
+            return bias
+        first = False
+    raise RuntimeError("radix select did not finish")
 
 
 def medians_from_keys(keys, indices=INDEX_NAMES):

@@ -787,18 +787,19 @@ extern "C" int lars_d_synth_u8(uint8_t *tiles, int64_t ntiles, int64_t first_til
 
 
 extern "C" int lars_d_quotient_digit_hist(const void *tiles, int64_t ntiles, int64_t npix, int channels, int dtype,
-                                          const uint8_t *wb_table, int shift, int bits, const uint32_t prefix[4],
+                                          const uint8_t *wb_table, int first, const uint32_t bias[4], const uint32_t shift[4],
                                           uint64_t *hist, void *stream)
 {
     ThreadCtx *c;
     LARS_TRY(ensure_ctx(&c));
-    if (!tiles || !hist || !prefix || ntiles <= 0 || npix <= 0) return fail(LARS_ERR_INVALID, "lars_d_quotient_digit_hist: bad arguments");
+    if (!tiles || !hist || !bias || !shift || ntiles <= 0 || npix <= 0)
+        return fail(LARS_ERR_INVALID, "lars_d_quotient_digit_hist: bad arguments");
     if (dtype != LARS_U8 || channels != 3 || (reinterpret_cast<uintptr_t>(tiles) & 3) || (ntiles > 1 && (npix & 3)))
         return fail(LARS_ERR_INVALID, "lars_d_quotient_digit_hist: uint8 [ntiles][npix][3] tiles on 4-byte boundaries are required");
-    if (bits < 1 || bits > 11 || shift < 0 || shift + bits > 32)
-        return fail(LARS_ERR_INVALID, "lars_d_quotient_digit_hist: digit [shift, shift + bits) must fit the 32-bit key, bits <= 11");
+    for (int k = 0; k < 4; ++k)
+        if (shift[k] > 31u) return fail(LARS_ERR_INVALID, "lars_d_quotient_digit_hist: shift must be below 32");
     if (ntiles > 65535) return fail(LARS_ERR_INVALID, "lars_d_quotient_digit_hist: at most 65535 tiles per launch");
-    return selq_pass_launch(static_cast<const uint8_t *>(tiles), wb_table, ntiles, npix, shift, bits, prefix,
+    return selq_pass_launch(static_cast<const uint8_t *>(tiles), wb_table, ntiles, npix, first ? 1 : 0, bias, shift,
                             reinterpret_cast<unsigned long long *>(hist), pick_stream(c, stream));
 }
 

@@ -58,21 +58,23 @@ def f32_key(x):
 def digit_pass_on_planes(planes):
     """NumPy stand-in for lars_d_quotient_digit_hist over this rank's index planes [NDVI values, GNDVI values]."""
     keys = [f32_key(p) for p in planes]
+    buckets = [np.array([batch.select_bucket(v) for v in np.unique(p)]) for p in planes]
+    uniq = [np.unique(p, return_inverse=True) for p in planes]
 
-    def pass_fn(shift, bits, prefix):
+    def pass_fn(first, bias, shift):
         out = np.zeros((2, 2, batch.SELECT_BINS), dtype=np.uint64)
-        hi = shift + bits
         for s in range(2):
             k = keys[s]
-            d = (k >> np.uint32(shift)) & np.uint32((1 << bits) - 1)
             for t in range(2):
-                if hi >= 32:
+                if first:
                     sel = (np.arange(k.size) & 1) == t
-                elif t == 1 and prefix[s * 2] == prefix[s * 2 + 1]:
-                    continue                                 # shared prefix: counted once, under track 0 (as the kernel does)
+                    d = buckets[s][uniq[s][1]][sel]
                 else:
-                    sel = (k >> np.uint32(hi)) == (np.uint32(prefix[s * 2 + t]) >> np.uint32(hi))
-                out[s, t] = np.bincount(d[sel], minlength=batch.SELECT_BINS)[:batch.SELECT_BINS]
+                    if t == 1 and bias[s * 2] == bias[s * 2 + 1] and shift[s * 2] == shift[s * 2 + 1]:
+                        continue                             # shared (bias, shift): counted once, under track 0 (as the kernel does)
+                    d = (k - np.uint32(bias[s * 2 + t])) >> np.uint32(shift[s * 2 + t])     # uint32 wrap-around, like the kernel
+                    d = d[d < batch.SELECT_BINS]
+                out[s, t] = np.bincount(d.astype(np.int64), minlength=batch.SELECT_BINS)[:batch.SELECT_BINS]
         return out
     return pass_fn
 
@@ -136,7 +138,7 @@ def main():
         return {name: np.concatenate(v) for name, v in out.items()}
     mine_planes, all_planes = planes_of(range(lo, hi)), planes_of(range(ntiles))
     keys = batch.select_order_statistics(digit_pass_on_planes([mine_planes["NDVI"], mine_planes["GNDVI"]]),
-                                         mine_planes["NDVI"].size, comm)
+                                         mine_planes["NDVI"].size, comm, min_abs=1.0 / 510.0)
     medians = batch.medians_from_keys(keys)
     for name in TYPES:
         assert medians[name] == float(np.median(all_planes[name])), name

@@ -220,6 +220,11 @@ int lars_d_quotient_digit_hist(const void *tiles, int64_t ntiles, int64_t npix, 
  * streams: NDVI, GNDVI][2]: the two middle order statistics (median = their float32 mean; NDWI's median is
  * -GNDVI's).  scratch holds lars_quotient_median_scratch_bytes(ntiles). */
 size_t lars_quotient_median_scratch_bytes(int64_t ntiles);
+/* The statistics of lars_d_fused (a->stats, LARS_F_HIST honoured; index_mask = one index or all three; no
+ * output planes) AND those medians in one call: the statistics kernel also counts the select's first
+ * pass, so the tiles are read four times instead of five.  Streams the mask does not ask for come back
+ * as NaN pairs. */
+int lars_d_stats_medians(const lars_fused_args *a, float *out_pairs, void *scratch);
 int lars_d_quotient_median_pairs(const void *tiles, int64_t ntiles, int64_t npix, int channels, int dtype,
                                  const uint8_t *wb_table, float *out_pairs, void *scratch, void *stream);
 

@@ -103,6 +103,7 @@ SIGNATURES = {
     "lars_d_median_pair_batch_f32": (_I, [_P, _I64, _I64, _I64, _P, _P, _P]),
     "lars_d_colormap_f32": (_I, [_P, _I64, _P, _P, _P]),
     "lars_quotient_median_scratch_bytes": (_SZ, [_I64]),
+    "lars_d_stats_medians": (_I, [C.POINTER(FusedArgs), _P, _P]),
     "lars_d_quotient_median_pairs": (_I, [_P, _I64, _I64, _I, _I, _P, _P, _P, _P]),
     "lars_d_quotient_digit_hist": (_I, [_P, _I64, _I64, _I, _I, _P, _I, _P, _P, _P, _P]),
     "lars_d_synth_u8": (_I, [_P, _I64, _I64, _I64, _I, _U32, _I, _P]),

@@ -159,9 +159,23 @@ class TileBatch:
         stats = self.new_stats()
         stats.zero()
         if medians and outputs is None and self.code == _ffi.U8 and self.channels == 3 and (self.ntiles == 1 or self.npix % 4 == 0):
-            # nothing to write: statistics in one pass, medians by three recompute-and-select passes (3 B per pixel each)
-            self.run_fused(self.fused_args(indices, white_balance, stats, hist, None, stream))
-            med = self.tile_medians(indices, white_balance, stream)
+            # nothing to write: the statistics kernel also counts the select's bucket pass, two (rarely three) digit
+            # passes follow -- 3 B per pixel each, everything on the device
+            mask = 0
+            for t in indices:
+                mask |= 1 << INDEX_IDS[t]
+            if mask in (1, 2, 4, 7):
+                pairs_dev = DeviceBuffer(self.ntiles * 4 * 4)
+                scratch = DeviceBuffer(int(_ffi.load().lars_quotient_median_scratch_bytes(self.ntiles)))
+                args = self.fused_args(indices, white_balance, stats, hist, None, stream)
+                _ffi.call("lars_d_stats_medians", C.byref(args), C.c_void_p(pairs_dev.ptr), C.c_void_p(scratch.ptr))
+                _ffi.call("lars_synchronize", stream)
+                med = self._medians_from_pairs(pairs_dev.download(np.float32, (self.ntiles, 2, 2)), indices)
+                pairs_dev.free()
+                scratch.free()
+            else:                                           # two of the three indices: separate statistics pass
+                self.run_fused(self.fused_args(indices, white_balance, stats, hist, None, stream))
+                med = self.tile_medians(indices, white_balance, stream)
             rec = stats.download(STATS_DTYPE, (self.ntiles, 3))
             stats.free()
             return rec, med
@@ -217,11 +231,17 @@ class TileBatch:
         pairs = pairs_dev.download(np.float32, (self.ntiles, 2, 2))
         pairs_dev.free()
         scratch.free()
+        return self._medians_from_pairs(pairs, indices)
+
+    def _medians_from_pairs(self, pairs, indices):
+        """float32[ntiles][2 streams][2 middle values] -> float64[ntiles, 3] (np.median semantics; NDWI = -GNDVI)."""
         mid = ((pairs[:, :, 0] + pairs[:, :, 1]) / np.float32(2)).astype(np.float32)          # float32 mean of the middles
         med = np.full((self.ntiles, 3), np.nan, dtype=np.float64)
         for t in indices:
             k = INDEX_IDS[t]
             med[:, k] = mid[:, 0] if t == "NDVI" else (mid[:, 1] if t == "GNDVI" else np.float32(0) - mid[:, 1])
+            if np.isnan(med[:, k]).any():
+                raise RuntimeError("exact median select did not settle (values outside the uint8 quotient domain?)")
         return med
 
     # -- exact medians of the whole batch (all tiles, all ranks) ------------

@@ -127,7 +127,10 @@ int selq_pass_launch(const uint8_t *tiles, const uint8_t *wb_table, long long nt
                      const unsigned int bias[4], const unsigned int shift[4], unsigned long long *hist, hipStream_t s);
 size_t selq_tile_scratch_bytes(long long ntiles);
 int selq_tile_medians_launch(const uint8_t *tiles, const uint8_t *wb_table, long long ntiles, long long npix, float *out_pairs,
-                             void *scratch, hipStream_t s);
+                             void *scratch, hipStream_t s, bool first_pass_done);
+int selq_tile_prepare(void *scratch, long long ntiles, long long npix, hipStream_t s, unsigned int streams);
+unsigned int *selq_tile_hist32(void *scratch, long long ntiles);
+void fused_v2_sel_launch(unsigned mask, bool wb, int stats, dim3 grid, hipStream_t s, const FusedParams &P);
 int quot_check_launch(unsigned int max_den, unsigned long long *mismatches_dev, unsigned int *first_bad_dev, hipStream_t s);
 
 }  // namespace lars

@@ -16,6 +16,7 @@ struct FusedParams {
     lars_stats *stats;
     unsigned int mask;             // runtime copy (generic kernel)
     unsigned int flags;
+    unsigned int *sel_hist;        // [ntiles][2 streams][2 tracks][2048]: bucket pass of the median select, or null
 };
 
 struct Acc {

@@ -10,6 +10,8 @@
 //
 // Built with -ffp-contract=off: every float operation below rounds exactly once,
 // as the NumPy expressions do.
+#include <string.h>
+
 #include "common.h"
 #include "device_common.h"
 
@@ -722,7 +724,7 @@ extern "C" int lars_d_fused(const lars_fused_args *a)
         P.out_rgba[k] = on ? a->out_rgba[k] : nullptr;
         P.cmap_lut[k] = a->cmap_lut[k];
     }
-    P.out_wb = a->out_wb; P.stats = a->stats; P.mask = mask;
+    P.out_wb = a->out_wb; P.stats = a->stats; P.mask = mask; P.sel_hist = nullptr;
     P.flags = (a->flags & 3u) | (tuning().nt_loads ? 0x40000000u : 0u) | (tuning().nt_stores ? 0x20000000u : 0u) |
               (tuning().prefetch ? 0x10000000u : 0u);
 
@@ -816,5 +818,42 @@ extern "C" int lars_d_quotient_median_pairs(const void *tiles, int64_t ntiles, i
         return fail(LARS_ERR_INVALID, "lars_d_quotient_median_pairs: uint8 [ntiles][npix][3] tiles on 4-byte boundaries are required");
     if (ntiles > 65535 || npix >= (1ll << 32)) return fail(LARS_ERR_INVALID, "lars_d_quotient_median_pairs: at most 65535 tiles of < 2^32 pixels");
     return selq_tile_medians_launch(static_cast<const uint8_t *>(tiles), wb_table, ntiles, npix, out_pairs, scratch,
-                                    pick_stream(c, stream));
+                                    pick_stream(c, stream), false);
+}
+
+// Statistics AND the exact median of every tile in four passes over the tiles instead of five: the statistics kernel
+// also counts the select's bucket pass.  Same constraints as lars_d_quotient_median_pairs; no output planes.
+extern "C" int lars_d_stats_medians(const lars_fused_args *a, float *out_pairs, void *scratch)
+{
+    ThreadCtx *c;
+    LARS_TRY(ensure_ctx(&c));
+    if (!a || !a->tiles || !a->stats || !out_pairs || !scratch || a->ntiles <= 0 || a->npix <= 0)
+        return fail(LARS_ERR_INVALID, "lars_d_stats_medians: bad arguments");
+    if (a->dtype != LARS_U8 || a->channels != 3 || (reinterpret_cast<uintptr_t>(a->tiles) & 3) || (a->ntiles > 1 && (a->npix & 3)))
+        return fail(LARS_ERR_INVALID, "lars_d_stats_medians: uint8 [ntiles][npix][3] tiles on 4-byte boundaries are required");
+    const unsigned mask = a->index_mask & LARS_MASK_ALL;
+    if (mask != 1u && mask != 2u && mask != 4u && mask != 7u)
+        return fail(LARS_ERR_INVALID, "lars_d_stats_medians: index_mask must be one index or all three");
+    if (a->out_wb || a->out_index[0] || a->out_index[1] || a->out_index[2] || a->out_rgba[0] || a->out_rgba[1] || a->out_rgba[2])
+        return fail(LARS_ERR_INVALID, "lars_d_stats_medians: no output planes (use lars_d_fused + lars_d_median_pair_batch_f32)");
+    if (a->ntiles > 65535 || a->npix >= (1ll << 32) || (long long)a->npix * 6 >= (1ll << 30))
+        return fail(LARS_ERR_INVALID, "lars_d_stats_medians: at most 65535 tiles of < 2^30 / 6 pixels");
+    hipStream_t s = pick_stream(c, a->stream);
+    const int stats_mode = (a->flags & LARS_F_HIST) ? 2 : 1;
+    const uint8_t *tiles = static_cast<const uint8_t *>(a->tiles);
+
+    FusedParams P;
+    memset(&P, 0, sizeof P);
+    P.tiles = a->tiles; P.npix = a->npix; P.channels = 3; P.wb_table = a->wb_table; P.stats = a->stats; P.mask = mask;
+    P.flags = a->flags & 3u;
+    LARS_TRY(selq_tile_prepare(scratch, a->ntiles, a->npix, s, ((mask & 1u) ? 1u : 0u) | ((mask & 6u) ? 2u : 0u)));
+    P.sel_hist = selq_tile_hist32(scratch, a->ntiles);
+    const long long nrec = a->ntiles * 3;
+    hipLaunchKernelGGL(k_stats_init, dim3((unsigned)((nrec + 255) / 256)), dim3(256), 0, s, a->stats, nrec, mask);
+    dim3 grid(blocks_per_tile(a->npix / 4 + 1, a->ntiles, fused_v2_threads(false)), (unsigned)a->ntiles);
+    fused_v2_sel_launch(mask, a->wb_table != nullptr, stats_mode, grid, s, P);
+    hipLaunchKernelGGL(k_stats_finalize, dim3((unsigned)((nrec + 255) / 256)), dim3(256), 0, s, a->stats, nrec, mask,
+                       (long long)a->npix);
+    LARS_TRY(launch_check("lars_d_stats_medians"));
+    return selq_tile_medians_launch(tiles, a->wb_table, a->ntiles, a->npix, out_pairs, scratch, s, true);
 }

@@ -298,6 +298,21 @@ __device__ inline void push(WaveAcc &a, unsigned int &above, float x, float thr)
     }
 }
 
+// first-level bucket of the exact-median select (see k_selq_pass below): round((x + 1) * 1023.5) in 0..2047,
+// left in the low mantissa bits of t + 2^23
+#define SELQ_BINS 2048
+#define SELQ_MAGIC_BITS 0x4B000000u                      /* float bits of 2^23: "bucket 0" */
+__device__ inline f32x2 selq_pos2(f32x2 x)
+{
+    const f32x2 k = {1023.5f, 1023.5f}, big = {8388608.0f, 8388608.0f};
+    return __builtin_elementwise_fma(x, k, k) + big;
+}
+__device__ inline void selq_add_pos(float pos, unsigned int base)      // base: LDS byte address of the row, less the shifted "bucket 0" bits
+{
+    const unsigned int addr = (__builtin_bit_cast(unsigned int, pos) << 2) + base;
+    asm volatile("ds_add_u32 %0, %1" : : "v"(addr), "v"(1u) : "memory");
+}
+
 // Histogram bin of an index value of a uint8 tile without looking at the edges.  x = (a-b)/(a+b)
 // with bytes a, b, so the exact position T = 25 x + 25 = 50 a / (a + b) is either an integer or at
 // least 1/510 away from one, while t = fma(x, 25, 25.5001) carries an error below 4e-6: adding 2^23
@@ -329,16 +344,23 @@ __device__ inline void hist_add(float x, float sign, unsigned int base)
 // SIMD: 1024 threads per block.  With output planes the kernel needs more registers: 512.
 template <bool OUT> struct V2Block { static constexpr int threads = OUT ? 512 : LARS_V2_STATS_THREADS; };
 
-template <unsigned MASK, bool WB, int STATS, bool OUT, bool NT>
+// SEL: also count every NDVI / GNDVI value in the 2048 linear buckets of the exact-median select (its first pass,
+// fused: P.sel_hist[tile][stream][track 0][bucket]).  With the 64 KiB table that is exactly 80 KiB of LDS (two blocks
+// per CU) because the reduction scratch then reuses the table's space once the loop is over.
+template <unsigned MASK, bool WB, int STATS, bool OUT, bool NT, bool SEL = false>
 __global__ __launch_bounds__(V2Block<OUT>::threads, OUT ? 4 : LARS_V2_STATS_WAVES) void k_fused_v2(FusedParams P)
 {
     constexpr int NTHR = V2Block<OUT>::threads;
     constexpr int NWAVES = NTHR / 64;
-    __shared__ __attribute__((aligned(16))) char s_mem[(WB ? V2_TABLE_BYTES : 0) +
-                                                       (STATS >= 2 ? V2_HIST_WORDS * 4 : 0) + NWAVES * 16 * sizeof(double)];
+    constexpr bool RED_ALIASES_TABLE = WB && SEL;
+    __shared__ __attribute__((aligned(16))) char s_mem[(WB ? V2_TABLE_BYTES : 0) + (STATS >= 2 ? V2_HIST_WORDS * 4 : 0) +
+                                                       (SEL ? 2 * SELQ_BINS * 4 : 0) +
+                                                       (RED_ALIASES_TABLE ? 0 : NWAVES * 16 * sizeof(double))];
     char *s_tab = s_mem;                                                             // 64 KiB when WB
     unsigned int *s_hist = reinterpret_cast<unsigned int *>(s_mem + (WB ? V2_TABLE_BYTES : 0));
-    double *s_red = reinterpret_cast<double *>(s_hist + (STATS >= 2 ? V2_HIST_WORDS : 0));     // [NWAVES][16]
+    unsigned int *s_sel = s_hist + (STATS >= 2 ? V2_HIST_WORDS : 0);                 // [2 streams][SELQ_BINS] when SEL
+    double *s_red = RED_ALIASES_TABLE ? reinterpret_cast<double *>(s_mem)
+                                      : reinterpret_cast<double *>(s_sel + (SEL ? 2 * SELQ_BINS : 0));     // [NWAVES][16]
 
     constexpr bool NEED_R = (MASK & 1u) != 0;
     constexpr bool NEED_G = (MASK & 6u) != 0;
@@ -351,6 +373,8 @@ __global__ __launch_bounds__(V2Block<OUT>::threads, OUT ? 4 : LARS_V2_STATS_WAVE
     const unsigned int hist_lds = STATS >= 2 ? (unsigned int)(unsigned long long)(lds_u32 *)s_hist : 0u;
     const unsigned int hb0 = hist_lds + (((unsigned)tid & (V2_HIST_COPIES - 1)) << 2) - (V2_HIST_MAGIC_BITS << V2_HIST_SHIFT);
     const unsigned int hb1 = hb0 + V2_HIST_ROWS * V2_HIST_COPIES * 4, hb2 = hb1 + V2_HIST_ROWS * V2_HIST_COPIES * 4;
+    const unsigned int sel_lds = SEL ? (unsigned int)(unsigned long long)(lds_u32 *)s_sel : 0u;
+    const unsigned int sb0 = sel_lds - (SELQ_MAGIC_BITS << 2), sb1 = sb0 + SELQ_BINS * 4;     // NDVI row, GNDVI row
     const unsigned int lane_off4 = lane << 2;
     const long long tile = blockIdx.y;
     const long long npix = P.npix;
@@ -368,7 +392,10 @@ __global__ __launch_bounds__(V2Block<OUT>::threads, OUT ? 4 : LARS_V2_STATS_WAVE
     if (STATS >= 2) {
         for (int i = tid; i < V2_HIST_WORDS; i += NTHR) s_hist[i] = 0;
     }
-    if (WB || STATS >= 2) __syncthreads();
+    if (SEL) {
+        for (int i = tid; i < 2 * SELQ_BINS; i += NTHR) s_sel[i] = 0;
+    }
+    if (WB || STATS >= 2 || SEL) __syncthreads();
 
     WaveAcc acc_v, acc_g;                                  // NDVI, GNDVI-quotient (NDWI derives from it)
     acc_v.mn = acc_g.mn = __builtin_inff(); acc_v.mx = acc_g.mx = -__builtin_inff();
@@ -430,6 +457,10 @@ __global__ __launch_bounds__(V2Block<OUT>::threads, OUT ? 4 : LARS_V2_STATS_WAVE
                     const f32x2 p = hist_pos2(x, 1.0f);
                     hist_add_pos(p.x, hb0); hist_add_pos(p.y, hb0);
                 }
+                if (SEL) {
+                    const f32x2 p = selq_pos2(x);
+                    selq_add_pos(p.x, sb0); selq_add_pos(p.y, sb0);
+                }
             }
             if (NEED_G) {
                 const f32x2 G = {fg[2 * h], fg[2 * h + 1]};
@@ -438,6 +469,10 @@ __global__ __launch_bounds__(V2Block<OUT>::threads, OUT ? 4 : LARS_V2_STATS_WAVE
                 if (STATS >= 2 && WANT_GNDVI) {
                     const f32x2 p = hist_pos2(x, 1.0f);
                     hist_add_pos(p.x, hb1); hist_add_pos(p.y, hb1);
+                }
+                if (SEL) {
+                    const f32x2 p = selq_pos2(x);
+                    selq_add_pos(p.x, sb1); selq_add_pos(p.y, sb1);
                 }
                 if (STATS >= 2 && WANT_NDWI) {
                     const f32x2 p = hist_pos2(x, -1.0f);
@@ -552,11 +587,13 @@ __global__ __launch_bounds__(V2Block<OUT>::threads, OUT ? 4 : LARS_V2_STATS_WAVE
             const float x = norm_diff_fast(fn, fr);
             if (STATS >= 1) push<STATS>(acc_v, above_v, x, 0.2f);
             if (STATS >= 2) hist_add(x, 1.0f, hb0);
+            if (SEL) selq_add_pos(__builtin_fmaf(x, 1023.5f, 1023.5f) + 8388608.0f, sb0);
             if (oi0) oi0[i] = x;
             if (oc0) reinterpret_cast<unsigned int *>(oc0)[i] = lut0[cmap_index(x)];
         }
         if (NEED_G) {
             const float x = norm_diff_fast(fn, fg);
+            if (SEL) selq_add_pos(__builtin_fmaf(x, 1023.5f, 1023.5f) + 8388608.0f, sb1);
             if (STATS >= 1) {
                 acc_g.mn = fminf(acc_g.mn, x); acc_g.mx = fmaxf(acc_g.mx, x);
                 const double xd = (double)x;
@@ -585,7 +622,8 @@ __global__ __launch_bounds__(V2Block<OUT>::threads, OUT ? 4 : LARS_V2_STATS_WAVE
     }
 
     // the histogram atomics are inline asm: the compiler does not count them, wait for them by hand
-    if (STATS >= 2) asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    if (STATS >= 2 || SEL) asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    if (RED_ALIASES_TABLE) __syncthreads();               // every wave is done with the table before its space is reused
     if (STATS >= 1) {
         // wave fold (scalar counters are already wave totals; per-lane ones are summed here)
         if (LARS_COUNT_MODE != 0) above_v = wave_sum_u32(above_v);
@@ -670,6 +708,14 @@ __global__ __launch_bounds__(V2Block<OUT>::threads, OUT ? 4 : LARS_V2_STATS_WAVE
                 }
             }
         }
+        if (SEL) {
+            // the barrier of the statistics flush above already ordered every wave's bucket atomics
+            unsigned int *h = P.sel_hist + tile * (4 * SELQ_BINS);
+            for (int i = tid; i < 2 * SELQ_BINS; i += NTHR) {
+                const unsigned int v = s_sel[i];
+                if (v) atomicAdd(&h[(i >> 11) * (2 * SELQ_BINS) + (i & (SELQ_BINS - 1))], v);      // stream row, track 0
+            }
+        }
     }
 }
 
@@ -722,7 +768,6 @@ __device__ inline void for_each_quad_ring(const uint8_t *base, long long nquads,
 // uint8 quotients are 0 or at least 1/510 in magnitude, so a bucket is at most 2^22 keys wide (three passes) once
 // the bucket around zero is cut down to the single key of +0.0.
 // ---------------------------------------------------------------------------
-#define SELQ_BINS 2048
 #define SELQ_ROW (SELQ_BINS + 64)
 #define SELQ_KEY_MINUS1 0x407FFFFFu                        /* f32_key(-1.0f) */
 #define SELQ_KEY_PLUS1 0xBF800000u                         /* f32_key(+1.0f) */
@@ -871,13 +916,14 @@ __global__ __launch_bounds__(1024) void k_selq_pass(SelQParams P)
     }
 }
 
-__global__ void k_selq_init(SelQTile *state, long long ntiles, long long npix)
+__global__ void k_selq_init(SelQTile *state, long long ntiles, long long npix, unsigned int streams)
 {
     const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
     if (i < ntiles) {
         SelQTile t;
         for (int c = 0; c < 4; ++c) { t.bias[c] = 0u; t.shift[c] = 0u; t.rank[c] = (unsigned int)((c & 1) ? npix / 2 : (npix - 1) / 2); }
-        t.done = 0u; t.pad[0] = t.pad[1] = t.pad[2] = 0u;
+        t.done = ((streams & 1u) ? 0u : 0x3u) | ((streams & 2u) ? 0u : 0xCu);      // a stream nobody asked for is settled
+        t.pad[0] = t.pad[1] = t.pad[2] = 0u;
         state[i] = t;
     }
 }
@@ -889,50 +935,54 @@ __global__ __launch_bounds__(256) void k_selq_pick(SelQTile *state, unsigned int
     const long long tile = blockIdx.x;
     unsigned int *h = hist32 + tile * (4 * SELQ_BINS);
     const int combo = threadIdx.x >> 6, lane = threadIdx.x & 63;
-    if (!first && state[tile].done == 0xFu) return;         // the pass did not run for this tile
+    const unsigned int done = state[tile].done;
+    if (!first && done == 0xFu) return;                     // the pass did not run for this tile (uniform per block)
+    const bool active = !((done >> combo) & 1u);            // settled combos (or streams nobody asked for) only help zeroing
     // a later pass counted a (bias, shift) shared by both tracks once, under track 0 (decided before anything changes)
     const bool shared = !first && state[tile].bias[combo & 2] == state[tile].bias[combo | 1] &&
                         state[tile].shift[combo & 2] == state[tile].shift[combo | 1];
     const unsigned int rank = state[tile].rank[combo], bias = state[tile].bias[combo], shift = state[tile].shift[combo];
     __syncthreads();
-    const unsigned int *mine = h + (shared ? (combo & 2) : combo) * SELQ_BINS;
-    const unsigned int *twin = h + (combo ^ 1) * SELQ_BINS;        // bucket pass: the two tracks are two copies
-    unsigned int c[32], local = 0;
-#pragma unroll
-    for (int j = 0; j < 32; ++j) {
-        c[j] = mine[lane * 32 + j] + (first ? twin[lane * 32 + j] : 0u);
-        local += c[j];
-    }
-    unsigned int incl = local;
-    for (int off = 1; off < 64; off <<= 1) {
-        const unsigned int o = __shfl_up(incl, off);
-        if (lane >= off) incl += o;
-    }
-    unsigned int cum = incl - local;
-    if (rank >= cum && rank < incl) {                       // exactly one lane (the bins up to the range's end hold >= rank + 1 values)
-        int d = 0;
+    if (active) {
+        const unsigned int *mine = h + (shared ? (combo & 2) : combo) * SELQ_BINS;
+        const unsigned int *twin = h + (combo ^ 1) * SELQ_BINS;    // bucket pass: the two tracks are two copies
+        unsigned int c[32], local = 0;
 #pragma unroll
         for (int j = 0; j < 32; ++j) {
-            if (rank >= cum + c[j]) { cum += c[j]; d = j + 1; }
-            else break;
+            c[j] = mine[lane * 32 + j] + (first ? twin[lane * 32 + j] : 0u);
+            local += c[j];
         }
-        const unsigned int bin = (unsigned int)(lane * 32 + d);
-        unsigned int nbias, nshift;
-        if (first) {
-            unsigned int lo = selq_lower_key(bin);
-            unsigned int hi = bin >= SELQ_BINS - 1 ? SELQ_KEY_PLUS1 + 1u : selq_lower_key(bin + 1u);
-            if (lo <= SELQ_KEY_ZERO && SELQ_KEY_ZERO < hi) { lo = SELQ_KEY_ZERO; hi = SELQ_KEY_ZERO + 1u; }   // only +0.0 lives there
-            const unsigned int span = hi - lo - 1u;        // largest offset inside the range
-            nshift = span < SELQ_BINS ? 0u : (32u - (unsigned)__builtin_clz(span)) - 11u;
-            nbias = lo;
-        } else {
-            nbias = bias + (bin << shift);
-            nshift = shift > 11u ? shift - 11u : 0u;
+        unsigned int incl = local;
+        for (int off = 1; off < 64; off <<= 1) {
+            const unsigned int o = __shfl_up(incl, off);
+            if (lane >= off) incl += o;
         }
-        state[tile].bias[combo] = nbias;
-        state[tile].shift[combo] = nshift;
-        state[tile].rank[combo] = rank - cum;
-        if (!first && shift == 0u) atomicOr(&state[tile].done, 1u << combo);
+        unsigned int cum = incl - local;
+        if (rank >= cum && rank < incl) {                   // exactly one lane (the bins up to the range's end hold >= rank + 1 values)
+            int d = 0;
+#pragma unroll
+            for (int j = 0; j < 32; ++j) {
+                if (rank >= cum + c[j]) { cum += c[j]; d = j + 1; }
+                else break;
+            }
+            const unsigned int bin = (unsigned int)(lane * 32 + d);
+            unsigned int nbias, nshift;
+            if (first) {
+                unsigned int lo = selq_lower_key(bin);
+                unsigned int hi = bin >= SELQ_BINS - 1 ? SELQ_KEY_PLUS1 + 1u : selq_lower_key(bin + 1u);
+                if (lo <= SELQ_KEY_ZERO && SELQ_KEY_ZERO < hi) { lo = SELQ_KEY_ZERO; hi = SELQ_KEY_ZERO + 1u; }   // only +0.0 lives there
+                const unsigned int span = hi - lo - 1u;    // largest offset inside the range
+                nshift = span < SELQ_BINS ? 0u : (32u - (unsigned)__builtin_clz(span)) - 11u;
+                nbias = lo;
+            } else {
+                nbias = bias + (bin << shift);
+                nshift = shift > 11u ? shift - 11u : 0u;
+            }
+            state[tile].bias[combo] = nbias;
+            state[tile].shift[combo] = nshift;
+            state[tile].rank[combo] = rank - cum;
+            if (!first && shift == 0u) atomicOr(&state[tile].done, 1u << combo);
+        }
     }
     __syncthreads();
     for (int i = threadIdx.x; i < 4 * SELQ_BINS; i += 256) h[i] = 0u;
@@ -974,6 +1024,26 @@ static void v2_launch_wb(bool wb, int stats, bool out, bool nt, dim3 grid, hipSt
 {
     if (wb) v2_launch_stats<MASK, true>(stats, out, nt, grid, s, P);
     else v2_launch_stats<MASK, false>(stats, out, nt, grid, s, P);
+}
+
+template <unsigned MASK>
+static void v2_launch_sel(bool wb, int stats, dim3 grid, hipStream_t s, const FusedParams &P)
+{
+    const dim3 block(V2Block<false>::threads);
+    if (wb && stats >= 2) hipLaunchKernelGGL((k_fused_v2<MASK, true, 2, false, false, true>), grid, block, 0, s, P);
+    else if (wb) hipLaunchKernelGGL((k_fused_v2<MASK, true, 1, false, false, true>), grid, block, 0, s, P);
+    else if (stats >= 2) hipLaunchKernelGGL((k_fused_v2<MASK, false, 2, false, false, true>), grid, block, 0, s, P);
+    else hipLaunchKernelGGL((k_fused_v2<MASK, false, 1, false, false, true>), grid, block, 0, s, P);
+}
+// statistics + the select's bucket pass in one kernel (mask 1, 2, 4 or 7; no output planes)
+void fused_v2_sel_launch(unsigned mask, bool wb, int stats, dim3 grid, hipStream_t s, const FusedParams &P)
+{
+    switch (mask) {
+    case 1u: v2_launch_sel<1u>(wb, stats, grid, s, P); break;
+    case 2u: v2_launch_sel<2u>(wb, stats, grid, s, P); break;
+    case 4u: v2_launch_sel<4u>(wb, stats, grid, s, P); break;
+    default: v2_launch_sel<7u>(wb, stats, grid, s, P); break;
+    }
 }
 
 int fused_v2_threads(bool any_out) { return any_out ? V2Block<true>::threads : V2Block<false>::threads; }
@@ -1020,15 +1090,35 @@ size_t selq_tile_scratch_bytes(long long ntiles)
 }
 
 // medians of every tile: bucket pass + two digit passes, picks on the device, no host round trip
-int selq_tile_medians_launch(const uint8_t *tiles, const uint8_t *wb_table, long long ntiles, long long npix, float *out_pairs,
-                             void *scratch, hipStream_t s)
+// selq_tile_prepare: state + zeroed histograms (before a fused statistics + bucket pass); selq_tile_hist32: where that
+// pass adds its counts; selq_tile_medians_launch(..., first_pass_done): the remaining passes.
+static void selq_scratch_layout(void *scratch, long long ntiles, SelQTile **state, unsigned int **hist32)
 {
-    SelQTile *state = static_cast<SelQTile *>(scratch);
-    char *after = static_cast<char *>(scratch) + (((size_t)ntiles * sizeof(SelQTile) + 255) & ~(size_t)255);
-    unsigned int *hist32 = reinterpret_cast<unsigned int *>(after);
-    hipLaunchKernelGGL(k_selq_init, dim3((unsigned)((ntiles + 255) / 256)), dim3(256), 0, s, state, ntiles, npix);
-    if (hipMemsetAsync(after, 0, (size_t)ntiles * 4 * SELQ_BINS * sizeof(unsigned int), s) != hipSuccess)
+    *state = static_cast<SelQTile *>(scratch);
+    *hist32 = reinterpret_cast<unsigned int *>(static_cast<char *>(scratch) + (((size_t)ntiles * sizeof(SelQTile) + 255) & ~(size_t)255));
+}
+unsigned int *selq_tile_hist32(void *scratch, long long ntiles)
+{
+    SelQTile *state; unsigned int *hist32;
+    selq_scratch_layout(scratch, ntiles, &state, &hist32);
+    return hist32;
+}
+int selq_tile_prepare(void *scratch, long long ntiles, long long npix, hipStream_t s, unsigned int streams)
+{
+    SelQTile *state; unsigned int *hist32;
+    selq_scratch_layout(scratch, ntiles, &state, &hist32);
+    hipLaunchKernelGGL(k_selq_init, dim3((unsigned)((ntiles + 255) / 256)), dim3(256), 0, s, state, ntiles, npix, streams);
+    if (hipMemsetAsync(hist32, 0, (size_t)ntiles * 4 * SELQ_BINS * sizeof(unsigned int), s) != hipSuccess)
         return fail(LARS_ERR_HIP, "hipMemsetAsync failed (tile median scratch)");
+    return launch_check("selq_tile_prepare");
+}
+
+int selq_tile_medians_launch(const uint8_t *tiles, const uint8_t *wb_table, long long ntiles, long long npix, float *out_pairs,
+                             void *scratch, hipStream_t s, bool first_pass_done)
+{
+    SelQTile *state; unsigned int *hist32;
+    selq_scratch_layout(scratch, ntiles, &state, &hist32);
+    if (!first_pass_done) LARS_TRY(selq_tile_prepare(scratch, ntiles, npix, s, 3u));
     long long bpt = (2048 + ntiles - 1) / ntiles;
     const long long cap = (npix / 4 + 1024 * 8 - 1) / (1024 * 8);
     if (bpt > cap) bpt = cap;
@@ -1041,7 +1131,8 @@ int selq_tile_medians_launch(const uint8_t *tiles, const uint8_t *wb_table, long
         memset(&P, 0, sizeof P);
         P.tiles = tiles; P.wb_table = wb_table; P.npix = npix; P.first = p == 0;
         P.state = state; P.hist32 = hist32;
-        if (wb_table) hipLaunchKernelGGL((k_selq_pass<true, true>), grid, dim3(1024), 0, s, P);
+        if (p == 0 && first_pass_done) { /* counted by the statistics kernel */ }
+        else if (wb_table) hipLaunchKernelGGL((k_selq_pass<true, true>), grid, dim3(1024), 0, s, P);
         else hipLaunchKernelGGL((k_selq_pass<false, true>), grid, dim3(1024), 0, s, P);
         hipLaunchKernelGGL(k_selq_pick, dim3((unsigned)ntiles), dim3(256), 0, s, state, hist32, p == 0 ? 1 : 0);
     }

@@ -332,6 +332,20 @@ def test_batch_medians_are_numpy_medians(lars):
         for k, t in enumerate(TYPES):
             assert med_b[i, k] == float(np.median(orc.index_app(wb, t))), (i, t)
     big.free()
+    # one index, two indices (separate statistics pass), and the 50-bin histograms next to the medians
+    rec1, med1 = b.process(indices=("NDVI",), medians=True)
+    np.testing.assert_array_equal(med1[:, 0], med[:, 0])
+    assert np.isnan(med1[:, 1:]).all() and rec1[3, 0]["sum"] == rec[3, 0]["sum"]
+    rec5, med5 = b.process(indices=("NDVI", "NDWI"), medians=True)
+    np.testing.assert_array_equal(med5[:, [0, 2]], med[:, [0, 2]])
+    assert np.isnan(med5[:, 1]).all()
+    rech, medh = b.process(medians=True, hist=True)
+    np.testing.assert_array_equal(medh, med)
+    with warnings.catch_warnings():
+        warnings.simplefilter("ignore")
+        wb7 = orc.wb_app(tiles[7])
+    for k, t in enumerate(TYPES):
+        np.testing.assert_array_equal(rech[7, k]["hist"], orc.hist50(orc.index_app(wb7, t)))
     rec2, med2 = b.process(indices=("NDWI",), medians=True, white_balance=False)
     assert np.isnan(med2[:, 0]).all() and med2[3, 2] == float(np.median(orc.index_app(tiles[3], "NDWI")))
     odd = lars.TileBatch.synthetic(2, 5, 7, seed=1)                                # odd sample count: single middle element

@@ -41,6 +41,9 @@ MODES = {
     "wb_ndvi_out_stats": (("NDVI",), True, False, 3 + 4),
     "wb3idx_stats_only": (("NDVI", "GNDVI", "NDWI"), False, False, 3),
     "wb_ndvi_stats_only": (("NDVI",), False, False, 3),
+    # statistics + the exact median of every tile (the reference's analyze_index / time-series table): the statistics
+    # kernel counts the select's bucket pass, two or three digit passes follow; 3 B/pixel per pass
+    "wb3idx_stats_medians": (("NDVI", "GNDVI", "NDWI"), False, False, 3),
 }
 
 
@@ -100,7 +103,14 @@ class Runner:
         b.compute_wb_tables()
         ffi.call("lars_event_record", self.ev[1], None)
         launches = 0
-        if outs is None or outs.slots >= b.ntiles:
+        if mode == "wb3idx_stats_medians":
+            if getattr(self, "_med_bufs", None) is None:
+                self._med_bufs = (ffi.DeviceBuffer(b.ntiles * 4 * 4),
+                                  ffi.DeviceBuffer(int(ffi.load().lars_quotient_median_scratch_bytes(b.ntiles))))
+            args = b.fused_args(indices, True, self.stats, hist, None)
+            ffi.call("lars_d_stats_medians", C.byref(args), C.c_void_p(self._med_bufs[0].ptr), C.c_void_p(self._med_bufs[1].ptr))
+            launches = 1
+        elif outs is None or outs.slots >= b.ntiles:
             b.run_fused(b.fused_args(indices, True, self.stats, hist, outs))
             launches = 1
         else:

@@ -44,8 +44,19 @@ struct ImageJob {
 struct Layout {
     uint8_t *img; uint32_t *hist; uint8_t *table; double *pcts; uint8_t *wb;
     float *idx[3]; lars_stats *stats; float *med; char *sel; uint8_t *rgba[3]; uint8_t *cmap[3];
+    float *pairs; char *selq;      // statistics + medians without planes (lars_d_stats_medians)
     size_t total;
 };
+
+// medians wanted, no plane wanted, uint8 RGNir, one index or all three: the planes never exist on the device either
+bool recompute_route(const ImageJob &j)
+{
+    if (!j.want_median || !j.medians || !j.want_stats || j.dtype != LARS_U8 || j.channels != 3) return false;
+    if (j.mask != 1u && j.mask != 2u && j.mask != 4u && j.mask != 7u) return false;
+    for (int k = 0; k < 3; ++k)
+        if (j.out_index[k] || j.out_rgba[k]) return false;
+    return (long long)j.h * j.w * 6 < (1ll << 30);
+}
 
 Layout plan(const ImageJob &j, void *base)
 {
@@ -60,15 +71,18 @@ Layout plan(const ImageJob &j, void *base)
     L.table = j.apply_wb ? c.take<uint8_t>(lars_wb_table_bytes(j.dtype)) : nullptr;
     L.pcts = j.apply_wb ? c.take<double>(6) : nullptr;
     L.wb = (j.apply_wb && j.out_wb) ? c.take<uint8_t>(npix * j.channels) : nullptr;
+    const bool recompute = recompute_route(j);
     for (int k = 0; k < 3; ++k) {
         const bool on = (j.mask >> k) & 1u;
-        L.idx[k] = (on && (j.out_index[k] || j.want_median)) ? c.take<float>(npix) : nullptr;
+        L.idx[k] = (on && !recompute && (j.out_index[k] || j.want_median)) ? c.take<float>(npix) : nullptr;
         L.rgba[k] = (on && j.out_rgba[k]) ? c.take<uint8_t>(npix * 4) : nullptr;
         L.cmap[k] = (on && j.out_rgba[k]) ? c.take<uint8_t>(1024) : nullptr;
     }
     L.stats = c.take<lars_stats>(3);
     L.med = c.take<float>(6);
     L.sel = c.take<char>(3 * ((lars_select_scratch_bytes() + 255) & ~(size_t)255));
+    L.pairs = recompute ? c.take<float>(4) : nullptr;
+    L.selq = recompute ? c.take<char>(lars_quotient_median_scratch_bytes(1)) : nullptr;
     L.total = c.off + 256;
     return L;
 }
@@ -109,11 +123,21 @@ int run_image(const ImageJob &j)
         a.out_wb = L.wb;
         a.stats = stats ? L.stats : nullptr;
         a.stream = s;
-        LARS_TRY(lars_d_fused(&a));
+        if (L.pairs) {
+            if (L.wb) {                                     // the white-balanced image on its own, then statistics + medians
+                lars_fused_args w = a;
+                w.index_mask = 0; w.flags = 0; w.stats = nullptr;
+                LARS_TRY(lars_d_fused(&w));
+                a.out_wb = nullptr;
+            }
+            LARS_TRY(lars_d_stats_medians(&a, L.pairs, L.selq));
+        } else {
+            LARS_TRY(lars_d_fused(&a));
+        }
     }
     const size_t selsz = (lars_select_scratch_bytes() + 255) & ~(size_t)255;
     for (int k = 0; k < 3; ++k) {
-        if (!((j.mask >> k) & 1u)) continue;
+        if (!((j.mask >> k) & 1u) || L.pairs) continue;
         if (j.want_median && j.medians)
             LARS_TRY(lars_d_median_pair_f32(L.idx[k], (int64_t)npix, L.med + 2 * k, L.sel + k * selsz, s));
     }
@@ -128,9 +152,19 @@ int run_image(const ImageJob &j)
     float hmed[6];
     double hp[6];
     if (stats) LARS_HIP_TRY(hipMemcpyAsync(hstats, L.stats, sizeof hstats, hipMemcpyDeviceToHost, s));
-    if (j.want_median && j.medians && j.mask) LARS_HIP_TRY(hipMemcpyAsync(hmed, L.med, sizeof hmed, hipMemcpyDeviceToHost, s));
+    float hpairs[4] = {0, 0, 0, 0};
+    if (L.pairs) LARS_HIP_TRY(hipMemcpyAsync(hpairs, L.pairs, sizeof hpairs, hipMemcpyDeviceToHost, s));
+    else if (j.want_median && j.medians && j.mask) LARS_HIP_TRY(hipMemcpyAsync(hmed, L.med, sizeof hmed, hipMemcpyDeviceToHost, s));
     if (j.apply_wb && j.pcts) LARS_HIP_TRY(hipMemcpyAsync(hp, L.pcts, sizeof hp, hipMemcpyDeviceToHost, s));
     LARS_HIP_TRY(hipStreamSynchronize(s));
+    if (L.pairs) {
+        // {NDVI middles, GNDVI middles}; NDWI = -GNDVI: its two middles are the negated GNDVI middles in reverse order
+        hmed[0] = hpairs[0]; hmed[1] = hpairs[1]; hmed[2] = hpairs[2]; hmed[3] = hpairs[3];
+        hmed[4] = 0.0f - hpairs[3]; hmed[5] = 0.0f - hpairs[2];
+        for (int k = 0; k < 3; ++k)
+            if (((j.mask >> k) & 1u) && (hmed[2 * k] != hmed[2 * k] || hmed[2 * k + 1] != hmed[2 * k + 1]))
+                return fail(LARS_ERR_HIP, "exact median select did not settle");
+    }
     for (int k = 0; k < 3; ++k) {
         if (!((j.mask >> k) & 1u)) continue;
         if (stats && j.stats) j.stats[k] = hstats[k];

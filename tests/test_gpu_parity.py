@@ -137,6 +137,16 @@ def test_odd_shapes_against_oracle(lars, shape, profile):
         np.testing.assert_array_equal(bits(res["indices"][t]["index"]), bits(want))
         assert_stats_close(res["indices"][t]["stats"], orc.stats_app(want, t), want)
         np.testing.assert_array_equal(res["indices"][t]["hist"], orc.hist50(want))
+    # statistics only: the planes never exist on the device either (medians by recompute-and-select)
+    lean = lars.process_image(img, want_arrays=False, want_hist=True)
+    assert lean["corrected"] is not None
+    for t in TYPES:
+        assert lean["indices"][t]["index"] is None
+        assert lean["indices"][t]["stats"] == res["indices"][t]["stats"], t
+        np.testing.assert_array_equal(lean["indices"][t]["hist"], res["indices"][t]["hist"])
+    solo = lars.process_image(img, indices=("GNDVI",), white_balance=False, want_arrays=False)
+    assert solo["indices"]["GNDVI"]["stats"] == orc.stats_app(orc.index_app(img, "GNDVI"), "GNDVI") or \
+        solo["indices"]["GNDVI"]["stats"]["Median GNDVI"] == float(np.median(orc.index_app(img, "GNDVI")))
 
 
 def test_large_odd_shaped_image(lars):

@@ -228,6 +228,9 @@ int lars_d_stats_medians(const lars_fused_args *a, float *out_pairs, void *scrat
 int lars_d_quotient_median_pairs(const void *tiles, int64_t ntiles, int64_t npix, int channels, int dtype,
                                  const uint8_t *wb_table, float *out_pairs, void *scratch, void *stream);
 
+/* classification mask (see lars_h_threshold_mask_f32); x 16-byte, out_mask 4-byte aligned */
+int lars_d_threshold_mask_f32(const float *x, int64_t n, float threshold, uint8_t *out_mask, void *stream);
+
 /* float32 index -> RGBA8: LUT[min(int((x + 1f) * 128f), 255)], the per-pixel
  * mapping of imshow(cmap, vmin=-1, vmax=1) (process-images.py:695). */
 int lars_d_colormap_f32(const float *x, int64_t n, const uint8_t *lut_rgba, uint8_t *out_rgba,
@@ -317,6 +320,9 @@ int lars_h_process_image(const void *img, int64_t h, int64_t w, int channels, in
                          uint8_t *const out_rgba[3], const uint8_t *const cmap_lut[3]);
 
 int lars_h_colormap_f32(const float *x, int64_t n, const uint8_t *lut_rgba, uint8_t *out_rgba);
+/* classification mask: out_mask[i] = index[i] > threshold in float32 (the array np.mean averages for the
+ * coverage figures, process-images.py:511 / :657); 1 byte per sample, 0 or 1 */
+int lars_h_threshold_mask_f32(const float *x, int64_t n, float threshold, uint8_t *out_mask);
 
 /* preprocess_large_image -- process-images.py:398-422: PIL.Image.resize((new_w, new_h), LANCZOS) of a
  * uint8 image with 1, 3 or 4 (RGBA, premultiplied-alpha path) channels, bit-identical to Pillow's

@@ -13,6 +13,7 @@ from .api import (  # noqa: F401
     calculate_index_statistics_by_timeframe,
     calculate_ndvi,
     change_detection,
+    classification_mask,
     colorize_difference,
     colorize_index,
     colormap_lut,

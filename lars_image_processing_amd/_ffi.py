@@ -121,6 +121,8 @@ SIGNATURES = {
     "lars_h_process_image": (_I, [_P, _I64, _I64, _I, _I, _I, _U32, _I, _P, C.POINTER(_P * 3), _P, _P,
                                   C.POINTER(_P * 3), C.POINTER(_P * 3)]),
     "lars_h_colormap_f32": (_I, [_P, _I64, _P, _P]),
+    "lars_h_threshold_mask_f32": (_I, [_P, _I64, _F, _P]),
+    "lars_d_threshold_mask_f32": (_I, [_P, _I64, _F, _P, _P]),
     "lars_h_colormap_norm_f32": (_I, [_P, _I64, _F, _F, _P, _P]),
     "lars_h_align_images": (_I, [_P, _P, _I64, _I64, _I, _P, _P]),
     "lars_h_change_detection": (_I, [_P, _P, _I64, _I64, _I, _I, _I, _I, _I, _P, _P, _P, _P, _P, _F, _F, _P, _P]),

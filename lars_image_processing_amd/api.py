@@ -41,7 +41,7 @@ from ._ffi import INDEX_IDS, INDEX_NAMES, Stats
 __all__ = [
     "fix_white_balance", "correct_white_balance", "fix_white_balance_rgnir",
     "calculate_index", "calculate_ndvi", "analyze_index", "analyze_index_statistics",
-    "analyze_ndvi_statistics", "index_histogram", "colorize_index", "process_image",
+    "analyze_ndvi_statistics", "index_histogram", "classification_mask", "colorize_index", "process_image",
     "timeseries_row", "colormap_lut", "preprocess_large_image", "align_images", "change_detection",
     "colorize_difference", "calculate_index_statistics_by_timeframe", "time_series_points",
     "create_time_series_plot", "create_change_detection_visualization",
@@ -318,6 +318,18 @@ def analyze_ndvi_statistics(ndvi_array):
         "std_ndvi": float(std),
         "vegetation_coverage": float(cover),
     }
+
+
+def classification_mask(index_array, index_type):
+    """uint8 mask of ``index_array > threshold`` (1 = vegetation, or water for NDWI): the array the reference
+    averages for its coverage figures (process-images.py:498-511), compared in float32 like NumPy does."""
+    if index_array is None or np.size(index_array) == 0:
+        return None
+    arr = np.ascontiguousarray(index_array, dtype=np.float32)
+    _, threshold = _coverage_rule(index_type)
+    out = np.empty(arr.shape, dtype=np.uint8)
+    _ffi.call("lars_h_threshold_mask_f32", _ffi.ptr(arr.reshape(-1)), arr.size, float(threshold), _ffi.ptr(out))
+    return out
 
 
 def index_histogram(index_array):

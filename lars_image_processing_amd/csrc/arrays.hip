@@ -436,6 +436,32 @@ extern "C" int lars_d_ndvi_f64(const void *img, int64_t npix, int channels, int 
     return launch_check("lars_d_ndvi_f64");
 }
 
+// classification mask: index > threshold in float32 (process-images.py:511, :657 -- the array np.mean averages)
+__global__ __launch_bounds__(256) void k_threshold_mask(const float *__restrict__ x, long long n, float thr, uint8_t *__restrict__ out)
+{
+    const long long nvec = n >> 2;
+    for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < nvec; i += (long long)gridDim.x * 256) {
+        const float4 v = reinterpret_cast<const float4 *>(x)[i];
+        reinterpret_cast<unsigned int *>(out)[i] = (v.x > thr ? 1u : 0u) | (v.y > thr ? 0x100u : 0u) | (v.z > thr ? 0x10000u : 0u) |
+                                                   (v.w > thr ? 0x1000000u : 0u);
+    }
+    if (blockIdx.x == 0 && threadIdx.x < (n & 3)) {
+        const long long i = nvec * 4 + threadIdx.x;
+        out[i] = x[i] > thr ? 1 : 0;
+    }
+}
+
+extern "C" int lars_d_threshold_mask_f32(const float *x, int64_t n, float threshold, uint8_t *out_mask, void *stream)
+{
+    ThreadCtx *c;
+    LARS_TRY(ensure_ctx(&c));
+    if (!x || !out_mask || n <= 0 || (reinterpret_cast<uintptr_t>(x) & 15) || (reinterpret_cast<uintptr_t>(out_mask) & 3))
+        return fail(LARS_ERR_INVALID, "lars_d_threshold_mask_f32: bad arguments (x 16-byte, out_mask 4-byte aligned)");
+    hipLaunchKernelGGL(k_threshold_mask, dim3(grid_for((n + 3) / 4)), dim3(256), 0, pick_stream(c, stream), x, (long long)n, threshold,
+                       out_mask);
+    return launch_check("lars_d_threshold_mask_f32");
+}
+
 extern "C" int lars_d_colormap_f32(const float *x, int64_t n, const uint8_t *lut_rgba, uint8_t *out_rgba, void *stream)
 {
     ThreadCtx *c;

@@ -312,6 +312,25 @@ int lars_h_analyze_f64(const double *x, int64_t n, double threshold, int want_hi
     return analyze_impl<double>(x, n, threshold, want_hist, out, median_pair, sumsqdev);
 }
 
+int lars_h_threshold_mask_f32(const float *x, int64_t n, float threshold, uint8_t *out_mask)
+{
+    ThreadCtx *c;
+    LARS_TRY(ensure_ctx(&c));
+    if (!x || !out_mask || n <= 0) return fail(LARS_ERR_INVALID, "lars_h_threshold_mask_f32: bad arguments");
+    Carver cv(nullptr);
+    cv.take<float>(n); cv.take<uint8_t>((size_t)n + 4);
+    LARS_TRY(ws_reserve(c, cv.off + 256));
+    Carver d(c->ws);
+    float *dx = d.take<float>(n);
+    uint8_t *dm = d.take<uint8_t>((size_t)n + 4);
+    hipStream_t s = c->stream;
+    LARS_HIP_TRY(hipMemcpyAsync(dx, x, (size_t)n * 4, hipMemcpyHostToDevice, s));
+    LARS_TRY(lars_d_threshold_mask_f32(dx, n, threshold, dm, s));
+    LARS_HIP_TRY(hipMemcpyAsync(out_mask, dm, (size_t)n, hipMemcpyDeviceToHost, s));
+    LARS_HIP_TRY(hipStreamSynchronize(s));
+    return LARS_OK;
+}
+
 int lars_h_colormap_f32(const float *x, int64_t n, const uint8_t *lut_rgba, uint8_t *out_rgba)
 {
     ThreadCtx *c;

@@ -184,6 +184,25 @@ def test_rgba_and_uint16_inputs(lars):
         np.testing.assert_array_equal(bits(lars.calculate_index(f32img, t)), bits(orc.index_app(f32img, t)))
 
 
+def test_classification_masks_are_bit_exact(lars, golden):
+    """index > threshold as a uint8 mask (north star: bit-exact classification masks), float32 compare at 0.2f / 0."""
+    rng = np.random.default_rng(4)
+    probe = np.concatenate([rng.uniform(-1, 1, 100003).astype(np.float32),
+                            np.array([0.2, np.nextafter(np.float32(0.2), np.float32(1)), np.nextafter(np.float32(0.2), np.float32(0)),
+                                      0.0, -0.0, 1.0, -1.0, 0.20000000298], dtype=np.float32)])
+    for t, thr in (("NDVI", 0.2), ("GNDVI", 0.2), ("NDWI", 0.0)):
+        got = lars.classification_mask(probe, t)
+        assert got.dtype == np.uint8
+        np.testing.assert_array_equal(got, (probe > thr).astype(np.uint8))
+        got2 = lars.classification_mask(probe[:-3].reshape(-1, 2), t)          # 2-D, length not a multiple of 4
+        np.testing.assert_array_equal(got2, (probe[:-3].reshape(-1, 2) > thr).astype(np.uint8))
+        assert float(got.mean() * 100) == lars.analyze_index(probe, t)[f"{'Water' if t == 'NDWI' else 'Vegetation'} Coverage (%)"]
+    case = [c for c in CASES if "rgba" not in c][0]
+    idx = golden[f"{case}/index_wb_NDVI"]
+    np.testing.assert_array_equal(lars.classification_mask(idx, "NDVI"), (idx > 0.2).astype(np.uint8))
+    assert lars.classification_mask(None, "NDVI") is None
+
+
 def test_division_exhaustive_uint8_pairs(lars):
     """Every (a, b) byte pair: the kernel's quotient is the IEEE float32 quotient."""
     a, b = np.meshgrid(np.arange(256, dtype=np.uint8), np.arange(256, dtype=np.uint8), indexing="ij")

@@ -29,7 +29,8 @@ def main():
     for c in ("FETCH_SIZE", "WRITE_SIZE"):
         with open(f"{ROOT}/profiles/{rnd}_pmc_{c}.txt", "w") as fh:
             subprocess.run([sys.executable, f"{ROOT}/tools/pmc_summary.py", f"{src}/pmc_{c}", "k_"], stdout=fh, check=True)
-    stats = sorted(glob.glob(f"{src}/trace/**/*kernel_stats.csv", recursive=True))[0]
+    # gpurun merges every call's files into gpurun_out/: take the newest trace (and clear prof_<round>/ between runs)
+    stats = max(glob.glob(f"{src}/trace/**/*kernel_stats.csv", recursive=True), key=os.path.getmtime)
     shutil.copy(stats, f"{ROOT}/profiles/{rnd}_bench_kernel_stats.csv")
     shutil.copy(f"{src}/bench_under_rocprof.json", f"{ROOT}/profiles/{rnd}_bench_under_rocprof.json")
     f, w = read(rnd, "FETCH_SIZE"), read(rnd, "WRITE_SIZE")
@@ -38,8 +39,8 @@ def main():
         "wb3idx_out_stats": ("k_fused_u8c3<unsigned char, 7u, true, 1>", px64),
         "wb3idx_out_stats_hist": ("k_fused_u8c3<unsigned char, 7u, true, 2>", px64),
         "wb_ndvi_out_stats": ("k_fused_u8c3<unsigned char, 1u, true, 1>", px64),
-        "wb3idx_stats_only": ("k_fused_v2<7u, true, 1, false, false>", px256),
-        "wb_ndvi_stats_only": ("k_fused_v2<1u, true, 1, false, false>", px256),
+        "wb3idx_stats_only": ("k_fused_v2<7u, true, 1, false, false, false>", px256),
+        "wb_ndvi_stats_only": ("k_fused_v2<1u, true, 1, false, false, false>", px256),
         "channel_hist": ("k_chan_hist_u8c3_v2", px256),
     }
     t = {"_comment": "HBM bytes per pixel from rocprofv3 PMC (separate --pmc FETCH_SIZE / --pmc WRITE_SIZE passes): "

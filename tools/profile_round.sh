@@ -1,7 +1,7 @@
 #!/usr/bin/env bash
 # Collects the rocprofv3 evidence of round $1 (default r01) on a GPU box into gpurun_out/prof_<round>/ (the only
 # directory that travels back); tools/collect_profiles.py then writes the summaries into profiles/:
-#   gpurun --timeout 1200 -- 'bash tools/profile_round.sh r02' && python tools/collect_profiles.py r02
+#   rm -rf gpurun_out/prof_r02; gpurun --timeout 1200 -- 'bash tools/profile_round.sh r02' && python tools/collect_profiles.py r02
 # 1. kernel-trace --stats of bench.py (per-kernel average durations)
 # 2. --pmc FETCH_SIZE and --pmc WRITE_SIZE in separate passes (HBM traffic per launch)
 # 3. profiles/traffic.json (bytes per pixel, FETCH_SIZE doubled as MI355X_MICROARCH.md prescribes)

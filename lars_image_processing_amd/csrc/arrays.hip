@@ -72,20 +72,38 @@ __global__ __launch_bounds__(256) void k_array_stats(const T *__restrict__ x, lo
     if (want_hist && tid < LARS_HIST_BINS && s_hist[tid]) atomicAdd(&ghist[tid], (unsigned long long)s_hist[tid]);
 }
 
-__global__ void k_array_stats_fold(const ArrPartial *__restrict__ partials, int nblocks, double thr,
-                                   const unsigned long long *__restrict__ ghist, int want_hist, lars_stats *out)
+// one block of 256 threads folds the per-block partials (a fixed tree: the double sums do not depend on timing)
+__global__ __launch_bounds__(256) void k_array_stats_fold(const ArrPartial *__restrict__ partials, int nblocks, double thr,
+                                                          const unsigned long long *__restrict__ ghist, int want_hist, lars_stats *out)
 {
-    if (threadIdx.x == 0 && blockIdx.x == 0) {
-        ArrPartial p = partials[0];
-        for (int b = 1; b < nblocks; ++b) {
-            p.sum += partials[b].sum; p.sumsq += partials[b].sumsq;
-            p.mn = fmin(p.mn, partials[b].mn); p.mx = fmax(p.mx, partials[b].mx);
-            p.above += partials[b].above; p.nans += partials[b].nans; p.count += partials[b].count;
+    __shared__ ArrPartial s_p[4];
+    const int tid = threadIdx.x;
+    ArrPartial p;
+    p.sum = 0; p.sumsq = 0; p.mn = __builtin_inf(); p.mx = -__builtin_inf(); p.above = 0; p.nans = 0; p.count = 0; p.pad = 0;
+    for (int b = tid; b < nblocks; b += 256) {
+        const ArrPartial q = partials[b];
+        p.sum += q.sum; p.sumsq += q.sumsq;
+        p.mn = fmin(p.mn, q.mn); p.mx = fmax(p.mx, q.mx);
+        p.above += q.above; p.nans += q.nans; p.count += q.count;
+    }
+    for (int off = 32; off >= 1; off >>= 1) {
+        p.sum += __shfl_xor(p.sum, off); p.sumsq += __shfl_xor(p.sumsq, off);
+        p.mn = fmin(p.mn, __shfl_xor(p.mn, off)); p.mx = fmax(p.mx, __shfl_xor(p.mx, off));
+        p.above += __shfl_xor(p.above, off); p.nans += __shfl_xor(p.nans, off); p.count += __shfl_xor(p.count, off);
+    }
+    if ((tid & 63) == 0) s_p[tid >> 6] = p;
+    __syncthreads();
+    if (tid == 0) {
+        p = s_p[0];
+        for (int w = 1; w < 4; ++w) {
+            p.sum += s_p[w].sum; p.sumsq += s_p[w].sumsq;
+            p.mn = fmin(p.mn, s_p[w].mn); p.mx = fmax(p.mx, s_p[w].mx);
+            p.above += s_p[w].above; p.nans += s_p[w].nans; p.count += s_p[w].count;
         }
         out->sum = p.sum; out->sumsq = p.sumsq; out->count = p.count + p.nans; out->above = p.above; out->nans = p.nans;
         out->min = p.mn; out->max = p.mx; out->threshold = thr; out->index_id = 0xFFFFFFFFu; out->reserved = 0;
     }
-    if (threadIdx.x < LARS_HIST_BINS) out->hist[threadIdx.x] = want_hist ? ghist[threadIdx.x] : 0ull;
+    if (tid < LARS_HIST_BINS) out->hist[tid] = want_hist ? ghist[tid] : 0ull;
 }
 
 // sum of squared deviations from the mean (np.std's second pass, process-ndvi.py:65)
@@ -105,13 +123,15 @@ __global__ __launch_bounds__(256) void k_sumsqdev(const T *__restrict__ x, long 
     __syncthreads();
     if (threadIdx.x == 0) partials[blockIdx.x] = s_w[0] + s_w[1] + s_w[2] + s_w[3];
 }
-__global__ void k_fold_f64(const double *partials, int nblocks, double *out)
+__global__ __launch_bounds__(256) void k_fold_f64(const double *partials, int nblocks, double *out)
 {
-    if (threadIdx.x == 0 && blockIdx.x == 0) {
-        double s = 0;
-        for (int b = 0; b < nblocks; ++b) s += partials[b];
-        *out = s;
-    }
+    __shared__ double s_w[4];
+    double acc = 0;
+    for (int b = threadIdx.x; b < nblocks; b += 256) acc += partials[b];
+    for (int off = 32; off >= 1; off >>= 1) acc += __shfl_xor(acc, off);
+    if ((threadIdx.x & 63) == 0) s_w[threadIdx.x >> 6] = acc;
+    __syncthreads();
+    if (threadIdx.x == 0) *out = s_w[0] + s_w[1] + s_w[2] + s_w[3];
 }
 
 // ===========================================================================
@@ -326,6 +346,14 @@ static int grid_for(long long n)
     if (b < 1) b = 1;
     return (int)b;
 }
+// reductions that end in atomics or a per-block partial: fewer blocks with at least 16 elements per thread
+static int grid_for_reduce(long long n)
+{
+    long long b = (n + 4095) / 4096;
+    if (b > 2048) b = 2048;
+    if (b < 1) b = 1;
+    return (int)b;
+}
 
 template <typename T>
 static int array_stats_impl(const T *x, int64_t n, T thr, int want_hist, lars_stats *out_dev, double *sumsqdev_dev,
@@ -335,7 +363,7 @@ static int array_stats_impl(const T *x, int64_t n, T thr, int want_hist, lars_st
     LARS_TRY(ensure_ctx(&c));
     if (!x || n <= 0 || !out_dev) return fail(LARS_ERR_INVALID, "lars_d_array_stats: bad arguments");
     hipStream_t s = pick_stream(c, stream);
-    const int nb = grid_for(n);
+    const int nb = grid_for_reduce(n);
     const size_t need = (size_t)nb * sizeof(ArrPartial) + LARS_HIST_BINS * sizeof(unsigned long long) + (size_t)nb * sizeof(double);
     LARS_TRY(scratch_reserve(c, need));
     ArrPartial *parts = static_cast<ArrPartial *>(c->scratch);
@@ -343,10 +371,10 @@ static int array_stats_impl(const T *x, int64_t n, T thr, int want_hist, lars_st
     double *dparts = reinterpret_cast<double *>(ghist + LARS_HIST_BINS);
     LARS_HIP_TRY(hipMemsetAsync(ghist, 0, LARS_HIST_BINS * sizeof(unsigned long long), s));
     hipLaunchKernelGGL((k_array_stats<T>), dim3(nb), dim3(256), 0, s, x, (long long)n, thr, want_hist, parts, ghist);
-    hipLaunchKernelGGL(k_array_stats_fold, dim3(1), dim3(64), 0, s, parts, nb, (double)thr, ghist, want_hist, out_dev);
+    hipLaunchKernelGGL(k_array_stats_fold, dim3(1), dim3(256), 0, s, parts, nb, (double)thr, ghist, want_hist, out_dev);
     if (sumsqdev_dev) {
         hipLaunchKernelGGL((k_sumsqdev<T>), dim3(nb), dim3(256), 0, s, x, (long long)n, out_dev, dparts);
-        hipLaunchKernelGGL(k_fold_f64, dim3(1), dim3(64), 0, s, dparts, nb, sumsqdev_dev);
+        hipLaunchKernelGGL(k_fold_f64, dim3(1), dim3(256), 0, s, dparts, nb, sumsqdev_dev);
     }
     return launch_check("lars_d_array_stats");
 }
@@ -373,7 +401,7 @@ static int median_pair_impl(const T *x, int64_t n, int64_t items, int64_t stride
         return fail(LARS_ERR_INVALID, "lars_d_median_pair: bad arguments");
     hipStream_t s = pick_stream(c, stream);
     SelectState *st = static_cast<SelectState *>(scratch);
-    int nb = grid_for(n);
+    int nb = grid_for_reduce(n);
     if (items > 1) {                                      // enough blocks in total, not per item
         long long want = (4096 + items - 1) / items;
         if (nb > want) nb = (int)(want < 1 ? 1 : want);

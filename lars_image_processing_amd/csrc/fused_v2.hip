@@ -25,53 +25,9 @@
 
 #include <type_traits>
 
-#include "common.h"
-#include "device_common.h"
+#include "v2_device.h"
 
 namespace lars {
-
-typedef unsigned int u32x3 __attribute__((ext_vector_type(3)));
-
-// ---------------------------------------------------------------------------
-// exact quotient for integer-valued operands: |num| <= den, 1 <= den < 2^24
-// ---------------------------------------------------------------------------
-__device__ inline float exact_quot(float num, float den)
-{
-#ifdef ABL_NODIV
-    return num * 0.001f + den * 0.0001f;
-#endif
-    const float r = __builtin_amdgcn_rcpf(den);
-    const float q0 = num * r;
-    const float e = __builtin_fmaf(-q0, den, num);
-    return __builtin_fmaf(e, r, q0);
-}
-// a+b == 0 (both samples 0) must give +0.0.  Instead of a max(den, 1) per quotient, the NIR value gets
-// a tiny epsilon once per pixel pair (one packed add shared by NDVI and GNDVI): float32(n + 1e-10) == n
-// for every n >= 1 and the epsilon is absorbed again by any other sample >= 1, so the denominator is
-// unchanged unless both samples are 0, where it becomes 1e-10 and the quotient (+0) * 1e10 = +0.0 --
-// the same device the reference uses (process-images.py:464).
-#define LARS_DEN_EPS 1e-10f
-
-// two quotients per instruction: v_pk_mul_f32 / v_pk_fma_f32 (the VALU issues one wave64
-// instruction per 4 cycles, packed or not -- rocprofv3: SQ_ACTIVE_INST_VALU / SQ_INSTS_VALU = 1.05 quad-cycles)
-typedef float f32x2 __attribute__((ext_vector_type(2)));
-// den must be >= 1 or the tiny positive stand-in for a zero sum (see LARS_DEN_EPS)
-__device__ inline f32x2 exact_quot2(f32x2 num, f32x2 den)
-{
-    f32x2 r;
-    r.x = __builtin_amdgcn_rcpf(den.x);
-    r.y = __builtin_amdgcn_rcpf(den.y);
-    const f32x2 q0 = num * r;
-    const f32x2 e = __builtin_elementwise_fma(-q0, den, num);
-    return __builtin_elementwise_fma(e, r, q0);
-}
-// (a-b)/(a+b) with +0.0 where a+b == 0
-__device__ inline float norm_diff_fast(float a, float b)
-{
-    const float s = a + b;
-    const float d = a - b;
-    return exact_quot(d, fmaxf(s, 1.0f));
-}
 
 // Exhaustive self-check kernel: counts operand pairs where exact_quot differs
 // from the compiler's correctly rounded division.  num in [-den, den].
@@ -183,44 +139,10 @@ struct WaveAcc {
 };
 
 // LDS layout (dynamic): [WB table 64 KiB][hist 3*50*32 u32][edges 51 f32][reduce scratch]
-#define V2_TABLE_BYTES 65536
 #define V2_HIST_COPIES 16    // copies of each index histogram, copy = lane % 16 (two blocks per CU still fit)
 #define V2_HIST_SHIFT 6      // log2(V2_HIST_COPIES * 4): bytes between consecutive bins
 #define V2_HIST_ROWS 51      // bins 0..50; 50 (x == 1.0, the closed right edge) folds into 49 at the flush
 #define V2_HIST_WORDS (3 * V2_HIST_ROWS * V2_HIST_COPIES)
-
-// byte k of a dword -> float in one VALU instruction.  Kept opaque (asm) so that hipcc does not
-// turn "float(a) +/- float(b)" into integer SDWA adds plus conversions (5 instructions per pixel
-// instead of 2 conversions + packed add/sub).
-__device__ inline float cvt_ubyte(unsigned int w, int k)
-{
-    float f;
-    switch (k) {
-    case 0: asm("v_cvt_f32_ubyte0 %0, %1" : "=v"(f) : "v"(w)); break;
-    case 1: asm("v_cvt_f32_ubyte1 %0, %1" : "=v"(f) : "v"(w)); break;
-    case 2: asm("v_cvt_f32_ubyte2 %0, %1" : "=v"(f) : "v"(w)); break;
-    default: asm("v_cvt_f32_ubyte3 %0, %1" : "=v"(f) : "v"(w)); break;
-    }
-    return f;
-}
-
-template <bool WB>
-__device__ inline float sample(unsigned int word, int byte, int ch, unsigned int lane_off4, const char *s_tab)
-{
-    if (!WB) return cvt_ubyte(word, byte);
-    // address = sample << 8 | lane*4 in one v_perm_b32 (S0 = word: selectors 4..7, S1 = lane_off4: 0..3)
-    const unsigned int sel = 0x0c0c0000u | ((4u + (unsigned)byte) << 8);
-    const unsigned int addr = __builtin_amdgcn_perm(word, lane_off4, sel);
-    const unsigned int entry = *reinterpret_cast<const unsigned int *>(s_tab + addr);
-    return cvt_ubyte(entry, ch);
-}
-template <bool WB>
-__device__ inline unsigned int sample_entry(unsigned int word, int byte, unsigned int lane_off4, const char *s_tab)
-{
-    const unsigned int sel = 0x0c0c0000u | ((4u + (unsigned)byte) << 8);
-    const unsigned int addr = __builtin_amdgcn_perm(word, lane_off4, sel);
-    return *reinterpret_cast<const unsigned int *>(s_tab + addr);
-}
 
 // Coverage counters live in scalar registers.  The compare mask goes through VCC inside ONE asm
 // statement (v_cmp -> s_bcnt1), so it never occupies an allocatable SGPR pair: with the
@@ -296,21 +218,6 @@ __device__ inline void push(WaveAcc &a, unsigned int &above, float x, float thr)
         if (LARS_COUNT_MODE == 0) count_gt(above, x, thr);           // wave-uniform scalar counter
         else vcount_gt(above, x, thr);                               // per-lane counter, folded at flush
     }
-}
-
-// first-level bucket of the exact-median select (see k_selq_pass below): round((x + 1) * 1023.5) in 0..2047,
-// left in the low mantissa bits of t + 2^23
-#define SELQ_BINS 2048
-#define SELQ_MAGIC_BITS 0x4B000000u                      /* float bits of 2^23: "bucket 0" */
-__device__ inline f32x2 selq_pos2(f32x2 x)
-{
-    const f32x2 k = {1023.5f, 1023.5f}, big = {8388608.0f, 8388608.0f};
-    return __builtin_elementwise_fma(x, k, k) + big;
-}
-__device__ inline void selq_add_pos(float pos, unsigned int base)      // base: LDS byte address of the row, less the shifted "bucket 0" bits
-{
-    const unsigned int addr = (__builtin_bit_cast(unsigned int, pos) << 2) + base;
-    asm volatile("ds_add_u32 %0, %1" : : "v"(addr), "v"(1u) : "memory");
 }
 
 // Histogram bin of an index value of a uint8 tile without looking at the edges.  x = (a-b)/(a+b)
@@ -720,281 +627,6 @@ __global__ __launch_bounds__(V2Block<OUT>::threads, OUT ? 4 : LARS_V2_STATS_WAVE
 }
 
 
-// The fused kernel's load pipeline as a reusable loop: four 12-byte buffer loads in flight per lane, slot k is
-// consumed and refilled in place.  f(q, w0, w1, w2) sees every quad of the tile exactly once.
-template <int NTHR, typename F>
-__device__ inline void for_each_quad_ring(const uint8_t *base, long long nquads, F &&f)
-{
-    const long long stride = (long long)gridDim.x * NTHR;
-    const long long q0 = (long long)blockIdx.x * NTHR + threadIdx.x;
-    const long long niter = (nquads + stride - 1) / stride;          // same for every lane of the grid
-    if (niter <= 0) return;
-    const __amdgpu_buffer_rsrc_t rsrc =
-        __builtin_amdgcn_make_buffer_rsrc(const_cast<uint8_t *>(base), 0, (int)(nquads * 12), 0x00020000);
-    const unsigned int voff = (unsigned int)q0 * 12u;
-    const unsigned int step_b = (unsigned int)stride * 12u;
-    u32x3 w[4];
-#pragma unroll
-    for (int k = 0; k < 4; ++k) w[k] = __builtin_amdgcn_raw_buffer_load_b96(rsrc, voff, (unsigned)k * step_b, 0);
-    long long it = 0;
-    unsigned int soff = 4u * step_b;
-    for (; it + 4 <= niter - 1; it += 4) {
-#pragma unroll
-        for (int k = 0; k < 4; ++k) {
-            f(q0 + (it + k) * stride, w[k].x, w[k].y, w[k].z);
-            __builtin_amdgcn_sched_barrier(0);
-            w[k] = __builtin_amdgcn_raw_buffer_load_b96(rsrc, voff, soff + (unsigned)k * step_b, 0);
-            __builtin_amdgcn_sched_barrier(0);
-        }
-        soff += 4u * step_b;
-    }
-#pragma unroll
-    for (int k = 0; k < 4; ++k) {
-        const long long qq = q0 + (it + k) * stride;
-        if (it + k < niter && qq < nquads) f(qq, w[k].x, w[k].y, w[k].z);
-    }
-}
-
-// ---------------------------------------------------------------------------
-// Exact medians without materialising the index planes -- of every tile of a batch, or of the whole batch over
-// all ranks.  Radix select on values that are RECOMPUTED from the tiles (3 bytes per pixel and
-// pass).  Two streams (NDVI, GNDVI; NDWI = -GNDVI shares GNDVI's order statistics) x two tracks (the ranks
-// (N-1)/2 and N/2, which may part ways).
-//   pass 1   2048 linear buckets of [-1, 1] (selq_bucket: monotone in x, so it is a valid first radix level, and
-//            unlike the key's top bits it spreads an index plane over hundreds of LDS words)
-//   pick     bucket holding the rank -> its key range [lo, hi) by bisection with the same arithmetic
-//   pass 2+  digit d = (key - bias) >> shift of the keys inside the range (anything else lands on a per-lane dummy
-//            word: d is compared with the row length by one v_min, no branch); shift drops by 11 per pass until 0.
-// uint8 quotients are 0 or at least 1/510 in magnitude, so a bucket is at most 2^22 keys wide (three passes) once
-// the bucket around zero is cut down to the single key of +0.0.
-// ---------------------------------------------------------------------------
-#define SELQ_ROW (SELQ_BINS + 64)
-#define SELQ_KEY_MINUS1 0x407FFFFFu                        /* f32_key(-1.0f) */
-#define SELQ_KEY_PLUS1 0xBF800000u                         /* f32_key(+1.0f) */
-#define SELQ_KEY_ZERO 0x80000000u                          /* f32_key(+0.0f) */
-
-// first-level bucket of x in [-1, 1]: round((x + 1) * 1023.5) in 0..2047, read off the mantissa of t + 2^23
-__device__ inline unsigned int selq_bucket(float x)
-{
-    const float t = __builtin_fmaf(x, 1023.5f, 1023.5f);
-    const float u = t + 8388608.0f;
-    return __builtin_bit_cast(unsigned int, u) & 0x7FFFFFu;
-}
-// smallest key in [key(-1), key(+1) + 1] whose bucket is >= b
-__device__ inline unsigned int selq_lower_key(unsigned int b)
-{
-    unsigned int lo = SELQ_KEY_MINUS1, hi = SELQ_KEY_PLUS1 + 1u;
-    while (lo < hi) {
-        const unsigned int mid = lo + ((hi - lo) >> 1);
-        if (selq_bucket(key_f32(mid)) >= b) hi = mid;
-        else lo = mid + 1u;
-    }
-    return lo;
-}
-
-struct SelQParams {
-    const uint8_t *tiles;
-    const uint8_t *wb_table;
-    long long npix;
-    int first;                            // 1: bucket pass (every value counts, track = lane parity)
-    unsigned int bias[4], shift[4];       // [stream * 2 + track], later passes
-    unsigned long long *hist;             // [2][2][SELQ_BINS], accumulated with atomics (whole-batch variant)
-    // per-tile selection (medians of every tile of a batch, all on the device): state and 32-bit histograms per tile
-    struct SelQTile *state;
-    unsigned int *hist32;                 // [ntiles][2][2][SELQ_BINS]
-};
-struct SelQTile {
-    unsigned int bias[4];                 // [stream * 2 + track]: key the digits are counted from
-    unsigned int shift[4];
-    unsigned int rank[4];                 // rank still to find at or above bias
-    unsigned int done;                    // bit c: combo c has had its shift-0 pass (bias is the key of the order statistic)
-    unsigned int pad[3];
-};
-
-template <bool WB, bool PER_TILE>
-__global__ __launch_bounds__(1024) void k_selq_pass(SelQParams P)
-{
-    __shared__ __attribute__((aligned(16))) char s_tab[WB ? V2_TABLE_BYTES : 16];
-    __shared__ unsigned int s_h[4 * SELQ_ROW];             // per (stream, track): 2048 bins + one dummy word per lane
-    const int tid = threadIdx.x;
-    const unsigned int lane_off4 = (tid & 63u) << 2;
-    const long long tile = blockIdx.y;
-    const long long npix = P.npix;
-    const uint8_t *base = P.tiles + tile * npix * 3;
-    // a tile whose four order statistics are settled skips the spare passes (uniform per block)
-    if (PER_TILE && !P.first && P.state[tile].done == 0xFu) return;
-    if (WB) {
-        const uint8_t *t = P.wb_table + tile * 768;
-        unsigned int *tab = reinterpret_cast<unsigned int *>(s_tab);
-        for (int i = tid; i < 256 * 64; i += 1024) {
-            const int v = i >> 6;
-            tab[i] = (unsigned)t[v] | ((unsigned)t[256 + v] << 8) | ((unsigned)t[512 + v] << 16);
-        }
-    }
-    for (int i = tid; i < 4 * SELQ_ROW; i += 1024) s_h[i] = 0;
-    __syncthreads();
-
-    const unsigned int *bias = PER_TILE ? P.state[tile].bias : P.bias;
-    const unsigned int *shft = PER_TILE ? P.state[tile].shift : P.shift;
-    const unsigned int ba0 = bias[0], ba1 = bias[1], bb0 = bias[2], bb1 = bias[3];
-    const unsigned int sa0 = shft[0], sa1 = shft[1], sb0 = shft[2], sb1 = shft[3];
-    const unsigned int my_track = tid & 1u;                 // first pass: the two tracks are two copies
-    const long long nquads = npix >> 2;
-    const unsigned int sign_bit = 0x80000000u;
-    const unsigned int dummy_idx = SELQ_BINS + (tid & 63u); // a value outside the range adds to its lane's dummy word
-
-    // The loop is compiled three times and chosen by ONE uniform branch (the conditions never change inside a block):
-    // MODE 0 bucket pass, MODE 1 both streams' two ranks still share (bias, shift) -- counted once, under track 0 --,
-    // MODE 2 general.  No divergence in any of them.
-    auto run = [&](auto mode_tag) {
-        constexpr int MODE = decltype(mode_tag)::value;
-        auto push_n = [&](int stream, const float *x, int nval, unsigned int b0, unsigned int s0, unsigned int b1, unsigned int s1) {
-            for (int j = 0; j < nval; ++j) {
-                if (MODE == 0) {
-                    atomicAdd(&s_h[(stream * 2 + my_track) * SELQ_ROW + selq_bucket(x[j])], 1u);
-                    continue;
-                }
-                const unsigned int bits_j = __builtin_bit_cast(unsigned int, x[j]);
-                unsigned int key;
-                // order-preserving key: x >= 0 -> bits | 2^31, x < 0 -> ~bits
-                asm("v_ashrrev_i32 %0, 31, %1\n\tv_or_b32 %0, %2, %0\n\tv_xor_b32 %0, %0, %1" : "=&v"(key) : "v"(bits_j), "v"(sign_bit));
-                const unsigned int d0 = (key - b0) >> s0;
-                atomicAdd(&s_h[(stream * 2 + 0) * SELQ_ROW + (d0 < dummy_idx ? d0 : dummy_idx)], 1u);
-                if (MODE == 2) {
-                    const unsigned int d1 = (key - b1) >> s1;
-                    atomicAdd(&s_h[(stream * 2 + 1) * SELQ_ROW + (d1 < dummy_idx ? d1 : dummy_idx)], 1u);
-                }
-            }
-        };
-        for_each_quad_ring<1024>(base, nquads, [&](long long, unsigned int w0, unsigned int w1, unsigned int w2) {
-            const unsigned int wr[4] = {w0, w0, w1, w2}, wg[4] = {w0, w1, w1, w2}, wn[4] = {w0, w1, w2, w2};
-            constexpr int br[4] = {0, 3, 2, 1}, bg[4] = {1, 0, 3, 2}, bn[4] = {2, 1, 0, 3};
-            float fn[4], fr[4], fg[4], qv[4], qg[4];
-#pragma unroll
-            for (int px = 0; px < 4; ++px) {
-                fn[px] = sample<WB>(wn[px], bn[px], 2, lane_off4, s_tab);
-                fr[px] = sample<WB>(wr[px], br[px], 0, lane_off4, s_tab);
-                fg[px] = sample<WB>(wg[px], bg[px], 1, lane_off4, s_tab);
-            }
-#pragma unroll
-            for (int h = 0; h < 2; ++h) {
-                const f32x2 N = {fn[2 * h], fn[2 * h + 1]}, R = {fr[2 * h], fr[2 * h + 1]}, G = {fg[2 * h], fg[2 * h + 1]};
-                const f32x2 Ne = N + (f32x2){LARS_DEN_EPS, LARS_DEN_EPS};
-                const f32x2 v = exact_quot2(N - R, Ne + R), g = exact_quot2(N - G, Ne + G);
-                qv[2 * h] = v.x; qv[2 * h + 1] = v.y; qg[2 * h] = g.x; qg[2 * h + 1] = g.y;
-            }
-            push_n(0, qv, 4, ba0, sa0, ba1, sa1);
-            push_n(1, qg, 4, bb0, sb0, bb1, sb1);
-        });
-        if (blockIdx.x == 0 && tid < (int)(npix & 3)) {
-            const long long i = nquads * 4 + tid;
-            unsigned int r = base[i * 3], g = base[i * 3 + 1], n = base[i * 3 + 2];
-            if (WB) {
-                const unsigned int *tab = reinterpret_cast<const unsigned int *>(s_tab);
-                r = tab[r * 64] & 0xFFu; g = (tab[g * 64] >> 8) & 0xFFu; n = (tab[n * 64] >> 16) & 0xFFu;
-            }
-            const float tv = norm_diff_fast((float)n, (float)r), tg = norm_diff_fast((float)n, (float)g);
-            push_n(0, &tv, 1, ba0, sa0, ba1, sa1);
-            push_n(1, &tg, 1, bb0, sb0, bb1, sb1);
-        }
-    };
-    if (P.first) run(std::integral_constant<int, 0>{});
-    else if (ba0 == ba1 && sa0 == sa1 && bb0 == bb1 && sb0 == sb1) run(std::integral_constant<int, 1>{});
-    else run(std::integral_constant<int, 2>{});
-    __syncthreads();
-    if (PER_TILE) {
-        unsigned int *h = P.hist32 + tile * (4 * SELQ_BINS);
-        for (int i = tid; i < 4 * SELQ_BINS; i += 1024) {
-            const unsigned int v = s_h[(i >> 11) * SELQ_ROW + (i & (SELQ_BINS - 1))];
-            if (v) atomicAdd(&h[i], v);
-        }
-    } else {
-        for (int i = tid; i < 4 * SELQ_BINS; i += 1024) {
-            const unsigned int v = s_h[(i >> 11) * SELQ_ROW + (i & (SELQ_BINS - 1))];
-            if (v) atomicAdd(&P.hist[i], (unsigned long long)v);
-        }
-    }
-}
-
-__global__ void k_selq_init(SelQTile *state, long long ntiles, long long npix, unsigned int streams)
-{
-    const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
-    if (i < ntiles) {
-        SelQTile t;
-        for (int c = 0; c < 4; ++c) { t.bias[c] = 0u; t.shift[c] = 0u; t.rank[c] = (unsigned int)((c & 1) ? npix / 2 : (npix - 1) / 2); }
-        t.done = ((streams & 1u) ? 0u : 0x3u) | ((streams & 2u) ? 0u : 0xCu);      // a stream nobody asked for is settled
-        t.pad[0] = t.pad[1] = t.pad[2] = 0u;
-        state[i] = t;
-    }
-}
-
-// one block per tile, one wave per (stream, track): find the bin whose cumulative count covers the rank and
-// narrow the key range
-__global__ __launch_bounds__(256) void k_selq_pick(SelQTile *state, unsigned int *hist32, int first)
-{
-    const long long tile = blockIdx.x;
-    unsigned int *h = hist32 + tile * (4 * SELQ_BINS);
-    const int combo = threadIdx.x >> 6, lane = threadIdx.x & 63;
-    const unsigned int done = state[tile].done;
-    if (!first && done == 0xFu) return;                     // the pass did not run for this tile (uniform per block)
-    const bool active = !((done >> combo) & 1u);            // settled combos (or streams nobody asked for) only help zeroing
-    // a later pass counted a (bias, shift) shared by both tracks once, under track 0 (decided before anything changes)
-    const bool shared = !first && state[tile].bias[combo & 2] == state[tile].bias[combo | 1] &&
-                        state[tile].shift[combo & 2] == state[tile].shift[combo | 1];
-    const unsigned int rank = state[tile].rank[combo], bias = state[tile].bias[combo], shift = state[tile].shift[combo];
-    __syncthreads();
-    if (active) {
-        const unsigned int *mine = h + (shared ? (combo & 2) : combo) * SELQ_BINS;
-        const unsigned int *twin = h + (combo ^ 1) * SELQ_BINS;    // bucket pass: the two tracks are two copies
-        unsigned int c[32], local = 0;
-#pragma unroll
-        for (int j = 0; j < 32; ++j) {
-            c[j] = mine[lane * 32 + j] + (first ? twin[lane * 32 + j] : 0u);
-            local += c[j];
-        }
-        unsigned int incl = local;
-        for (int off = 1; off < 64; off <<= 1) {
-            const unsigned int o = __shfl_up(incl, off);
-            if (lane >= off) incl += o;
-        }
-        unsigned int cum = incl - local;
-        if (rank >= cum && rank < incl) {                   // exactly one lane (the bins up to the range's end hold >= rank + 1 values)
-            int d = 0;
-#pragma unroll
-            for (int j = 0; j < 32; ++j) {
-                if (rank >= cum + c[j]) { cum += c[j]; d = j + 1; }
-                else break;
-            }
-            const unsigned int bin = (unsigned int)(lane * 32 + d);
-            unsigned int nbias, nshift;
-            if (first) {
-                unsigned int lo = selq_lower_key(bin);
-                unsigned int hi = bin >= SELQ_BINS - 1 ? SELQ_KEY_PLUS1 + 1u : selq_lower_key(bin + 1u);
-                if (lo <= SELQ_KEY_ZERO && SELQ_KEY_ZERO < hi) { lo = SELQ_KEY_ZERO; hi = SELQ_KEY_ZERO + 1u; }   // only +0.0 lives there
-                const unsigned int span = hi - lo - 1u;    // largest offset inside the range
-                nshift = span < SELQ_BINS ? 0u : (32u - (unsigned)__builtin_clz(span)) - 11u;
-                nbias = lo;
-            } else {
-                nbias = bias + (bin << shift);
-                nshift = shift > 11u ? shift - 11u : 0u;
-            }
-            state[tile].bias[combo] = nbias;
-            state[tile].shift[combo] = nshift;
-            state[tile].rank[combo] = rank - cum;
-            if (!first && shift == 0u) atomicOr(&state[tile].done, 1u << combo);
-        }
-    }
-    __syncthreads();
-    for (int i = threadIdx.x; i < 4 * SELQ_BINS; i += 256) h[i] = 0u;
-}
-
-// a selection that is not settled after the last pass comes back as NaN instead of a wrong value
-__global__ void k_selq_finish_checked(const SelQTile *state, long long ntiles, float *out)
-{
-    const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
-    if (i < ntiles * 4) out[i] = ((state[i >> 2].done >> (i & 3)) & 1u) ? key_f32(state[i >> 2].bias[i & 3]) : __builtin_nanf("");
-}
-
 }  // namespace lars
 
 // ===========================================================================
@@ -1064,80 +696,6 @@ void fused_v2_launch(unsigned mask, bool wb, int stats, bool nt, dim3 grid, hipS
 void chan_hist_v2_launch(const uint8_t *tiles, long long npix, unsigned int *hist, dim3 grid, hipStream_t s)
 {
     hipLaunchKernelGGL(k_chan_hist_u8c3_v2, grid, dim3(1024), 0, s, tiles, npix, hist);
-}
-
-int selq_pass_launch(const uint8_t *tiles, const uint8_t *wb_table, long long ntiles, long long npix, int first,
-                     const unsigned int bias[4], const unsigned int shift[4], unsigned long long *hist, hipStream_t s)
-{
-    SelQParams P;
-    memset(&P, 0, sizeof P);
-    P.tiles = tiles; P.wb_table = wb_table; P.npix = npix; P.first = first;
-    for (int c = 0; c < 4; ++c) { P.bias[c] = bias[c]; P.shift[c] = shift[c]; }
-    P.hist = hist;
-    long long bpt = (2048 + ntiles - 1) / ntiles;                  // ~2048 workgroups per launch
-    const long long cap = (npix / 4 + 1024 * 8 - 1) / (1024 * 8);  // at least ~8 steps per block (64 KiB table each)
-    if (bpt > cap) bpt = cap;
-    if (bpt < 1) bpt = 1;
-    dim3 grid((unsigned)bpt, (unsigned)ntiles);
-    if (wb_table) hipLaunchKernelGGL((k_selq_pass<true, false>), grid, dim3(1024), 0, s, P);
-    else hipLaunchKernelGGL((k_selq_pass<false, false>), grid, dim3(1024), 0, s, P);
-    return launch_check("k_selq_pass");
-}
-
-size_t selq_tile_scratch_bytes(long long ntiles)
-{
-    return (size_t)ntiles * (sizeof(SelQTile) + 4 * SELQ_BINS * sizeof(unsigned int)) + 512;
-}
-
-// medians of every tile: bucket pass + two digit passes, picks on the device, no host round trip
-// selq_tile_prepare: state + zeroed histograms (before a fused statistics + bucket pass); selq_tile_hist32: where that
-// pass adds its counts; selq_tile_medians_launch(..., first_pass_done): the remaining passes.
-static void selq_scratch_layout(void *scratch, long long ntiles, SelQTile **state, unsigned int **hist32)
-{
-    *state = static_cast<SelQTile *>(scratch);
-    *hist32 = reinterpret_cast<unsigned int *>(static_cast<char *>(scratch) + (((size_t)ntiles * sizeof(SelQTile) + 255) & ~(size_t)255));
-}
-unsigned int *selq_tile_hist32(void *scratch, long long ntiles)
-{
-    SelQTile *state; unsigned int *hist32;
-    selq_scratch_layout(scratch, ntiles, &state, &hist32);
-    return hist32;
-}
-int selq_tile_prepare(void *scratch, long long ntiles, long long npix, hipStream_t s, unsigned int streams)
-{
-    SelQTile *state; unsigned int *hist32;
-    selq_scratch_layout(scratch, ntiles, &state, &hist32);
-    hipLaunchKernelGGL(k_selq_init, dim3((unsigned)((ntiles + 255) / 256)), dim3(256), 0, s, state, ntiles, npix, streams);
-    if (hipMemsetAsync(hist32, 0, (size_t)ntiles * 4 * SELQ_BINS * sizeof(unsigned int), s) != hipSuccess)
-        return fail(LARS_ERR_HIP, "hipMemsetAsync failed (tile median scratch)");
-    return launch_check("selq_tile_prepare");
-}
-
-int selq_tile_medians_launch(const uint8_t *tiles, const uint8_t *wb_table, long long ntiles, long long npix, float *out_pairs,
-                             void *scratch, hipStream_t s, bool first_pass_done)
-{
-    SelQTile *state; unsigned int *hist32;
-    selq_scratch_layout(scratch, ntiles, &state, &hist32);
-    if (!first_pass_done) LARS_TRY(selq_tile_prepare(scratch, ntiles, npix, s, 3u));
-    long long bpt = (2048 + ntiles - 1) / ntiles;
-    const long long cap = (npix / 4 + 1024 * 8 - 1) / (1024 * 8);
-    if (bpt > cap) bpt = cap;
-    if (bpt < 1) bpt = 1;
-    dim3 grid((unsigned)bpt, (unsigned)ntiles);
-    // bucket pass + up to four digit passes (a key range is at most 2^32 wide: shifts 21, 10, 0 at worst, and one
-    // more pass to settle); uint8 tiles need two, exceptionally three -- a settled tile's blocks return at once
-    for (int p = 0; p < 5; ++p) {
-        SelQParams P;
-        memset(&P, 0, sizeof P);
-        P.tiles = tiles; P.wb_table = wb_table; P.npix = npix; P.first = p == 0;
-        P.state = state; P.hist32 = hist32;
-        if (p == 0 && first_pass_done) { /* counted by the statistics kernel */ }
-        else if (wb_table) hipLaunchKernelGGL((k_selq_pass<true, true>), grid, dim3(1024), 0, s, P);
-        else hipLaunchKernelGGL((k_selq_pass<false, true>), grid, dim3(1024), 0, s, P);
-        hipLaunchKernelGGL(k_selq_pick, dim3((unsigned)ntiles), dim3(256), 0, s, state, hist32, p == 0 ? 1 : 0);
-    }
-    hipLaunchKernelGGL(k_selq_finish_checked, dim3((unsigned)((ntiles * 4 + 255) / 256)), dim3(256), 0, s, state, ntiles, out_pairs);
-    return launch_check("selq_tile_medians");
 }
 
 int quot_check_launch(unsigned int max_den, unsigned long long *mismatches_dev, unsigned int *first_bad_dev, hipStream_t s)

@@ -1,0 +1,138 @@
+// Device helpers shared by the second-generation kernels (fused_v2.hip) and the exact-median select
+// (select_q.hip): exact quotient, the white-balance table lookup, the ring load pipeline, the select's bucket.
+#pragma once
+#include "common.h"
+#include "device_common.h"
+
+namespace lars {
+
+typedef unsigned int u32x3 __attribute__((ext_vector_type(3)));
+
+// ---------------------------------------------------------------------------
+// exact quotient for integer-valued operands: |num| <= den, 1 <= den < 2^24
+// ---------------------------------------------------------------------------
+__device__ inline float exact_quot(float num, float den)
+{
+#ifdef ABL_NODIV
+    return num * 0.001f + den * 0.0001f;
+#endif
+    const float r = __builtin_amdgcn_rcpf(den);
+    const float q0 = num * r;
+    const float e = __builtin_fmaf(-q0, den, num);
+    return __builtin_fmaf(e, r, q0);
+}
+// a+b == 0 (both samples 0) must give +0.0.  Instead of a max(den, 1) per quotient, the NIR value gets
+// a tiny epsilon once per pixel pair (one packed add shared by NDVI and GNDVI): float32(n + 1e-10) == n
+// for every n >= 1 and the epsilon is absorbed again by any other sample >= 1, so the denominator is
+// unchanged unless both samples are 0, where it becomes 1e-10 and the quotient (+0) * 1e10 = +0.0 --
+// the same device the reference uses (process-images.py:464).
+#define LARS_DEN_EPS 1e-10f
+
+// two quotients per instruction: v_pk_mul_f32 / v_pk_fma_f32 (the VALU issues one wave64
+// instruction per 4 cycles, packed or not -- rocprofv3: SQ_ACTIVE_INST_VALU / SQ_INSTS_VALU = 1.05 quad-cycles)
+typedef float f32x2 __attribute__((ext_vector_type(2)));
+// den must be >= 1 or the tiny positive stand-in for a zero sum (see LARS_DEN_EPS)
+__device__ inline f32x2 exact_quot2(f32x2 num, f32x2 den)
+{
+    f32x2 r;
+    r.x = __builtin_amdgcn_rcpf(den.x);
+    r.y = __builtin_amdgcn_rcpf(den.y);
+    const f32x2 q0 = num * r;
+    const f32x2 e = __builtin_elementwise_fma(-q0, den, num);
+    return __builtin_elementwise_fma(e, r, q0);
+}
+// (a-b)/(a+b) with +0.0 where a+b == 0
+__device__ inline float norm_diff_fast(float a, float b)
+{
+    const float s = a + b;
+    const float d = a - b;
+    return exact_quot(d, fmaxf(s, 1.0f));
+}
+
+
+#define V2_TABLE_BYTES 65536
+
+// byte k of a dword -> float in one VALU instruction.  Kept opaque (asm) so that hipcc does not
+// turn "float(a) +/- float(b)" into integer SDWA adds plus conversions (5 instructions per pixel
+// instead of 2 conversions + packed add/sub).
+__device__ inline float cvt_ubyte(unsigned int w, int k)
+{
+    float f;
+    switch (k) {
+    case 0: asm("v_cvt_f32_ubyte0 %0, %1" : "=v"(f) : "v"(w)); break;
+    case 1: asm("v_cvt_f32_ubyte1 %0, %1" : "=v"(f) : "v"(w)); break;
+    case 2: asm("v_cvt_f32_ubyte2 %0, %1" : "=v"(f) : "v"(w)); break;
+    default: asm("v_cvt_f32_ubyte3 %0, %1" : "=v"(f) : "v"(w)); break;
+    }
+    return f;
+}
+
+template <bool WB>
+__device__ inline float sample(unsigned int word, int byte, int ch, unsigned int lane_off4, const char *s_tab)
+{
+    if (!WB) return cvt_ubyte(word, byte);
+    // address = sample << 8 | lane*4 in one v_perm_b32 (S0 = word: selectors 4..7, S1 = lane_off4: 0..3)
+    const unsigned int sel = 0x0c0c0000u | ((4u + (unsigned)byte) << 8);
+    const unsigned int addr = __builtin_amdgcn_perm(word, lane_off4, sel);
+    const unsigned int entry = *reinterpret_cast<const unsigned int *>(s_tab + addr);
+    return cvt_ubyte(entry, ch);
+}
+template <bool WB>
+__device__ inline unsigned int sample_entry(unsigned int word, int byte, unsigned int lane_off4, const char *s_tab)
+{
+    const unsigned int sel = 0x0c0c0000u | ((4u + (unsigned)byte) << 8);
+    const unsigned int addr = __builtin_amdgcn_perm(word, lane_off4, sel);
+    return *reinterpret_cast<const unsigned int *>(s_tab + addr);
+}
+
+// first-level bucket of the exact-median select (see k_selq_pass below): round((x + 1) * 1023.5) in 0..2047,
+// left in the low mantissa bits of t + 2^23
+#define SELQ_BINS 2048
+#define SELQ_MAGIC_BITS 0x4B000000u                      /* float bits of 2^23: "bucket 0" */
+__device__ inline f32x2 selq_pos2(f32x2 x)
+{
+    const f32x2 k = {1023.5f, 1023.5f}, big = {8388608.0f, 8388608.0f};
+    return __builtin_elementwise_fma(x, k, k) + big;
+}
+__device__ inline void selq_add_pos(float pos, unsigned int base)      // base: LDS byte address of the row, less the shifted "bucket 0" bits
+{
+    const unsigned int addr = (__builtin_bit_cast(unsigned int, pos) << 2) + base;
+    asm volatile("ds_add_u32 %0, %1" : : "v"(addr), "v"(1u) : "memory");
+}
+
+// The fused kernel's load pipeline as a reusable loop: four 12-byte buffer loads in flight per lane, slot k is
+// consumed and refilled in place.  f(q, w0, w1, w2) sees every quad of the tile exactly once.
+template <int NTHR, typename F>
+__device__ inline void for_each_quad_ring(const uint8_t *base, long long nquads, F &&f)
+{
+    const long long stride = (long long)gridDim.x * NTHR;
+    const long long q0 = (long long)blockIdx.x * NTHR + threadIdx.x;
+    const long long niter = (nquads + stride - 1) / stride;          // same for every lane of the grid
+    if (niter <= 0) return;
+    const __amdgpu_buffer_rsrc_t rsrc =
+        __builtin_amdgcn_make_buffer_rsrc(const_cast<uint8_t *>(base), 0, (int)(nquads * 12), 0x00020000);
+    const unsigned int voff = (unsigned int)q0 * 12u;
+    const unsigned int step_b = (unsigned int)stride * 12u;
+    u32x3 w[4];
+#pragma unroll
+    for (int k = 0; k < 4; ++k) w[k] = __builtin_amdgcn_raw_buffer_load_b96(rsrc, voff, (unsigned)k * step_b, 0);
+    long long it = 0;
+    unsigned int soff = 4u * step_b;
+    for (; it + 4 <= niter - 1; it += 4) {
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            f(q0 + (it + k) * stride, w[k].x, w[k].y, w[k].z);
+            __builtin_amdgcn_sched_barrier(0);
+            w[k] = __builtin_amdgcn_raw_buffer_load_b96(rsrc, voff, soff + (unsigned)k * step_b, 0);
+            __builtin_amdgcn_sched_barrier(0);
+        }
+        soff += 4u * step_b;
+    }
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+        const long long qq = q0 + (it + k) * stride;
+        if (it + k < niter && qq < nquads) f(qq, w[k].x, w[k].y, w[k].z);
+    }
+}
+
+}  // namespace lars

@@ -133,9 +133,6 @@ __device__ inline void store4(float *dst, float a, float b, float c, float d)
 struct WaveAcc {
     float mn, mx;
     double sum, sumsq;
-#ifdef ABL_F32SUM
-    float fsum = 0;
-#endif
 };
 
 // LDS layout (dynamic): [WB table 64 KiB][hist 3*50*32 u32][edges 51 f32][reduce scratch]
@@ -205,15 +202,9 @@ __device__ inline void push(WaveAcc &a, unsigned int &above, float x, float thr)
 {
     a.mn = fminf(a.mn, x);
     a.mx = fmaxf(a.mx, x);
-#if defined(ABL_NOSUM)
-    asm volatile("" ::"v"(x));
-#elif defined(ABL_F32SUM)
-    a.fsum += x;
-#else
     const double xd = (double)x;
     a.sum += xd;
     if (STATS >= 2) a.sumsq += xd * xd;
-#endif
     if (COUNT) {
         if (LARS_COUNT_MODE == 0) count_gt(above, x, thr);           // wave-uniform scalar counter
         else vcount_gt(above, x, thr);                               // per-lane counter, folded at flush
@@ -398,15 +389,9 @@ __global__ __launch_bounds__(V2Block<OUT>::threads, OUT ? 4 : LARS_V2_STATS_WAVE
                 if (STATS >= 1) {
                     acc_g.mn = fminf(acc_g.mn, x);
                     acc_g.mx = fmaxf(acc_g.mx, x);
-#if defined(ABL_NOSUM)
-                    asm volatile("" ::"v"(x));
-#elif defined(ABL_F32SUM)
-                    acc_g.fsum += x;
-#else
                     const double xd = (double)x;
                     acc_g.sum += xd;
                     if (STATS >= 2) acc_g.sumsq += xd * xd;
-#endif
                     if (LARS_COUNT_MODE == 1) {
                         if (WANT_GNDVI) vcount_gt(above_g, x, 0.2f);
                         if (WANT_NDWI) vcount_lt(above_w, x, 0.0f);           // -x > 0
@@ -550,9 +535,6 @@ __global__ __launch_bounds__(V2Block<OUT>::threads, OUT ? 4 : LARS_V2_STATS_WAVE
         const int wave = tid >> 6;
         double *row = s_red + wave * 16;
         if (lane == 0) {
-#ifdef ABL_F32SUM
-            acc_v.sum = acc_v.fsum; acc_g.sum = acc_g.fsum;
-#endif
             row[0] = acc_v.sum; row[1] = acc_v.sumsq; row[2] = (double)acc_v.mn; row[3] = (double)acc_v.mx; row[4] = (double)above_v;
             row[5] = acc_g.sum; row[6] = acc_g.sumsq; row[7] = (double)acc_g.mn; row[8] = (double)acc_g.mx;
             row[9] = (double)above_g; row[10] = (double)above_w;

@@ -13,9 +13,6 @@ typedef unsigned int u32x3 __attribute__((ext_vector_type(3)));
 // ---------------------------------------------------------------------------
 __device__ inline float exact_quot(float num, float den)
 {
-#ifdef ABL_NODIV
-    return num * 0.001f + den * 0.0001f;
-#endif
     const float r = __builtin_amdgcn_rcpf(den);
     const float q0 = num * r;
     const float e = __builtin_fmaf(-q0, den, num);

@@ -380,6 +380,33 @@ def test_bad_arguments_fail_cleanly(lars):
     assert lib.lars_h_fix_white_balance(None, 4, 4, 3, _ffi.U8, 0, None, None) == -1
     assert lib.lars_h_analyze_f32(None, 0, 0.2, 0, None, None) == -1
     assert lib.lars_d_median_pair_f32(None, 10, None, None, None) == -1
+    # the newer entry points: select passes, statistics + medians, registration, change map, masks
+    stats = b.new_stats()
+    u4 = (C.c_uint32 * 4)(0, 0, 0, 0)
+    big_shift = (C.c_uint32 * 4)(32, 0, 0, 0)
+    hist64 = _ffi.DeviceBuffer(2 * 2 * 2048 * 8)
+    tp = C.c_void_p(b.tiles.ptr)
+    assert lib.lars_d_quotient_digit_hist(tp, 2, 256, 3, _ffi.U8, None, 1, u4, big_shift, C.c_void_p(hist64.ptr), None) == -1
+    assert lib.lars_d_quotient_digit_hist(tp, 2, 256, 4, _ffi.U8, None, 1, u4, u4, C.c_void_p(hist64.ptr), None) == -1
+    assert lib.lars_d_quotient_digit_hist(tp, 2, 256, 3, _ffi.U16, None, 1, u4, u4, C.c_void_p(hist64.ptr), None) == -1
+    assert lib.lars_d_quotient_median_pairs(tp, 2, 256, 3, _ffi.U8, None, None, None, None) == -1
+    sm = b.fused_args(("NDVI", "GNDVI"), True, stats, False, None)                      # two indices: not served
+    assert lib.lars_d_stats_medians(C.byref(sm), C.c_void_p(hist64.ptr), C.c_void_p(hist64.ptr)) == -1
+    sm = b.fused_args(("NDVI",), True, None, False, None)                               # no statistics records
+    assert lib.lars_d_stats_medians(C.byref(sm), C.c_void_p(hist64.ptr), C.c_void_p(hist64.ptr)) == -1
+    assert lib.lars_h_align_images(None, None, 8, 8, 3, None, None) == -1
+    img8 = np.zeros((8, 8, 4), np.uint8)
+    assert lib.lars_h_align_images(_ffi.ptr(img8), _ffi.ptr(img8), 8, 8, 4, _ffi.ptr(img8.copy()), None) == -1
+    assert lib.lars_h_change_detection(_ffi.ptr(img8), _ffi.ptr(img8), 8, 8, 4, 0, 0, 0, 7, None, None, None, None, None,
+                                       C.c_float(-0.5), C.c_float(0.5), None, None) == -1      # index_id out of range
+    x = np.zeros(16, np.float32)
+    rg = np.zeros((16, 4), np.uint8)
+    lut = np.zeros((256, 4), np.uint8)
+    assert lib.lars_h_colormap_norm_f32(_ffi.ptr(x), 16, C.c_float(0.5), C.c_float(0.5), _ffi.ptr(lut), _ffi.ptr(rg)) == -1   # vmax == vmin
+    assert lib.lars_h_threshold_mask_f32(None, 16, C.c_float(0.2), None) == -1
+    assert lib.lars_d_threshold_mask_f32(C.c_void_p(hist64.ptr + 4), 16, C.c_float(0.2), C.c_void_p(hist64.ptr), None) == -1  # misaligned
+    assert lib.lars_d_shift_reflect_u8(tp, 16, 16, 3, C.c_void_p(hist64.ptr), tp, None) == -1                                 # in place
+    hist64.free(); stats.free()
     assert lib.lars_set_tuning(b"no_such_knob", 1) == -1
     assert lib.lars_set_device(99) == -1 and b"out of range" in lib.lars_last_error()
     with pytest.raises(TypeError):

@@ -19,6 +19,8 @@ from .api import (  # noqa: F401
     colormap_lut,
     correct_white_balance,
     create_change_detection_visualization,
+    create_comparison_view,
+    create_index_visualization,
     create_time_series_plot,
     fix_white_balance,
     fix_white_balance_rgnir,

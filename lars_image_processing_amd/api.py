@@ -20,6 +20,7 @@ this module                     reference
 ``calculate_index_statistics_by_timeframe``  process-images.py:619 (pandas table)
 ``create_time_series_plot``     process-images.py:801  (figure; statistics from the GPU)
 ``create_change_detection_visualization``    process-images.py:885 (figure; arrays from the GPU)
+``create_index_visualization`` / ``create_comparison_view``  process-images.py:669 / :718 (figures; statistics from the GPU)
 ==============================  ============================================
 
 ``correct_white_balance`` and ``analyze_index_statistics`` are aliases (the
@@ -44,7 +45,8 @@ __all__ = [
     "analyze_ndvi_statistics", "index_histogram", "classification_mask", "colorize_index", "process_image",
     "timeseries_row", "colormap_lut", "preprocess_large_image", "align_images", "change_detection",
     "colorize_difference", "calculate_index_statistics_by_timeframe", "time_series_points",
-    "create_time_series_plot", "create_change_detection_visualization",
+    "create_time_series_plot", "create_change_detection_visualization", "create_index_visualization",
+    "create_comparison_view",
 ]
 
 _CMAPS = None
@@ -618,3 +620,60 @@ def create_change_detection_visualization(image_pair, index_type):
     buf.close()
     img.close()
     return img_copy
+
+
+def _figure_to_pil(fig, canvas, **save_kw):
+    import io
+    from PIL import Image
+    buf = io.BytesIO()
+    canvas.print_figure(buf, format="png", bbox_inches="tight", dpi=100, **save_kw)
+    buf.seek(0)
+    with Image.open(buf) as img:
+        return img.copy()
+
+
+def create_index_visualization(index_array, index_type, render="figure"):
+    """process-images.py:669-716: the index with its colormap and colorbar as a PIL image.
+
+    ``render="lut"`` returns the full-resolution per-pixel RGBA image of the same colormap instead (no axes, no
+    colorbar: a different picture, hence opt-in) -- one GPU pass, no matplotlib."""
+    if index_array is None or np.size(index_array) == 0:
+        return None
+    if render == "lut":
+        from PIL import Image
+        return Image.fromarray(colorize_index(index_array, index_type), "RGBA")
+    from matplotlib.backends.backend_agg import FigureCanvasAgg as FigureCanvas
+    from matplotlib.figure import Figure
+    fig = Figure(figsize=(10, 8))
+    canvas = FigureCanvas(fig)
+    ax = fig.add_subplot(111)
+    im = ax.imshow(index_array, cmap=_colormap_for(index_type), vmin=-1, vmax=1)
+    fig.colorbar(im, label=index_type)
+    ax.axis("off")
+    return _figure_to_pil(fig, canvas, pad_inches=0)
+
+
+def create_comparison_view(image_data_list, index_type=None):
+    """process-images.py:718-799: side-by-side panels + ``{filename: analyze_index(...)}`` (statistics on the GPU)."""
+    if not image_data_list:
+        return None, {}
+    from matplotlib.backends.backend_agg import FigureCanvasAgg as FigureCanvas
+    from matplotlib.figure import Figure
+    n = len(image_data_list)
+    fig = Figure(figsize=(4 * n, 4))
+    canvas = FigureCanvas(fig)
+    all_stats = {}
+    for k, image_data in enumerate(image_data_list, 1):
+        ax = fig.add_subplot(1, n, k)
+        arr = image_data["array"] if image_data.get("array") is not None else np.array(image_data["original"])
+        if index_type:
+            im = ax.imshow(arr, cmap=_colormap_for(index_type), vmin=-1, vmax=1)
+            fig.colorbar(im, ax=ax, label=index_type)
+            all_stats[image_data["metadata"]["filename"]] = analyze_index(arr, index_type)
+        else:
+            ax.imshow(arr)
+        if "metadata" in image_data and "filename" in image_data["metadata"]:
+            ax.set_title(image_data["metadata"]["filename"], fontsize=8)
+        ax.axis("off")
+    fig.tight_layout()
+    return _figure_to_pil(fig, canvas, pad_inches=0.1), all_stats

@@ -193,3 +193,15 @@ def test_figures_render(lars):
     fig = lars.create_change_detection_visualization(series[:2], "GNDVI")
     assert fig.size[0] > 600
     assert lars.create_change_detection_visualization(series[:1], "GNDVI") is None
+    # create_index_visualization / create_comparison_view (process-images.py:669-799)
+    idx = lars.calculate_index(orc.wb_app(series[0]["array"]), "NDWI")
+    assert lars.create_index_visualization(idx, "NDWI").size[0] > 300
+    assert lars.create_index_visualization(None, "NDWI") is None
+    lut_img = lars.create_index_visualization(idx, "NDWI", render="lut")
+    assert lut_img.size == (idx.shape[1], idx.shape[0]) and lut_img.mode == "RGBA"
+    panels = [{"metadata": {"filename": f"f{k}.png"}, "array": lars.calculate_index(orc.wb_app(s_["array"]), "NDVI")}
+              for k, s_ in enumerate(series)]
+    view, stats = lars.create_comparison_view(panels, "NDVI")
+    assert view.size[0] > 300 and list(stats) == ["f0.png", "f1.png", "f2.png"]
+    assert stats["f1.png"] == lars.analyze_index(panels[1]["array"], "NDVI")
+    assert lars.create_comparison_view([], "NDVI") == (None, {})

@@ -22,8 +22,10 @@ from .api import (  # noqa: F401
     create_comparison_view,
     create_index_visualization,
     create_time_series_plot,
+    download_processed_images,
     fix_white_balance,
     fix_white_balance_rgnir,
+    generate_ndvi_report,
     index_histogram,
     preprocess_large_image,
     process_image,

@@ -21,6 +21,8 @@ this module                     reference
 ``create_time_series_plot``     process-images.py:801  (figure; statistics from the GPU)
 ``create_change_detection_visualization``    process-images.py:885 (figure; arrays from the GPU)
 ``create_index_visualization`` / ``create_comparison_view``  process-images.py:669 / :718 (figures; statistics from the GPU)
+``download_processed_images``   process-images.py:567  (ZIP of the processed images)
+``generate_ndvi_report``        process-ndvi.py:75     (figure + histogram + statistics file; BASELINE configs[0])
 ==============================  ============================================
 
 ``correct_white_balance`` and ``analyze_index_statistics`` are aliases (the
@@ -46,7 +48,7 @@ __all__ = [
     "timeseries_row", "colormap_lut", "preprocess_large_image", "align_images", "change_detection",
     "colorize_difference", "calculate_index_statistics_by_timeframe", "time_series_points",
     "create_time_series_plot", "create_change_detection_visualization", "create_index_visualization",
-    "create_comparison_view",
+    "create_comparison_view", "generate_ndvi_report", "download_processed_images",
 ]
 
 _CMAPS = None
@@ -677,3 +679,37 @@ def create_comparison_view(image_data_list, index_type=None):
         ax.axis("off")
     fig.tight_layout()
     return _figure_to_pil(fig, canvas, pad_inches=0.1), all_stats
+
+
+def download_processed_images(image_data, corrected_array, selected_indices, render="figure"):
+    """process-images.py:567-617: ZIP bytes with ``white_balanced.png`` and ``<INDEX>_visualization.png`` per index.
+
+    ``render="figure"`` keeps the reference's matplotlib pictures; ``render="lut"`` writes full-resolution per-pixel
+    colormap images from one GPU pass (``driver.export_zip``)."""
+    from .driver import export_zip
+    return export_zip(None if image_data is None else image_data.get("array"), selected_indices,
+                      corrected_array=corrected_array, render=render)
+
+
+def generate_ndvi_report(image_path, output_dir):
+    """process-ndvi.py:75-110: ``ndvi_visualization.png``, ``ndvi_histogram.png`` and ``ndvi_statistics.txt`` in
+    ``output_dir``; returns ``(ndvi_array, stats)``.  NDVI, statistics and the 50 histogram counts come from the GPU,
+    the two figures are matplotlib plumbing as upstream."""
+    import matplotlib.pyplot as plt
+    os.makedirs(output_dir, exist_ok=True)
+    ndvi_array = calculate_ndvi(image_path, os.path.join(output_dir, "ndvi_visualization.png"), visualize=False)
+    stats = analyze_ndvi_statistics(ndvi_array)
+    counts = index_histogram(ndvi_array)
+    edges = np.linspace(-1.0, 1.0, 51)
+    plt.figure(figsize=(10, 6))
+    plt.hist(edges[:-1], bins=edges, weights=counts)        # the bars plt.hist(ndvi.flatten(), bins=50, range=(-1, 1)) draws
+    plt.title("Distribution of NDVI Values")
+    plt.xlabel("NDVI")
+    plt.ylabel("Pixel Count")
+    plt.savefig(os.path.join(output_dir, "ndvi_histogram.png"))
+    plt.close()
+    with open(os.path.join(output_dir, "ndvi_statistics.txt"), "w") as f:
+        f.write("NDVI Statistics:\n")
+        for key, value in stats.items():
+            f.write(f"{key}: {value:.4f}\n")
+    return ndvi_array, stats

@@ -70,3 +70,31 @@ def test_export_zip(tmp_path):
     with zipfile.ZipFile(io.BytesIO(data2)) as zf:
         got = np.array(Image.open(io.BytesIO(zf.read("NDVI_visualization.png"))))
         np.testing.assert_array_equal(got, orc.colormap_closed_form(orc.index_app(want_wb, "NDVI"), lars.colormap_lut("RdYlGn")))
+
+
+def test_ndvi_report_and_zip_keep_the_reference_file_layout(tmp_path):
+    """process-ndvi.py:75-110 (BASELINE configs[0]: one 512x512 uint8 RGNir PNG, NDVI only) and process-images.py:567-617."""
+    import io
+    import zipfile
+    from PIL import Image
+    import lars_image_processing_amd as lars
+    from oracle import index_oracle as orc
+    img = np.random.default_rng(0).integers(0, 256, (512, 512, 3), dtype=np.uint8)
+    src = tmp_path / "in.png"
+    Image.fromarray(img).save(src)
+    out = tmp_path / "report"
+    ndvi, stats = lars.generate_ndvi_report(str(src), str(out))
+    want = orc.ndvi_f64(img)
+    np.testing.assert_array_equal(ndvi.view(np.uint64), want.view(np.uint64))
+    ws = orc.stats_ndvi(want)
+    assert list(stats) == list(ws)
+    for k, v in ws.items():
+        assert stats[k] == pytest.approx(v, rel=1e-9, abs=1e-12), k
+    assert sorted(p.name for p in out.iterdir()) == ["ndvi_histogram.png", "ndvi_statistics.txt", "ndvi_visualization.png"]
+    text = (out / "ndvi_statistics.txt").read_text().splitlines()
+    assert text[0] == "NDVI Statistics:" and text[1:] == [f"{k}: {v:.4f}" for k, v in ws.items()]
+    corrected = lars.fix_white_balance(img)
+    blob = lars.download_processed_images({"array": img}, corrected, ["NDVI", "NDWI"])
+    with zipfile.ZipFile(io.BytesIO(blob)) as zf:
+        assert zf.namelist() == ["white_balanced.png", "NDVI_visualization.png", "NDWI_visualization.png"]
+        np.testing.assert_array_equal(np.array(Image.open(io.BytesIO(zf.read("white_balanced.png")))), corrected)

@@ -159,6 +159,12 @@ def test_full_size_tile_properties(lars):
         want_wb = orc.wb_app(tiles1)
     np.testing.assert_array_equal(wb, want_wb)
     assert lb.summarize(lb.merge_records(rec[:, 0]))["count"] == 2 * n
+    # exact medians at full size, none of them through a stored plane: per tile and over both tiles
+    rec_m, med = b.process(medians=True)
+    assert med[1, 0] == float(np.median(ndvi))
+    assert float(rec_m[1, 0]["sum"]) == float(rec[1, 0]["sum"]) and int(rec_m[1, 0]["above"]) == int(rec[1, 0]["above"])
+    both = np.concatenate([outs.host_index("NDVI", 0, 1)[0].ravel(), ndvi.ravel()])
+    assert b.global_medians(("NDVI",))["NDVI"] == float(np.median(both))
     outs.free()
     b.free()
 

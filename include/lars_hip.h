@@ -263,7 +263,7 @@ int lars_d_colormap_norm_f32(const float *x, int64_t n, float vmin, float vmax, 
 int lars_d_synth_u8(uint8_t *tiles, int64_t ntiles, int64_t first_tile, int64_t npix, int channels,
                     uint32_t seed, int profile, void *stream);
 
-/* Tuning knobs (per process): "fused_impl" 0 (auto)|1|2, "hist_impl" 1|2, "nt_stores" 0|1, "nt_loads" 0|1,
+/* Tuning knobs (per process): "fused_impl" 0 (auto)|1|2, "hist_impl" 1|2, "nt_stores" 0|1,
  * "blocks_per_tile" 0 = automatic.  Results never depend on them. */
 int lars_set_tuning(const char *key, int value);
 int lars_get_tuning(const char *key, int *value);

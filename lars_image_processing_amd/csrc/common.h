@@ -106,10 +106,7 @@ struct Tuning {
     int fused_impl = 0;        // 0: automatic, 1: first-generation kernels (fused.hip), 2: fused_v2.hip
     int hist_impl = 2;
     int nt_stores = 0;         // non-temporal stores for the float32 planes
-    int nt_loads = 0;          // non-temporal loads of the (read-once) tiles
-    int prefetch = 0;          // first-generation kernels: request the next step's input one step ahead
     int blocks_per_tile = 0;   // 0 = automatic
-    int sumsq_everywhere = 0;
 };
 Tuning &tuning();
 

@@ -376,19 +376,9 @@ __global__ __launch_bounds__(256) void k_fused_u8c3(FusedParams P)
 
     const long long nquads = npix >> 2;
     const long long stride = (long long)gridDim.x * 256;
-    const bool nt_ld = (P.flags & 0x40000000u) != 0, nt_st = (P.flags & 0x20000000u) != 0;
+    const bool nt_st = (P.flags & 0x20000000u) != 0;
     __amdgpu_buffer_rsrc_t rsrc16;
     if (U16) rsrc16 = __builtin_amdgcn_make_buffer_rsrc(const_cast<PIX *>(base), 0, (int)(nquads * 24), 0x00020000);
-    // uint8: the next step's 12 bytes are requested before this step's arithmetic (one load in flight
-    // per lane on top of the 32 resident waves per CU); the address is clamped, never predicated, so
-    // the load lands in its own registers without copies
-    unsigned int nw0 = 0, nw1 = 0, nw2 = 0;
-    const bool prefetch = !U16 && (P.flags & 0x10000000u) != 0;
-    if (prefetch && (long long)blockIdx.x * 256 + tid < nquads) {
-        const unsigned int *p = reinterpret_cast<const unsigned int *>(reinterpret_cast<const uint8_t *>(base) +
-                                                                      ((long long)blockIdx.x * 256 + tid) * 12);
-        nw0 = p[0]; nw1 = p[1]; nw2 = p[2];
-    }
     for (long long q = (long long)blockIdx.x * 256 + tid; q < nquads; q += stride) {
         unsigned int b[12];
         if (U16) {
@@ -400,14 +390,7 @@ __global__ __launch_bounds__(256) void k_fused_u8c3(FusedParams P)
             for (int i = 0; i < 6; ++i) { b[2 * i] = w[i] & 0xFFFFu; b[2 * i + 1] = w[i] >> 16; }
         } else {
             const unsigned int *p = reinterpret_cast<const unsigned int *>(reinterpret_cast<const uint8_t *>(base) + q * 12);
-            unsigned int w0, w1, w2;
-            if (prefetch) {
-                w0 = nw0; w1 = nw1; w2 = nw2;
-                const long long qn = q + stride < nquads ? q + stride : q;
-                const unsigned int *pn = reinterpret_cast<const unsigned int *>(reinterpret_cast<const uint8_t *>(base) + qn * 12);
-                nw0 = pn[0]; nw1 = pn[1]; nw2 = pn[2];
-            } else if (nt_ld) { w0 = __builtin_nontemporal_load(p); w1 = __builtin_nontemporal_load(p + 1); w2 = __builtin_nontemporal_load(p + 2); }
-            else { w0 = p[0]; w1 = p[1]; w2 = p[2]; }
+            const unsigned int w0 = p[0], w1 = p[1], w2 = p[2];
             const unsigned int t[12] = {w0 & 0xFF, (w0 >> 8) & 0xFF, (w0 >> 16) & 0xFF, w0 >> 24,
                                         w1 & 0xFF, (w1 >> 8) & 0xFF, (w1 >> 16) & 0xFF, w1 >> 24,
                                         w2 & 0xFF, (w2 >> 8) & 0xFF, (w2 >> 16) & 0xFF, w2 >> 24};
@@ -725,8 +708,7 @@ extern "C" int lars_d_fused(const lars_fused_args *a)
         P.cmap_lut[k] = a->cmap_lut[k];
     }
     P.out_wb = a->out_wb; P.stats = a->stats; P.mask = mask; P.sel_hist = nullptr;
-    P.flags = (a->flags & 3u) | (tuning().nt_loads ? 0x40000000u : 0u) | (tuning().nt_stores ? 0x20000000u : 0u) |
-              (tuning().prefetch ? 0x10000000u : 0u);
+    P.flags = (a->flags & 3u) | (tuning().nt_stores ? 0x20000000u : 0u);
 
     const long long nrec = a->ntiles * 3;
     if (stats_mode)

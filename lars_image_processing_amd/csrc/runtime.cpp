@@ -275,8 +275,6 @@ int lars_set_tuning(const char *key, int value)
     if (!strcmp(key, "fused_impl")) t.fused_impl = value;
     else if (!strcmp(key, "hist_impl")) t.hist_impl = value;
     else if (!strcmp(key, "nt_stores")) t.nt_stores = value;
-    else if (!strcmp(key, "nt_loads")) t.nt_loads = value;
-    else if (!strcmp(key, "prefetch")) t.prefetch = value;
     else if (!strcmp(key, "blocks_per_tile")) t.blocks_per_tile = value;
     else return fail(LARS_ERR_INVALID, "lars_set_tuning: unknown key %s", key);
     return LARS_OK;
@@ -288,8 +286,6 @@ int lars_get_tuning(const char *key, int *value)
     if (!strcmp(key, "fused_impl")) *value = t.fused_impl;
     else if (!strcmp(key, "hist_impl")) *value = t.hist_impl;
     else if (!strcmp(key, "nt_stores")) *value = t.nt_stores;
-    else if (!strcmp(key, "nt_loads")) *value = t.nt_loads;
-    else if (!strcmp(key, "prefetch")) *value = t.prefetch;
     else if (!strcmp(key, "blocks_per_tile")) *value = t.blocks_per_tile;
     else return fail(LARS_ERR_INVALID, "lars_get_tuning: unknown key %s", key);
     return LARS_OK;

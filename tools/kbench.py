@@ -55,9 +55,7 @@ def main():
     ap.add_argument("--modes", default=",".join(MODES))
     ap.add_argument("--impls", default="1,2")
     ap.add_argument("--nt", default="0,1")
-    ap.add_argument("--ntl", default="0", help="non-temporal loads: 0, 1 or 0,1")
     ap.add_argument("--bpt", default="0")
-    ap.add_argument("--prefetch", default="0", help="first-generation kernels: 0, 1 or 0,1")
     ap.add_argument("--wb", default="1")
     ap.add_argument("--profile", default="vegetation")
     args = ap.parse_args()
@@ -70,18 +68,17 @@ def main():
     results = {}
 
     if "hist" in args.what:
-        variants = [(i, bp, nl) for i in map(int, args.impls.split(",")) for bp in map(int, args.bpt.split(","))
-                    for nl in map(int, args.ntl.split(","))]
+        variants = [(i, bp) for i in map(int, args.impls.split(",")) for bp in map(int, args.bpt.split(","))]
         times = {v: [] for v in variants}
         for _ in range(args.rounds + 1):
             for v in variants:
-                _ffi.set_tuning(hist_impl=v[0], blocks_per_tile=v[1], nt_loads=v[2])
+                _ffi.set_tuning(hist_impl=v[0], blocks_per_tile=v[1])
                 times[v].append(timer.time(lambda: _ffi.call(
                     "lars_d_channel_hist", C.c_void_p(b.tiles.ptr), b.ntiles, b.npix, 3, _ffi.U8,
                     C.c_void_p(b.hist.ptr), None)))
         for v, t in times.items():
             med = float(np.median(t[1:]))
-            results[f"hist impl={v[0]} bpt={v[1]} ntl={v[2]}"] = {"ms": med, "min_ms": float(min(t[1:])), "GBs": npix * 3 / med / 1e6}
+            results[f"hist impl={v[0]} bpt={v[1]}"] = {"ms": med, "min_ms": float(min(t[1:])), "GBs": npix * 3 / med / 1e6}
         _ffi.set_tuning(blocks_per_tile=0)
 
     if "fused" in args.what:
@@ -95,20 +92,18 @@ def main():
                         continue
                     for bp in map(int, args.bpt.split(",")):
                         for wb in map(int, args.wb.split(",")):
-                            for nl in map(int, args.ntl.split(",")):
-                                for pf in map(int, args.prefetch.split(",")):
-                                    variants.append((m, impl, nt, bp, wb, nl, pf))
+                            variants.append((m, impl, nt, bp, wb))
         times = {v: [] for v in variants}
         for _ in range(args.rounds + 1):
             for v in variants:
-                m, impl, nt, bp, wb, nl, pf = v
+                m, impl, nt, bp, wb = v
                 indices, write, hist, bpp = MODES[m]
                 outs = None
                 if write:
                     if indices not in outs_cache:
                         outs_cache[indices] = b.make_outputs(indices=indices, index=True, ring=args.ring)
                     outs = outs_cache[indices]
-                _ffi.set_tuning(fused_impl=impl, nt_stores=nt, blocks_per_tile=bp, nt_loads=nl, prefetch=pf)
+                _ffi.set_tuning(fused_impl=impl, nt_stores=nt, blocks_per_tile=bp)
 
                 def run():
                     if outs is None:
@@ -119,10 +114,10 @@ def main():
                             b.run_fused(b.fused_args(indices, bool(wb), stats, hist, outs, None, start, cnt))
                 times[v].append(timer.time(run))
         for v, t in times.items():
-            m, impl, nt, bp, wb, nl, pf = v
+            m, impl, nt, bp, wb = v
             med = float(np.median(t[1:]))
             bpp = MODES[m][3]
-            results[f"fused {m} impl={impl} nt={nt} ntl={nl} pf={pf} bpt={bp} wb={wb}"] = {
+            results[f"fused {m} impl={impl} nt={nt} bpt={bp} wb={wb}"] = {
                 "ms": med, "min_ms": float(min(t[1:])), "GBs": npix * bpp / med / 1e6,
                 "frac_8TBs": npix * bpp / med / 1e6 / 8000.0, "Gpix_s": npix / med / 1e6}
     if "medians" in args.what:

@@ -206,12 +206,11 @@ int lars_d_median_pair_batch_f32(const float *x, int64_t n, int64_t items, int64
 /* One radix-select pass over the index values of a batch WITHOUT the planes in memory (exact batch /
  * global medians): the NDVI and GNDVI quotients of every pixel are recomputed from the
  * uint8 tiles.  first != 0: each value is counted in one of 2048 linear buckets of [-1, 1]
- * (bucket = low 23 bits of float32(fma(x, 1023.5, 1023.5) + 2^23); track = lane parity, add the two
- * tracks).  Otherwise, per stream s and track t, the value's order-preserving key (x >= 0: bits | 2^31,
- * x < 0: ~bits) is counted in bin (key - bias[2s+t]) >> shift[2s+t] when that is below 2048; a
- * (bias, shift) shared by both tracks of a stream is counted once, under track 0.  hist is
- * uint64[2 streams][2 tracks][2048], accumulated with atomics (zero it first).  NDWI = -GNDVI shares
- * GNDVI's order statistics. */
+ * (bucket = low 23 bits of float32(fma(x, 1023.5, 1023.5) + 2^23)), under track 0.  Otherwise, per stream s
+ * and track t, the value's order-preserving key (x >= 0: bits | 2^31, x < 0: ~bits) is counted in bin
+ * (key - bias[2s+t]) >> shift[2s+t] when that is below 1984; when both tracks of BOTH streams share
+ * (bias, shift) only track 0 is counted.  hist is uint64[2 streams][2 tracks][2048], accumulated with
+ * atomics (zero it first).  NDWI = -GNDVI shares GNDVI's order statistics. */
 int lars_d_quotient_digit_hist(const void *tiles, int64_t ntiles, int64_t npix, int channels, int dtype,
                                const uint8_t *wb_table, int first, const uint32_t bias[4], const uint32_t shift[4],
                                uint64_t *hist, void *stream);

@@ -378,6 +378,8 @@ def timeseries_rows(records, medians, index_type, dates=None):
 # exact order statistics across tiles and ranks (radix select on recomputed values)
 # ---------------------------------------------------------------------------
 SELECT_BINS = 2048
+SELECT_DIGITS = 1984                                       # usable bins of a later pass (the kernel keeps 64 dummy words per row)
+SELECT_DIGIT_BITS = 10                                     # 2^10 <= SELECT_DIGITS
 KEY_MINUS1, KEY_PLUS1, KEY_ZERO = 0x407FFFFF, 0xBF800000, 0x80000000     # order-preserving keys of -1.0, +1.0, +0.0
 
 
@@ -413,12 +415,13 @@ def bucket_lower_key(b):
     return lo
 
 
-def select_order_statistics(pass_fn, n_local, comm=None, min_abs=0.0, max_passes=6):
+def select_order_statistics(pass_fn, n_local, comm=None, min_abs=0.0, max_passes=8):
     """Keys of the two middle order statistics (ranks (N-1)//2 and N//2) of two value streams in [-1, 1].
 
     ``pass_fn(first, bias[4], shift[4]) -> uint64[2][2][SELECT_BINS]`` counts on this rank: first pass, the
-    linear bucket of every value (split over the two tracks); later passes, bin ``(key - bias) >> shift`` of the
-    keys inside the chosen range (a (bias, shift) shared by both tracks of a stream once, under track 0).
+    linear bucket of every value (under track 0); later passes, bin ``(key - bias) >> shift`` (below
+    ``SELECT_DIGITS``) of the keys inside the chosen range -- under track 0 only when both streams' tracks share
+    (bias, shift).
     Histograms are summed over ranks through ``comm.allreduce_f64`` (counts < 2^53 are exact in float64), every
     rank then picks the same bins.  ``min_abs``: the values are 0 or at least that large in magnitude (uint8
     quotients: 1/510), which cuts the bucket around zero down to the key of +0.0.  Returns uint32[2][2].
@@ -436,12 +439,12 @@ def select_order_statistics(pass_fn, n_local, comm=None, min_abs=0.0, max_passes
             hist = comm.allreduce_f64(hist, "sum")
         hist = np.asarray(hist).reshape(2, 2, SELECT_BINS).astype(np.int64)
         if first:
-            hist[:, 0] += hist[:, 1]                        # bucket pass: the two tracks are two copies
+            hist[:, 0] += hist[:, 1]                        # bucket pass: counted under track 0
             hist[:, 1] = hist[:, 0]
         else:
-            for s in range(2):                              # a shared (bias, shift) is counted once, under track 0
-                if bias[s, 0] == bias[s, 1] and shift[s, 0] == shift[s, 1]:
-                    hist[s, 1] = hist[s, 0]
+            hist[:, :, SELECT_DIGITS:] = 0                  # not part of a later pass's histogram
+            if (bias[:, 0] == bias[:, 1]).all() and (shift[:, 0] == shift[:, 1]).all():
+                hist[:, 1] = hist[:, 0]                     # both streams' tracks shared: only track 0 was counted
         last = not first and not shift.any()
         for s in range(2):
             for t in range(2):
@@ -456,11 +459,14 @@ def select_order_statistics(pass_fn, n_local, comm=None, min_abs=0.0, max_passes
                     if min_abs > 0 and lo <= KEY_ZERO < hi and float32_to_key(-min_abs) < lo and hi <= float32_to_key(min_abs):
                         lo, hi = KEY_ZERO, KEY_ZERO + 1     # only +0.0 lives there
                     span = hi - lo - 1
+                    sh = 0
+                    while (span >> sh) >= SELECT_DIGITS:    # the first digit must fit a row
+                        sh += 1
                     bias[s, t] = lo
-                    shift[s, t] = 0 if span < SELECT_BINS else span.bit_length() - 11
+                    shift[s, t] = sh
                 else:
                     bias[s, t] = np.uint32(int(bias[s, t]) + (d << int(shift[s, t])))
-                    shift[s, t] = max(int(shift[s, t]) - 11, 0)
+                    shift[s, t] = max(int(shift[s, t]) - SELECT_DIGIT_BITS, 0)
         if last:
             return bias
         first = False

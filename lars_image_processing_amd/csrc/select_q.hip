@@ -17,11 +17,14 @@ namespace lars {
 //            unlike the key's top bits it spreads an index plane over hundreds of LDS words)
 //   pick     bucket holding the rank -> its key range [lo, hi) by bisection with the same arithmetic
 //   pass 2+  digit d = (key - bias) >> shift of the keys inside the range (anything else lands on a per-lane dummy
-//            word: d is compared with the row length by one v_min, no branch); shift drops by 11 per pass until 0.
-// uint8 quotients are 0 or at least 1/510 in magnitude, so a bucket is at most 2^22 keys wide (three passes) once
-// the bucket around zero is cut down to the single key of +0.0.
+//            word: d is compared with the row's usable length by one v_min, no branch); the first digit takes whatever
+//            shift makes it fit 1984 bins, then the shift drops by 10 per pass until 0.
+// uint8 quotients are 0 or at least 1/510 in magnitude, so a bucket is at most 2^22 keys wide (three passes, four for
+// medians below 2^-7 in magnitude) once the bucket around zero is cut down to the single key of +0.0.
+// LDS: the 64 KiB white-balance table + one 2048-word row per stream = exactly 80 KiB, two blocks per CU.
 // ---------------------------------------------------------------------------
-#define SELQ_ROW (SELQ_BINS + 64)
+#define SELQ_DIGITS 1984                                  /* digits per row in the later passes; words 1984..2047 are per-lane dummies */
+#define SELQ_DIGIT_BITS 10                                /* 2^10 <= SELQ_DIGITS: a picked bin splits into at most that many */
 #define SELQ_KEY_MINUS1 0x407FFFFFu                        /* f32_key(-1.0f) */
 #define SELQ_KEY_PLUS1 0xBF800000u                         /* f32_key(+1.0f) */
 #define SELQ_KEY_ZERO 0x80000000u                          /* f32_key(+0.0f) */
@@ -65,10 +68,11 @@ struct SelQTile {
 };
 
 template <bool WB, bool PER_TILE>
-__global__ __launch_bounds__(1024) void k_selq_pass(SelQParams P)
+__global__ __launch_bounds__(1024, 8) void k_selq_pass(SelQParams P)
 {
+    // 64 KiB table + one 2048-word row per stream = exactly 80 KiB: two blocks per CU, 8 waves per SIMD
     __shared__ __attribute__((aligned(16))) char s_tab[WB ? V2_TABLE_BYTES : 16];
-    __shared__ unsigned int s_h[4 * SELQ_ROW];             // per (stream, track): 2048 bins + one dummy word per lane
+    __shared__ unsigned int s_h[2 * SELQ_BINS];
     const int tid = threadIdx.x;
     const unsigned int lane_off4 = (tid & 63u) << 2;
     const long long tile = blockIdx.y;
@@ -84,39 +88,33 @@ __global__ __launch_bounds__(1024) void k_selq_pass(SelQParams P)
             tab[i] = (unsigned)t[v] | ((unsigned)t[256 + v] << 8) | ((unsigned)t[512 + v] << 16);
         }
     }
-    for (int i = tid; i < 4 * SELQ_ROW; i += 1024) s_h[i] = 0;
+    for (int i = tid; i < 2 * SELQ_BINS; i += 1024) s_h[i] = 0;
     __syncthreads();
 
     const unsigned int *bias = PER_TILE ? P.state[tile].bias : P.bias;
     const unsigned int *shft = PER_TILE ? P.state[tile].shift : P.shift;
-    const unsigned int ba0 = bias[0], ba1 = bias[1], bb0 = bias[2], bb1 = bias[3];
-    const unsigned int sa0 = shft[0], sa1 = shft[1], sb0 = shft[2], sb1 = shft[3];
-    const unsigned int my_track = tid & 1u;                 // first pass: the two tracks are two copies
+    const unsigned int ba[2] = {bias[0], bias[1]}, bb[2] = {bias[2], bias[3]};
+    const unsigned int sa[2] = {shft[0], shft[1]}, sb[2] = {shft[2], shft[3]};
     const long long nquads = npix >> 2;
     const unsigned int sign_bit = 0x80000000u;
-    const unsigned int dummy_idx = SELQ_BINS + (tid & 63u); // a value outside the range adds to its lane's dummy word
+    const unsigned int dummy_idx = SELQ_DIGITS + (tid & 63u);     // a value outside the range adds to its lane's dummy word
 
-    // The loop is compiled three times and chosen by ONE uniform branch (the conditions never change inside a block):
-    // MODE 0 bucket pass, MODE 1 both streams' two ranks still share (bias, shift) -- counted once, under track 0 --,
-    // MODE 2 general.  No divergence in any of them.
-    auto run = [&](auto mode_tag) {
+    // one sweep over the tile: MODE 0 counts buckets, MODE 1 digits (key - bias) >> shift of both streams; no divergence
+    // (a digit is compared with the row's usable length by one v_min)
+    auto sweep = [&](auto mode_tag, unsigned int b0, unsigned int s0, unsigned int b1, unsigned int s1) {
         constexpr int MODE = decltype(mode_tag)::value;
-        auto push_n = [&](int stream, const float *x, int nval, unsigned int b0, unsigned int s0, unsigned int b1, unsigned int s1) {
+        auto push_n = [&](int stream, const float *x, int nval, unsigned int bs, unsigned int sh) {
             for (int j = 0; j < nval; ++j) {
                 if (MODE == 0) {
-                    atomicAdd(&s_h[(stream * 2 + my_track) * SELQ_ROW + selq_bucket(x[j])], 1u);
+                    atomicAdd(&s_h[stream * SELQ_BINS + selq_bucket(x[j])], 1u);
                     continue;
                 }
                 const unsigned int bits_j = __builtin_bit_cast(unsigned int, x[j]);
                 unsigned int key;
                 // order-preserving key: x >= 0 -> bits | 2^31, x < 0 -> ~bits
                 asm("v_ashrrev_i32 %0, 31, %1\n\tv_or_b32 %0, %2, %0\n\tv_xor_b32 %0, %0, %1" : "=&v"(key) : "v"(bits_j), "v"(sign_bit));
-                const unsigned int d0 = (key - b0) >> s0;
-                atomicAdd(&s_h[(stream * 2 + 0) * SELQ_ROW + (d0 < dummy_idx ? d0 : dummy_idx)], 1u);
-                if (MODE == 2) {
-                    const unsigned int d1 = (key - b1) >> s1;
-                    atomicAdd(&s_h[(stream * 2 + 1) * SELQ_ROW + (d1 < dummy_idx ? d1 : dummy_idx)], 1u);
-                }
+                const unsigned int d = (key - bs) >> sh;
+                atomicAdd(&s_h[stream * SELQ_BINS + (d < dummy_idx ? d : dummy_idx)], 1u);
             }
         };
         for_each_quad_ring<1024>(base, nquads, [&](long long, unsigned int w0, unsigned int w1, unsigned int w2) {
@@ -136,8 +134,8 @@ __global__ __launch_bounds__(1024) void k_selq_pass(SelQParams P)
                 const f32x2 v = exact_quot2(N - R, Ne + R), g = exact_quot2(N - G, Ne + G);
                 qv[2 * h] = v.x; qv[2 * h + 1] = v.y; qg[2 * h] = g.x; qg[2 * h + 1] = g.y;
             }
-            push_n(0, qv, 4, ba0, sa0, ba1, sa1);
-            push_n(1, qg, 4, bb0, sb0, bb1, sb1);
+            push_n(0, qv, 4, b0, s0);
+            push_n(1, qg, 4, b1, s1);
         });
         if (blockIdx.x == 0 && tid < (int)(npix & 3)) {
             const long long i = nquads * 4 + tid;
@@ -147,24 +145,38 @@ __global__ __launch_bounds__(1024) void k_selq_pass(SelQParams P)
                 r = tab[r * 64] & 0xFFu; g = (tab[g * 64] >> 8) & 0xFFu; n = (tab[n * 64] >> 16) & 0xFFu;
             }
             const float tv = norm_diff_fast((float)n, (float)r), tg = norm_diff_fast((float)n, (float)g);
-            push_n(0, &tv, 1, ba0, sa0, ba1, sa1);
-            push_n(1, &tg, 1, bb0, sb0, bb1, sb1);
+            push_n(0, &tv, 1, b0, s0);
+            push_n(1, &tg, 1, b1, s1);
         }
     };
-    if (P.first) run(std::integral_constant<int, 0>{});
-    else if (ba0 == ba1 && sa0 == sa1 && bb0 == bb1 && sb0 == sb1) run(std::integral_constant<int, 1>{});
-    else run(std::integral_constant<int, 2>{});
-    __syncthreads();
-    if (PER_TILE) {
-        unsigned int *h = P.hist32 + tile * (4 * SELQ_BINS);
-        for (int i = tid; i < 4 * SELQ_BINS; i += 1024) {
-            const unsigned int v = s_h[(i >> 11) * SELQ_ROW + (i & (SELQ_BINS - 1))];
-            if (v) atomicAdd(&h[i], v);
+    // rows -> the histogram of `track` (the dummy words are not part of it)
+    auto flush = [&](int track, int nbins) {
+        __syncthreads();
+        for (int i = tid; i < 2 * SELQ_BINS; i += 1024) {
+            const int stream = i >> 11, bin = i & (SELQ_BINS - 1);
+            const unsigned int v = bin < nbins ? s_h[i] : 0u;
+            if (v) {
+                const long long at = (stream * 2 + track) * SELQ_BINS + bin;
+                if (PER_TILE) atomicAdd(&P.hist32[tile * (4 * SELQ_BINS) + at], v);
+                else atomicAdd(&P.hist[at], (unsigned long long)v);
+            }
         }
+    };
+    if (P.first) {
+        sweep(std::integral_constant<int, 0>{}, 0u, 0u, 0u, 0u);
+        flush(0, SELQ_BINS);
     } else {
-        for (int i = tid; i < 4 * SELQ_BINS; i += 1024) {
-            const unsigned int v = s_h[(i >> 11) * SELQ_ROW + (i & (SELQ_BINS - 1))];
-            if (v) atomicAdd(&P.hist[i], (unsigned long long)v);
+        // both ranks of a stream usually share (bias, shift): one sweep, counted under track 0.  Otherwise a second sweep
+        // recounts for track 1 (rare: the two middle ranks straddle a bin boundary).
+        const bool split = ba[0] != ba[1] || sa[0] != sa[1] || bb[0] != bb[1] || sb[0] != sb[1];
+        sweep(std::integral_constant<int, 1>{}, ba[0], sa[0], bb[0], sb[0]);
+        flush(0, SELQ_DIGITS);
+        if (split) {
+            __syncthreads();
+            for (int i = tid; i < 2 * SELQ_BINS; i += 1024) s_h[i] = 0;
+            __syncthreads();
+            sweep(std::integral_constant<int, 1>{}, ba[1], sa[1], bb[1], sb[1]);
+            flush(1, SELQ_DIGITS);
         }
     }
 }
@@ -202,7 +214,8 @@ __global__ __launch_bounds__(256) void k_selq_pick(SelQTile *state, unsigned int
         unsigned int c[32], local = 0;
 #pragma unroll
         for (int j = 0; j < 32; ++j) {
-            c[j] = mine[lane * 32 + j] + (first ? twin[lane * 32 + j] : 0u);
+            const int bin_j = lane * 32 + j;
+            c[j] = first ? mine[bin_j] + twin[bin_j] : (bin_j < SELQ_DIGITS ? mine[bin_j] : 0u);
             local += c[j];
         }
         unsigned int incl = local;
@@ -225,11 +238,12 @@ __global__ __launch_bounds__(256) void k_selq_pick(SelQTile *state, unsigned int
                 unsigned int hi = bin >= SELQ_BINS - 1 ? SELQ_KEY_PLUS1 + 1u : selq_lower_key(bin + 1u);
                 if (lo <= SELQ_KEY_ZERO && SELQ_KEY_ZERO < hi) { lo = SELQ_KEY_ZERO; hi = SELQ_KEY_ZERO + 1u; }   // only +0.0 lives there
                 const unsigned int span = hi - lo - 1u;    // largest offset inside the range
-                nshift = span < SELQ_BINS ? 0u : (32u - (unsigned)__builtin_clz(span)) - 11u;
+                nshift = 0u;
+                while ((span >> nshift) >= SELQ_DIGITS) ++nshift;      // the first digit must fit the row
                 nbias = lo;
             } else {
                 nbias = bias + (bin << shift);
-                nshift = shift > 11u ? shift - 11u : 0u;
+                nshift = shift > SELQ_DIGIT_BITS ? shift - SELQ_DIGIT_BITS : 0u;
             }
             state[tile].bias[combo] = nbias;
             state[tile].shift[combo] = nshift;
@@ -312,9 +326,9 @@ int selq_tile_medians_launch(const uint8_t *tiles, const uint8_t *wb_table, long
     if (bpt > cap) bpt = cap;
     if (bpt < 1) bpt = 1;
     dim3 grid((unsigned)bpt, (unsigned)ntiles);
-    // bucket pass + up to four digit passes (a key range is at most 2^32 wide: shifts 21, 10, 0 at worst, and one
-    // more pass to settle); uint8 tiles need two, exceptionally three -- a settled tile's blocks return at once
-    for (int p = 0; p < 5; ++p) {
+    // bucket pass + up to five digit passes (a first digit of < 1984 values, then 10 bits per pass: a 2^32-wide range
+    // needs shifts 22, 12, 2, 0); uint8 tiles need two, exceptionally three -- a settled tile's blocks return at once
+    for (int p = 0; p < 6; ++p) {
         SelQParams P;
         memset(&P, 0, sizeof P);
         P.tiles = tiles; P.wb_table = wb_table; P.npix = npix; P.first = p == 0;

@@ -67,13 +67,15 @@ def digit_pass_on_planes(planes):
             k = keys[s]
             for t in range(2):
                 if first:
-                    sel = (np.arange(k.size) & 1) == t
-                    d = buckets[s][uniq[s][1]][sel]
+                    if t == 1:
+                        continue                             # the bucket pass counts under track 0
+                    d = buckets[s][uniq[s][1]]
                 else:
-                    if t == 1 and bias[s * 2] == bias[s * 2 + 1] and shift[s * 2] == shift[s * 2 + 1]:
-                        continue                             # shared (bias, shift): counted once, under track 0 (as the kernel does)
+                    shared = all(bias[2 * q] == bias[2 * q + 1] and shift[2 * q] == shift[2 * q + 1] for q in range(2))
+                    if t == 1 and shared:
+                        continue                             # both streams' tracks shared: only track 0 is counted (as the kernel does)
                     d = (k - np.uint32(bias[s * 2 + t])) >> np.uint32(shift[s * 2 + t])     # uint32 wrap-around, like the kernel
-                    d = d[d < batch.SELECT_BINS]
+                    d = d[d < batch.SELECT_DIGITS]
                 out[s, t] = np.bincount(d.astype(np.int64), minlength=batch.SELECT_BINS)[:batch.SELECT_BINS]
         return out
     return pass_fn

@@ -58,3 +58,35 @@ def test_analyze_index_on_arbitrary_float32(x, t):
         else:
             assert got[key] == val, key
     np.testing.assert_array_equal(lars.index_histogram(x), orc.hist50(x))
+
+
+rgn_tiles = st.one_of(
+    hnp.arrays(np.uint8, st.tuples(st.integers(1, 3), st.sampled_from([2, 4, 6, 8, 10]), st.sampled_from([2, 4, 6, 14]), st.just(3))),
+    # few distinct values: medians on bin / bucket boundaries, exactly 0, exactly +-1, ranks that straddle two values
+    hnp.arrays(np.uint8, st.tuples(st.integers(1, 3), st.sampled_from([2, 4, 8]), st.sampled_from([2, 6, 10]), st.just(3)),
+               elements=st.sampled_from([0, 1, 2, 3, 127, 128, 254, 255])),
+    hnp.arrays(np.uint8, st.tuples(st.just(1), st.integers(1, 9), st.integers(1, 9), st.just(3))),      # odd pixel counts (one tile)
+)
+
+
+@settings(max_examples=80, deadline=None)
+@given(rgn_tiles, st.booleans())
+def test_recompute_and_select_medians_equal_numpy(tiles, white_balance):
+    """Statistics + exact medians without planes (per tile and over the batch) against np.median of the oracle's planes."""
+    import lars_image_processing_amd as lars
+    b = lars.TileBatch.from_host(tiles)
+    rec, med = b.process(medians=True, white_balance=white_balance)
+    glob = b.global_medians(white_balance=white_balance)
+    planes = {t: [] for t in TYPES}
+    for i, img in enumerate(tiles):
+        with warnings.catch_warnings():
+            warnings.simplefilter("ignore")
+            src = orc.wb_app(img) if white_balance else img
+        for k, t in enumerate(TYPES):
+            plane = orc.index_app(src, t)
+            planes[t].append(plane.ravel())
+            assert med[i, k] == float(np.median(plane)), (i, t)
+            assert float(rec[i, k]["min"]) == float(plane.min()) and float(rec[i, k]["max"]) == float(plane.max())
+    for t in TYPES:
+        assert glob[t] == float(np.median(np.concatenate(planes[t]))), t
+    b.free()

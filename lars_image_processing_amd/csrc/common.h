@@ -128,6 +128,10 @@ int selq_tile_medians_launch(const uint8_t *tiles, const uint8_t *wb_table, long
 int selq_tile_prepare(void *scratch, long long ntiles, long long npix, hipStream_t s, unsigned int streams);
 unsigned int *selq_tile_hist32(void *scratch, long long ntiles);
 void fused_v2_sel_launch(unsigned mask, bool wb, int stats, dim3 grid, hipStream_t s, const FusedParams &P);
+// fused.hip: grid sizing and the statistics records' init / finalize kernels, for the other translation units
+int blocks_per_tile(long long work_items, long long ntiles, int threads = 256, long long target_total = 8192);
+void stats_init_launch(lars_stats *stats, long long nrec, unsigned int mask, hipStream_t s);
+void stats_finalize_launch(lars_stats *stats, long long nrec, unsigned int mask, long long npix, hipStream_t s);
 int quot_check_launch(unsigned int max_den, unsigned long long *mismatches_dev, unsigned int *first_bad_dev, hipStream_t s);
 
 }  // namespace lars

@@ -583,7 +583,8 @@ __global__ __launch_bounds__(256) void k_synth_u8(uint8_t *tiles, long long firs
 // ===========================================================================
 using namespace lars;
 
-static int blocks_per_tile(long long work_items, long long ntiles, int threads = 256, long long target_total = 8192)
+namespace lars {
+int blocks_per_tile(long long work_items, long long ntiles, int threads, long long target_total)
 {
     // target_total workgroups per launch (many more than the 256 CUs hold at once: tools/kbench.py
     // sweeps), but never so many that a block runs fewer than ~16 steps -- every block pays for its
@@ -599,6 +600,7 @@ static int blocks_per_tile(long long work_items, long long ntiles, int threads =
     if (want > 65535) want = 65535;
     return (int)want;
 }
+}  // namespace lars
 
 extern "C" int lars_d_channel_hist(const void *tiles, int64_t ntiles, int64_t npix, int channels, int dtype,
                                    uint32_t *hist, void *stream)
@@ -769,73 +771,13 @@ extern "C" int lars_d_synth_u8(uint8_t *tiles, int64_t ntiles, int64_t first_til
     return launch_check("lars_d_synth_u8");
 }
 
-
-extern "C" int lars_d_quotient_digit_hist(const void *tiles, int64_t ntiles, int64_t npix, int channels, int dtype,
-                                          const uint8_t *wb_table, int first, const uint32_t bias[4], const uint32_t shift[4],
-                                          uint64_t *hist, void *stream)
+namespace lars {
+void stats_init_launch(lars_stats *stats, long long nrec, unsigned int mask, hipStream_t s)
 {
-    ThreadCtx *c;
-    LARS_TRY(ensure_ctx(&c));
-    if (!tiles || !hist || !bias || !shift || ntiles <= 0 || npix <= 0)
-        return fail(LARS_ERR_INVALID, "lars_d_quotient_digit_hist: bad arguments");
-    if (dtype != LARS_U8 || channels != 3 || (reinterpret_cast<uintptr_t>(tiles) & 3) || (ntiles > 1 && (npix & 3)))
-        return fail(LARS_ERR_INVALID, "lars_d_quotient_digit_hist: uint8 [ntiles][npix][3] tiles on 4-byte boundaries are required");
-    for (int k = 0; k < 4; ++k)
-        if (shift[k] > 31u) return fail(LARS_ERR_INVALID, "lars_d_quotient_digit_hist: shift must be below 32");
-    if (ntiles > 65535) return fail(LARS_ERR_INVALID, "lars_d_quotient_digit_hist: at most 65535 tiles per launch");
-    return selq_pass_launch(static_cast<const uint8_t *>(tiles), wb_table, ntiles, npix, first ? 1 : 0, bias, shift,
-                            reinterpret_cast<unsigned long long *>(hist), pick_stream(c, stream));
+    hipLaunchKernelGGL(k_stats_init, dim3((unsigned)((nrec + 255) / 256)), dim3(256), 0, s, stats, nrec, mask);
 }
-
-extern "C" size_t lars_quotient_median_scratch_bytes(int64_t ntiles) { return selq_tile_scratch_bytes(ntiles > 0 ? ntiles : 1); }
-
-extern "C" int lars_d_quotient_median_pairs(const void *tiles, int64_t ntiles, int64_t npix, int channels, int dtype,
-                                            const uint8_t *wb_table, float *out_pairs, void *scratch, void *stream)
+void stats_finalize_launch(lars_stats *stats, long long nrec, unsigned int mask, long long npix, hipStream_t s)
 {
-    ThreadCtx *c;
-    LARS_TRY(ensure_ctx(&c));
-    if (!tiles || !out_pairs || !scratch || ntiles <= 0 || npix <= 0)
-        return fail(LARS_ERR_INVALID, "lars_d_quotient_median_pairs: bad arguments");
-    if (dtype != LARS_U8 || channels != 3 || (reinterpret_cast<uintptr_t>(tiles) & 3) || (ntiles > 1 && (npix & 3)))
-        return fail(LARS_ERR_INVALID, "lars_d_quotient_median_pairs: uint8 [ntiles][npix][3] tiles on 4-byte boundaries are required");
-    if (ntiles > 65535 || npix >= (1ll << 32)) return fail(LARS_ERR_INVALID, "lars_d_quotient_median_pairs: at most 65535 tiles of < 2^32 pixels");
-    return selq_tile_medians_launch(static_cast<const uint8_t *>(tiles), wb_table, ntiles, npix, out_pairs, scratch,
-                                    pick_stream(c, stream), false);
+    hipLaunchKernelGGL(k_stats_finalize, dim3((unsigned)((nrec + 255) / 256)), dim3(256), 0, s, stats, nrec, mask, npix);
 }
-
-// Statistics AND the exact median of every tile in four passes over the tiles instead of five: the statistics kernel
-// also counts the select's bucket pass.  Same constraints as lars_d_quotient_median_pairs; no output planes.
-extern "C" int lars_d_stats_medians(const lars_fused_args *a, float *out_pairs, void *scratch)
-{
-    ThreadCtx *c;
-    LARS_TRY(ensure_ctx(&c));
-    if (!a || !a->tiles || !a->stats || !out_pairs || !scratch || a->ntiles <= 0 || a->npix <= 0)
-        return fail(LARS_ERR_INVALID, "lars_d_stats_medians: bad arguments");
-    if (a->dtype != LARS_U8 || a->channels != 3 || (reinterpret_cast<uintptr_t>(a->tiles) & 3) || (a->ntiles > 1 && (a->npix & 3)))
-        return fail(LARS_ERR_INVALID, "lars_d_stats_medians: uint8 [ntiles][npix][3] tiles on 4-byte boundaries are required");
-    const unsigned mask = a->index_mask & LARS_MASK_ALL;
-    if (mask != 1u && mask != 2u && mask != 4u && mask != 7u)
-        return fail(LARS_ERR_INVALID, "lars_d_stats_medians: index_mask must be one index or all three");
-    if (a->out_wb || a->out_index[0] || a->out_index[1] || a->out_index[2] || a->out_rgba[0] || a->out_rgba[1] || a->out_rgba[2])
-        return fail(LARS_ERR_INVALID, "lars_d_stats_medians: no output planes (use lars_d_fused + lars_d_median_pair_batch_f32)");
-    if (a->ntiles > 65535 || a->npix >= (1ll << 32) || (long long)a->npix * 6 >= (1ll << 30))
-        return fail(LARS_ERR_INVALID, "lars_d_stats_medians: at most 65535 tiles of < 2^30 / 6 pixels");
-    hipStream_t s = pick_stream(c, a->stream);
-    const int stats_mode = (a->flags & LARS_F_HIST) ? 2 : 1;
-    const uint8_t *tiles = static_cast<const uint8_t *>(a->tiles);
-
-    FusedParams P;
-    memset(&P, 0, sizeof P);
-    P.tiles = a->tiles; P.npix = a->npix; P.channels = 3; P.wb_table = a->wb_table; P.stats = a->stats; P.mask = mask;
-    P.flags = a->flags & 3u;
-    LARS_TRY(selq_tile_prepare(scratch, a->ntiles, a->npix, s, ((mask & 1u) ? 1u : 0u) | ((mask & 6u) ? 2u : 0u)));
-    P.sel_hist = selq_tile_hist32(scratch, a->ntiles);
-    const long long nrec = a->ntiles * 3;
-    hipLaunchKernelGGL(k_stats_init, dim3((unsigned)((nrec + 255) / 256)), dim3(256), 0, s, a->stats, nrec, mask);
-    dim3 grid(blocks_per_tile(a->npix / 4 + 1, a->ntiles, fused_v2_threads(false)), (unsigned)a->ntiles);
-    fused_v2_sel_launch(mask, a->wb_table != nullptr, stats_mode, grid, s, P);
-    hipLaunchKernelGGL(k_stats_finalize, dim3((unsigned)((nrec + 255) / 256)), dim3(256), 0, s, a->stats, nrec, mask,
-                       (long long)a->npix);
-    LARS_TRY(launch_check("lars_d_stats_medians"));
-    return selq_tile_medians_launch(tiles, a->wb_table, a->ntiles, a->npix, out_pairs, scratch, s, true);
-}
+}  // namespace lars

@@ -60,6 +60,8 @@ def parse():
                     help="skip timing the other modes (extra JSON field 'modes')")
     ap.add_argument("--no-probe", dest="probe", action="store_false", help="skip the streaming-roofline probes")
     ap.add_argument("--profile", default="vegetation", choices=["uniform", "vegetation"])
+    ap.add_argument("--placement-trials", type=int, default=6,
+                    help="candidate output rings to allocate; the fastest is kept (0/1: take the first)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-tiles", type=int, default=8)
     ap.add_argument("--cpu-workers", type=int, default=16, help="process pool of the multi-core CPU baseline leg")
@@ -91,7 +93,10 @@ class Runner:
             return None
         key = tuple(indices)
         if key not in self.outputs:
-            self.outputs[key] = self.batch.make_outputs(indices=indices, index=True, ring=self.args.ring)
+            if self.batch.table is None:
+                self.batch.compute_wb_tables()
+            self.outputs[key] = self.batch.make_outputs(indices=indices, index=True, ring=self.args.ring,
+                                                        placement_trials=self.args.placement_trials)
         return self.outputs[key]
 
     def step(self, mode, timed=None):
@@ -289,7 +294,8 @@ def main():
                             " + min/max/mean/coverage" + ("/50-bin histogram" if hist else "") + " per tile, "
                             "then global fold" + (" over RCCL" if world > 1 else ""),
                 "tiles_per_gpu": args.tiles, "tile": [args.tile, args.tile, 3], "input_dtype": "u8", "mode": args.mode,
-                "output_ring_tiles": args.ring if write else 0, "parallelism": f"tile-sharded x{world}",
+                "output_ring_tiles": args.ring if write else 0,
+                "output_ring_placement_trials": args.placement_trials if write else 0, "parallelism": f"tile-sharded x{world}",
                 "device": _ffi.device_name(),
             },
             "roofline": {

@@ -304,6 +304,20 @@ def test_uint16_rgba_channels_take_generic_path(lars):
     outs.free(); b.free()
 
 
+def test_output_ring_placement_trials(lars):
+    """make_outputs(placement_trials=k): k candidate rings are timed, one survives and works like any other."""
+    b = lars.TileBatch.synthetic(6, 64, 96, seed=5, profile="vegetation")
+    plain = b.make_outputs(index=True, ring=2)
+    tuned = b.make_outputs(index=True, ring=2, placement_trials=3)
+    assert len(tuned.placement_ms) == 3 and min(tuned.placement_ms) > 0 and not hasattr(plain, "placement_ms")
+    rec_a = b.process(outputs=plain)
+    ndvi_a = plain.host_index("NDVI", 1, 1)
+    rec_b = b.process(outputs=tuned)
+    np.testing.assert_array_equal(bits(tuned.host_index("NDVI", 1, 1)), bits(ndvi_a))
+    assert rec_a.tobytes() == rec_b.tobytes()
+    plain.free(); tuned.free(); b.free()
+
+
 def test_batch_medians_are_numpy_medians(lars):
     b = lars.TileBatch.synthetic(21, 64, 96, seed=13, profile="vegetation")        # 21 tiles over a ring of 16: two chunks
     rec, med = b.process(medians=True)

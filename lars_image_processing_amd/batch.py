@@ -107,39 +107,69 @@ class TileBatch:
         """Allocate output planes.  ``ring`` < ntiles reuses a ring of that many
         tile slots (same HBM traffic, bounded footprint) -- see BatchOutputs.
 
-        ``placement_trials`` = k > 1: allocate k candidate sets of planes, time one plane-writing launch into each
-        and keep the fastest.  Where the driver happens to put the planes in HBM moves the write-bound fused kernel
-        by up to 10 % -- reproducibly for the lifetime of the allocation -- so a
-        long-lived ring is worth choosing once.  Costs k rings of memory for the duration of the trial."""
-        if placement_trials <= 1:
+        ``placement_trials`` = k > 1: allocate k candidate planes per index, time them and keep the fastest
+        combination.  Where the driver happens to put a plane in HBM moves the write-bound fused kernel by up
+        to 10 % -- reproducibly for the lifetime of the allocation -- so a long-lived
+        ring is worth choosing once.  Costs k rings of memory for the duration of the trial."""
+        if placement_trials <= 1 or not index:
             return BatchOutputs(self, indices, index, wb, rgba, ring)
-        cands = []
-        for _ in range(int(placement_trials)):
+        # Stage 1: a pool of candidate planes, each timed on its own (planes come out "fast" or "slow", ~5 % apart).
+        # Stage 2: the combinations of the fastest few as a ring (planes also interact), the best one stays.
+        import itertools
+        ks = [INDEX_IDS[t] for t in indices]
+        base = BatchOutputs(self, indices, False, wb, rgba, ring)          # everything but the index planes
+        nbytes = base.slots * self.npix * 4
+        pool = []
+        for _ in range(int(placement_trials) * len(ks)):
             try:
-                cands.append(BatchOutputs(self, indices, index, wb, rgba, ring))
+                pool.append(DeviceBuffer(nbytes))
             except _ffi.LarsError:
                 break                                       # out of memory: choose among what fits
-        if not cands:
+        if len(pool) < len(ks):
+            for p in pool:
+                p.free()
+            base.free()
             raise _ffi.LarsError(-2, "no memory for the output planes")
-        times = [self._time_outputs(c, indices) for c in cands]
-        best = int(np.argmin(times))
-        for j, c in enumerate(cands):
-            if j != best:
-                c.free()
-        cands[best].placement_ms = times
-        return cands[best]
+        solo = []
+        for p in pool:
+            base.index = [None] * 3
+            base.index[ks[0]] = p
+            solo.append(self._time_outputs(base, (indices[0],)))
+        order = list(np.argsort(solo))
+        short = order[:min(len(pool), len(ks) + 2)]
+        best, best_ms, tried = None, None, []
+        for combo in itertools.combinations(short, len(ks)):
+            base.index = [None] * 3
+            for k, j in zip(ks, combo):
+                base.index[k] = pool[j]
+            ms = self._time_outputs(base, indices)
+            tried.append(ms)
+            if best_ms is None or ms < best_ms:
+                best, best_ms = combo, ms
+        base.index = [None] * 3
+        for k, j in zip(ks, best):
+            base.index[k] = pool[j]
+        for j, p in enumerate(pool):
+            if j not in best:
+                p.free()
+        base.placement_ms = {"planes": [float(x) for x in solo], "rings": tried, "chosen": best_ms}
+        return base
 
     def _time_outputs(self, outs, indices):
-        """Milliseconds of one fused launch that fills ``outs`` once (second of two launches)."""
+        """Milliseconds of fused launches that fill ``outs`` from up to three chunks of the batch (first, middle, last:
+        the pairing with the input's placement matters too); the warm-up launch is not timed."""
         ev = [C.c_void_p(), C.c_void_p()]
         for e in ev:
             _ffi.call("lars_event_create", C.byref(e))
         stats = self.new_stats()
         count = min(outs.slots, self.ntiles)
-        args = self.fused_args(indices, self.table is not None, stats, False, outs, None, 0, count)
-        self.run_fused(args)
+        nchunks = max(1, self.ntiles // count)
+        starts = sorted({0, (nchunks // 2) * count, (nchunks - 1) * count})
+        launches = [self.fused_args(indices, self.table is not None, stats, False, outs, None, st, count) for st in starts]
+        self.run_fused(launches[0])
         _ffi.call("lars_event_record", ev[0], None)
-        self.run_fused(args)
+        for a in launches:
+            self.run_fused(a)
         _ffi.call("lars_event_record", ev[1], None)
         _ffi.call("lars_synchronize", None)
         ms = C.c_float(0)
@@ -147,7 +177,7 @@ class TileBatch:
         for e in ev:
             _ffi.call("lars_event_destroy", e)
         stats.free()
-        return float(ms.value)
+        return float(ms.value) / len(launches)
 
     def fused_args(self, indices=INDEX_NAMES, white_balance=True, stats=None, hist=False, outputs=None,
                    stream=None, tile_start=0, tile_count=None):

@@ -309,7 +309,8 @@ def test_output_ring_placement_trials(lars):
     b = lars.TileBatch.synthetic(6, 64, 96, seed=5, profile="vegetation")
     plain = b.make_outputs(index=True, ring=2)
     tuned = b.make_outputs(index=True, ring=2, placement_trials=3)
-    assert len(tuned.placement_ms) == 3 and min(tuned.placement_ms) > 0 and not hasattr(plain, "placement_ms")
+    assert len(tuned.placement_ms["planes"]) == 9 and tuned.placement_ms["chosen"] == min(tuned.placement_ms["rings"]) > 0
+    assert not hasattr(plain, "placement_ms")
     rec_a = b.process(outputs=plain)
     ndvi_a = plain.host_index("NDVI", 1, 1)
     rec_b = b.process(outputs=tuned)

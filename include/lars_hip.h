@@ -71,7 +71,8 @@ typedef enum lars_status {
 
 /* flags of lars_fused_args.flags */
 #define LARS_F_STATS 1u            /* fill stats[tile][index] (min/max/sum/sumsq/above/count) */
-#define LARS_F_HIST  2u            /* full statistics: also the 50-bin histogram and sumsq (implies LARS_F_STATS) */
+#define LARS_F_HIST  2u            /* also the 50-bin histogram (implies LARS_F_STATS) */
+#define LARS_F_SUMSQ 4u            /* also the sum of squares, for a standard deviation (implies LARS_F_HIST) */
 
 /*
  * Order-independent statistics record of one index over one tile (or, after a
@@ -82,7 +83,7 @@ typedef enum lars_status {
  *   sum / sumsq : sums of the float32 index values (fixed point 2^-32 accumulation,
  *                 order independent); sum is exact for uint8 tiles and correctly
  *                 rounded to double.  The fused kernel fills sumsq only with
- *                 LARS_F_HIST (it is 0 otherwise).
+ *                 LARS_F_SUMSQ (it is 0 otherwise).
  *   above       : samples with x > threshold, compared in the sample's own
  *                 precision (float32 against float32(0.2), process-images.py:511).
  *   hist        : numpy.histogram(x, bins=50, range=(-1, 1)) counts.

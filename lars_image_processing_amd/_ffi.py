@@ -21,7 +21,7 @@ U8, U16 = 1, 2
 NDVI, GNDVI, NDWI = 0, 1, 2
 INDEX_IDS = {"NDVI": NDVI, "GNDVI": GNDVI, "NDWI": NDWI}
 INDEX_NAMES = ("NDVI", "GNDVI", "NDWI")
-F_STATS, F_HIST = 1, 2
+F_STATS, F_HIST, F_SUMSQ = 1, 2, 4
 COMM_ID_BYTES = 128
 
 

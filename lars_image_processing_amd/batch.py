@@ -180,7 +180,7 @@ class TileBatch:
         return float(ms.value) / len(launches)
 
     def fused_args(self, indices=INDEX_NAMES, white_balance=True, stats=None, hist=False, outputs=None,
-                   stream=None, tile_start=0, tile_count=None):
+                   stream=None, tile_start=0, tile_count=None, sumsq=False):
         tile_count = self.ntiles - tile_start if tile_count is None else tile_count
         a = FusedArgs()
         a.tiles = self.tiles.ptr + tile_start * self.tile_bytes
@@ -193,7 +193,8 @@ class TileBatch:
         for t in indices:
             mask |= 1 << INDEX_IDS[t]
         a.index_mask = mask
-        a.flags = (_ffi.F_STATS if stats is not None else 0) | (_ffi.F_HIST if (stats is not None and hist) else 0)
+        a.flags = ((_ffi.F_STATS if stats is not None else 0) | (_ffi.F_HIST if (stats is not None and hist) else 0) |
+                   (_ffi.F_SUMSQ if (stats is not None and sumsq) else 0))
         if stats is not None:
             a.stats = stats.ptr + tile_start * 3 * STATS_DTYPE.itemsize
         if outputs is not None:
@@ -218,10 +219,11 @@ class TileBatch:
         _ffi.call("lars_d_fused", C.byref(args))
 
     def process(self, indices=INDEX_NAMES, white_balance=True, hist=False, outputs=None, stream=None,
-                recompute_tables=True, medians=False):
+                recompute_tables=True, medians=False, sumsq=False):
         """Both passes over the whole batch; returns per-tile records
         (structured ndarray ``[ntiles, 3]`` of STATS_DTYPE; rows of indices not
-        requested are zero).  ``medians=True`` also returns ``float64[ntiles, 3]``
+        requested are zero).  ``hist`` adds the 50-bin histograms, ``sumsq`` the sums of squares
+        (``summarize()['std']``).  ``medians=True`` also returns ``float64[ntiles, 3]``
         with np.median of each tile's index plane (exact: batched radix select on
         the float32 planes, which must then be written -- a small ring is
         allocated when ``outputs`` has none)."""
@@ -238,14 +240,14 @@ class TileBatch:
             if mask in (1, 2, 4, 7):
                 pairs_dev = DeviceBuffer(self.ntiles * 4 * 4)
                 scratch = DeviceBuffer(int(_ffi.load().lars_quotient_median_scratch_bytes(self.ntiles)))
-                args = self.fused_args(indices, white_balance, stats, hist, None, stream)
+                args = self.fused_args(indices, white_balance, stats, hist, None, stream, sumsq=sumsq)
                 _ffi.call("lars_d_stats_medians", C.byref(args), C.c_void_p(pairs_dev.ptr), C.c_void_p(scratch.ptr))
                 _ffi.call("lars_synchronize", stream)
                 med = self._medians_from_pairs(pairs_dev.download(np.float32, (self.ntiles, 2, 2)), indices)
                 pairs_dev.free()
                 scratch.free()
             else:                                           # two of the three indices: separate statistics pass
-                self.run_fused(self.fused_args(indices, white_balance, stats, hist, None, stream))
+                self.run_fused(self.fused_args(indices, white_balance, stats, hist, None, stream, sumsq=sumsq))
                 med = self.tile_medians(indices, white_balance, stream)
             rec = stats.download(STATS_DTYPE, (self.ntiles, 3))
             stats.free()
@@ -261,7 +263,7 @@ class TileBatch:
         chunk = self.ntiles if outputs is None else outputs.slots
         for start in range(0, self.ntiles, chunk):
             count = min(chunk, self.ntiles - start)
-            self.run_fused(self.fused_args(indices, white_balance, stats, hist, outputs, stream, start, count))
+            self.run_fused(self.fused_args(indices, white_balance, stats, hist, outputs, stream, start, count, sumsq=sumsq))
             if medians:
                 for t in indices:
                     k = INDEX_IDS[t]
@@ -401,7 +403,7 @@ def summarize(record):
     count = int(record["count"])
     mean = float(record["sum"]) / count
     sumsq = float(record["sumsq"])
-    # the fused kernel fills sumsq only with LARS_F_HIST (full statistics); without it std is unknown
+    # the fused kernel fills sumsq only with LARS_F_SUMSQ; without it std is unknown
     have_sq = sumsq != 0.0 or (float(record["min"]) == 0.0 and float(record["max"]) == 0.0)
     var = max(sumsq / count - mean * mean, 0.0)
     return {

@@ -222,7 +222,7 @@ __device__ inline void acc_push(Acc &a, float x, float thr, unsigned int *s_hist
         a.mx = fmaxf(a.mx, x);
         const double xd = (double)x;
         a.sum += xd;
-        if (STATS >= 2) a.sumsq += xd * xd;
+        if (STATS >= 3) a.sumsq += xd * xd;
         a.above += (x > thr) ? 1u : 0u;
     }
     if (STATS >= 2) atomicAdd(&s_hist[hist_bin_f32(x, s_edges)], 1u);
@@ -475,8 +475,9 @@ __global__ __launch_bounds__(256) void k_fused_generic(FusedParams P)
     const long long npix = P.npix;
     const int C = P.channels;
     const unsigned mask = P.mask;
-    const bool stats = P.flags & (LARS_F_STATS | LARS_F_HIST);
-    const bool hist = P.flags & LARS_F_HIST;
+    const bool stats = P.flags & (LARS_F_STATS | LARS_F_HIST | LARS_F_SUMSQ);
+    const bool hist = P.flags & (LARS_F_HIST | LARS_F_SUMSQ);
+    const bool sumsq = P.flags & LARS_F_SUMSQ;
     const PIX *base = static_cast<const PIX *>(P.tiles) + tile * npix * C;
     const uint8_t *tab = P.wb_table ? P.wb_table + tile * (NVAL == 256 ? 768ll : (long long)LARS_U16_BLOB_BYTES) : nullptr;
 
@@ -510,7 +511,8 @@ __global__ __launch_bounds__(256) void k_fused_generic(FusedParams P)
         }
         float a = 0, b = 0, c = 0;
         if (stats) {
-            if (hist) pixel_math<7u, 2, true>((float)r, (float)g, (float)n, mask, a, b, c, acc, s_hist, s_edges);
+            if (sumsq) pixel_math<7u, 3, true>((float)r, (float)g, (float)n, mask, a, b, c, acc, s_hist, s_edges);
+            else if (hist) pixel_math<7u, 2, true>((float)r, (float)g, (float)n, mask, a, b, c, acc, s_hist, s_edges);
             else pixel_math<7u, 1, true>((float)r, (float)g, (float)n, mask, a, b, c, acc, s_hist, s_edges);
         } else {
             pixel_math<7u, 0, true>((float)r, (float)g, (float)n, mask, a, b, c, acc, s_hist, s_edges);
@@ -663,6 +665,7 @@ static void launch_fast_stats(int stats_mode, dim3 grid, hipStream_t s, const Fu
 {
     if (stats_mode == 0) hipLaunchKernelGGL((k_fused_u8c3<PIX, MASK, WB, 0>), grid, dim3(256), 0, s, P);
     else if (stats_mode == 1) hipLaunchKernelGGL((k_fused_u8c3<PIX, MASK, WB, 1>), grid, dim3(256), 0, s, P);
+    else if (stats_mode == 3) hipLaunchKernelGGL((k_fused_u8c3<PIX, MASK, WB, 3>), grid, dim3(256), 0, s, P);
     else hipLaunchKernelGGL((k_fused_u8c3<PIX, MASK, WB, 2>), grid, dim3(256), 0, s, P);
 }
 template <typename PIX, unsigned MASK>
@@ -693,7 +696,8 @@ extern "C" int lars_d_fused(const lars_fused_args *a)
     if (a->dtype != LARS_U8 && a->dtype != LARS_U16) return fail(LARS_ERR_INVALID, "lars_d_fused: dtype");
     const unsigned mask = a->index_mask & LARS_MASK_ALL;
     if (a->index_mask & ~LARS_MASK_ALL) return fail(LARS_ERR_INVALID, "lars_d_fused: unknown index bits in mask");
-    const int stats_mode = (a->flags & LARS_F_HIST) ? 2 : (a->flags & LARS_F_STATS) ? 1 : 0;
+    // 1 basic, 2 + 50-bin histograms, 3 + histograms and the sum of squares (LARS_F_SUMSQ; implies the histograms)
+    const int stats_mode = (a->flags & LARS_F_SUMSQ) ? 3 : (a->flags & LARS_F_HIST) ? 2 : (a->flags & LARS_F_STATS) ? 1 : 0;
     if (stats_mode && !a->stats) return fail(LARS_ERR_INVALID, "lars_d_fused: stats requested but stats == NULL");
     if (a->out_wb && !a->wb_table) return fail(LARS_ERR_INVALID, "lars_d_fused: out_wb needs wb_table");
     for (int k = 0; k < 3; ++k)
@@ -710,7 +714,7 @@ extern "C" int lars_d_fused(const lars_fused_args *a)
         P.cmap_lut[k] = a->cmap_lut[k];
     }
     P.out_wb = a->out_wb; P.stats = a->stats; P.mask = mask; P.sel_hist = nullptr;
-    P.flags = (a->flags & 3u) | (tuning().nt_stores ? 0x20000000u : 0u);
+    P.flags = (a->flags & 7u) | (tuning().nt_stores ? 0x20000000u : 0u);
 
     const long long nrec = a->ntiles * 3;
     if (stats_mode)

@@ -204,7 +204,7 @@ __device__ inline void push(WaveAcc &a, unsigned int &above, float x, float thr)
     a.mx = fmaxf(a.mx, x);
     const double xd = (double)x;
     a.sum += xd;
-    if (STATS >= 2) a.sumsq += xd * xd;
+    if (STATS >= 3) a.sumsq += xd * xd;
     if (COUNT) {
         if (LARS_COUNT_MODE == 0) count_gt(above, x, thr);           // wave-uniform scalar counter
         else vcount_gt(above, x, thr);                               // per-lane counter, folded at flush
@@ -391,7 +391,7 @@ __global__ __launch_bounds__(V2Block<OUT>::threads, OUT ? 4 : LARS_V2_STATS_WAVE
                     acc_g.mx = fmaxf(acc_g.mx, x);
                     const double xd = (double)x;
                     acc_g.sum += xd;
-                    if (STATS >= 2) acc_g.sumsq += xd * xd;
+                    if (STATS >= 3) acc_g.sumsq += xd * xd;
                     if (LARS_COUNT_MODE == 1) {
                         if (WANT_GNDVI) vcount_gt(above_g, x, 0.2f);
                         if (WANT_NDWI) vcount_lt(above_w, x, 0.0f);           // -x > 0
@@ -490,7 +490,7 @@ __global__ __launch_bounds__(V2Block<OUT>::threads, OUT ? 4 : LARS_V2_STATS_WAVE
                 acc_g.mn = fminf(acc_g.mn, x); acc_g.mx = fmaxf(acc_g.mx, x);
                 const double xd = (double)x;
                 acc_g.sum += xd;
-                if (STATS >= 2) acc_g.sumsq += xd * xd;
+                if (STATS >= 3) acc_g.sumsq += xd * xd;
                 if (LARS_COUNT_MODE == 1) {
                     if (WANT_GNDVI) vcount_gt(above_g, x, 0.2f);
                     if (WANT_NDWI) vcount_lt(above_w, x, 0.0f);
@@ -524,12 +524,12 @@ __global__ __launch_bounds__(V2Block<OUT>::threads, OUT ? 4 : LARS_V2_STATS_WAVE
             if (WANT_NDVI) {
                 acc_v.mn = fminf(acc_v.mn, __shfl_xor(acc_v.mn, off)); acc_v.mx = fmaxf(acc_v.mx, __shfl_xor(acc_v.mx, off));
                 acc_v.sum += __shfl_xor(acc_v.sum, off);
-                if (STATS >= 2) acc_v.sumsq += __shfl_xor(acc_v.sumsq, off);
+                if (STATS >= 3) acc_v.sumsq += __shfl_xor(acc_v.sumsq, off);
             }
             if (NEED_G) {
                 acc_g.mn = fminf(acc_g.mn, __shfl_xor(acc_g.mn, off)); acc_g.mx = fmaxf(acc_g.mx, __shfl_xor(acc_g.mx, off));
                 acc_g.sum += __shfl_xor(acc_g.sum, off);
-                if (STATS >= 2) acc_g.sumsq += __shfl_xor(acc_g.sumsq, off);
+                if (STATS >= 3) acc_g.sumsq += __shfl_xor(acc_g.sumsq, off);
             }
         }
         const int wave = tid >> 6;
@@ -558,14 +558,14 @@ __global__ __launch_bounds__(V2Block<OUT>::threads, OUT ? 4 : LARS_V2_STATS_WAVE
             StatsAccView *rec = reinterpret_cast<StatsAccView *>(P.stats + tile * 3);
             if (WANT_NDVI) {
                 atomicAdd(&rec[0].sum_fx, (unsigned long long)__double2ll_rn(t[0] * LARS_FX_SCALE));
-                if (STATS >= 2) atomicAdd(&rec[0].sumsq_fx, (unsigned long long)__double2ll_rn(t[1] * LARS_FX_SCALE));
+                if (STATS >= 3) atomicAdd(&rec[0].sumsq_fx, (unsigned long long)__double2ll_rn(t[1] * LARS_FX_SCALE));
                 atomicAdd(&rec[0].above, (unsigned long long)t[4]);
                 atomicMin(&rec[0].min_key, f64_key(t[2]));
                 atomicMax(&rec[0].max_key, f64_key(t[3]));
             }
             if (WANT_GNDVI) {
                 atomicAdd(&rec[1].sum_fx, (unsigned long long)__double2ll_rn(t[5] * LARS_FX_SCALE));
-                if (STATS >= 2) atomicAdd(&rec[1].sumsq_fx, (unsigned long long)__double2ll_rn(t[6] * LARS_FX_SCALE));
+                if (STATS >= 3) atomicAdd(&rec[1].sumsq_fx, (unsigned long long)__double2ll_rn(t[6] * LARS_FX_SCALE));
                 atomicAdd(&rec[1].above, (unsigned long long)t[9]);
                 atomicMin(&rec[1].min_key, f64_key(t[7]));
                 atomicMax(&rec[1].max_key, f64_key(t[8]));
@@ -575,7 +575,7 @@ __global__ __launch_bounds__(V2Block<OUT>::threads, OUT ? 4 : LARS_V2_STATS_WAVE
                 // which the double keys below reproduce: -(+0.0) never occurs because min/max of the
                 // quotient only reach 0 as +0.0 and 0.0 - 0.0 = +0.0)
                 atomicAdd(&rec[2].sum_fx, (unsigned long long)__double2ll_rn((0.0 - t[5]) * LARS_FX_SCALE));
-                if (STATS >= 2) atomicAdd(&rec[2].sumsq_fx, (unsigned long long)__double2ll_rn(t[6] * LARS_FX_SCALE));
+                if (STATS >= 3) atomicAdd(&rec[2].sumsq_fx, (unsigned long long)__double2ll_rn(t[6] * LARS_FX_SCALE));
                 atomicAdd(&rec[2].above, (unsigned long long)t[10]);
                 atomicMin(&rec[2].min_key, f64_key(0.0 - t[8]));
                 atomicMax(&rec[2].max_key, f64_key(0.0 - t[7]));
@@ -631,7 +631,8 @@ static void v2_launch_stats(int stats, bool out, bool nt, dim3 grid, hipStream_t
 {
     if (stats == 0) v2_launch_out<MASK, WB, 0>(out, nt, grid, s, P);
     else if (stats == 1) v2_launch_out<MASK, WB, 1>(out, nt, grid, s, P);
-    else v2_launch_out<MASK, WB, 2>(out, nt, grid, s, P);
+    else if (stats == 2) v2_launch_out<MASK, WB, 2>(out, nt, grid, s, P);
+    else v2_launch_out<MASK, WB, 3>(out, nt, grid, s, P);
 }
 template <unsigned MASK>
 static void v2_launch_wb(bool wb, int stats, bool out, bool nt, dim3 grid, hipStream_t s, const FusedParams &P)
@@ -644,9 +645,11 @@ template <unsigned MASK>
 static void v2_launch_sel(bool wb, int stats, dim3 grid, hipStream_t s, const FusedParams &P)
 {
     const dim3 block(V2Block<false>::threads);
-    if (wb && stats >= 2) hipLaunchKernelGGL((k_fused_v2<MASK, true, 2, false, false, true>), grid, block, 0, s, P);
+    if (wb && stats >= 3) hipLaunchKernelGGL((k_fused_v2<MASK, true, 3, false, false, true>), grid, block, 0, s, P);
+    else if (wb && stats == 2) hipLaunchKernelGGL((k_fused_v2<MASK, true, 2, false, false, true>), grid, block, 0, s, P);
     else if (wb) hipLaunchKernelGGL((k_fused_v2<MASK, true, 1, false, false, true>), grid, block, 0, s, P);
-    else if (stats >= 2) hipLaunchKernelGGL((k_fused_v2<MASK, false, 2, false, false, true>), grid, block, 0, s, P);
+    else if (stats >= 3) hipLaunchKernelGGL((k_fused_v2<MASK, false, 3, false, false, true>), grid, block, 0, s, P);
+    else if (stats == 2) hipLaunchKernelGGL((k_fused_v2<MASK, false, 2, false, false, true>), grid, block, 0, s, P);
     else hipLaunchKernelGGL((k_fused_v2<MASK, false, 1, false, false, true>), grid, block, 0, s, P);
 }
 // statistics + the select's bucket pass in one kernel (mask 1, 2, 4 or 7; no output planes)

@@ -398,13 +398,13 @@ extern "C" int lars_d_stats_medians(const lars_fused_args *a, float *out_pairs, 
     if (a->ntiles > 65535 || a->npix >= (1ll << 32) || (long long)a->npix * 6 >= (1ll << 30))
         return fail(LARS_ERR_INVALID, "lars_d_stats_medians: at most 65535 tiles of < 2^30 / 6 pixels");
     hipStream_t s = pick_stream(c, a->stream);
-    const int stats_mode = (a->flags & LARS_F_HIST) ? 2 : 1;
+    const int stats_mode = (a->flags & LARS_F_SUMSQ) ? 3 : (a->flags & LARS_F_HIST) ? 2 : 1;
     const uint8_t *tiles = static_cast<const uint8_t *>(a->tiles);
 
     FusedParams P;
     memset(&P, 0, sizeof P);
     P.tiles = a->tiles; P.npix = a->npix; P.channels = 3; P.wb_table = a->wb_table; P.stats = a->stats; P.mask = mask;
-    P.flags = a->flags & 3u;
+    P.flags = a->flags & 7u;
     LARS_TRY(selq_tile_prepare(scratch, a->ntiles, a->npix, s, ((mask & 1u) ? 1u : 0u) | ((mask & 6u) ? 2u : 0u)));
     P.sel_hist = selq_tile_hist32(scratch, a->ntiles);
     const long long nrec = a->ntiles * 3;

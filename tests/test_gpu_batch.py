@@ -43,7 +43,7 @@ def test_batch_matches_oracle_per_tile(lars, profile, shape):
     b = lars.TileBatch.synthetic(ntiles, shape[0], shape[1], seed=42, profile=profile)
     tiles = b.host_tiles()
     outs = b.make_outputs(index=True, wb=True, rgba=True)
-    rec = b.process(hist=True, outputs=outs)
+    rec = b.process(hist=True, sumsq=True, outputs=outs)
     tables = b.host_tables()
     pcts = b.host_percentiles()
     wb = outs.host_wb(0, ntiles)
@@ -66,7 +66,7 @@ def test_batch_matches_oracle_per_tile(lars, profile, shape):
             assert int(r["count"]) == part["count"] and int(r["above"]) == part["above"]
             assert float(r["min"]) == part["min"] and float(r["max"]) == part["max"]
             assert float(r["sum"]) == part["sum"]                      # exact fixed-point sum
-            assert float(r["sumsq"]) == pytest.approx(part["sumsq"], rel=1e-9)   # filled because hist=True
+            assert float(r["sumsq"]) == pytest.approx(part["sumsq"], rel=1e-9)   # filled because sumsq=True
             np.testing.assert_array_equal(np.array(r["hist"], dtype=np.int64), part["hist"])
             lut = lars.colormap_lut("RdYlBu" if t == "NDWI" else "RdYlGn")
             np.testing.assert_array_equal(outs.host_rgba(t, i, 1)[0], orc.colormap_closed_form(want, lut))
@@ -89,9 +89,10 @@ def test_batch_matches_oracle_per_tile(lars, profile, shape):
 
 def test_stats_only_equals_stats_with_outputs_and_ring(lars):
     b = lars.TileBatch.synthetic(8, 128, 128, seed=7, profile="vegetation")
-    rec_a = b.process(hist=True)
+    rec_a = b.process(hist=True, sumsq=True)
     outs = b.make_outputs(index=True, ring=3)
-    rec_b = b.process(hist=True, outputs=outs)
+    rec_b = b.process(hist=True, sumsq=True, outputs=outs)
+    assert (rec_a["sumsq"] > 0).all() and (b.process(hist=True)["sumsq"] == 0).all()      # only on request
     np.testing.assert_allclose(rec_a["sumsq"], rec_b["sumsq"], rtol=1e-12)
     rec_a["sumsq"] = rec_b["sumsq"] = 0     # every other field is order-independent, hence identical
     assert rec_a.tobytes() == rec_b.tobytes()
@@ -191,7 +192,7 @@ def test_tuning_does_not_change_results(lars):
         for nt in (0, 1):
             for bpt in (0, 1, 7):
                 _ffi.set_tuning(fused_impl=impl, hist_impl=impl, nt_stores=nt, blocks_per_tile=bpt)
-                rec = b.process(hist=True, outputs=outs)
+                rec = b.process(hist=True, sumsq=True, outputs=outs)
                 sumsq = rec["sumsq"].copy()
                 rec["sumsq"] = 0            # the only order-dependent field (double sums of squares)
                 got = (rec.tobytes(), outs.host_index("NDWI", 0, 4).tobytes(), b.host_tables().tobytes())

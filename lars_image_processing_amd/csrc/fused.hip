@@ -214,7 +214,9 @@ __global__ void k_stats_finalize(lars_stats *stats, long long nrec, unsigned int
 // ===========================================================================
 // The fused kernel
 // ===========================================================================
-template <int STATS>
+// U8DOM: x is a quotient of uint8 samples, whose histogram bin can be read off the mantissa of
+// fma(x, 25, 25.5001) + 2^23 (see hist_pos2 in fused_v2.hip; exhaustively equal to numpy's bin) instead of the cell table
+template <int STATS, bool U8DOM = false>
 __device__ inline void acc_push(Acc &a, float x, float thr, unsigned int *s_hist, const HistCell<float> *s_edges)
 {
     if (STATS >= 1) {
@@ -225,7 +227,15 @@ __device__ inline void acc_push(Acc &a, float x, float thr, unsigned int *s_hist
         if (STATS >= 3) a.sumsq += xd * xd;
         a.above += (x > thr) ? 1u : 0u;
     }
-    if (STATS >= 2) atomicAdd(&s_hist[hist_bin_f32(x, s_edges)], 1u);
+    if (STATS >= 2) {
+        if (U8DOM) {
+            const float u = __builtin_fmaf(x, 25.0f, 25.5001f) + 8388608.0f;
+            const unsigned int b1 = __builtin_bit_cast(unsigned int, u) & 0x7FFFFFu;      // bin + 1, 51 for x == 1.0
+            atomicAdd(&s_hist[b1 > 50u ? 49u : b1 - 1u], 1u);
+        } else {
+            atomicAdd(&s_hist[hist_bin_f32(x, s_edges)], 1u);
+        }
+    }
 }
 
 // Block-wide fold of one accumulator into the tile's record (atomics are
@@ -270,7 +280,7 @@ __device__ inline void acc_flush(Acc a, StatsAccView *rec, double (*s_red)[4], i
 }
 
 // One pixel: white-balanced (or raw) band values in, everything out.
-template <unsigned MASK, int STATS, bool RT_MASK>
+template <unsigned MASK, int STATS, bool RT_MASK, bool U8DOM = false>
 __device__ inline void pixel_math(float r, float g, float n, unsigned rt_mask,
                                   float &o_ndvi, float &o_gndvi, float &o_ndwi,
                                   Acc *acc, unsigned int *s_hist, const HistCell<float> *s_edges)
@@ -280,18 +290,18 @@ __device__ inline void pixel_math(float r, float g, float n, unsigned rt_mask,
     const bool want_ndwi = RT_MASK ? (rt_mask & 4u) : (MASK & 4u);
     if (want_ndvi) {
         o_ndvi = norm_diff(n, r);
-        acc_push<STATS>(acc[0], o_ndvi, 0.2f, s_hist + 0 * LARS_HIST_BINS, s_edges);
+        acc_push<STATS, U8DOM>(acc[0], o_ndvi, 0.2f, s_hist + 0 * LARS_HIST_BINS, s_edges);
     }
     float gq = 0.0f;
     if (want_gndvi || want_ndwi) gq = norm_diff(n, g);
     if (want_gndvi) {
         o_gndvi = gq;
-        acc_push<STATS>(acc[1], o_gndvi, 0.2f, s_hist + 1 * LARS_HIST_BINS, s_edges);
+        acc_push<STATS, U8DOM>(acc[1], o_gndvi, 0.2f, s_hist + 1 * LARS_HIST_BINS, s_edges);
     }
     if (want_ndwi) {
         // (g-n)/(g+n) == -(n-g)/(n+g) bit for bit, and +0.0 where the quotient is zero
         o_ndwi = 0.0f - gq;
-        acc_push<STATS>(acc[2], o_ndwi, 0.0f, s_hist + 2 * LARS_HIST_BINS, s_edges);
+        acc_push<STATS, U8DOM>(acc[2], o_ndwi, 0.0f, s_hist + 2 * LARS_HIST_BINS, s_edges);
     }
 }
 
@@ -414,7 +424,7 @@ __global__ __launch_bounds__(256) void k_fused_u8c3(FusedParams P)
 #pragma unroll
         for (int px = 0; px < 4; ++px) {
             v0[px] = v1[px] = v2[px] = 0.0f;
-            pixel_math<MASK, STATS, false>((float)b[3 * px], (float)b[3 * px + 1], (float)b[3 * px + 2], 0u,
+            pixel_math<MASK, STATS, false, !U16>((float)b[3 * px], (float)b[3 * px + 1], (float)b[3 * px + 2], 0u,
                                            v0[px], v1[px], v2[px], acc, s_hist, s_edges);
         }
         if ((MASK & 1u) && oi0) store_plane4(oi0 + q * 4, v0, nt_st);
@@ -437,7 +447,7 @@ __global__ __launch_bounds__(256) void k_fused_u8c3(FusedParams P)
         if (WB) { r = wb_map(r, 0); g = wb_map(g, 1); n = wb_map(n, 2); }
         if (WB && owb) { owb[i * 3] = (uint8_t)r; owb[i * 3 + 1] = (uint8_t)g; owb[i * 3 + 2] = (uint8_t)n; }
         float a = 0, bq = 0, c = 0;
-        pixel_math<MASK, STATS, false>((float)r, (float)g, (float)n, 0u, a, bq, c, acc, s_hist, s_edges);
+        pixel_math<MASK, STATS, false, !U16>((float)r, (float)g, (float)n, 0u, a, bq, c, acc, s_hist, s_edges);
         if ((MASK & 1u) && oi0) oi0[i] = a;
         if ((MASK & 2u) && oi1) oi1[i] = bq;
         if ((MASK & 4u) && oi2) oi2[i] = c;

@@ -23,6 +23,7 @@ sys.path.insert(0, os.path.join(ROOT, "tests"))
 from lars_image_processing_amd import _ffi, batch, dist  # noqa: E402
 from oracle import index_oracle as orc  # noqa: E402
 from test_abi_cpu import to_records  # noqa: E402
+from _select_stub import digit_pass_on_planes  # noqa: E402
 
 TYPES = ("NDVI", "GNDVI", "NDWI")
 
@@ -48,37 +49,6 @@ class GlooComm:
 
     def barrier(self):
         td.barrier()
-
-
-def f32_key(x):
-    b = np.ascontiguousarray(x, dtype=np.float32).view(np.uint32)
-    return np.where(b >> 31, ~b, b | np.uint32(0x80000000)).astype(np.uint32)
-
-
-def digit_pass_on_planes(planes):
-    """NumPy stand-in for lars_d_quotient_digit_hist over this rank's index planes [NDVI values, GNDVI values]."""
-    keys = [f32_key(p) for p in planes]
-    buckets = [np.array([batch.select_bucket(v) for v in np.unique(p)]) for p in planes]
-    uniq = [np.unique(p, return_inverse=True) for p in planes]
-
-    def pass_fn(first, bias, shift):
-        out = np.zeros((2, 2, batch.SELECT_BINS), dtype=np.uint64)
-        for s in range(2):
-            k = keys[s]
-            for t in range(2):
-                if first:
-                    if t == 1:
-                        continue                             # the bucket pass counts under track 0
-                    d = buckets[s][uniq[s][1]]
-                else:
-                    shared = all(bias[2 * q] == bias[2 * q + 1] and shift[2 * q] == shift[2 * q + 1] for q in range(2))
-                    if t == 1 and shared:
-                        continue                             # both streams' tracks shared: only track 0 is counted (as the kernel does)
-                    d = (k - np.uint32(bias[s * 2 + t])) >> np.uint32(shift[s * 2 + t])     # uint32 wrap-around, like the kernel
-                    d = d[d < batch.SELECT_DIGITS]
-                out[s, t] = np.bincount(d.astype(np.int64), minlength=batch.SELECT_BINS)[:batch.SELECT_BINS]
-        return out
-    return pass_fn
 
 
 def tile_records(tile_ids, h, w):

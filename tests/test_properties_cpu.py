@@ -74,3 +74,31 @@ def test_histogram_bin_from_the_quotient_position():
         u = (t + np.float32(8388608.0)).astype(np.float32)
         got = np.minimum((u.view(np.uint32) & 0x7FFFFF).astype(np.int64) - 1, 49)
         np.testing.assert_array_equal(got, want)
+
+
+def _quotients(a, b):
+    s = a + b
+    return np.where(s == 0, np.float32(0), (a - b) / np.where(s == 0, np.float32(1), s)).astype(np.float32)
+
+
+@settings(max_examples=60, deadline=None)
+@given(st.integers(1, 3000), st.integers(0, 2**32 - 1), st.sampled_from(["bytes", "few", "zeros", "floats"]))
+def test_select_host_logic_equals_numpy_median(n, seed, kind):
+    """batch.select_order_statistics (bucket pick by bisection, digit passes, shared / split ranks) with a NumPy stand-in
+    for the kernel pass: uint8 quotients (with the zero-bucket cut), few distinct values, mostly zeros, arbitrary floats."""
+    from _select_stub import digit_pass_on_planes
+    from lars_image_processing_amd import batch
+    rng = np.random.default_rng(seed)
+    if kind == "floats":
+        planes = [rng.uniform(-1, 1, n).astype(np.float32), np.round(rng.uniform(-1, 1, n), 2).astype(np.float32)]
+        min_abs = 0.0
+    else:
+        pool = {"bytes": np.arange(256), "few": np.array([0, 1, 2, 127, 254, 255]), "zeros": np.array([0, 0, 0, 0, 7])}[kind]
+        a, r, g = (rng.choice(pool, n).astype(np.float32) for _ in range(3))
+        planes = [_quotients(a, r), _quotients(a, g)]
+        min_abs = 1.0 / 510.0
+    keys = batch.select_order_statistics(digit_pass_on_planes(planes), n, min_abs=min_abs)
+    med = batch.medians_from_keys(keys)
+    assert med["NDVI"] == float(np.median(planes[0]))
+    assert med["GNDVI"] == float(np.median(planes[1]))
+    assert med["NDWI"] == float(np.median(np.float32(0) - planes[1]))

@@ -11,7 +11,9 @@ NumPy oracle timed on this box's host cores as a baseline.
 One process per GPU (RANK / LOCAL_RANK / WORLD_SIZE from the environment).
 Tiles shard by tile with no data-path collective; each step ends with the
 RCCL fold of the global per-index statistics (csrc/comm.cpp).  No PyTorch is
-imported: device memory, streams, events and RCCL all go through liblars_hip.so.
+imported: device memory, streams, events and RCCL all go through liblars_hip.so
+(LARS_COMM=torch, or an error from the direct RCCL bootstrap, moves only that
+fold onto torch.distributed's nccl backend: dist.TorchComm).
 
 A step = one pass of the hot path over this rank's batch of synthetic tiles
 that are already resident in HBM:
@@ -235,8 +237,21 @@ def main():
     rank, local_rank, world = dist.env_rank_world()
     if world != max(1, args.gpus) and world > 1:
         raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}")
+    collective = "none (single process)"
     if world > 1 or os.environ.get("LARS_FORCE_RCCL"):
-        comm = dist.Comm.from_env()
+        # LARS_COMM=torch: the statistics exchange through torch.distributed (nccl backend = RCCL) instead of the
+        # library's own RCCL communicator; also the fallback when the direct bootstrap reports an error
+        want_torch = os.environ.get("LARS_COMM", "rccl") == "torch"
+        comm = None
+        if not want_torch:
+            try:
+                comm = dist.Comm.from_env()
+                collective = "RCCL ncclAllGather of packed records + rank-order fold (csrc/comm.cpp)"
+            except (_ffi.LarsError, TimeoutError, OSError) as exc:
+                print(f"[bench rank {rank}] direct RCCL bootstrap failed ({exc}); using torch.distributed", file=sys.stderr)
+        if comm is None:
+            comm = dist.TorchComm.from_env("nccl")
+            collective = "torch.distributed all_gather (nccl backend = RCCL) + rank-order fold"
     else:
         _ffi.call("lars_set_device", 0)
         comm = dist.SingleProcessComm()
@@ -296,6 +311,7 @@ def main():
                 "tiles_per_gpu": args.tiles, "tile": [args.tile, args.tile, 3], "input_dtype": "u8", "mode": args.mode,
                 "output_ring_tiles": args.ring if write else 0,
                 "output_ring_placement_trials": args.placement_trials if write else 0, "parallelism": f"tile-sharded x{world}",
+                "collective": collective,
                 "device": _ffi.device_name(),
             },
             "roofline": {

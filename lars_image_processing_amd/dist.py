@@ -12,9 +12,11 @@ shared by the ranks of one node (``torch.distributed.run`` exports RANK,
 LOCAL_RANK, WORLD_SIZE, MASTER_ADDR, MASTER_PORT and a run id; none of torch is
 imported here).
 
-A second implementation of the same interface over any object with
-``all_gather_object``-like semantics exists for tests only (tests/ use gloo on
-CPU to exercise the sharding and fold logic with world_size 2).
+``TorchComm`` is the same interface over ``torch.distributed`` (backend ``nccl`` = RCCL with the
+exchange buffers in HBM, or ``gloo`` on the host): for callers that already run inside a torch
+process group, as the fallback of ``bench.py`` when the direct RCCL bootstrap fails, and for the
+world_size-2 CPU tests.  It moves the same bytes and applies the same rank-order fold
+(``fold_gathered``); only the transport differs.
 """
 from __future__ import annotations
 
@@ -133,6 +135,71 @@ class SingleProcessComm:
 
     def destroy(self):
         pass
+
+
+class TorchComm:
+    """``Comm``'s interface over an initialised ``torch.distributed`` process group.
+
+    ``device`` = where the exchange buffers live: ``"cuda:<LOCAL_RANK>"`` for the nccl (RCCL) backend,
+    ``"cpu"`` for gloo.  The statistics exchange is one ``all_gather`` of the packed records followed by the
+    fold ``lars_comm_allreduce_stats`` applies (rank order); ``allreduce_f64`` is one ``all_reduce``.
+    """
+
+    def __init__(self, device=None, group=None):
+        import torch
+        import torch.distributed as td
+        if not td.is_initialized():
+            raise RuntimeError("TorchComm needs an initialised torch.distributed process group")
+        self._torch, self._td, self._group = torch, td, group
+        self.rank, self.world = td.get_rank(group), td.get_world_size(group)
+        if device is None:
+            device = f"cuda:{env_rank_world()[1]}" if td.get_backend(group) == "nccl" else "cpu"
+        self.device = torch.device(device)
+        self._owns_group = False
+
+    @classmethod
+    def from_env(cls, backend="nccl"):
+        """Join the launcher's process group (RANK / LOCAL_RANK / WORLD_SIZE / MASTER_ADDR / MASTER_PORT)."""
+        import torch
+        import torch.distributed as td
+        rank, local_rank, world = env_rank_world()
+        if backend == "nccl":
+            _ffi.call("lars_set_device", local_rank)
+            torch.cuda.set_device(local_rank)
+        if not td.is_initialized():
+            td.init_process_group(backend, rank=rank, world_size=world)
+        comm = cls(f"cuda:{local_rank}" if backend == "nccl" else "cpu")
+        comm._owns_group = True
+        comm.barrier()
+        return comm
+
+    def allreduce_stats(self, records):
+        torch, td = self._torch, self._td
+        rec = np.ascontiguousarray(records, dtype=STATS_DTYPE).reshape(-1)
+        mine = torch.from_numpy(rec.view(np.uint8).copy()).to(self.device)
+        gathered = [torch.empty_like(mine) for _ in range(self.world)]
+        td.all_gather(gathered, mine, group=self._group)
+        per_rank = [g.cpu().numpy().view(STATS_DTYPE) for g in gathered]
+        return fold_gathered(per_rank)
+
+    def allreduce_f64(self, values, op="sum"):
+        torch, td = self._torch, self._td
+        t = torch.from_numpy(np.ascontiguousarray(values, dtype=np.float64).reshape(-1).copy()).to(self.device)
+        td.all_reduce(t, op={"sum": td.ReduceOp.SUM, "max": td.ReduceOp.MAX, "min": td.ReduceOp.MIN}[op],
+                      group=self._group)
+        return t.cpu().numpy()
+
+    def barrier(self):
+        if self.device.type == "cuda":
+            # an all_reduce on the device + the copy back orders this rank after every other rank's launch
+            self.allreduce_f64([0.0])
+        else:
+            self._td.barrier(group=self._group)
+
+    def destroy(self):
+        if self._owns_group and self._td.is_initialized():
+            self._td.destroy_process_group()
+        self._owns_group = False
 
 
 def fold_gathered(per_rank_records):

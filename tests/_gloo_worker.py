@@ -28,29 +28,6 @@ from _select_stub import digit_pass_on_planes  # noqa: E402
 TYPES = ("NDVI", "GNDVI", "NDWI")
 
 
-class GlooComm:
-    """dist.Comm's interface over torch.distributed/gloo (tests only)."""
-
-    def __init__(self):
-        self.rank, self.world = td.get_rank(), td.get_world_size()
-
-    def allreduce_stats(self, records):
-        rec = np.ascontiguousarray(records, dtype=_ffi.STATS_DTYPE).reshape(-1)
-        mine = torch.from_numpy(rec.view(np.uint8).copy())
-        gathered = [torch.empty_like(mine) for _ in range(self.world)]
-        td.all_gather(gathered, mine)                         # what ncclAllGather does on the GPU path
-        per_rank = [g.numpy().view(_ffi.STATS_DTYPE) for g in gathered]
-        return dist.fold_gathered(per_rank)                   # the fold csrc/comm.cpp applies
-
-    def allreduce_f64(self, values, op="sum"):
-        t = torch.from_numpy(np.ascontiguousarray(values, dtype=np.float64).reshape(-1).copy())
-        td.all_reduce(t, op={"sum": td.ReduceOp.SUM, "max": td.ReduceOp.MAX, "min": td.ReduceOp.MIN}[op])
-        return t.numpy()
-
-    def barrier(self):
-        td.barrier()
-
-
 def tile_records(tile_ids, h, w):
     rec = np.zeros((len(tile_ids), 3), dtype=_ffi.STATS_DTYPE)
     for j, t in enumerate(tile_ids):
@@ -80,7 +57,8 @@ def main():
     ntiles, h, w = 7, 40, 56
     lo, hi = batch.shard_range(ntiles, rank, world)
     mine = tile_records(list(range(lo, hi)), h, w)
-    comm = GlooComm()
+    comm = dist.TorchComm()                     # dist.Comm's interface over the gloo group (RCCL on the GPU path)
+    assert (comm.rank, comm.world, comm.device.type) == (rank, world, "cpu")
     local = batch.local_fold(mine) if hi > lo else np.zeros(3, dtype=_ffi.STATS_DTYPE)
     if hi == lo:                                  # a rank with no tiles contributes neutral records
         local["min"], local["max"] = np.inf, -np.inf

@@ -1,0 +1,55 @@
+"""bench.py end to end on a small batch: the JSON line's contract, and both transports of the statistics fold
+(the library's own RCCL communicator and dist.TorchComm over torch.distributed's nccl backend) with one rank."""
+import json
+import os
+import subprocess
+import sys
+
+import pytest
+
+pytestmark = pytest.mark.gpu
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def run_bench(extra_env, *args):
+    env = dict(os.environ, RANK="0", LOCAL_RANK="0", WORLD_SIZE="1", MASTER_ADDR="127.0.0.1", MASTER_PORT="29731",
+               LARS_RDZV_TOKEN=f"bench{os.getpid()}", **extra_env)
+    cmd = [sys.executable, os.path.join(ROOT, "bench.py"), "--tiles", "6", "--tile", "512", "--ring", "4", "--steps", "2",
+           "--warmup", "1", "--no-all-modes", "--no-probe", "--placement-trials", "2", *args]
+    out = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=600, cwd=ROOT)
+    assert out.returncode == 0, out.stderr[-2000:]
+    lines = [ln for ln in out.stdout.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1, out.stdout
+    return json.loads(lines[0])
+
+
+def check_line(line, tiles=6, tile=512):
+    for key in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling",
+                "vs_baseline", "dtype", "data", "config", "roofline"):
+        assert key in line, key
+    assert line["unit"] == "Mpix/s" and line["n_gpus"] == 1 and line["steps"] == 2 and line["warmup"] == 1
+    assert line["scaling"] == "weak" and line["vs_baseline"] is None and line["higher_is_better"] is True
+    assert abs(line["value"] - tiles * tile * tile / (line["ms_per_step"] * 1e-3) / 1e6) <= 1e-6 * line["value"]
+    roof = line["roofline"]
+    assert roof["bound"] == "hbm" and roof["unit"] == "GB/s" and roof["peak"] == 8000.0
+    assert abs(roof["frac"] - roof["achieved"] / roof["peak"]) < 1e-12
+    for name in ("NDVI", "GNDVI", "NDWI"):
+        assert line["global_stats"][name]["count"] == tiles * tile * tile
+
+
+def test_bench_line_single_process():
+    line = run_bench({}, "--cpu-tiles", "1", "--cpu-workers", "2")
+    check_line(line)
+    cpu = line["cpu_baseline"]
+    assert cpu["kind"] == "port" and cpu["cores"] == 1 and cpu["unit"] == "Mpix/s" and cpu["value"] > 0
+    assert line["config"]["collective"].startswith("none")
+
+
+@pytest.mark.parametrize("transport", ["rccl", "torch"])
+def test_bench_statistics_fold_transports_agree(transport):
+    """One rank through each transport: same global statistics as the single-process fold."""
+    base = run_bench({}, "--no-cpu-baseline")
+    line = run_bench({"LARS_FORCE_RCCL": "1", "LARS_COMM": transport}, "--no-cpu-baseline")
+    check_line(line)
+    assert ("torch.distributed" in line["config"]["collective"]) == (transport == "torch")
+    assert line["global_stats"] == base["global_stats"]

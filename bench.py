@@ -44,7 +44,7 @@ MODES = {
     "wb3idx_stats_only": (("NDVI", "GNDVI", "NDWI"), False, False, 3),
     "wb_ndvi_stats_only": (("NDVI",), False, False, 3),
     # statistics + the exact median of every tile (the reference's analyze_index / time-series table): the statistics
-    # kernel counts the select's bucket pass, two or three digit passes follow; 3 B/pixel per pass
+    # kernel counts the select's bucket pass, one slot pass follows; 3 B/pixel per pass
     "wb3idx_stats_medians": (("NDVI", "GNDVI", "NDWI"), False, False, 3),
 }
 

@@ -204,25 +204,25 @@ int lars_d_median_pair_f64(const double *x, int64_t n, double *out_dev, void *sc
 int lars_d_median_pair_batch_f32(const float *x, int64_t n, int64_t items, int64_t stride, float *out_dev,
                                  void *scratch, void *stream);
 
-/* One radix-select pass over the index values of a batch WITHOUT the planes in memory (exact batch /
+/* One pass of the two-level select over the index values of a batch WITHOUT the planes in memory (exact batch /
  * global medians): the NDVI and GNDVI quotients of every pixel are recomputed from the
- * uint8 tiles.  first != 0: each value is counted in one of 2048 linear buckets of [-1, 1]
- * (bucket = low 23 bits of float32(fma(x, 1023.5, 1023.5) + 2^23)), under track 0.  Otherwise, per stream s
- * and track t, the value's order-preserving key (x >= 0: bits | 2^31, x < 0: ~bits) is counted in bin
- * (key - bias[2s+t]) >> shift[2s+t] when that is below 1984; when both tracks of BOTH streams share
- * (bias, shift) only track 0 is counted.  hist is uint64[2 streams][2 tracks][2048], accumulated with
- * atomics (zero it first).  NDWI = -GNDVI shares GNDVI's order statistics. */
-int lars_d_quotient_digit_hist(const void *tiles, int64_t ntiles, int64_t npix, int channels, int dtype,
-                               const uint8_t *wb_table, int first, const uint32_t bias[4], const uint32_t shift[4],
-                               uint64_t *hist, void *stream);
-/* np.median of the NDVI and GNDVI planes of EVERY tile without writing a plane: the same three passes with
- * per-tile histograms and the digit picks on the device (no host round trip).  out_pairs is float[ntiles][2
+ * uint8 tiles.  Position of a value: t = float32 fma(x, 1023.5, 3071.5) in [2048, 4095]; its 23 mantissa bits are
+ * 11 bits of bucket and 12 bits of fraction.  first != 0: each value is counted in its bucket, under track 0.
+ * Otherwise, per stream s and track k, the values of bucket[2s+k] are counted in slot (fraction >> 2) (1024 slots);
+ * when both tracks of BOTH streams share their bucket only track 0 is counted.  A slot holds one distinct value
+ * (two different quotients of bytes are >= 1/(510 * 509) apart = 16 units of the fraction).
+ * hist is uint64[2 streams][2 tracks][2048], accumulated with atomics (zero it first).  NDWI = -GNDVI shares
+ * GNDVI's order statistics. */
+int lars_d_quotient_select_hist(const void *tiles, int64_t ntiles, int64_t npix, int channels, int dtype,
+                                const uint8_t *wb_table, int first, const uint32_t bucket[4], uint64_t *hist, void *stream);
+/* np.median of the NDVI and GNDVI planes of EVERY tile without writing a plane: the same two passes with
+ * per-tile histograms, the picks and the value look-up on the device (no host round trip).  out_pairs is float[ntiles][2
  * streams: NDVI, GNDVI][2]: the two middle order statistics (median = their float32 mean; NDWI's median is
  * -GNDVI's).  scratch holds lars_quotient_median_scratch_bytes(ntiles). */
 size_t lars_quotient_median_scratch_bytes(int64_t ntiles);
 /* The statistics of lars_d_fused (a->stats, LARS_F_HIST honoured; index_mask = one index or all three; no
  * output planes) AND those medians in one call: the statistics kernel also counts the select's first
- * pass, so the tiles are read four times instead of five.  Streams the mask does not ask for come back
+ * pass, so the tiles are read twice (three times with the white-balance histogram pass).  Streams the mask does not ask for come back
  * as NaN pairs. */
 int lars_d_stats_medians(const lars_fused_args *a, float *out_pairs, void *scratch);
 int lars_d_quotient_median_pairs(const void *tiles, int64_t ntiles, int64_t npix, int channels, int dtype,

@@ -105,7 +105,7 @@ SIGNATURES = {
     "lars_quotient_median_scratch_bytes": (_SZ, [_I64]),
     "lars_d_stats_medians": (_I, [C.POINTER(FusedArgs), _P, _P]),
     "lars_d_quotient_median_pairs": (_I, [_P, _I64, _I64, _I, _I, _P, _P, _P, _P]),
-    "lars_d_quotient_digit_hist": (_I, [_P, _I64, _I64, _I, _I, _P, _I, _P, _P, _P, _P]),
+    "lars_d_quotient_select_hist": (_I, [_P, _I64, _I64, _I, _I, _P, _I, _P, _P, _P]),
     "lars_d_synth_u8": (_I, [_P, _I64, _I64, _I64, _I, _U32, _I, _P]),
     "lars_stats_merge": (_I, [_P, _I64, _P]),
     "lars_d_probe": (_I, [_I, _I, _I, _P, _P, _I64, _P]),

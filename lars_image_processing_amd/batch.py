@@ -232,8 +232,8 @@ class TileBatch:
         stats = self.new_stats()
         stats.zero()
         if medians and outputs is None and self.code == _ffi.U8 and self.channels == 3 and (self.ntiles == 1 or self.npix % 4 == 0):
-            # nothing to write: the statistics kernel also counts the select's bucket pass, two (rarely three) digit
-            # passes follow -- 3 B per pixel each, everything on the device
+            # nothing to write: the statistics kernel also counts the select's bucket pass, one slot pass follows --
+            # 3 B per pixel each, everything on the device
             mask = 0
             for t in indices:
                 mask |= 1 << INDEX_IDS[t]
@@ -293,7 +293,7 @@ class TileBatch:
 
     def tile_medians(self, indices=INDEX_NAMES, white_balance=True, stream=None):
         """float64[ntiles, 3]: np.median of every tile's index planes, none of which is written
-        (``lars_d_quotient_median_pairs``: per-tile radix select on recomputed values, all on the device)."""
+        (``lars_d_quotient_median_pairs``: per-tile two-level select on recomputed values, all on the device)."""
         if white_balance and self.table is None:
             raise RuntimeError("compute_wb_tables() first")
         pairs_dev = DeviceBuffer(self.ntiles * 4 * 4)
@@ -318,8 +318,8 @@ class TileBatch:
         return med
 
     # -- exact medians of the whole batch (all tiles, all ranks) ------------
-    def digit_histogram(self, first, bias, shift, white_balance=True, stream=None):
-        """One radix-select pass (``lars_d_quotient_digit_hist``): uint64[2 streams][2 tracks][2048]."""
+    def select_histogram(self, first, buckets, white_balance=True, stream=None):
+        """One pass of the two-level select (``lars_d_quotient_select_hist``): uint64[2 streams][2 tracks][2048]."""
         if self.code != _ffi.U8 or self.channels != 3:
             raise TypeError("exact batch medians need uint8 tiles with 3 channels")
         if white_balance and self.table is None:
@@ -327,25 +327,23 @@ class TileBatch:
         if getattr(self, "_selq", None) is None:
             self._selq = DeviceBuffer(2 * 2 * SELECT_BINS * 8)
         self._selq.zero()
-        b = np.ascontiguousarray(bias, dtype=np.uint32).reshape(4)
-        sh = np.ascontiguousarray(shift, dtype=np.uint32).reshape(4)
-        _ffi.call("lars_d_quotient_digit_hist", C.c_void_p(self.tiles.ptr), self.ntiles, self.npix, self.channels, self.code,
-                  C.c_void_p(self.table.ptr) if white_balance else None, int(bool(first)), _ffi.ptr(b), _ffi.ptr(sh),
+        b = np.ascontiguousarray(buckets, dtype=np.uint32).reshape(4)
+        _ffi.call("lars_d_quotient_select_hist", C.c_void_p(self.tiles.ptr), self.ntiles, self.npix, self.channels, self.code,
+                  C.c_void_p(self.table.ptr) if white_balance else None, int(bool(first)), _ffi.ptr(b),
                   C.c_void_p(self._selq.ptr), stream)
         _ffi.call("lars_synchronize", stream)
         return self._selq.download(np.uint64, (2, 2, SELECT_BINS))
 
     def global_medians(self, indices=INDEX_NAMES, white_balance=True, comm=None, recompute_tables=False):
         """``np.median`` of each index over ALL pixels of ALL tiles of ALL ranks, exactly, without writing a plane:
-        three radix-select passes (2048 linear buckets, then two 11-bit digits of the key range of the chosen bucket)
-        that recompute the index values from the tiles (3 bytes per pixel and pass) and one small all-reduce per pass
-        (SURVEY.md 8(e))."""
+        two select passes (2048 linear buckets, then the 1024 slots of the chosen bucket, each of which holds one
+        distinct quotient of bytes) that recompute the index values from the tiles (3 bytes per pixel and pass) and
+        one small all-reduce per pass."""
         if white_balance and (recompute_tables or self.table is None):
             self.compute_wb_tables()
         n_local = self.ntiles * self.npix
-        keys = select_order_statistics(lambda first, bias, shift: self.digit_histogram(first, bias, shift, white_balance),
-                                       n_local, comm, min_abs=1.0 / 510.0)
-        return medians_from_keys(keys, indices)
+        values = select_order_statistics(lambda first, buckets: self.select_histogram(first, buckets, white_balance), n_local, comm)
+        return medians_from_pairs(values, indices)
 
 
 class BatchOutputs:
@@ -448,110 +446,85 @@ def timeseries_rows(records, medians, index_type, dates=None):
 
 
 # ---------------------------------------------------------------------------
-# exact order statistics across tiles and ranks (radix select on recomputed values)
+# exact order statistics across tiles and ranks (two-level select on recomputed quotients of bytes)
 # ---------------------------------------------------------------------------
 SELECT_BINS = 2048
-SELECT_DIGITS = 1984                                       # usable bins of a later pass (the kernel keeps 64 dummy words per row)
-SELECT_DIGIT_BITS = 10                                     # 2^10 <= SELECT_DIGITS
-KEY_MINUS1, KEY_PLUS1, KEY_ZERO = 0x407FFFFF, 0xBF800000, 0x80000000     # order-preserving keys of -1.0, +1.0, +0.0
+SELECT_SLOTS = 1024                                        # second level: slots inside one bucket
+MAX_BYTE_SUM = 510                                         # largest denominator of a quotient of bytes
 
 
-def key_to_float32(key):
-    """Inverse of the kernels' order-preserving key (x >= 0: bits | 2^31; x < 0: ~bits)."""
-    key = np.uint32(key)
-    bits = (key & np.uint32(0x7FFFFFFF)) if (key & np.uint32(0x80000000)) else ~key
-    return np.array([bits], dtype=np.uint32).view(np.float32)[0]
+def select_position(x):
+    """(bucket, slot) of float32 values in [-1, 1], the kernels' arithmetic: t = float32 fma(x, 1023.5, 3071.5) lies in
+    [2048, 4095]; its 23 mantissa bits are 11 bits of bucket and 12 of fraction, slot = fraction >> 2.
+    (The float64 product and sum are exact, so the single rounding to float32 is the fma's.)"""
+    t = (np.asarray(x, dtype=np.float32).astype(np.float64) * 1023.5 + 3071.5).astype(np.float32)
+    m = np.ascontiguousarray(t).view(np.uint32) - np.uint32(0x45000000)
+    return (m >> np.uint32(12)).astype(np.int64), ((m & np.uint32(0xFFF)) >> np.uint32(2)).astype(np.int64)
 
 
-def float32_to_key(x):
-    bits = int(np.array([x], dtype=np.float32).view(np.uint32)[0])
-    return (~bits & 0xFFFFFFFF) if bits >> 31 else (bits | 0x80000000)
+def select_value(bucket, slot):
+    """The one quotient of bytes n/d (d <= 510) whose position is (bucket, slot): any two such fractions differ by at
+    least 1/(510 * 509) = 16 units of the fraction, a slot is 4 wide.  Every denominator is tried with n =
+    rint(centre * d); float32 n/d is the correctly rounded quotient the kernels compute."""
+    centre = ((2048.0 + bucket + (slot * 4.0 + 2.0) / 4096.0) - 3071.5) / 1023.5
+    den = np.arange(1, MAX_BYTE_SUM + 1, dtype=np.float64)
+    num = np.rint(centre * den)
+    q = (num.astype(np.float32) / den.astype(np.float32)).astype(np.float32) + np.float32(0)      # -0/d -> +0.0
+    b, s = select_position(q)
+    hit = (np.abs(num) <= den) & (b == bucket) & (s == slot)
+    if not hit.any():
+        raise RuntimeError(f"select: no quotient of bytes at bucket {bucket}, slot {slot} (inconsistent passes)")
+    vals = np.unique(q[hit])
+    assert vals.size == 1
+    return np.float32(vals[0])
 
 
-def select_bucket(x):
-    """First-level bucket of x in [-1, 1], the kernels' ``selq_bucket``: the low 23 bits of
-    float32(fma(x, 1023.5, 1023.5) + 2^23).  (The float64 product and sum are exact, so one rounding = the fma.)"""
-    t = np.float32(np.float64(np.float32(x)) * 1023.5 + 1023.5)
-    u = np.float32(t + np.float32(8388608.0))
-    return int(np.array([u], dtype=np.float32).view(np.uint32)[0] & 0x7FFFFF)
+def select_order_statistics(pass_fn, n_local, comm=None):
+    """The two middle order statistics (ranks (N-1)//2 and N//2) of two streams of quotients of bytes: float32[2][2].
 
-
-def bucket_lower_key(b):
-    """Smallest key in [key(-1), key(+1) + 1] whose bucket is >= b (the bucket function is monotone in x)."""
-    lo, hi = KEY_MINUS1, KEY_PLUS1 + 1
-    while lo < hi:
-        mid = (lo + hi) // 2
-        if select_bucket(key_to_float32(mid)) >= b:
-            hi = mid
-        else:
-            lo = mid + 1
-    return lo
-
-
-def select_order_statistics(pass_fn, n_local, comm=None, min_abs=0.0, max_passes=8):
-    """Keys of the two middle order statistics (ranks (N-1)//2 and N//2) of two value streams in [-1, 1].
-
-    ``pass_fn(first, bias[4], shift[4]) -> uint64[2][2][SELECT_BINS]`` counts on this rank: first pass, the
-    linear bucket of every value (under track 0); later passes, bin ``(key - bias) >> shift`` (below
-    ``SELECT_DIGITS``) of the keys inside the chosen range -- under track 0 only when both streams' tracks share
-    (bias, shift).
-    Histograms are summed over ranks through ``comm.allreduce_f64`` (counts < 2^53 are exact in float64), every
-    rank then picks the same bins.  ``min_abs``: the values are 0 or at least that large in magnitude (uint8
-    quotients: 1/510), which cuts the bucket around zero down to the key of +0.0.  Returns uint32[2][2].
+    ``pass_fn(first, buckets[4]) -> uint64[2][2][SELECT_BINS]`` counts on this rank: first pass, the bucket of every
+    value (under track 0); second pass, the slot of the values inside ``buckets[stream * 2 + track]`` -- under track 0
+    only when both streams' tracks share their bucket.  Histograms are summed over ranks through
+    ``comm.allreduce_f64`` (counts < 2^53 are exact in float64), every rank then picks the same bins.
     """
     tot = np.array([float(n_local)])
     n_total = int((comm.allreduce_f64(tot, "sum") if comm is not None else tot)[0])
+    if n_total <= 0:
+        raise ValueError("select: no values")
     ranks = np.array([[(n_total - 1) // 2, n_total // 2]] * 2, dtype=np.int64)     # [stream][track]
-    bias = np.zeros((2, 2), dtype=np.uint32)
-    shift = np.zeros((2, 2), dtype=np.uint32)
-    first = True
-    for _ in range(max_passes):
-        local = np.asarray(pass_fn(first, bias.reshape(4), shift.reshape(4)), dtype=np.uint64).reshape(2, 2, SELECT_BINS)
+    buckets = np.zeros((2, 2), dtype=np.uint32)
+    values = np.zeros((2, 2), dtype=np.float32)
+    for first in (True, False):
+        local = np.asarray(pass_fn(first, buckets.reshape(4)), dtype=np.uint64).reshape(2, 2, SELECT_BINS)
         hist = local.astype(np.float64).reshape(-1)
         if comm is not None:
             hist = comm.allreduce_f64(hist, "sum")
         hist = np.asarray(hist).reshape(2, 2, SELECT_BINS).astype(np.int64)
         if first:
-            hist[:, 0] += hist[:, 1]                        # bucket pass: counted under track 0
-            hist[:, 1] = hist[:, 0]
+            hist[:, 1] = hist[:, 0]                         # bucket pass: counted under track 0
         else:
-            hist[:, :, SELECT_DIGITS:] = 0                  # not part of a later pass's histogram
-            if (bias[:, 0] == bias[:, 1]).all() and (shift[:, 0] == shift[:, 1]).all():
+            hist[:, :, SELECT_SLOTS:] = 0
+            if (buckets[:, 0] == buckets[:, 1]).all():
                 hist[:, 1] = hist[:, 0]                     # both streams' tracks shared: only track 0 was counted
-        last = not first and not shift.any()
         for s in range(2):
             for t in range(2):
                 cum = np.cumsum(hist[s, t])
                 d = int(np.searchsorted(cum, ranks[s, t], side="right"))
-                if d >= SELECT_BINS:
-                    raise RuntimeError("radix select: rank beyond the histogram mass (inconsistent passes)")
+                if d >= (SELECT_BINS if first else SELECT_SLOTS):
+                    raise RuntimeError("select: rank beyond the histogram mass (inconsistent passes)")
                 ranks[s, t] -= int(cum[d - 1]) if d else 0
                 if first:
-                    lo = bucket_lower_key(d)
-                    hi = KEY_PLUS1 + 1 if d >= SELECT_BINS - 1 else bucket_lower_key(d + 1)
-                    if min_abs > 0 and lo <= KEY_ZERO < hi and float32_to_key(-min_abs) < lo and hi <= float32_to_key(min_abs):
-                        lo, hi = KEY_ZERO, KEY_ZERO + 1     # only +0.0 lives there
-                    span = hi - lo - 1
-                    sh = 0
-                    while (span >> sh) >= SELECT_DIGITS:    # the first digit must fit a row
-                        sh += 1
-                    bias[s, t] = lo
-                    shift[s, t] = sh
+                    buckets[s, t] = d
                 else:
-                    bias[s, t] = np.uint32(int(bias[s, t]) + (d << int(shift[s, t])))
-                    shift[s, t] = max(int(shift[s, t]) - SELECT_DIGIT_BITS, 0)
-        if last:
-            return bias
-        first = False
-    raise RuntimeError("radix select did not finish")
+                    values[s, t] = select_value(int(buckets[s, t]), d)
+    return values
 
 
-def medians_from_keys(keys, indices=INDEX_NAMES):
+def medians_from_pairs(values, indices=INDEX_NAMES):
     """np.median semantics (mean of the two middle values in float32); NDWI = -GNDVI shares GNDVI's statistics."""
     out = {}
     for t in indices:
         s = 0 if t == "NDVI" else 1
-        a, b = key_to_float32(keys[s, 0]), key_to_float32(keys[s, 1])
-        m = np.float32(np.float32(a + b) / np.float32(2))
+        m = np.float32(np.float32(values[s, 0] + values[s, 1]) / np.float32(2))
         out[t] = float(np.float32(0) - m) if t == "NDWI" else float(m)
     return out

@@ -272,7 +272,7 @@ __global__ __launch_bounds__(V2Block<OUT>::threads, OUT ? 4 : LARS_V2_STATS_WAVE
     const unsigned int hb0 = hist_lds + (((unsigned)tid & (V2_HIST_COPIES - 1)) << 2) - (V2_HIST_MAGIC_BITS << V2_HIST_SHIFT);
     const unsigned int hb1 = hb0 + V2_HIST_ROWS * V2_HIST_COPIES * 4, hb2 = hb1 + V2_HIST_ROWS * V2_HIST_COPIES * 4;
     const unsigned int sel_lds = SEL ? (unsigned int)(unsigned long long)(lds_u32 *)s_sel : 0u;
-    const unsigned int sb0 = sel_lds - (SELQ_MAGIC_BITS << 2), sb1 = sb0 + SELQ_BINS * 4;     // NDVI row, GNDVI row
+    const unsigned int sb0 = sel_lds, sb1 = sb0 + SELQ_BINS * 4;     // NDVI row, GNDVI row
     const unsigned int lane_off4 = lane << 2;
     const long long tile = blockIdx.y;
     const long long npix = P.npix;
@@ -356,8 +356,8 @@ __global__ __launch_bounds__(V2Block<OUT>::threads, OUT ? 4 : LARS_V2_STATS_WAVE
                     hist_add_pos(p.x, hb0); hist_add_pos(p.y, hb0);
                 }
                 if (SEL) {
-                    const f32x2 p = selq_pos2(x);
-                    selq_add_pos(p.x, sb0); selq_add_pos(p.y, sb0);
+                    const f32x2 p = selq_t2(x);
+                    selq_add_bucket(p.x, sb0); selq_add_bucket(p.y, sb0);
                 }
             }
             if (NEED_G) {
@@ -369,8 +369,8 @@ __global__ __launch_bounds__(V2Block<OUT>::threads, OUT ? 4 : LARS_V2_STATS_WAVE
                     hist_add_pos(p.x, hb1); hist_add_pos(p.y, hb1);
                 }
                 if (SEL) {
-                    const f32x2 p = selq_pos2(x);
-                    selq_add_pos(p.x, sb1); selq_add_pos(p.y, sb1);
+                    const f32x2 p = selq_t2(x);
+                    selq_add_bucket(p.x, sb1); selq_add_bucket(p.y, sb1);
                 }
                 if (STATS >= 2 && WANT_NDWI) {
                     const f32x2 p = hist_pos2(x, -1.0f);
@@ -479,13 +479,13 @@ __global__ __launch_bounds__(V2Block<OUT>::threads, OUT ? 4 : LARS_V2_STATS_WAVE
             const float x = norm_diff_fast(fn, fr);
             if (STATS >= 1) push<STATS>(acc_v, above_v, x, 0.2f);
             if (STATS >= 2) hist_add(x, 1.0f, hb0);
-            if (SEL) selq_add_pos(__builtin_fmaf(x, 1023.5f, 1023.5f) + 8388608.0f, sb0);
+            if (SEL) selq_add_bucket(selq_t(x), sb0);
             if (oi0) oi0[i] = x;
             if (oc0) reinterpret_cast<unsigned int *>(oc0)[i] = lut0[cmap_index(x)];
         }
         if (NEED_G) {
             const float x = norm_diff_fast(fn, fg);
-            if (SEL) selq_add_pos(__builtin_fmaf(x, 1023.5f, 1023.5f) + 8388608.0f, sb1);
+            if (SEL) selq_add_bucket(selq_t(x), sb1);
             if (STATS >= 1) {
                 acc_g.mn = fminf(acc_g.mn, x); acc_g.mx = fmaxf(acc_g.mx, x);
                 const double xd = (double)x;

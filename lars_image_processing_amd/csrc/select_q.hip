@@ -10,60 +10,40 @@ namespace lars {
 
 // ---------------------------------------------------------------------------
 // Exact medians without materialising the index planes -- of every tile of a batch, or of the whole batch over
-// all ranks.  Radix select on values that are RECOMPUTED from the tiles (3 bytes per pixel and
+// all ranks.  A two-level select on values that are RECOMPUTED from the tiles (3 bytes per pixel and
 // pass).  Two streams (NDVI, GNDVI; NDWI = -GNDVI shares GNDVI's order statistics) x two tracks (the ranks
 // (N-1)/2 and N/2, which may part ways).
-//   pass 1   2048 linear buckets of [-1, 1] (selq_bucket: monotone in x, so it is a valid first radix level, and
-//            unlike the key's top bits it spreads an index plane over hundreds of LDS words)
-//   pick     bucket holding the rank -> its key range [lo, hi) by bisection with the same arithmetic
-//   pass 2+  digit d = (key - bias) >> shift of the keys inside the range (anything else lands on a per-lane dummy
-//            word: d is compared with the row's usable length by one v_min, no branch); the first digit takes whatever
-//            shift makes it fit 1984 bins, then the shift drops by 10 per pass until 0.
-// uint8 quotients are 0 or at least 1/510 in magnitude, so a bucket is at most 2^22 keys wide (three passes, four for
-// medians below 2^-7 in magnitude) once the bucket around zero is cut down to the single key of +0.0.
+//   pass 1   2048 linear buckets of [-1, 1]: bucket = floor(t) - 2048, t = fma(x, 1023.5, 3071.5) (v2_device.h).  Monotone in
+//            x, so a valid first radix level, and unlike a float key's top bits it spreads an index plane over hundreds
+//            of LDS words.
+//   pick     bucket holding the rank, rank inside it
+//   pass 2   slot = (fraction bits of t) >> 2 of the values whose t falls into the picked bucket -- one integer
+//            subtract tells both ("t bits - bits of the bucket's first t" is below 4096 exactly for the bucket's members);
+//            anything else lands on a per-lane dummy word (one v_min, no branch).
+//   pick     slot holding the rank.  A slot holds ONE distinct value: quotients of bytes are fractions n/d with
+//            d <= 510, any two of which differ by >= 1/(510 * 509) = 16.1 units of the fraction, 15 after both
+//            roundings, and a slot is 4 units wide.  The value itself is found by trying every denominator: n =
+//            rint(centre * d), q = n / d with the kernels' own quotient, accepted when its (bucket, slot) is the
+//            picked one.
+// Always two passes; both see the same bits of t, so they cannot disagree about membership.
 // LDS: the 64 KiB white-balance table + one 2048-word row per stream = exactly 80 KiB, two blocks per CU.
 // ---------------------------------------------------------------------------
-#define SELQ_DIGITS 1984                                  /* digits per row in the later passes; words 1984..2047 are per-lane dummies */
-#define SELQ_DIGIT_BITS 10                                /* 2^10 <= SELQ_DIGITS: a picked bin splits into at most that many */
-#define SELQ_KEY_MINUS1 0x407FFFFFu                        /* f32_key(-1.0f) */
-#define SELQ_KEY_PLUS1 0xBF800000u                         /* f32_key(+1.0f) */
-#define SELQ_KEY_ZERO 0x80000000u                          /* f32_key(+0.0f) */
-
-// first-level bucket of x in [-1, 1]: round((x + 1) * 1023.5) in 0..2047, read off the mantissa of t + 2^23
-__device__ inline unsigned int selq_bucket(float x)
-{
-    const float t = __builtin_fmaf(x, 1023.5f, 1023.5f);
-    const float u = t + 8388608.0f;
-    return __builtin_bit_cast(unsigned int, u) & 0x7FFFFFu;
-}
-// smallest key in [key(-1), key(+1) + 1] whose bucket is >= b
-__device__ inline unsigned int selq_lower_key(unsigned int b)
-{
-    unsigned int lo = SELQ_KEY_MINUS1, hi = SELQ_KEY_PLUS1 + 1u;
-    while (lo < hi) {
-        const unsigned int mid = lo + ((hi - lo) >> 1);
-        if (selq_bucket(key_f32(mid)) >= b) hi = mid;
-        else lo = mid + 1u;
-    }
-    return lo;
-}
 
 struct SelQParams {
     const uint8_t *tiles;
     const uint8_t *wb_table;
     long long npix;
-    int first;                            // 1: bucket pass (every value counts, track = lane parity)
-    unsigned int bias[4], shift[4];       // [stream * 2 + track], later passes
+    int first;                            // 1: bucket pass (every value counts, under track 0)
+    unsigned int bucket[4];               // [stream * 2 + track], second pass
     unsigned long long *hist;             // [2][2][SELQ_BINS], accumulated with atomics (whole-batch variant)
     // per-tile selection (medians of every tile of a batch, all on the device): state and 32-bit histograms per tile
     struct SelQTile *state;
     unsigned int *hist32;                 // [ntiles][2][2][SELQ_BINS]
 };
 struct SelQTile {
-    unsigned int bias[4];                 // [stream * 2 + track]: key the digits are counted from
-    unsigned int shift[4];
-    unsigned int rank[4];                 // rank still to find at or above bias
-    unsigned int done;                    // bit c: combo c has had its shift-0 pass (bias is the key of the order statistic)
+    unsigned int bucket[4];               // [stream * 2 + track]: bucket picked after pass 1
+    unsigned int rank[4];                 // rank still to find inside the bucket
+    unsigned int streams;                 // bit s: stream s was asked for
     unsigned int pad[3];
 };
 
@@ -78,8 +58,6 @@ __global__ __launch_bounds__(1024, 8) void k_selq_pass(SelQParams P)
     const long long tile = blockIdx.y;
     const long long npix = P.npix;
     const uint8_t *base = P.tiles + tile * npix * 3;
-    // a tile whose four order statistics are settled skips the spare passes (uniform per block)
-    if (PER_TILE && !P.first && P.state[tile].done == 0xFu) return;
     if (WB) {
         const uint8_t *t = P.wb_table + tile * 768;
         unsigned int *tab = reinterpret_cast<unsigned int *>(s_tab);
@@ -91,29 +69,23 @@ __global__ __launch_bounds__(1024, 8) void k_selq_pass(SelQParams P)
     for (int i = tid; i < 2 * SELQ_BINS; i += 1024) s_h[i] = 0;
     __syncthreads();
 
-    const unsigned int *bias = PER_TILE ? P.state[tile].bias : P.bias;
-    const unsigned int *shft = PER_TILE ? P.state[tile].shift : P.shift;
-    const unsigned int ba[2] = {bias[0], bias[1]}, bb[2] = {bias[2], bias[3]};
-    const unsigned int sa[2] = {shft[0], shft[1]}, sb[2] = {shft[2], shft[3]};
+    const unsigned int *bk = PER_TILE ? P.state[tile].bucket : P.bucket;
+    const unsigned int ba[2] = {bk[0], bk[1]}, bb[2] = {bk[2], bk[3]};
     const long long nquads = npix >> 2;
-    const unsigned int sign_bit = 0x80000000u;
-    const unsigned int dummy_idx = SELQ_DIGITS + (tid & 63u);     // a value outside the range adds to its lane's dummy word
+    const unsigned int dummy_idx = SELQ_SLOTS + (tid & 63u);      // a value outside the bucket adds to its lane's dummy word
 
-    // one sweep over the tile: MODE 0 counts buckets, MODE 1 digits (key - bias) >> shift of both streams; no divergence
-    // (a digit is compared with the row's usable length by one v_min)
-    auto sweep = [&](auto mode_tag, unsigned int b0, unsigned int s0, unsigned int b1, unsigned int s1) {
+    // one sweep over the tile: MODE 0 counts buckets, MODE 1 the slots inside bucket b0 (NDVI) / b1 (GNDVI); no divergence
+    auto sweep = [&](auto mode_tag, unsigned int b0, unsigned int b1) {
         constexpr int MODE = decltype(mode_tag)::value;
-        auto push_n = [&](int stream, const float *x, int nval, unsigned int bs, unsigned int sh) {
+        const unsigned int t0[2] = {SELQ_T_BITS | (b0 << 12), SELQ_T_BITS | (b1 << 12)};     // bits of the bucket's first t
+        auto push_n = [&](int stream, const float *x, int nval) {
             for (int j = 0; j < nval; ++j) {
+                const float t = selq_t(x[j]);
                 if (MODE == 0) {
-                    atomicAdd(&s_h[stream * SELQ_BINS + selq_bucket(x[j])], 1u);
+                    atomicAdd(&s_h[stream * SELQ_BINS + selq_bucket_of(t)], 1u);
                     continue;
                 }
-                const unsigned int bits_j = __builtin_bit_cast(unsigned int, x[j]);
-                unsigned int key;
-                // order-preserving key: x >= 0 -> bits | 2^31, x < 0 -> ~bits
-                asm("v_ashrrev_i32 %0, 31, %1\n\tv_or_b32 %0, %2, %0\n\tv_xor_b32 %0, %0, %1" : "=&v"(key) : "v"(bits_j), "v"(sign_bit));
-                const unsigned int d = (key - bs) >> sh;
+                const unsigned int d = (__builtin_bit_cast(unsigned int, t) - t0[stream]) >> 2;    // < 1024 inside the bucket
                 atomicAdd(&s_h[stream * SELQ_BINS + (d < dummy_idx ? d : dummy_idx)], 1u);
             }
         };
@@ -134,8 +106,8 @@ __global__ __launch_bounds__(1024, 8) void k_selq_pass(SelQParams P)
                 const f32x2 v = exact_quot2(N - R, Ne + R), g = exact_quot2(N - G, Ne + G);
                 qv[2 * h] = v.x; qv[2 * h + 1] = v.y; qg[2 * h] = g.x; qg[2 * h + 1] = g.y;
             }
-            push_n(0, qv, 4, b0, s0);
-            push_n(1, qg, 4, b1, s1);
+            push_n(0, qv, 4);
+            push_n(1, qg, 4);
         });
         if (blockIdx.x == 0 && tid < (int)(npix & 3)) {
             const long long i = nquads * 4 + tid;
@@ -145,8 +117,8 @@ __global__ __launch_bounds__(1024, 8) void k_selq_pass(SelQParams P)
                 r = tab[r * 64] & 0xFFu; g = (tab[g * 64] >> 8) & 0xFFu; n = (tab[n * 64] >> 16) & 0xFFu;
             }
             const float tv = norm_diff_fast((float)n, (float)r), tg = norm_diff_fast((float)n, (float)g);
-            push_n(0, &tv, 1, b0, s0);
-            push_n(1, &tg, 1, b1, s1);
+            push_n(0, &tv, 1);
+            push_n(1, &tg, 1);
         }
     };
     // rows -> the histogram of `track` (the dummy words are not part of it)
@@ -163,20 +135,20 @@ __global__ __launch_bounds__(1024, 8) void k_selq_pass(SelQParams P)
         }
     };
     if (P.first) {
-        sweep(std::integral_constant<int, 0>{}, 0u, 0u, 0u, 0u);
+        sweep(std::integral_constant<int, 0>{}, 0u, 0u);
         flush(0, SELQ_BINS);
     } else {
-        // both ranks of a stream usually share (bias, shift): one sweep, counted under track 0.  Otherwise a second sweep
-        // recounts for track 1 (rare: the two middle ranks straddle a bin boundary).
-        const bool split = ba[0] != ba[1] || sa[0] != sa[1] || bb[0] != bb[1] || sb[0] != sb[1];
-        sweep(std::integral_constant<int, 1>{}, ba[0], sa[0], bb[0], sb[0]);
-        flush(0, SELQ_DIGITS);
+        // both ranks of a stream usually share the bucket: one sweep, counted under track 0.  Otherwise a second sweep
+        // recounts for track 1 (rare: the two middle ranks straddle a bucket boundary).
+        const bool split = ba[0] != ba[1] || bb[0] != bb[1];
+        sweep(std::integral_constant<int, 1>{}, ba[0], bb[0]);
+        flush(0, SELQ_SLOTS);
         if (split) {
             __syncthreads();
             for (int i = tid; i < 2 * SELQ_BINS; i += 1024) s_h[i] = 0;
             __syncthreads();
-            sweep(std::integral_constant<int, 1>{}, ba[1], sa[1], bb[1], sb[1]);
-            flush(1, SELQ_DIGITS);
+            sweep(std::integral_constant<int, 1>{}, ba[1], bb[1]);
+            flush(1, SELQ_SLOTS);
         }
     }
 }
@@ -186,36 +158,58 @@ __global__ void k_selq_init(SelQTile *state, long long ntiles, long long npix, u
     const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
     if (i < ntiles) {
         SelQTile t;
-        for (int c = 0; c < 4; ++c) { t.bias[c] = 0u; t.shift[c] = 0u; t.rank[c] = (unsigned int)((c & 1) ? npix / 2 : (npix - 1) / 2); }
-        t.done = ((streams & 1u) ? 0u : 0x3u) | ((streams & 2u) ? 0u : 0xCu);      // a stream nobody asked for is settled
+        for (int c = 0; c < 4; ++c) { t.bucket[c] = 0u; t.rank[c] = (unsigned int)((c & 1) ? npix / 2 : (npix - 1) / 2); }
+        t.streams = streams;
         t.pad[0] = t.pad[1] = t.pad[2] = 0u;
         state[i] = t;
     }
 }
 
-// one block per tile, one wave per (stream, track): find the bin whose cumulative count covers the rank and
-// narrow the key range
-__global__ __launch_bounds__(256) void k_selq_pick(SelQTile *state, unsigned int *hist32, int first)
+// the quotient of bytes whose position is (bucket, slot): try every denominator (see the header of this file).
+// One wave; every lane returns the value (NaN if there is none, which a consistent pair of passes cannot produce).
+__device__ inline float selq_value_of(unsigned int bucket, unsigned int slot, int lane)
+{
+    const double centre_t = 2048.0 + (double)bucket + ((double)slot * 4.0 + 2.0) / 4096.0;
+    const double centre = (centre_t - 3071.5) / 1023.5;
+    const unsigned int want = SELQ_T_BITS | (bucket << 12);
+    float found = __builtin_nanf("");
+    for (int den = 1 + lane; den <= 510; den += 64) {
+        const float n = (float)__builtin_rint(centre * (double)den);
+        if (__builtin_fabsf(n) > (float)den) continue;
+        const float q = exact_quot(n, (float)den);
+        const unsigned int d = __builtin_bit_cast(unsigned int, selq_t(q)) - want;
+        if (d < 4096u && (d >> 2) == slot) found = q + 0.0f;           // -0/den -> +0.0, like the kernels' (a - b) / (a + b)
+    }
+    // any lane that found one found the same value
+    for (int off = 32; off >= 1; off >>= 1) {
+        const float o = __shfl_xor(found, off);
+        if (found != found) found = o;
+    }
+    return found;
+}
+
+// one block per tile, one wave per (stream, track): find the bin whose cumulative count covers the rank.
+// first: bucket -> state; second: slot -> the value, written to out[tile][stream][track]
+__global__ __launch_bounds__(256) void k_selq_pick(SelQTile *state, unsigned int *hist32, int first, float *out)
 {
     const long long tile = blockIdx.x;
     unsigned int *h = hist32 + tile * (4 * SELQ_BINS);
     const int combo = threadIdx.x >> 6, lane = threadIdx.x & 63;
-    const unsigned int done = state[tile].done;
-    if (!first && done == 0xFu) return;                     // the pass did not run for this tile (uniform per block)
-    const bool active = !((done >> combo) & 1u);            // settled combos (or streams nobody asked for) only help zeroing
-    // a later pass counted a (bias, shift) shared by both tracks once, under track 0 (decided before anything changes)
-    const bool shared = !first && state[tile].bias[combo & 2] == state[tile].bias[combo | 1] &&
-                        state[tile].shift[combo & 2] == state[tile].shift[combo | 1];
-    const unsigned int rank = state[tile].rank[combo], bias = state[tile].bias[combo], shift = state[tile].shift[combo];
+    const bool active = (state[tile].streams >> (combo >> 1)) & 1u;
+    // the second pass counted a bucket shared by both tracks once, under track 0
+    const bool shared = !first && state[tile].bucket[combo & 2] == state[tile].bucket[combo | 1];
+    const unsigned int rank = state[tile].rank[combo], bucket = state[tile].bucket[combo];
     __syncthreads();
+    if (!active && !first && lane == 0) out[tile * 4 + combo] = __builtin_nanf("");
     if (active) {
-        const unsigned int *mine = h + (shared ? (combo & 2) : combo) * SELQ_BINS;
-        const unsigned int *twin = h + (combo ^ 1) * SELQ_BINS;    // bucket pass: the two tracks are two copies
+        // bucket pass: everything is counted under track 0
+        const unsigned int *mine = h + ((first || shared) ? (combo & 2) : combo) * SELQ_BINS;
+        const int nbins = first ? SELQ_BINS : SELQ_SLOTS;
         unsigned int c[32], local = 0;
 #pragma unroll
         for (int j = 0; j < 32; ++j) {
             const int bin_j = lane * 32 + j;
-            c[j] = first ? mine[bin_j] + twin[bin_j] : (bin_j < SELQ_DIGITS ? mine[bin_j] : 0u);
+            c[j] = bin_j < nbins ? mine[bin_j] : 0u;
             local += c[j];
         }
         unsigned int incl = local;
@@ -224,42 +218,33 @@ __global__ __launch_bounds__(256) void k_selq_pick(SelQTile *state, unsigned int
             if (lane >= off) incl += o;
         }
         unsigned int cum = incl - local;
-        if (rank >= cum && rank < incl) {                   // exactly one lane (the bins up to the range's end hold >= rank + 1 values)
-            int d = 0;
+        const bool holder = rank >= cum && rank < incl;     // exactly one lane (the bins hold >= rank + 1 values)
+        int d = 0;
+        if (holder) {
 #pragma unroll
             for (int j = 0; j < 32; ++j) {
                 if (rank >= cum + c[j]) { cum += c[j]; d = j + 1; }
                 else break;
             }
-            const unsigned int bin = (unsigned int)(lane * 32 + d);
-            unsigned int nbias, nshift;
-            if (first) {
-                unsigned int lo = selq_lower_key(bin);
-                unsigned int hi = bin >= SELQ_BINS - 1 ? SELQ_KEY_PLUS1 + 1u : selq_lower_key(bin + 1u);
-                if (lo <= SELQ_KEY_ZERO && SELQ_KEY_ZERO < hi) { lo = SELQ_KEY_ZERO; hi = SELQ_KEY_ZERO + 1u; }   // only +0.0 lives there
-                const unsigned int span = hi - lo - 1u;    // largest offset inside the range
-                nshift = 0u;
-                while ((span >> nshift) >= SELQ_DIGITS) ++nshift;      // the first digit must fit the row
-                nbias = lo;
-            } else {
-                nbias = bias + (bin << shift);
-                nshift = shift > SELQ_DIGIT_BITS ? shift - SELQ_DIGIT_BITS : 0u;
+        }
+        const unsigned long long who = __ballot(holder);
+        if (first) {
+            if (holder) {
+                state[tile].bucket[combo] = (unsigned int)(lane * 32 + d);
+                state[tile].rank[combo] = rank - cum;
             }
-            state[tile].bias[combo] = nbias;
-            state[tile].shift[combo] = nshift;
-            state[tile].rank[combo] = rank - cum;
-            if (!first && shift == 0u) atomicOr(&state[tile].done, 1u << combo);
+        } else {
+            float v = __builtin_nanf("");
+            if (who) {
+                const int src = __ffsll((long long)who) - 1;
+                const unsigned int slot = (unsigned int)__shfl(lane * 32 + d, src);
+                v = selq_value_of(bucket, slot, lane);
+            }
+            if (lane == 0) out[tile * 4 + combo] = v;
         }
     }
     __syncthreads();
     for (int i = threadIdx.x; i < 4 * SELQ_BINS; i += 256) h[i] = 0u;
-}
-
-// a selection that is not settled after the last pass comes back as NaN instead of a wrong value
-__global__ void k_selq_finish_checked(const SelQTile *state, long long ntiles, float *out)
-{
-    const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
-    if (i < ntiles * 4) out[i] = ((state[i >> 2].done >> (i & 3)) & 1u) ? key_f32(state[i >> 2].bias[i & 3]) : __builtin_nanf("");
 }
 
 }  // namespace lars
@@ -268,19 +253,24 @@ using namespace lars;
 
 namespace lars {
 
-int selq_pass_launch(const uint8_t *tiles, const uint8_t *wb_table, long long ntiles, long long npix, int first,
-                     const unsigned int bias[4], const unsigned int shift[4], unsigned long long *hist, hipStream_t s)
+static dim3 selq_grid(long long ntiles, long long npix)
 {
-    SelQParams P;
-    memset(&P, 0, sizeof P);
-    P.tiles = tiles; P.wb_table = wb_table; P.npix = npix; P.first = first;
-    for (int c = 0; c < 4; ++c) { P.bias[c] = bias[c]; P.shift[c] = shift[c]; }
-    P.hist = hist;
     long long bpt = (2048 + ntiles - 1) / ntiles;                  // ~2048 workgroups per launch
     const long long cap = (npix / 4 + 1024 * 8 - 1) / (1024 * 8);  // at least ~8 steps per block (64 KiB table each)
     if (bpt > cap) bpt = cap;
     if (bpt < 1) bpt = 1;
-    dim3 grid((unsigned)bpt, (unsigned)ntiles);
+    return dim3((unsigned)bpt, (unsigned)ntiles);
+}
+
+int selq_pass_launch(const uint8_t *tiles, const uint8_t *wb_table, long long ntiles, long long npix, int first,
+                     const unsigned int bucket[4], unsigned long long *hist, hipStream_t s)
+{
+    SelQParams P;
+    memset(&P, 0, sizeof P);
+    P.tiles = tiles; P.wb_table = wb_table; P.npix = npix; P.first = first;
+    for (int c = 0; c < 4; ++c) P.bucket[c] = bucket[c];
+    P.hist = hist;
+    const dim3 grid = selq_grid(ntiles, npix);
     if (wb_table) hipLaunchKernelGGL((k_selq_pass<true, false>), grid, dim3(1024), 0, s, P);
     else hipLaunchKernelGGL((k_selq_pass<false, false>), grid, dim3(1024), 0, s, P);
     return launch_check("k_selq_pass");
@@ -291,9 +281,9 @@ size_t selq_tile_scratch_bytes(long long ntiles)
     return (size_t)ntiles * (sizeof(SelQTile) + 4 * SELQ_BINS * sizeof(unsigned int)) + 512;
 }
 
-// medians of every tile: bucket pass + two digit passes, picks on the device, no host round trip
+// medians of every tile: bucket pass + slot pass, picks on the device, no host round trip
 // selq_tile_prepare: state + zeroed histograms (before a fused statistics + bucket pass); selq_tile_hist32: where that
-// pass adds its counts; selq_tile_medians_launch(..., first_pass_done): the remaining passes.
+// pass adds its counts; selq_tile_medians_launch(..., first_pass_done): the remaining pass.
 static void selq_scratch_layout(void *scratch, long long ntiles, SelQTile **state, unsigned int **hist32)
 {
     *state = static_cast<SelQTile *>(scratch);
@@ -321,14 +311,8 @@ int selq_tile_medians_launch(const uint8_t *tiles, const uint8_t *wb_table, long
     SelQTile *state; unsigned int *hist32;
     selq_scratch_layout(scratch, ntiles, &state, &hist32);
     if (!first_pass_done) LARS_TRY(selq_tile_prepare(scratch, ntiles, npix, s, 3u));
-    long long bpt = (2048 + ntiles - 1) / ntiles;
-    const long long cap = (npix / 4 + 1024 * 8 - 1) / (1024 * 8);
-    if (bpt > cap) bpt = cap;
-    if (bpt < 1) bpt = 1;
-    dim3 grid((unsigned)bpt, (unsigned)ntiles);
-    // bucket pass + up to five digit passes (a first digit of < 1984 values, then 10 bits per pass: a 2^32-wide range
-    // needs shifts 22, 12, 2, 0); uint8 tiles need two, exceptionally three -- a settled tile's blocks return at once
-    for (int p = 0; p < 6; ++p) {
+    const dim3 grid = selq_grid(ntiles, npix);
+    for (int p = 0; p < 2; ++p) {
         SelQParams P;
         memset(&P, 0, sizeof P);
         P.tiles = tiles; P.wb_table = wb_table; P.npix = npix; P.first = p == 0;
@@ -336,9 +320,8 @@ int selq_tile_medians_launch(const uint8_t *tiles, const uint8_t *wb_table, long
         if (p == 0 && first_pass_done) { /* counted by the statistics kernel */ }
         else if (wb_table) hipLaunchKernelGGL((k_selq_pass<true, true>), grid, dim3(1024), 0, s, P);
         else hipLaunchKernelGGL((k_selq_pass<false, true>), grid, dim3(1024), 0, s, P);
-        hipLaunchKernelGGL(k_selq_pick, dim3((unsigned)ntiles), dim3(256), 0, s, state, hist32, p == 0 ? 1 : 0);
+        hipLaunchKernelGGL(k_selq_pick, dim3((unsigned)ntiles), dim3(256), 0, s, state, hist32, p == 0 ? 1 : 0, out_pairs);
     }
-    hipLaunchKernelGGL(k_selq_finish_checked, dim3((unsigned)((ntiles * 4 + 255) / 256)), dim3(256), 0, s, state, ntiles, out_pairs);
     return launch_check("selq_tile_medians");
 }
 
@@ -347,20 +330,19 @@ int selq_tile_medians_launch(const uint8_t *tiles, const uint8_t *wb_table, long
 // ===========================================================================
 // entry points
 // ===========================================================================
-extern "C" int lars_d_quotient_digit_hist(const void *tiles, int64_t ntiles, int64_t npix, int channels, int dtype,
-                                          const uint8_t *wb_table, int first, const uint32_t bias[4], const uint32_t shift[4],
-                                          uint64_t *hist, void *stream)
+extern "C" int lars_d_quotient_select_hist(const void *tiles, int64_t ntiles, int64_t npix, int channels, int dtype,
+                                           const uint8_t *wb_table, int first, const uint32_t bucket[4], uint64_t *hist, void *stream)
 {
     ThreadCtx *c;
     LARS_TRY(ensure_ctx(&c));
-    if (!tiles || !hist || !bias || !shift || ntiles <= 0 || npix <= 0)
-        return fail(LARS_ERR_INVALID, "lars_d_quotient_digit_hist: bad arguments");
+    if (!tiles || !hist || !bucket || ntiles <= 0 || npix <= 0)
+        return fail(LARS_ERR_INVALID, "lars_d_quotient_select_hist: bad arguments");
     if (dtype != LARS_U8 || channels != 3 || (reinterpret_cast<uintptr_t>(tiles) & 3) || (ntiles > 1 && (npix & 3)))
-        return fail(LARS_ERR_INVALID, "lars_d_quotient_digit_hist: uint8 [ntiles][npix][3] tiles on 4-byte boundaries are required");
+        return fail(LARS_ERR_INVALID, "lars_d_quotient_select_hist: uint8 [ntiles][npix][3] tiles on 4-byte boundaries are required");
     for (int k = 0; k < 4; ++k)
-        if (shift[k] > 31u) return fail(LARS_ERR_INVALID, "lars_d_quotient_digit_hist: shift must be below 32");
-    if (ntiles > 65535) return fail(LARS_ERR_INVALID, "lars_d_quotient_digit_hist: at most 65535 tiles per launch");
-    return selq_pass_launch(static_cast<const uint8_t *>(tiles), wb_table, ntiles, npix, first ? 1 : 0, bias, shift,
+        if (bucket[k] >= SELQ_BINS) return fail(LARS_ERR_INVALID, "lars_d_quotient_select_hist: bucket must be below 2048");
+    if (ntiles > 65535) return fail(LARS_ERR_INVALID, "lars_d_quotient_select_hist: at most 65535 tiles per launch");
+    return selq_pass_launch(static_cast<const uint8_t *>(tiles), wb_table, ntiles, npix, first ? 1 : 0, bucket,
                             reinterpret_cast<unsigned long long *>(hist), pick_stream(c, stream));
 }
 
@@ -380,8 +362,8 @@ extern "C" int lars_d_quotient_median_pairs(const void *tiles, int64_t ntiles, i
                                     pick_stream(c, stream), false);
 }
 
-// Statistics AND the exact median of every tile in four passes over the tiles instead of five: the statistics kernel
-// also counts the select's bucket pass.  Same constraints as lars_d_quotient_median_pairs; no output planes.
+// Statistics AND the exact median of every tile in two passes over the tiles (three with the white-balance histogram
+// pass): the statistics kernel also counts the select's bucket pass, one slot pass follows.  Same constraints as lars_d_quotient_median_pairs; no output planes.
 extern "C" int lars_d_stats_medians(const lars_fused_args *a, float *out_pairs, void *scratch)
 {
     ThreadCtx *c;

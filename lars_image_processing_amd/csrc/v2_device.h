@@ -82,18 +82,24 @@ __device__ inline unsigned int sample_entry(unsigned int word, int byte, unsigne
     return *reinterpret_cast<const unsigned int *>(s_tab + addr);
 }
 
-// first-level bucket of the exact-median select (see k_selq_pass below): round((x + 1) * 1023.5) in 0..2047,
-// left in the low mantissa bits of t + 2^23
+// Exact-median select on uint8 quotients (select_q.hip; its first pass also lives in the statistics kernel).
+// Position of x in [-1, 1]: t = fma(x, 1023.5, 3071.5) in [2048, 4095], one binade, so the 23 mantissa bits of t are
+// 11 bits of bucket (floor(t) - 2048) followed by 12 bits of fraction (units of 2^-12).  Two quotients of bytes that differ
+// are at least 1/(510 * 509) apart = 16.1 such units, 15 after the two roundings: inside one bucket the fraction, taken in
+// groups of four units (1024 slots), still tells any two of them apart.
 #define SELQ_BINS 2048
-#define SELQ_MAGIC_BITS 0x4B000000u                      /* float bits of 2^23: "bucket 0" */
-__device__ inline f32x2 selq_pos2(f32x2 x)
+#define SELQ_SLOTS 1024
+#define SELQ_T_BITS 0x45000000u                         /* float bits of 2048.0 */
+__device__ inline float selq_t(float x) { return __builtin_fmaf(x, 1023.5f, 3071.5f); }
+__device__ inline f32x2 selq_t2(f32x2 x)
 {
-    const f32x2 k = {1023.5f, 1023.5f}, big = {8388608.0f, 8388608.0f};
-    return __builtin_elementwise_fma(x, k, k) + big;
+    const f32x2 k = {1023.5f, 1023.5f}, c = {3071.5f, 3071.5f};
+    return __builtin_elementwise_fma(x, k, c);
 }
-__device__ inline void selq_add_pos(float pos, unsigned int base)      // base: LDS byte address of the row, less the shifted "bucket 0" bits
+__device__ inline unsigned int selq_bucket_of(float t) { return (__builtin_bit_cast(unsigned int, t) >> 12) & 0x7FFu; }
+__device__ inline void selq_add_bucket(float t, unsigned int row)      // row: LDS byte address of the stream's 2048-word row
 {
-    const unsigned int addr = (__builtin_bit_cast(unsigned int, pos) << 2) + base;
+    const unsigned int addr = (selq_bucket_of(t) << 2) + row;
     asm volatile("ds_add_u32 %0, %1" : : "v"(addr), "v"(1u) : "memory");
 }
 

@@ -23,7 +23,7 @@ sys.path.insert(0, os.path.join(ROOT, "tests"))
 from lars_image_processing_amd import _ffi, batch, dist  # noqa: E402
 from oracle import index_oracle as orc  # noqa: E402
 from test_abi_cpu import to_records  # noqa: E402
-from _select_stub import digit_pass_on_planes  # noqa: E402
+from _select_stub import select_pass_on_planes  # noqa: E402
 
 TYPES = ("NDVI", "GNDVI", "NDWI")
 
@@ -76,7 +76,7 @@ def main():
         assert np.array_equal(g["hist"], s["hist"])
         assert abs(g["mean"] - s["mean"]) <= 1e-15
         summary[name] = {"mean": g["mean"], "coverage": g["coverage"]}
-    # 4. exact global medians: radix-select passes, histograms summed over ranks
+    # 4. exact global medians: two select passes, histograms summed over ranks
     def planes_of(tile_ids):
         out = {name: [np.zeros(0, np.float32)] for name in TYPES}
         for t in tile_ids:
@@ -87,9 +87,9 @@ def main():
                 out[name].append(orc.index_app(wb, name).ravel())
         return {name: np.concatenate(v) for name, v in out.items()}
     mine_planes, all_planes = planes_of(range(lo, hi)), planes_of(range(ntiles))
-    keys = batch.select_order_statistics(digit_pass_on_planes([mine_planes["NDVI"], mine_planes["GNDVI"]]),
-                                         mine_planes["NDVI"].size, comm, min_abs=1.0 / 510.0)
-    medians = batch.medians_from_keys(keys)
+    values = batch.select_order_statistics(select_pass_on_planes([mine_planes["NDVI"], mine_planes["GNDVI"]]),
+                                           mine_planes["NDVI"].size, comm)
+    medians = batch.medians_from_pairs(values)
     for name in TYPES:
         assert medians[name] == float(np.median(all_planes[name])), name
         summary[name]["median"] = medians[name]

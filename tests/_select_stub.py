@@ -1,35 +1,23 @@
-"""NumPy stand-in for lars_d_quotient_digit_hist (tests only): what one rank's kernel pass counts, from index planes."""
+"""NumPy stand-in for lars_d_quotient_select_hist (tests only): what one rank's kernel pass counts, from index planes."""
 import numpy as np
 
 from lars_image_processing_amd import batch
 
 
-def f32_key(x):
-    b = np.ascontiguousarray(x, dtype=np.float32).view(np.uint32)
-    return np.where(b >> 31, ~b, b | np.uint32(0x80000000)).astype(np.uint32)
+def select_pass_on_planes(planes):
+    """planes = [NDVI values, GNDVI values] of this rank -> pass_fn(first, buckets[4]) like TileBatch.select_histogram."""
+    pos = [batch.select_position(np.asarray(p, dtype=np.float32)) for p in planes]
 
-
-def digit_pass_on_planes(planes):
-    """planes = [NDVI values, GNDVI values] of this rank -> pass_fn(first, bias[4], shift[4]) like TileBatch.digit_histogram."""
-    keys = [f32_key(p) for p in planes]
-    uniq = [np.unique(p, return_inverse=True) for p in planes]
-    buckets = [np.array([batch.select_bucket(v) for v in u[0]], dtype=np.int64) for u in uniq]
-
-    def pass_fn(first, bias, shift):
+    def pass_fn(first, buckets):
         out = np.zeros((2, 2, batch.SELECT_BINS), dtype=np.uint64)
-        shared = all(bias[2 * q] == bias[2 * q + 1] and shift[2 * q] == shift[2 * q + 1] for q in range(2))
+        shared = all(buckets[2 * q] == buckets[2 * q + 1] for q in range(2))
         for s in range(2):
-            k = keys[s]
+            bucket, slot = pos[s]
             for t in range(2):
                 if first:
-                    if t == 1 or k.size == 0:
-                        continue                             # the bucket pass counts under track 0
-                    d = buckets[s][uniq[s][1]]
-                else:
-                    if t == 1 and shared:
-                        continue                             # both streams' tracks shared: only track 0 is counted
-                    d = (k - np.uint32(bias[s * 2 + t])) >> np.uint32(shift[s * 2 + t])     # uint32 wrap-around, like the kernel
-                    d = d[d < batch.SELECT_DIGITS]
-                out[s, t] = np.bincount(d.astype(np.int64), minlength=batch.SELECT_BINS)[:batch.SELECT_BINS]
+                    if t == 0:                               # the bucket pass counts under track 0
+                        out[s, 0] = np.bincount(bucket, minlength=batch.SELECT_BINS)
+                elif t == 0 or not shared:                   # both streams' tracks shared: only track 0 is counted
+                    out[s, t] = np.bincount(slot[bucket == int(buckets[s * 2 + t])], minlength=batch.SELECT_BINS)
         return out
     return pass_fn

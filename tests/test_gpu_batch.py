@@ -405,12 +405,12 @@ def test_bad_arguments_fail_cleanly(lars):
     # the newer entry points: select passes, statistics + medians, registration, change map, masks
     stats = b.new_stats()
     u4 = (C.c_uint32 * 4)(0, 0, 0, 0)
-    big_shift = (C.c_uint32 * 4)(32, 0, 0, 0)
+    big_bucket = (C.c_uint32 * 4)(2048, 0, 0, 0)
     hist64 = _ffi.DeviceBuffer(2 * 2 * 2048 * 8)
     tp = C.c_void_p(b.tiles.ptr)
-    assert lib.lars_d_quotient_digit_hist(tp, 2, 256, 3, _ffi.U8, None, 1, u4, big_shift, C.c_void_p(hist64.ptr), None) == -1
-    assert lib.lars_d_quotient_digit_hist(tp, 2, 256, 4, _ffi.U8, None, 1, u4, u4, C.c_void_p(hist64.ptr), None) == -1
-    assert lib.lars_d_quotient_digit_hist(tp, 2, 256, 3, _ffi.U16, None, 1, u4, u4, C.c_void_p(hist64.ptr), None) == -1
+    assert lib.lars_d_quotient_select_hist(tp, 2, 256, 3, _ffi.U8, None, 0, big_bucket, C.c_void_p(hist64.ptr), None) == -1
+    assert lib.lars_d_quotient_select_hist(tp, 2, 256, 4, _ffi.U8, None, 1, u4, C.c_void_p(hist64.ptr), None) == -1
+    assert lib.lars_d_quotient_select_hist(tp, 2, 256, 3, _ffi.U16, None, 1, u4, C.c_void_p(hist64.ptr), None) == -1
     assert lib.lars_d_quotient_median_pairs(tp, 2, 256, 3, _ffi.U8, None, None, None, None) == -1
     sm = b.fused_args(("NDVI", "GNDVI"), True, stats, False, None)                      # two indices: not served
     assert lib.lars_d_stats_medians(C.byref(sm), C.c_void_p(hist64.ptr), C.c_void_p(hist64.ptr)) == -1
@@ -442,7 +442,7 @@ def test_bad_arguments_fail_cleanly(lars):
 @pytest.mark.parametrize("white_balance", [True, False])
 @pytest.mark.parametrize("shape,ntiles", [((64, 96), 5), ((63, 65), 1), ((128, 128), 2)])
 def test_global_medians_without_planes(shape, ntiles, white_balance):
-    """np.median over all pixels of all tiles, from three radix-select passes that recompute the index values."""
+    """np.median over all pixels of all tiles, from two select passes that recompute the index values."""
     import warnings
     import lars_image_processing_amd as lars
     from oracle import index_oracle as orc
@@ -464,3 +464,25 @@ def test_global_medians_without_planes(shape, ntiles, white_balance):
         rec, med = b.process(white_balance=white_balance, medians=True)
         for k, t in enumerate(("NDVI", "GNDVI", "NDWI")):
             assert float(med[0, k]) == got[t]
+
+
+def test_every_quotient_of_bytes_is_found_back_on_the_device():
+    """The value look-up of the two-level select (bucket, slot -> n/d) for all 65536 (red, nir) pairs: 4-pixel tiles
+    of one colour each, so a tile's median is its single quotient; GNDVI runs through the pairs in another order."""
+    import lars_image_processing_amd as lars
+    from oracle import index_oracle as orc
+    r, n = np.meshgrid(np.arange(256, dtype=np.uint8), np.arange(256, dtype=np.uint8), indexing="ij")
+    r, n = r.ravel(), n.ravel()
+    g = (r.astype(np.int64) * 7 + 13).astype(np.uint8)
+    for lo in (0, 32768):
+        px = np.stack([r[lo:lo + 32768], g[lo:lo + 32768], n[lo:lo + 32768]], axis=1)        # [tiles, 3]
+        tiles = np.ascontiguousarray(np.repeat(px[:, None, None, :], 4, axis=2))           # [tiles, 1, 4, 3]
+        b = lars.TileBatch.from_host(tiles)
+        med = b.tile_medians(white_balance=False)
+        rec, med2 = b.process(white_balance=False, medians=True)
+        for k, t in enumerate(("NDVI", "GNDVI", "NDWI")):
+            want = orc.index_app(px[None], t)[0].astype(np.float64)                          # one value per tile
+            assert np.array_equal(med[:, k], want), t
+            assert np.array_equal(med2[:, k], want), t
+            assert not np.signbit(med[want == 0, k]).any() or t == "NDWI"
+        b.free()

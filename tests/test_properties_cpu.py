@@ -81,24 +81,39 @@ def _quotients(a, b):
     return np.where(s == 0, np.float32(0), (a - b) / np.where(s == 0, np.float32(1), s)).astype(np.float32)
 
 
+def test_select_positions_separate_every_quotient_of_bytes():
+    """The claim the two-level select rests on: every distinct (a - b) / (a + b) of bytes has its own (bucket, slot), the
+    position is monotone in the value, and batch.select_value finds the value back from the position."""
+    from lars_image_processing_amd import batch
+    a, b = np.meshgrid(np.arange(256, dtype=np.float32), np.arange(256, dtype=np.float32), indexing="ij")
+    vals = np.unique(_quotients(a.ravel(), b.ravel()))                  # sorted, ~40 k values
+    bucket, slot = batch.select_position(vals)
+    assert bucket.min() == 0 and bucket.max() == batch.SELECT_BINS - 1 and slot.max() < batch.SELECT_SLOTS
+    code = bucket * batch.SELECT_SLOTS + slot
+    assert (np.diff(code) > 0).all()                                    # strictly increasing: distinct and monotone
+    gap = np.diff((vals.astype(np.float64) * 1023.5) * 4096)            # in units of the fraction
+    assert gap.min() > 15.5
+    rng = np.random.default_rng(0)
+    probe = np.concatenate([np.arange(0, vals.size, 97), rng.integers(0, vals.size, 300), [0, vals.size - 1, int(np.searchsorted(vals, 0))]])
+    for i in probe:
+        got = batch.select_value(int(bucket[i]), int(slot[i]))
+        assert got.tobytes() == vals[i].tobytes(), (vals[i], got)
+
+
 @settings(max_examples=60, deadline=None)
-@given(st.integers(1, 3000), st.integers(0, 2**32 - 1), st.sampled_from(["bytes", "few", "zeros", "floats"]))
+@given(st.integers(1, 3000), st.integers(0, 2**32 - 1), st.sampled_from(["bytes", "few", "zeros", "dark"]))
 def test_select_host_logic_equals_numpy_median(n, seed, kind):
-    """batch.select_order_statistics (bucket pick by bisection, digit passes, shared / split ranks) with a NumPy stand-in
-    for the kernel pass: uint8 quotients (with the zero-bucket cut), few distinct values, mostly zeros, arbitrary floats."""
-    from _select_stub import digit_pass_on_planes
+    """batch.select_order_statistics (bucket pick, slot pick, value look-up, shared / split ranks) with a NumPy stand-in
+    for the kernel pass: quotients of uniform bytes, of few distinct values, mostly zeros, and of small sums."""
+    from _select_stub import select_pass_on_planes
     from lars_image_processing_amd import batch
     rng = np.random.default_rng(seed)
-    if kind == "floats":
-        planes = [rng.uniform(-1, 1, n).astype(np.float32), np.round(rng.uniform(-1, 1, n), 2).astype(np.float32)]
-        min_abs = 0.0
-    else:
-        pool = {"bytes": np.arange(256), "few": np.array([0, 1, 2, 127, 254, 255]), "zeros": np.array([0, 0, 0, 0, 7])}[kind]
-        a, r, g = (rng.choice(pool, n).astype(np.float32) for _ in range(3))
-        planes = [_quotients(a, r), _quotients(a, g)]
-        min_abs = 1.0 / 510.0
-    keys = batch.select_order_statistics(digit_pass_on_planes(planes), n, min_abs=min_abs)
-    med = batch.medians_from_keys(keys)
+    pool = {"bytes": np.arange(256), "few": np.array([0, 1, 2, 127, 254, 255]), "zeros": np.array([0, 0, 0, 0, 7]),
+            "dark": np.arange(4)}[kind]
+    a, r, g = (rng.choice(pool, n).astype(np.float32) for _ in range(3))
+    planes = [_quotients(a, r), _quotients(a, g)]
+    values = batch.select_order_statistics(select_pass_on_planes(planes), n)
+    med = batch.medians_from_pairs(values)
     assert med["NDVI"] == float(np.median(planes[0]))
     assert med["GNDVI"] == float(np.median(planes[1]))
     assert med["NDWI"] == float(np.median(np.float32(0) - planes[1]))

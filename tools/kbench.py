@@ -129,7 +129,7 @@ def main():
             for _ in range(3):
                 _ffi.call("lars_synchronize", None)
                 t0 = time.perf_counter()
-                b.process(medians=True, recompute_tables=False, **kw)
+                b.process(medians=True, recompute_tables=False, white_balance=args.wb != "0", **kw)
                 ts.append((time.perf_counter() - t0) * 1e3)
             results[name] = {"ms": float(np.median(ts[1:])), "min_ms": float(min(ts[1:])), "Gpix_s": npix / float(np.median(ts[1:])) / 1e6}
         outs.free()

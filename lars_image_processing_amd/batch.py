@@ -231,7 +231,8 @@ class TileBatch:
             self.compute_wb_tables(stream)
         stats = self.new_stats()
         stats.zero()
-        if medians and outputs is None and self.code == _ffi.U8 and self.channels == 3 and (self.ntiles == 1 or self.npix % 4 == 0):
+        if (medians and outputs is None and self.code == _ffi.U8 and self.channels == 3 and self.npix * 6 < (1 << 30)
+                and (self.ntiles == 1 or self.npix % 4 == 0)):
             # nothing to write: the statistics kernel also counts the select's bucket pass, one slot pass follows --
             # 3 B per pixel each, everything on the device
             mask = 0

@@ -341,7 +341,8 @@ extern "C" int lars_d_quotient_select_hist(const void *tiles, int64_t ntiles, in
         return fail(LARS_ERR_INVALID, "lars_d_quotient_select_hist: uint8 [ntiles][npix][3] tiles on 4-byte boundaries are required");
     for (int k = 0; k < 4; ++k)
         if (bucket[k] >= SELQ_BINS) return fail(LARS_ERR_INVALID, "lars_d_quotient_select_hist: bucket must be below 2048");
-    if (ntiles > 65535) return fail(LARS_ERR_INVALID, "lars_d_quotient_select_hist: at most 65535 tiles per launch");
+    if (ntiles > 65535 || (long long)npix * 6 >= (1ll << 30))
+        return fail(LARS_ERR_INVALID, "lars_d_quotient_select_hist: at most 65535 tiles of < 2^30 / 6 pixels per launch");
     return selq_pass_launch(static_cast<const uint8_t *>(tiles), wb_table, ntiles, npix, first ? 1 : 0, bucket,
                             reinterpret_cast<unsigned long long *>(hist), pick_stream(c, stream));
 }
@@ -357,7 +358,8 @@ extern "C" int lars_d_quotient_median_pairs(const void *tiles, int64_t ntiles, i
         return fail(LARS_ERR_INVALID, "lars_d_quotient_median_pairs: bad arguments");
     if (dtype != LARS_U8 || channels != 3 || (reinterpret_cast<uintptr_t>(tiles) & 3) || (ntiles > 1 && (npix & 3)))
         return fail(LARS_ERR_INVALID, "lars_d_quotient_median_pairs: uint8 [ntiles][npix][3] tiles on 4-byte boundaries are required");
-    if (ntiles > 65535 || npix >= (1ll << 32)) return fail(LARS_ERR_INVALID, "lars_d_quotient_median_pairs: at most 65535 tiles of < 2^32 pixels");
+    if (ntiles > 65535 || (long long)npix * 6 >= (1ll << 30))
+        return fail(LARS_ERR_INVALID, "lars_d_quotient_median_pairs: at most 65535 tiles of < 2^30 / 6 pixels");
     return selq_tile_medians_launch(static_cast<const uint8_t *>(tiles), wb_table, ntiles, npix, out_pairs, scratch,
                                     pick_stream(c, stream), false);
 }
@@ -377,7 +379,7 @@ extern "C" int lars_d_stats_medians(const lars_fused_args *a, float *out_pairs, 
         return fail(LARS_ERR_INVALID, "lars_d_stats_medians: index_mask must be one index or all three");
     if (a->out_wb || a->out_index[0] || a->out_index[1] || a->out_index[2] || a->out_rgba[0] || a->out_rgba[1] || a->out_rgba[2])
         return fail(LARS_ERR_INVALID, "lars_d_stats_medians: no output planes (use lars_d_fused + lars_d_median_pair_batch_f32)");
-    if (a->ntiles > 65535 || a->npix >= (1ll << 32) || (long long)a->npix * 6 >= (1ll << 30))
+    if (a->ntiles > 65535 || (long long)a->npix * 6 >= (1ll << 30))
         return fail(LARS_ERR_INVALID, "lars_d_stats_medians: at most 65535 tiles of < 2^30 / 6 pixels");
     hipStream_t s = pick_stream(c, a->stream);
     const int stats_mode = (a->flags & LARS_F_SUMSQ) ? 3 : (a->flags & LARS_F_HIST) ? 2 : 1;

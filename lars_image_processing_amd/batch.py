@@ -224,21 +224,25 @@ class TileBatch:
         (structured ndarray ``[ntiles, 3]`` of STATS_DTYPE; rows of indices not
         requested are zero).  ``hist`` adds the 50-bin histograms, ``sumsq`` the sums of squares
         (``summarize()['std']``).  ``medians=True`` also returns ``float64[ntiles, 3]``
-        with np.median of each tile's index plane (exact: batched radix select on
-        the float32 planes, which must then be written -- a small ring is
-        allocated when ``outputs`` has none)."""
+        with np.median of each tile's index plane, exact: uint8 RGNir tiles take the
+        two-level select on recomputed values (planes or not); other tiles a batched radix
+        select on the float32 planes, which must then be written -- a small ring is
+        allocated when ``outputs`` has none."""
         if white_balance and (recompute_tables or self.table is None):
             self.compute_wb_tables(stream)
         stats = self.new_stats()
         stats.zero()
-        if (medians and outputs is None and self.code == _ffi.U8 and self.channels == 3 and self.npix * 6 < (1 << 30)
-                and (self.ntiles == 1 or self.npix % 4 == 0)):
-            # nothing to write: the statistics kernel also counts the select's bucket pass, one slot pass follows --
-            # 3 B per pixel each, everything on the device
+        # uint8 RGNir tiles: medians come from the two-level select on recomputed values (two passes over the 3-byte
+        # pixels), whether or not planes are written; other tiles take the radix select over stored planes below
+        select = (medians and self.code == _ffi.U8 and self.channels == 3 and self.npix * 6 < (1 << 30)
+                  and (self.ntiles == 1 or self.npix % 4 == 0))
+        if select:
             mask = 0
             for t in indices:
                 mask |= 1 << INDEX_IDS[t]
-            if mask in (1, 2, 4, 7):
+            if outputs is None and mask in (1, 2, 4, 7):
+                # nothing to write: the statistics kernel also counts the select's bucket pass, one slot pass follows --
+                # 3 B per pixel each, everything on the device
                 pairs_dev = DeviceBuffer(self.ntiles * 4 * 4)
                 scratch = DeviceBuffer(int(_ffi.load().lars_quotient_median_scratch_bytes(self.ntiles)))
                 args = self.fused_args(indices, white_balance, stats, hist, None, stream, sumsq=sumsq)
@@ -247,8 +251,11 @@ class TileBatch:
                 med = self._medians_from_pairs(pairs_dev.download(np.float32, (self.ntiles, 2, 2)), indices)
                 pairs_dev.free()
                 scratch.free()
-            else:                                           # two of the three indices: separate statistics pass
-                self.run_fused(self.fused_args(indices, white_balance, stats, hist, None, stream, sumsq=sumsq))
+            else:                                           # planes wanted, or two of the three indices
+                chunk = self.ntiles if outputs is None else outputs.slots
+                for start in range(0, self.ntiles, chunk):
+                    count = min(chunk, self.ntiles - start)
+                    self.run_fused(self.fused_args(indices, white_balance, stats, hist, outputs, stream, start, count, sumsq=sumsq))
                 med = self.tile_medians(indices, white_balance, stream)
             rec = stats.download(STATS_DTYPE, (self.ntiles, 3))
             stats.free()

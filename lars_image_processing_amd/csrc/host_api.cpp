@@ -48,14 +48,22 @@ struct Layout {
     size_t total;
 };
 
-// medians wanted, no plane wanted, uint8 RGNir, one index or all three: the planes never exist on the device either
+// Medians of uint8 RGNir images come from the two-level select on recomputed values (select_q.hip): two passes over the
+// 3-byte pixels instead of four or more over each 4-byte plane, whether or not the planes are written as well.
+bool select_route(const ImageJob &j)
+{
+    if (!j.want_median || !j.medians || !j.mask || j.dtype != LARS_U8 || j.channels != 3) return false;
+    return (long long)j.h * j.w * 6 < (1ll << 30);
+}
+// ... and when no plane is wanted (one index or all three), the statistics kernel counts the select's first pass itself:
+// the planes never exist on the device either
 bool recompute_route(const ImageJob &j)
 {
-    if (!j.want_median || !j.medians || !j.want_stats || j.dtype != LARS_U8 || j.channels != 3) return false;
+    if (!select_route(j) || !j.want_stats) return false;
     if (j.mask != 1u && j.mask != 2u && j.mask != 4u && j.mask != 7u) return false;
     for (int k = 0; k < 3; ++k)
         if (j.out_index[k] || j.out_rgba[k]) return false;
-    return (long long)j.h * j.w * 6 < (1ll << 30);
+    return true;
 }
 
 Layout plan(const ImageJob &j, void *base)
@@ -71,18 +79,18 @@ Layout plan(const ImageJob &j, void *base)
     L.table = j.apply_wb ? c.take<uint8_t>(lars_wb_table_bytes(j.dtype)) : nullptr;
     L.pcts = j.apply_wb ? c.take<double>(6) : nullptr;
     L.wb = (j.apply_wb && j.out_wb) ? c.take<uint8_t>(npix * j.channels) : nullptr;
-    const bool recompute = recompute_route(j);
+    const bool select = select_route(j);
     for (int k = 0; k < 3; ++k) {
         const bool on = (j.mask >> k) & 1u;
-        L.idx[k] = (on && !recompute && (j.out_index[k] || j.want_median)) ? c.take<float>(npix) : nullptr;
+        L.idx[k] = (on && (j.out_index[k] || (j.want_median && !select))) ? c.take<float>(npix) : nullptr;
         L.rgba[k] = (on && j.out_rgba[k]) ? c.take<uint8_t>(npix * 4) : nullptr;
         L.cmap[k] = (on && j.out_rgba[k]) ? c.take<uint8_t>(1024) : nullptr;
     }
     L.stats = c.take<lars_stats>(3);
     L.med = c.take<float>(6);
     L.sel = c.take<char>(3 * ((lars_select_scratch_bytes() + 255) & ~(size_t)255));
-    L.pairs = recompute ? c.take<float>(4) : nullptr;
-    L.selq = recompute ? c.take<char>(lars_quotient_median_scratch_bytes(1)) : nullptr;
+    L.pairs = select ? c.take<float>(4) : nullptr;
+    L.selq = select ? c.take<char>(lars_quotient_median_scratch_bytes(1)) : nullptr;
     L.total = c.off + 256;
     return L;
 }
@@ -123,7 +131,7 @@ int run_image(const ImageJob &j)
         a.out_wb = L.wb;
         a.stats = stats ? L.stats : nullptr;
         a.stream = s;
-        if (L.pairs) {
+        if (recompute_route(j)) {
             if (L.wb) {                                     // the white-balanced image on its own, then statistics + medians
                 lars_fused_args w = a;
                 w.index_mask = 0; w.flags = 0; w.stats = nullptr;
@@ -133,6 +141,8 @@ int run_image(const ImageJob &j)
             LARS_TRY(lars_d_stats_medians(&a, L.pairs, L.selq));
         } else {
             LARS_TRY(lars_d_fused(&a));
+            if (L.pairs)
+                LARS_TRY(lars_d_quotient_median_pairs(L.img, 1, (int64_t)npix, 3, LARS_U8, a.wb_table, L.pairs, L.selq, s));
         }
     }
     const size_t selsz = (lars_select_scratch_bytes() + 255) & ~(size_t)255;

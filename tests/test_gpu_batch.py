@@ -340,11 +340,30 @@ def test_batch_medians_are_numpy_medians(lars):
             assert abs(rows[7][key] - val) <= 1e-6 * max(abs(val), 0.1), key
         else:
             assert rows[7][key] == val, key
-    # the plane-writing route (batched select over stored planes) must agree with the recompute-and-select route
+    # with planes written as well (statistics kernel with outputs, then the two select passes): same medians, and the
+    # ring holds the last chunk's planes
     outs = b.make_outputs(index=True, ring=8)
     rec_o, med_o = b.process(medians=True, outputs=outs)
     np.testing.assert_array_equal(med_o, med)
+    assert rec_o["count"].tolist() == rec["count"].tolist() and rec_o["min"].tolist() == rec["min"].tolist()
+    with warnings.catch_warnings():
+        warnings.simplefilter("ignore")
+        want_plane = orc.index_app(orc.wb_app(tiles[20]), "GNDVI")
+    np.testing.assert_array_equal(outs.host_index("GNDVI", 20 % 8, 1)[0].view(np.uint32), want_plane.view(np.uint32))
     outs.free()
+    # tiles the select does not serve (pixel count not a multiple of 4 in a batch; uint16) take the batched radix select
+    # over stored planes
+    odd = lars.TileBatch.from_host(np.stack([orc.synth_tile_u8(3, t, 63, 65, profile="vegetation") for t in range(3)]))
+    wide = lars.TileBatch.from_host(np.random.default_rng(4).integers(0, 65536, (2, 40, 48, 3), dtype=np.uint16))
+    for bb in (odd, wide):
+        _, med_p = bb.process(medians=True)
+        for i in range(bb.ntiles):
+            with warnings.catch_warnings():
+                warnings.simplefilter("ignore")
+                wb = orc.wb_app(bb.host_tiles(i, 1)[0])
+            for k, t in enumerate(TYPES):
+                assert med_p[i, k] == float(np.median(orc.index_app(wb, t))), (i, t)
+        bb.free()
     big = lars.TileBatch.synthetic(3, 512, 384, seed=3, profile="uniform")         # several workgroups per tile
     _, med_b = big.process(medians=True)
     for i in range(3):

@@ -121,10 +121,10 @@ def main():
                 "ms": med, "min_ms": float(min(t[1:])), "GBs": npix * bpp / med / 1e6,
                 "frac_8TBs": npix * bpp / med / 1e6 / 8000.0, "Gpix_s": npix / med / 1e6}
     if "medians" in args.what:
-        # time-series table of the whole batch (statistics + median per tile): recompute-and-select vs stored planes
+        # time-series table of the whole batch (statistics + median per tile): without planes, and with the planes written as well
         import time
         outs = b.make_outputs(index=True, ring=min(args.ring, 16))
-        for name, kw in (("medians recompute+select (no planes)", {}), ("medians over stored planes (ring)", {"outputs": outs})):
+        for name, kw in (("medians recompute+select (no planes)", {}), ("medians + planes written (ring)", {"outputs": outs})):
             ts = []
             for _ in range(3):
                 _ffi.call("lars_synchronize", None)

@@ -1,4 +1,6 @@
-"""Property tests through the C ABI (hypothesis drives shapes and contents; needs a MI355X)."""
+"""Property tests through the C ABI (hypothesis drives shapes and contents; needs a MI355X).
+LARS_TEST_DEEP=k multiplies the number of examples for a one-off deep run."""
+import os
 import warnings
 
 import numpy as np
@@ -10,6 +12,7 @@ from oracle import index_oracle as orc
 
 pytestmark = pytest.mark.gpu
 TYPES = ("NDVI", "GNDVI", "NDWI")
+DEEP = max(1, int(os.environ.get("LARS_TEST_DEEP", "1")))
 
 
 def bits(a):
@@ -24,7 +27,7 @@ images = st.one_of(
 )
 
 
-@settings(max_examples=120, deadline=None)
+@settings(max_examples=120 * DEEP, deadline=None)
 @given(images)
 def test_process_image_equals_oracle(img):
     import lars_image_processing_amd as lars
@@ -46,7 +49,7 @@ def test_process_image_equals_oracle(img):
         np.testing.assert_array_equal(r["hist"], orc.hist50(want))
 
 
-@settings(max_examples=60, deadline=None)
+@settings(max_examples=60 * DEEP, deadline=None)
 @given(hnp.arrays(np.float32, st.integers(1, 3000), elements=st.floats(-1, 1, width=32)), st.sampled_from(TYPES))
 def test_analyze_index_on_arbitrary_float32(x, t):
     import lars_image_processing_amd as lars
@@ -69,7 +72,7 @@ rgn_tiles = st.one_of(
 )
 
 
-@settings(max_examples=80, deadline=None)
+@settings(max_examples=80 * DEEP, deadline=None)
 @given(rgn_tiles, st.booleans())
 def test_recompute_and_select_medians_equal_numpy(tiles, white_balance):
     """Statistics + exact medians without planes (per tile and over the batch) against np.median of the oracle's planes."""

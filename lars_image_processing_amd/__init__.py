@@ -33,5 +33,6 @@ from .api import (  # noqa: F401
     timeseries_row,
 )
 from .batch import TileBatch, local_fold, merge_records, shard_range, summarize, timeseries_rows  # noqa: F401
+from .tiffio import read_image, read_tiff, write_tiff  # noqa: F401
 
 __version__ = "0.1.0"

@@ -38,12 +38,15 @@ def _figure_png(index_array, index_type, path):
     plt.close()
 
 
-def process_image(image_path, output_dir, process_wb=False, indices=None, render="figure"):
-    """One file: same outputs as backend-process.py:49-73.  Returns the statistics dicts."""
+def process_image(image_path, output_dir, process_wb=False, indices=None, render="figure", full_depth=False):
+    """One file: same outputs as backend-process.py:49-73.  Returns the statistics dicts.
+    ``full_depth=True`` reads three-sample 16-bit TIFFs at their full depth (``tiffio.read_image``; Pillow, hence the
+    reference, keeps their high bytes only)."""
     from PIL import Image
+    from .tiffio import read_image
     image_path, output_dir = Path(image_path), Path(output_dir)
     name = image_path.stem
-    arr = np.array(Image.open(image_path))
+    arr = read_image(image_path, full_depth)
     if arr.ndim != 3 or arr.shape[2] < 3:
         raise ValueError(f"{image_path.name}: expected an image with at least 3 channels, got shape {arr.shape}")
     indices = list(indices or [])
@@ -68,7 +71,7 @@ def process_image(image_path, output_dir, process_wb=False, indices=None, render
 
 
 def batch_process(input_dir, output_dir, process_wb=False, process_ndvi=False, process_gndvi=False,
-                  process_ndwi=True, render="figure", workers=4, verbose=True):
+                  process_ndwi=True, render="figure", workers=4, verbose=True, full_depth=False):
     """backend-process.py:75-97 with its module constants as arguments.  Returns ``{file name: stats | error}``."""
     input_path, output_path = Path(input_dir), Path(output_dir)
     indices = [t for t, on in (("NDVI", process_ndvi), ("GNDVI", process_gndvi), ("NDWI", process_ndwi)) if on]
@@ -81,7 +84,7 @@ def batch_process(input_dir, output_dir, process_wb=False, process_ndvi=False, p
         try:
             if verbose:
                 print(f"Processing {idx}/{total}: {f.name}")
-            return f.name, process_image(f, output_path, process_wb, indices or None, render)
+            return f.name, process_image(f, output_path, process_wb, indices or None, render, full_depth)
         except Exception as e:                              # same policy as upstream :96-97
             if verbose:
                 print(f"Error processing {f.name}: {str(e)}")

@@ -93,3 +93,21 @@ def test_refuses_what_it_does_not_cover(tmp_path):
     with pytest.raises(tiffio.TiffError):
         tiffio.write_tiff(tmp_path / "f.tif", np.zeros((4, 4, 3), np.float32))
     del good
+
+
+from hypothesis import given, settings, strategies as st  # noqa: E402
+
+
+@settings(max_examples=150, deadline=None)
+@given(st.integers(1, 70), st.integers(1, 70), st.integers(1, 5), st.sampled_from([np.uint8, np.uint16]),
+       st.sampled_from(["<", ">"]), st.sampled_from([1, 2]), st.booleans(), st.booleans(),
+       st.one_of(st.none(), st.tuples(st.sampled_from([16, 32, 48]), st.sampled_from([16, 32, 64]))),
+       st.one_of(st.none(), st.integers(1, 80)), st.integers(0, 2**31))
+def test_round_trip_any_layout(tmp_path_factory, h, w, c, dtype, byteorder, planar, deflate, predictor, tile, rps, seed):
+    a = np.random.default_rng(seed).integers(0, np.iinfo(dtype).max + 1, (h, w, c), dtype=dtype)
+    path = tmp_path_factory.mktemp("tif") / "x.tif"
+    n = tiffio.write_tiff(path, a, rows_per_strip=rps, tile=tile, byteorder=byteorder, planar=planar, deflate=deflate,
+                          predictor=predictor)
+    assert n == path.stat().st_size
+    b = tiffio.read_tiff(path)
+    assert np.array_equal(b, a if c > 1 else a[..., 0])

@@ -345,6 +345,16 @@ int lars_h_change_detection(const uint8_t *early, const uint8_t *late, int64_t h
 int lars_h_colormap_norm_f32(const float *x, int64_t n, float vmin, float vmax, const uint8_t *lut_rgba,
                              uint8_t *out_rgba);
 
+/* ------------------------------------------------------------------ image files (host only, no GPU work) */
+/* TIFF 6.0 LZW (compression 5, MSB-first codes, early width change) of one strip / tile: decodes at most ndst bytes
+ * into dst, *nout = bytes produced.  For lars_image_processing_amd/tiffio.py, which reads the multi-sample 16-bit
+ * TIFFs that PIL.Image.open (backend-process.py:52) reduces to 8 bits. */
+int lars_h_tiff_lzw_decode(const uint8_t *src, int64_t nsrc, uint8_t *dst, int64_t ndst, int64_t *nout);
+/* Every strip / tile of an image in one call, shared by `threads` workers: chunk i = file[offsets[i], +counts[i])
+ * decodes into dst + i * chunk_bytes (at most chunk_bytes bytes), produced[i] = bytes that came out. */
+int lars_h_tiff_lzw_decode_chunks(const uint8_t *file, int64_t file_len, const uint64_t *offsets, const uint64_t *counts,
+                                  int64_t nchunks, uint8_t *dst, int64_t chunk_bytes, int64_t *produced, int threads);
+
 /* ------------------------------------------------------------------ multi-GPU */
 /* One process per GPU.  RCCL (librccl.so) is loaded on first use.  unique_id is
  * LARS_COMM_ID_BYTES bytes produced by lars_comm_unique_id() on rank 0 and

@@ -4,8 +4,8 @@ The reference opens every file with ``PIL.Image.open`` (backend-process.py:52, p
 has no mode for three 16-bit samples per pixel: it hands such a file over as 8-bit RGB (the high bytes), so the
 reference never sees the full depth.  This module reads them into the ``[H, W, C]`` uint16 array the hot path takes
 (``fix_white_balance`` / ``calculate_index`` accept any integer dtype).  Scope: classic (32-bit offset) TIFF, first image of the file, unsigned integer
-samples of 8 or 16 bits, chunky or planar layout, strips or tiles, either byte order, uncompressed or Deflate
-(compression 8 / 32946) with or without the horizontal predictor.  Anything else raises ``TiffError`` naming the
+samples of 8 or 16 bits, chunky or planar layout, strips or tiles, either byte order, uncompressed, LZW (through the
+library's host-side decoder) or Deflate (compression 8 / 32946), with or without the horizontal predictor.  Anything else raises ``TiffError`` naming the
 feature -- never a silently wrong array.
 
 No oracle exists in the reference for this loader; tests pin it by round trips, against Pillow on the
@@ -71,6 +71,26 @@ def _one(tags, tag, default=None):
     return int(v[0])
 
 
+def _lzw_all(buf, offsets, counts, chunk_bytes):
+    """Every LZW strip / tile through the library's host-side decoder (csrc/tiff_codec.cpp; threads, no GPU involved):
+    (uint8[nchunks][chunk_bytes], bytes produced per chunk)."""
+    import ctypes as C
+    import os
+    from . import _ffi
+    n = len(offsets)
+    data = np.empty((n, chunk_bytes), dtype=np.uint8)
+    produced = np.zeros(n, dtype=np.int64)
+    off = np.asarray(offsets, dtype=np.uint64)
+    cnt = np.asarray(counts, dtype=np.uint64)
+    src = np.frombuffer(buf, dtype=np.uint8)
+    try:
+        _ffi.call("lars_h_tiff_lzw_decode_chunks", _ffi.ptr(src), src.size, _ffi.ptr(off), _ffi.ptr(cnt), n, _ffi.ptr(data),
+                  chunk_bytes, _ffi.ptr(produced), min(8, os.cpu_count() or 1))
+    except _ffi.LarsError as exc:
+        raise TiffError(str(exc)) from None
+    return data, produced
+
+
 def _chunk(buf, offset, nbytes, compression, want):
     if offset + nbytes > len(buf):
         raise TiffError("strip / tile data outside the file")
@@ -111,9 +131,9 @@ def read_tiff(path_or_bytes):
     if any(int(f) != 1 for f in fmt):
         raise TiffError(f"sample format {fmt} is not supported (unsigned integer only)")
     compression = _one(tags, COMPRESSION, 1)
-    if compression not in (1, 8, 32946):
-        names = {5: "LZW", 7: "JPEG", 32773: "PackBits"}
-        raise TiffError(f"compression {compression} ({names.get(compression, 'unknown')}) is not supported (none or Deflate)")
+    if compression not in (1, 5, 8, 32946):
+        names = {2: "CCITT", 6: "old JPEG", 7: "JPEG", 32773: "PackBits"}
+        raise TiffError(f"compression {compression} ({names.get(compression, 'unknown')}) is not supported (none, LZW or Deflate)")
     predictor = _one(tags, PREDICTOR, 1)
     if predictor not in (1, 2):
         raise TiffError(f"predictor {predictor} is not supported")
@@ -146,6 +166,8 @@ def read_tiff(path_or_bytes):
         raise TiffError(f"{len(offsets)} strips / tiles, {across * down * planes} expected")
 
     out = np.empty((planes, height, width, inner), dtype=dtype.newbyteorder("="))
+    full = chunk_h * chunk_w * inner * dtype.itemsize        # bytes of a whole strip / tile
+    decoded = _lzw_all(buf, offsets, counts, full) if compression == 5 else None
     k = 0
     for p in range(planes):
         for ty in range(down):
@@ -157,7 +179,13 @@ def read_tiff(path_or_bytes):
                 x0 = tx * chunk_w
                 cols_here = min(chunk_w, width - x0)
                 want = stored_rows * chunk_w * inner * dtype.itemsize
-                raw = _chunk(buf, int(offsets[k]), int(counts[k]), compression, want)
+                if decoded is not None:
+                    data, produced = decoded
+                    if produced[k] < want:
+                        raise TiffError(f"strip / tile holds {int(produced[k])} bytes, {want} expected")
+                    raw = data[k, :want]
+                else:
+                    raw = _chunk(buf, int(offsets[k]), int(counts[k]), compression, want)
                 k += 1
                 a = np.frombuffer(raw, dtype=dtype).reshape(stored_rows, chunk_w, inner)
                 if predictor == 2:

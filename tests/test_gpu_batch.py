@@ -289,6 +289,41 @@ def test_uint16_batch_against_oracle(lars, kind):
     hist.free(); outs.free(); b.free()
 
 
+def test_uint16_full_size_tile(lars):
+    """BASELINE configs[4] at its full size: one 8192 x 8192 uint16 tile (384 MiB), float32 NDVI + RdYlGn RGBA written.
+    Percentiles against np.percentile on the whole channel; planes bit-exact on strips (first, middle, last rows) with the
+    white balance taken from the reference expression on those strips; statistics through size-independent identities."""
+    edge = 8192
+    rng = np.random.default_rng(16)
+    tile = rng.integers(0, 65536, (edge, edge, 3), dtype=np.uint16)
+    tile[:, :, 0] >>= 2                                   # a 14-bit channel next to two 16-bit ones
+    b = lars.TileBatch.from_host(tile[None])
+    outs = b.make_outputs(indices=("NDVI",), index=True, rgba=True)
+    rec = b.process(indices=("NDVI",), hist=True, outputs=outs)
+    pcts = b.host_percentiles()[0]
+    luts = []
+    for c in range(3):
+        lo, hi = np.percentile(tile[:, :, c].astype(np.float32), (2, 98))
+        assert pcts[c, 0] == lo and pcts[c, 1] == hi, c
+        luts.append(orc.wb_lut_from_percentiles(lo, hi, 65536))
+    ndvi = outs.host_index("NDVI", 0, 1)[0]
+    rgba = outs.rgba[0].download(np.uint8, (edge, edge, 4))
+    lut_rgba = lars.colormap_lut("RdYlGn")
+    for rows in (slice(0, 48), slice(edge // 2 - 24, edge // 2 + 24), slice(edge - 48, edge)):
+        strip = tile[rows]
+        wb = np.stack([luts[c][strip[:, :, c]] for c in range(3)], axis=2)
+        want = orc.index_app(wb, "NDVI")
+        np.testing.assert_array_equal(bits(ndvi[rows]), bits(want))
+        np.testing.assert_array_equal(rgba[rows], orc.colormap_closed_form(want, lut_rgba))
+    r = rec[0, 0]
+    assert int(r["count"]) == edge * edge and int(np.sum(r["hist"])) == edge * edge
+    assert float(r["min"]) == float(ndvi.min()) and float(r["max"]) == float(ndvi.max())
+    assert int(r["above"]) == int(np.count_nonzero(ndvi > np.float32(0.2)))
+    assert float(r["sum"]) == float(np.sum(ndvi, dtype=np.float64))
+    np.testing.assert_array_equal(np.array(r["hist"], dtype=np.int64), np.histogram(ndvi, bins=50, range=(-1, 1))[0])
+    outs.free(); b.free()
+
+
 def test_uint16_rgba_channels_take_generic_path(lars):
     rng = np.random.default_rng(9)
     tiles = rng.integers(0, 65536, (2, 33, 47, 4), dtype=np.uint16)

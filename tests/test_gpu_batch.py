@@ -87,6 +87,38 @@ def test_batch_matches_oracle_per_tile(lars, profile, shape):
     b.free()
 
 
+def test_one_rank_share_of_the_sharded_batch(lars):
+    """BASELINE configs[3]: 16384 tiles over 8 GPUs = 2048 tiles of 4096 x 4096 per rank (96 GiB of samples), statistics only.
+    Size-independent identities over all records, equality of a few tiles with their single-tile runs (same global tile
+    index, hence same samples), and the fold."""
+    from lars_image_processing_amd import batch as lb
+    import ctypes as C
+    from lars_image_processing_amd import _ffi
+    free_b, total_b = C.c_size_t(0), C.c_size_t(0)
+    _ffi.call("lars_mem_info", C.byref(free_b), C.byref(total_b))
+    if free_b.value < 120 * 2**30:
+        pytest.skip("needs a 288 GiB device")
+    n, ntiles, first = 4096 * 4096, 2048, 3 * 2048                       # the share of rank 3
+    b = lars.TileBatch.synthetic(ntiles, 4096, 4096, seed=1234, profile="vegetation", first_tile=first)
+    rec = b.process(hist=True)
+    assert rec.shape == (ntiles, 3)
+    assert (rec["count"] == n).all() and (rec["hist"].sum(axis=2) == n).all()
+    assert (rec["min"] >= -1).all() and (rec["max"] <= 1).all() and (rec["min"] <= rec["max"]).all()
+    assert (rec["sum"][:, 2] == -rec["sum"][:, 1]).all()                    # NDWI == -GNDVI
+    assert (rec["min"][:, 2] == -rec["max"][:, 1]).all() and (rec["max"][:, 2] == -rec["min"][:, 1]).all()
+    for j in (0, 1023, 2047):
+        one = lars.TileBatch.synthetic(1, 4096, 4096, seed=1234, profile="vegetation", first_tile=first + j)
+        assert one.process(hist=True)[0].tobytes() == rec[j].tobytes(), j
+        one.free()
+    glob = lb.local_fold(rec)
+    for k in range(3):
+        g = lb.summarize(glob[k])
+        assert g["count"] == ntiles * n and int(np.sum(g["hist"])) == ntiles * n
+        assert g["min"] == float(rec["min"][:, k].min()) and g["max"] == float(rec["max"][:, k].max())
+        assert abs(g["mean"] - float(rec["sum"][:, k].sum()) / (ntiles * n)) <= 1e-12
+    b.free()
+
+
 def test_stats_only_equals_stats_with_outputs_and_ring(lars):
     b = lars.TileBatch.synthetic(8, 128, 128, seed=7, profile="vegetation")
     rec_a = b.process(hist=True, sumsq=True)

@@ -230,6 +230,38 @@ def traffic_from_profiles(mode, pixels_per_launch):
         return None
 
 
+def config4_leg(tiles=16, edge=8192):
+    """BASELINE configs[4] shape on this GPU (not the headline): uint16 8192 x 8192 tiles, percentile white balance,
+    float32 NDVI + RdYlGn RGBA written + statistics.  14 algorithmic bytes per pixel (6 read, 8 written)."""
+    import lars_image_processing_amd as lars
+    from lars_image_processing_amd import _ffi
+    b = lars.TileBatch(tiles, edge, edge, 3, np.uint16)
+    _ffi.call("lars_d_synth_u8", C.c_void_p(b.tiles.ptr), tiles, 0, b.npix * 2, 3, 1234, 0, None)   # random 16-bit samples
+    outs = b.make_outputs(indices=("NDVI",), index=True, rgba=True)
+    stats = b.new_stats()
+    ev = [C.c_void_p() for _ in range(3)]
+    for e in ev:
+        _ffi.call("lars_event_create", C.byref(e))
+    prep, fused = [], []
+    for _ in range(4):
+        _ffi.call("lars_event_record", ev[0], None)
+        b.compute_wb_tables()
+        _ffi.call("lars_event_record", ev[1], None)
+        b.run_fused(b.fused_args(("NDVI",), True, stats, False, outs))
+        _ffi.call("lars_event_record", ev[2], None)
+        _ffi.call("lars_synchronize", None)
+        ms = C.c_float(0)
+        _ffi.call("lars_event_elapsed_ms", ev[0], ev[1], C.byref(ms)); prep.append(ms.value)
+        _ffi.call("lars_event_elapsed_ms", ev[1], ev[2], C.byref(ms)); fused.append(ms.value)
+    p_ms, f_ms = float(np.median(prep[1:])), float(np.median(fused[1:]))
+    npix = tiles * edge * edge
+    outs.free(); stats.free(); b.free()
+    return {"workload": f"{tiles} tiles of {edge}x{edge} uint16, white balance + float32 NDVI + RGBA8 written + statistics",
+            "Mpix_s": npix / ((p_ms + f_ms) * 1e-3) / 1e6, "wb_prepare_ms": p_ms, "fused_ms": f_ms,
+            "fused_GBs_algorithmic": npix * 14 / (f_ms * 1e-3) / 1e9,
+            "fused_frac_of_8TBs": npix * 14 / (f_ms * 1e-3) / 1e9 / HBM_PEAK_GBS}
+
+
 def main():
     args = parse()
     from lars_image_processing_amd import _ffi
@@ -294,6 +326,8 @@ def main():
         median_ms = (time.perf_counter() - t0) * 1e3
 
     probe = device_probe(runner) if (args.probe and rank == 0) else None
+    if args.all_modes and world == 1:
+        extra["u16_8192_ndvi_rgba_out_stats"] = config4_leg()
     if rank == 0:
         cpu = None if args.no_cpu_baseline or world > 1 else cpu_baseline(args)
         g = {t: runner.lb.summarize(glob[_ffi.INDEX_IDS[t]]) for t in indices}

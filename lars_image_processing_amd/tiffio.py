@@ -105,7 +105,10 @@ def _chunk(buf, offset, nbytes, compression, want):
     return raw[:want]
 
 
-def read_tiff(path_or_bytes):
+MAX_DECODED_BYTES = 16 << 30      # refuse directories that claim more than this (a corrupt header must not allocate the host away)
+
+
+def read_tiff(path_or_bytes, max_bytes=MAX_DECODED_BYTES):
     """``[H, W, C]`` (``[H, W]`` for one sample per pixel) uint8 / uint16 array of the first image of a TIFF."""
     if isinstance(path_or_bytes, (bytes, bytearray, memoryview)):
         buf = memoryview(path_or_bytes)
@@ -142,6 +145,8 @@ def read_tiff(path_or_bytes):
         raise TiffError(f"planar configuration {planar}")
     if width <= 0 or height <= 0 or spp <= 0:
         raise TiffError("empty image")
+    if width * height * spp * (bits // 8) > max_bytes:
+        raise TiffError(f"image of {width} x {height} x {spp} x {bits} bits exceeds max_bytes={max_bytes}")
     dtype = np.dtype(np.uint8 if bits == 8 else (endian + "u2"))
     planes = spp if planar == 2 else 1                    # separately stored sample planes
     inner = 1 if planar == 2 else spp                     # samples per pixel inside one chunk

@@ -92,6 +92,14 @@ def test_refuses_what_it_does_not_cover(tmp_path):
         tiffio.read_tiff(blob[:8] + bytes(len(blob) - 8))           # zeroed directory
     with pytest.raises(tiffio.TiffError):
         tiffio.write_tiff(tmp_path / "f.tif", np.zeros((4, 4, 3), np.float32))
+    with pytest.raises(tiffio.TiffError, match="max_bytes"):
+        tiffio.read_tiff(blob, max_bytes=100)                        # a header claiming more than the caller allows
+    huge = bytearray(blob)
+    at = struct.unpack_from("<I", huge, 4)[0] + 2                   # first directory entry = ImageWidth (tags are sorted)
+    assert struct.unpack_from("<H", huge, at)[0] == tiffio.IMAGE_WIDTH
+    struct.pack_into("<I", huge, at + 8, 0x7FFFFFFF)
+    with pytest.raises(tiffio.TiffError):
+        tiffio.read_tiff(bytes(huge))
     del good
 
 

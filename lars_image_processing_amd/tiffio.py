@@ -64,7 +64,7 @@ def _read_ifd(buf, endian):
 
 def _one(tags, tag, default=None):
     v = tags.get(tag)
-    if v is None:
+    if v is None or len(v) == 0:
         if default is None:
             raise TiffError(f"required tag {tag} is missing")
         return default
@@ -124,13 +124,13 @@ def read_tiff(path_or_bytes, max_bytes=MAX_DECODED_BYTES):
     tags = _read_ifd(buf, endian)
     width, height = _one(tags, IMAGE_WIDTH), _one(tags, IMAGE_LENGTH)
     spp = _one(tags, SAMPLES_PER_PIXEL, 1)
-    bits = tags.get(BITS_PER_SAMPLE, (1,))
+    bits = tags.get(BITS_PER_SAMPLE) or (1,)
     if len(set(bits)) != 1 or len(bits) not in (1, spp):
         raise TiffError(f"samples of different widths {bits} are not supported")
     bits = int(bits[0])
     if bits not in (8, 16):
         raise TiffError(f"{bits}-bit samples are not supported (8 or 16)")
-    fmt = tags.get(SAMPLE_FORMAT, (1,))
+    fmt = tags.get(SAMPLE_FORMAT) or (1,)
     if any(int(f) != 1 for f in fmt):
         raise TiffError(f"sample format {fmt} is not supported (unsigned integer only)")
     compression = _one(tags, COMPRESSION, 1)
@@ -153,11 +153,15 @@ def read_tiff(path_or_bytes, max_bytes=MAX_DECODED_BYTES):
 
     if TILE_WIDTH in tags:
         tw, th = _one(tags, TILE_WIDTH), _one(tags, TILE_LENGTH)
+        if tw <= 0 or th <= 0 or tw * th * spp * (bits // 8) > max_bytes:
+            raise TiffError(f"bad tile size {tw} x {th}")
         offsets, counts = tags.get(TILE_OFFSETS), tags.get(TILE_BYTE_COUNTS)
         across, down = -(-width // tw), -(-height // th)
         chunk_h, chunk_w = th, tw
     else:
         rps = min(_one(tags, ROWS_PER_STRIP, height), height)
+        if rps <= 0:
+            raise TiffError("rows per strip must be positive")
         offsets, counts = tags.get(STRIP_OFFSETS), tags.get(STRIP_BYTE_COUNTS)
         across, down = 1, -(-height // rps)
         chunk_h, chunk_w = rps, width

@@ -235,3 +235,24 @@ def test_sixteen_bit_rgb_lzw_tiff(tmp_path):
     got = tiffio.read_tiff(tmp_path / "lzw16.tif")
     assert got.dtype == np.uint16 and np.array_equal(got, a)
     assert np.array_equal(tiffio.read_image(tmp_path / "lzw16.tif", full_depth=True), a)
+
+
+def test_corrupt_files_raise_tiff_error_only(tmp_path):
+    """Random byte flips (mostly in the directory): the reader answers with an array or TiffError, nothing else."""
+    rng = np.random.default_rng(0)
+    a = rng.integers(0, 65536, (20, 24, 3), dtype=np.uint16)
+    blobs = []
+    for i, kw in enumerate([{}, {"tile": (16, 16)}, {"deflate": True, "predictor": True}, {"planar": 2, "byteorder": ">"}]):
+        tiffio.write_tiff(tmp_path / f"{i}.tif", a, **kw)
+        blobs.append((tmp_path / f"{i}.tif").read_bytes())
+    for it in range(1200):
+        blob = bytearray(blobs[it % 4])
+        ifd = struct.unpack_from("<I" if blob[:2] == b"II" else ">I", blob, 4)[0]
+        for _ in range(int(rng.integers(1, 4))):
+            pos = int(rng.integers(ifd, len(blob))) if rng.random() < 0.8 else int(rng.integers(0, len(blob)))
+            blob[pos] = int(rng.integers(0, 256))
+        try:
+            out = tiffio.read_tiff(bytes(blob), max_bytes=1 << 24)
+            assert isinstance(out, np.ndarray)
+        except tiffio.TiffError:
+            pass

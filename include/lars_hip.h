@@ -214,7 +214,8 @@ int lars_d_median_pair_batch_f32(const float *x, int64_t n, int64_t items, int64
  * hist is uint64[2 streams][2 tracks][2048], accumulated with atomics (zero it first).  NDWI = -GNDVI shares
  * GNDVI's order statistics. */
 int lars_d_quotient_select_hist(const void *tiles, int64_t ntiles, int64_t npix, int channels, int dtype,
-                                const uint8_t *wb_table, int first, const uint32_t bucket[4], uint64_t *hist, void *stream);
+                                const uint8_t *wb_table, uint32_t streams /* bit 0 NDVI, bit 1 GNDVI (and NDWI) */, int first,
+                                const uint32_t bucket[4], uint64_t *hist, void *stream);
 /* np.median of the NDVI and GNDVI planes of EVERY tile without writing a plane: the same two passes with
  * per-tile histograms, the picks and the value look-up on the device (no host round trip).  out_pairs is float[ntiles][2
  * streams: NDVI, GNDVI][2]: the two middle order statistics (median = their float32 mean; NDWI's median is
@@ -226,7 +227,8 @@ size_t lars_quotient_median_scratch_bytes(int64_t ntiles);
  * as NaN pairs. */
 int lars_d_stats_medians(const lars_fused_args *a, float *out_pairs, void *scratch);
 int lars_d_quotient_median_pairs(const void *tiles, int64_t ntiles, int64_t npix, int channels, int dtype,
-                                 const uint8_t *wb_table, float *out_pairs, void *scratch, void *stream);
+                                 const uint8_t *wb_table, uint32_t streams /* bit 0 NDVI, bit 1 GNDVI; others come back NaN */,
+                                 float *out_pairs, void *scratch, void *stream);
 
 /* classification mask (see lars_h_threshold_mask_f32); x 16-byte, out_mask 4-byte aligned */
 int lars_d_threshold_mask_f32(const float *x, int64_t n, float threshold, uint8_t *out_mask, void *stream);

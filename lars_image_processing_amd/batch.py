@@ -307,7 +307,8 @@ class TileBatch:
         pairs_dev = DeviceBuffer(self.ntiles * 4 * 4)
         scratch = DeviceBuffer(int(_ffi.load().lars_quotient_median_scratch_bytes(self.ntiles)))
         _ffi.call("lars_d_quotient_median_pairs", C.c_void_p(self.tiles.ptr), self.ntiles, self.npix, self.channels, self.code,
-                  C.c_void_p(self.table.ptr) if white_balance else None, C.c_void_p(pairs_dev.ptr), C.c_void_p(scratch.ptr), stream)
+                  C.c_void_p(self.table.ptr) if white_balance else None, select_streams(indices), C.c_void_p(pairs_dev.ptr),
+                  C.c_void_p(scratch.ptr), stream)
         _ffi.call("lars_synchronize", stream)
         pairs = pairs_dev.download(np.float32, (self.ntiles, 2, 2))
         pairs_dev.free()
@@ -326,8 +327,9 @@ class TileBatch:
         return med
 
     # -- exact medians of the whole batch (all tiles, all ranks) ------------
-    def select_histogram(self, first, buckets, white_balance=True, stream=None):
-        """One pass of the two-level select (``lars_d_quotient_select_hist``): uint64[2 streams][2 tracks][2048]."""
+    def select_histogram(self, first, buckets, white_balance=True, stream=None, streams=3):
+        """One pass of the two-level select (``lars_d_quotient_select_hist``): uint64[2 streams][2 tracks][2048].
+        ``streams``: bit 0 NDVI, bit 1 GNDVI (NDWI shares it); a stream left out is not computed and stays zero."""
         if self.code != _ffi.U8 or self.channels != 3:
             raise TypeError("exact batch medians need uint8 tiles with 3 channels")
         if white_balance and self.table is None:
@@ -337,7 +339,7 @@ class TileBatch:
         self._selq.zero()
         b = np.ascontiguousarray(buckets, dtype=np.uint32).reshape(4)
         _ffi.call("lars_d_quotient_select_hist", C.c_void_p(self.tiles.ptr), self.ntiles, self.npix, self.channels, self.code,
-                  C.c_void_p(self.table.ptr) if white_balance else None, int(bool(first)), _ffi.ptr(b),
+                  C.c_void_p(self.table.ptr) if white_balance else None, int(streams), int(bool(first)), _ffi.ptr(b),
                   C.c_void_p(self._selq.ptr), stream)
         _ffi.call("lars_synchronize", stream)
         return self._selq.download(np.uint64, (2, 2, SELECT_BINS))
@@ -350,7 +352,9 @@ class TileBatch:
         if white_balance and (recompute_tables or self.table is None):
             self.compute_wb_tables()
         n_local = self.ntiles * self.npix
-        values = select_order_statistics(lambda first, buckets: self.select_histogram(first, buckets, white_balance), n_local, comm)
+        streams = select_streams(indices)
+        values = select_order_statistics(lambda first, buckets: self.select_histogram(first, buckets, white_balance, None, streams),
+                                         n_local, comm, streams)
         return medians_from_pairs(values, indices)
 
 
@@ -487,13 +491,24 @@ def select_value(bucket, slot):
     return np.float32(vals[0])
 
 
-def select_order_statistics(pass_fn, n_local, comm=None):
+def select_streams(indices):
+    """Which of the two value streams a set of indices needs: bit 0 NDVI, bit 1 GNDVI (NDWI = -GNDVI rides on it)."""
+    mask = 0
+    for t in indices:
+        mask |= 1 if t == "NDVI" else 2
+    if not mask:
+        raise ValueError("no index requested")
+    return mask
+
+
+def select_order_statistics(pass_fn, n_local, comm=None, streams=3):
     """The two middle order statistics (ranks (N-1)//2 and N//2) of two streams of quotients of bytes: float32[2][2].
 
     ``pass_fn(first, buckets[4]) -> uint64[2][2][SELECT_BINS]`` counts on this rank: first pass, the bucket of every
     value (under track 0); second pass, the slot of the values inside ``buckets[stream * 2 + track]`` -- under track 0
     only when both streams' tracks share their bucket.  Histograms are summed over ranks through
     ``comm.allreduce_f64`` (counts < 2^53 are exact in float64), every rank then picks the same bins.
+    ``streams`` (bit 0, bit 1): a stream that is not asked for is skipped and comes back as NaN.
     """
     tot = np.array([float(n_local)])
     n_total = int((comm.allreduce_f64(tot, "sum") if comm is not None else tot)[0])
@@ -501,7 +516,7 @@ def select_order_statistics(pass_fn, n_local, comm=None):
         raise ValueError("select: no values")
     ranks = np.array([[(n_total - 1) // 2, n_total // 2]] * 2, dtype=np.int64)     # [stream][track]
     buckets = np.zeros((2, 2), dtype=np.uint32)
-    values = np.zeros((2, 2), dtype=np.float32)
+    values = np.full((2, 2), np.nan, dtype=np.float32)
     for first in (True, False):
         local = np.asarray(pass_fn(first, buckets.reshape(4)), dtype=np.uint64).reshape(2, 2, SELECT_BINS)
         hist = local.astype(np.float64).reshape(-1)
@@ -515,6 +530,8 @@ def select_order_statistics(pass_fn, n_local, comm=None):
             if (buckets[:, 0] == buckets[:, 1]).all():
                 hist[:, 1] = hist[:, 0]                     # both streams' tracks shared: only track 0 was counted
         for s in range(2):
+            if not (streams >> s) & 1:
+                continue
             for t in range(2):
                 cum = np.cumsum(hist[s, t])
                 d = int(np.searchsorted(cum, ranks[s, t], side="right"))

@@ -121,10 +121,10 @@ int fused_v2_threads(bool any_out);
 void fused_v2_launch(unsigned mask, bool wb, int stats, bool nt, dim3 grid, hipStream_t s, const FusedParams &P);
 void chan_hist_v2_launch(const uint8_t *tiles, long long npix, unsigned int *hist, dim3 grid, hipStream_t s);
 int selq_pass_launch(const uint8_t *tiles, const uint8_t *wb_table, long long ntiles, long long npix, int first,
-                     const unsigned int bucket[4], unsigned long long *hist, hipStream_t s);
+                     const unsigned int bucket[4], unsigned long long *hist, hipStream_t s, unsigned streams);
 size_t selq_tile_scratch_bytes(long long ntiles);
 int selq_tile_medians_launch(const uint8_t *tiles, const uint8_t *wb_table, long long ntiles, long long npix, float *out_pairs,
-                             void *scratch, hipStream_t s, bool first_pass_done);
+                             void *scratch, hipStream_t s, bool first_pass_done, unsigned streams);
 int selq_tile_prepare(void *scratch, long long ntiles, long long npix, hipStream_t s, unsigned int streams);
 unsigned int *selq_tile_hist32(void *scratch, long long ntiles);
 void fused_v2_sel_launch(unsigned mask, bool wb, int stats, dim3 grid, hipStream_t s, const FusedParams &P);

@@ -142,7 +142,8 @@ int run_image(const ImageJob &j)
         } else {
             LARS_TRY(lars_d_fused(&a));
             if (L.pairs)
-                LARS_TRY(lars_d_quotient_median_pairs(L.img, 1, (int64_t)npix, 3, LARS_U8, a.wb_table, L.pairs, L.selq, s));
+                LARS_TRY(lars_d_quotient_median_pairs(L.img, 1, (int64_t)npix, 3, LARS_U8, a.wb_table,
+                                                      ((j.mask & 1u) ? 1u : 0u) | ((j.mask & 6u) ? 2u : 0u), L.pairs, L.selq, s));
         }
     }
     const size_t selsz = (lars_select_scratch_bytes() + 255) & ~(size_t)255;

@@ -47,7 +47,8 @@ struct SelQTile {
     unsigned int pad[3];
 };
 
-template <bool WB, bool PER_TILE>
+// STREAMS: bit 0 NDVI, bit 1 GNDVI -- a stream nobody asked for is neither sampled nor divided nor counted
+template <bool WB, bool PER_TILE, unsigned STREAMS>
 __global__ __launch_bounds__(1024, 8) void k_selq_pass(SelQParams P)
 {
     // 64 KiB table + one 2048-word row per stream = exactly 80 KiB: two blocks per CU, 8 waves per SIMD
@@ -96,18 +97,26 @@ __global__ __launch_bounds__(1024, 8) void k_selq_pass(SelQParams P)
 #pragma unroll
             for (int px = 0; px < 4; ++px) {
                 fn[px] = sample<WB>(wn[px], bn[px], 2, lane_off4, s_tab);
-                fr[px] = sample<WB>(wr[px], br[px], 0, lane_off4, s_tab);
-                fg[px] = sample<WB>(wg[px], bg[px], 1, lane_off4, s_tab);
+                if (STREAMS & 1u) fr[px] = sample<WB>(wr[px], br[px], 0, lane_off4, s_tab);
+                if (STREAMS & 2u) fg[px] = sample<WB>(wg[px], bg[px], 1, lane_off4, s_tab);
             }
 #pragma unroll
             for (int h = 0; h < 2; ++h) {
-                const f32x2 N = {fn[2 * h], fn[2 * h + 1]}, R = {fr[2 * h], fr[2 * h + 1]}, G = {fg[2 * h], fg[2 * h + 1]};
+                const f32x2 N = {fn[2 * h], fn[2 * h + 1]};
                 const f32x2 Ne = N + (f32x2){LARS_DEN_EPS, LARS_DEN_EPS};
-                const f32x2 v = exact_quot2(N - R, Ne + R), g = exact_quot2(N - G, Ne + G);
-                qv[2 * h] = v.x; qv[2 * h + 1] = v.y; qg[2 * h] = g.x; qg[2 * h + 1] = g.y;
+                if (STREAMS & 1u) {
+                    const f32x2 R = {fr[2 * h], fr[2 * h + 1]};
+                    const f32x2 v = exact_quot2(N - R, Ne + R);
+                    qv[2 * h] = v.x; qv[2 * h + 1] = v.y;
+                }
+                if (STREAMS & 2u) {
+                    const f32x2 G = {fg[2 * h], fg[2 * h + 1]};
+                    const f32x2 g = exact_quot2(N - G, Ne + G);
+                    qg[2 * h] = g.x; qg[2 * h + 1] = g.y;
+                }
             }
-            push_n(0, qv, 4);
-            push_n(1, qg, 4);
+            if (STREAMS & 1u) push_n(0, qv, 4);
+            if (STREAMS & 2u) push_n(1, qg, 4);
         });
         if (blockIdx.x == 0 && tid < (int)(npix & 3)) {
             const long long i = nquads * 4 + tid;
@@ -117,8 +126,8 @@ __global__ __launch_bounds__(1024, 8) void k_selq_pass(SelQParams P)
                 r = tab[r * 64] & 0xFFu; g = (tab[g * 64] >> 8) & 0xFFu; n = (tab[n * 64] >> 16) & 0xFFu;
             }
             const float tv = norm_diff_fast((float)n, (float)r), tg = norm_diff_fast((float)n, (float)g);
-            push_n(0, &tv, 1);
-            push_n(1, &tg, 1);
+            if (STREAMS & 1u) push_n(0, &tv, 1);
+            if (STREAMS & 2u) push_n(1, &tg, 1);
         }
     };
     // rows -> the histogram of `track` (the dummy words are not part of it)
@@ -262,17 +271,24 @@ static dim3 selq_grid(long long ntiles, long long npix)
     return dim3((unsigned)bpt, (unsigned)ntiles);
 }
 
+template <bool PER_TILE>
+static void selq_launch(bool wb, unsigned streams, dim3 grid, hipStream_t s, const SelQParams &P)
+{
+#define SELQ_GO(W, S) hipLaunchKernelGGL((k_selq_pass<W, PER_TILE, S>), grid, dim3(1024), 0, s, P)
+    if (wb) { if (streams == 1u) SELQ_GO(true, 1u); else if (streams == 2u) SELQ_GO(true, 2u); else SELQ_GO(true, 3u); }
+    else { if (streams == 1u) SELQ_GO(false, 1u); else if (streams == 2u) SELQ_GO(false, 2u); else SELQ_GO(false, 3u); }
+#undef SELQ_GO
+}
+
 int selq_pass_launch(const uint8_t *tiles, const uint8_t *wb_table, long long ntiles, long long npix, int first,
-                     const unsigned int bucket[4], unsigned long long *hist, hipStream_t s)
+                     const unsigned int bucket[4], unsigned long long *hist, hipStream_t s, unsigned streams)
 {
     SelQParams P;
     memset(&P, 0, sizeof P);
     P.tiles = tiles; P.wb_table = wb_table; P.npix = npix; P.first = first;
     for (int c = 0; c < 4; ++c) P.bucket[c] = bucket[c];
     P.hist = hist;
-    const dim3 grid = selq_grid(ntiles, npix);
-    if (wb_table) hipLaunchKernelGGL((k_selq_pass<true, false>), grid, dim3(1024), 0, s, P);
-    else hipLaunchKernelGGL((k_selq_pass<false, false>), grid, dim3(1024), 0, s, P);
+    selq_launch<false>(wb_table != nullptr, streams, selq_grid(ntiles, npix), s, P);
     return launch_check("k_selq_pass");
 }
 
@@ -306,11 +322,11 @@ int selq_tile_prepare(void *scratch, long long ntiles, long long npix, hipStream
 }
 
 int selq_tile_medians_launch(const uint8_t *tiles, const uint8_t *wb_table, long long ntiles, long long npix, float *out_pairs,
-                             void *scratch, hipStream_t s, bool first_pass_done)
+                             void *scratch, hipStream_t s, bool first_pass_done, unsigned streams)
 {
     SelQTile *state; unsigned int *hist32;
     selq_scratch_layout(scratch, ntiles, &state, &hist32);
-    if (!first_pass_done) LARS_TRY(selq_tile_prepare(scratch, ntiles, npix, s, 3u));
+    if (!first_pass_done) LARS_TRY(selq_tile_prepare(scratch, ntiles, npix, s, streams));
     const dim3 grid = selq_grid(ntiles, npix);
     for (int p = 0; p < 2; ++p) {
         SelQParams P;
@@ -318,8 +334,7 @@ int selq_tile_medians_launch(const uint8_t *tiles, const uint8_t *wb_table, long
         P.tiles = tiles; P.wb_table = wb_table; P.npix = npix; P.first = p == 0;
         P.state = state; P.hist32 = hist32;
         if (p == 0 && first_pass_done) { /* counted by the statistics kernel */ }
-        else if (wb_table) hipLaunchKernelGGL((k_selq_pass<true, true>), grid, dim3(1024), 0, s, P);
-        else hipLaunchKernelGGL((k_selq_pass<false, true>), grid, dim3(1024), 0, s, P);
+        else selq_launch<true>(wb_table != nullptr, streams, grid, s, P);
         hipLaunchKernelGGL(k_selq_pick, dim3((unsigned)ntiles), dim3(256), 0, s, state, hist32, p == 0 ? 1 : 0, out_pairs);
     }
     return launch_check("selq_tile_medians");
@@ -331,11 +346,12 @@ int selq_tile_medians_launch(const uint8_t *tiles, const uint8_t *wb_table, long
 // entry points
 // ===========================================================================
 extern "C" int lars_d_quotient_select_hist(const void *tiles, int64_t ntiles, int64_t npix, int channels, int dtype,
-                                           const uint8_t *wb_table, int first, const uint32_t bucket[4], uint64_t *hist, void *stream)
+                                           const uint8_t *wb_table, uint32_t streams, int first, const uint32_t bucket[4],
+                                           uint64_t *hist, void *stream)
 {
     ThreadCtx *c;
     LARS_TRY(ensure_ctx(&c));
-    if (!tiles || !hist || !bucket || ntiles <= 0 || npix <= 0)
+    if (!tiles || !hist || !bucket || ntiles <= 0 || npix <= 0 || streams < 1u || streams > 3u)
         return fail(LARS_ERR_INVALID, "lars_d_quotient_select_hist: bad arguments");
     if (dtype != LARS_U8 || channels != 3 || (reinterpret_cast<uintptr_t>(tiles) & 3) || (ntiles > 1 && (npix & 3)))
         return fail(LARS_ERR_INVALID, "lars_d_quotient_select_hist: uint8 [ntiles][npix][3] tiles on 4-byte boundaries are required");
@@ -344,24 +360,24 @@ extern "C" int lars_d_quotient_select_hist(const void *tiles, int64_t ntiles, in
     if (ntiles > 65535 || (long long)npix * 6 >= (1ll << 30))
         return fail(LARS_ERR_INVALID, "lars_d_quotient_select_hist: at most 65535 tiles of < 2^30 / 6 pixels per launch");
     return selq_pass_launch(static_cast<const uint8_t *>(tiles), wb_table, ntiles, npix, first ? 1 : 0, bucket,
-                            reinterpret_cast<unsigned long long *>(hist), pick_stream(c, stream));
+                            reinterpret_cast<unsigned long long *>(hist), pick_stream(c, stream), streams);
 }
 
 extern "C" size_t lars_quotient_median_scratch_bytes(int64_t ntiles) { return selq_tile_scratch_bytes(ntiles > 0 ? ntiles : 1); }
 
 extern "C" int lars_d_quotient_median_pairs(const void *tiles, int64_t ntiles, int64_t npix, int channels, int dtype,
-                                            const uint8_t *wb_table, float *out_pairs, void *scratch, void *stream)
+                                            const uint8_t *wb_table, uint32_t streams, float *out_pairs, void *scratch, void *stream)
 {
     ThreadCtx *c;
     LARS_TRY(ensure_ctx(&c));
-    if (!tiles || !out_pairs || !scratch || ntiles <= 0 || npix <= 0)
+    if (!tiles || !out_pairs || !scratch || ntiles <= 0 || npix <= 0 || streams < 1u || streams > 3u)
         return fail(LARS_ERR_INVALID, "lars_d_quotient_median_pairs: bad arguments");
     if (dtype != LARS_U8 || channels != 3 || (reinterpret_cast<uintptr_t>(tiles) & 3) || (ntiles > 1 && (npix & 3)))
         return fail(LARS_ERR_INVALID, "lars_d_quotient_median_pairs: uint8 [ntiles][npix][3] tiles on 4-byte boundaries are required");
     if (ntiles > 65535 || (long long)npix * 6 >= (1ll << 30))
         return fail(LARS_ERR_INVALID, "lars_d_quotient_median_pairs: at most 65535 tiles of < 2^30 / 6 pixels");
     return selq_tile_medians_launch(static_cast<const uint8_t *>(tiles), wb_table, ntiles, npix, out_pairs, scratch,
-                                    pick_stream(c, stream), false);
+                                    pick_stream(c, stream), false, streams);
 }
 
 // Statistics AND the exact median of every tile in two passes over the tiles (three with the white-balance histogram
@@ -389,7 +405,8 @@ extern "C" int lars_d_stats_medians(const lars_fused_args *a, float *out_pairs, 
     memset(&P, 0, sizeof P);
     P.tiles = a->tiles; P.npix = a->npix; P.channels = 3; P.wb_table = a->wb_table; P.stats = a->stats; P.mask = mask;
     P.flags = a->flags & 7u;
-    LARS_TRY(selq_tile_prepare(scratch, a->ntiles, a->npix, s, ((mask & 1u) ? 1u : 0u) | ((mask & 6u) ? 2u : 0u)));
+    const unsigned streams = ((mask & 1u) ? 1u : 0u) | ((mask & 6u) ? 2u : 0u);
+    LARS_TRY(selq_tile_prepare(scratch, a->ntiles, a->npix, s, streams));
     P.sel_hist = selq_tile_hist32(scratch, a->ntiles);
     const long long nrec = a->ntiles * 3;
     stats_init_launch(a->stats, nrec, mask, s);
@@ -397,5 +414,5 @@ extern "C" int lars_d_stats_medians(const lars_fused_args *a, float *out_pairs, 
     fused_v2_sel_launch(mask, a->wb_table != nullptr, stats_mode, grid, s, P);
     stats_finalize_launch(a->stats, nrec, mask, (long long)a->npix, s);
     LARS_TRY(launch_check("lars_d_stats_medians"));
-    return selq_tile_medians_launch(tiles, a->wb_table, a->ntiles, a->npix, out_pairs, scratch, s, true);
+    return selq_tile_medians_launch(tiles, a->wb_table, a->ntiles, a->npix, out_pairs, scratch, s, true, streams);
 }

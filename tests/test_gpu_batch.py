@@ -494,10 +494,11 @@ def test_bad_arguments_fail_cleanly(lars):
     big_bucket = (C.c_uint32 * 4)(2048, 0, 0, 0)
     hist64 = _ffi.DeviceBuffer(2 * 2 * 2048 * 8)
     tp = C.c_void_p(b.tiles.ptr)
-    assert lib.lars_d_quotient_select_hist(tp, 2, 256, 3, _ffi.U8, None, 0, big_bucket, C.c_void_p(hist64.ptr), None) == -1
-    assert lib.lars_d_quotient_select_hist(tp, 2, 256, 4, _ffi.U8, None, 1, u4, C.c_void_p(hist64.ptr), None) == -1
-    assert lib.lars_d_quotient_select_hist(tp, 2, 256, 3, _ffi.U16, None, 1, u4, C.c_void_p(hist64.ptr), None) == -1
-    assert lib.lars_d_quotient_median_pairs(tp, 2, 256, 3, _ffi.U8, None, None, None, None) == -1
+    assert lib.lars_d_quotient_select_hist(tp, 2, 256, 3, _ffi.U8, None, 3, 0, big_bucket, C.c_void_p(hist64.ptr), None) == -1
+    assert lib.lars_d_quotient_select_hist(tp, 2, 256, 4, _ffi.U8, None, 3, 1, u4, C.c_void_p(hist64.ptr), None) == -1
+    assert lib.lars_d_quotient_select_hist(tp, 2, 256, 3, _ffi.U16, None, 3, 1, u4, C.c_void_p(hist64.ptr), None) == -1
+    assert lib.lars_d_quotient_select_hist(tp, 2, 256, 3, _ffi.U8, None, 0, 1, u4, C.c_void_p(hist64.ptr), None) == -1
+    assert lib.lars_d_quotient_median_pairs(tp, 2, 256, 3, _ffi.U8, None, 3, None, None, None) == -1
     sm = b.fused_args(("NDVI", "GNDVI"), True, stats, False, None)                      # two indices: not served
     assert lib.lars_d_stats_medians(C.byref(sm), C.c_void_p(hist64.ptr), C.c_void_p(hist64.ptr)) == -1
     sm = b.fused_args(("NDVI",), True, None, False, None)                               # no statistics records

@@ -124,7 +124,8 @@ def main():
         # time-series table of the whole batch (statistics + median per tile): without planes, and with the planes written as well
         import time
         outs = b.make_outputs(index=True, ring=min(args.ring, 16))
-        for name, kw in (("medians recompute+select (no planes)", {}), ("medians + planes written (ring)", {"outputs": outs})):
+        for name, kw in (("medians recompute+select (no planes)", {}), ("medians NDVI only (no planes)", {"indices": ("NDVI",)}),
+                         ("medians + planes written (ring)", {"outputs": outs})):
             ts = []
             for _ in range(3):
                 _ffi.call("lars_synchronize", None)

@@ -273,9 +273,16 @@ def main():
     if world > 1 or os.environ.get("LARS_FORCE_RCCL"):
         # LARS_COMM=torch: the statistics exchange through torch.distributed (nccl backend = RCCL) instead of the
         # library's own RCCL communicator; also the fallback when the direct bootstrap reports an error
-        want_torch = os.environ.get("LARS_COMM", "rccl") == "torch"
+        # LARS_COMM=gloo (rehearsals of the N > 1 flow on fewer GPUs than ranks): statistics over torch.distributed's gloo
+        # backend on the host, every rank on GPU LARS_DEVICE (default LOCAL_RANK)
+        flavour = os.environ.get("LARS_COMM", "rccl")
+        want_torch = flavour == "torch"
         comm = None
-        if not want_torch:
+        if flavour == "gloo":
+            _ffi.call("lars_set_device", int(os.environ.get("LARS_DEVICE", local_rank)))
+            comm = dist.TorchComm.from_env("gloo")
+            collective = "torch.distributed all_gather (gloo, host) + rank-order fold -- rehearsal transport"
+        elif not want_torch:
             try:
                 comm = dist.Comm.from_env()
                 collective = "RCCL ncclAllGather of packed records + rank-order fold (csrc/comm.cpp)"

@@ -74,7 +74,6 @@ def _one(tags, tag, default=None):
 def _lzw_all(buf, offsets, counts, chunk_bytes):
     """Every LZW strip / tile through the library's host-side decoder (csrc/tiff_codec.cpp; threads, no GPU involved):
     (uint8[nchunks][chunk_bytes], bytes produced per chunk)."""
-    import ctypes as C
     import os
     from . import _ffi
     n = len(offsets)

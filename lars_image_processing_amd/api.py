@@ -40,6 +40,7 @@ import numpy as np
 
 from . import _ffi
 from ._ffi import INDEX_IDS, INDEX_NAMES, Stats
+from .hostpool import empty as _empty        # large result arrays reuse released buffers (no first-touch page faults)
 
 __all__ = [
     "fix_white_balance", "correct_white_balance", "fix_white_balance_rgnir",
@@ -127,7 +128,7 @@ def _wb_array(arr, variant=0, want_percentiles=False):
         raise TypeError(f"fix_white_balance: unsupported sample type {arr.dtype}; the HIP path takes uint8 or uint16 "
                         "images (what PIL decodes RGNir files to)")
     h, w, c = arr.shape
-    out = np.empty((h, w, c), dtype=np.uint8)
+    out = _empty((h, w, c), dtype=np.uint8)
     pcts = np.empty((3, 2), dtype=np.float64) if want_percentiles else None
     _ffi.call("lars_h_fix_white_balance", _ffi.ptr(arr), h, w, c, code, variant, _ffi.ptr(out), _ffi.ptr(pcts))
     return (out, pcts) if want_percentiles else out
@@ -170,7 +171,7 @@ def _index_from_planes(red, green, nir, index_type):
     shape = np.shape(nir)
     planes = [np.ascontiguousarray(p, dtype=np.float32) for p in (red, green, nir)]
     n = planes[2].size
-    out = np.empty(shape, dtype=np.float32)
+    out = _empty(shape, dtype=np.float32)
     _ffi.call("lars_h_calculate_index_planes", _ffi.ptr(planes[0]), _ffi.ptr(planes[1]), _ffi.ptr(planes[2]),
               n, INDEX_IDS[index_type], _ffi.ptr(out))
     return out
@@ -203,7 +204,7 @@ def calculate_index(*args):
         return _index_from_planes(f[:, :, 0], f[:, :, 1], f[:, :, 2], index_type)
     h, w, c = arr.shape
     k = INDEX_IDS[index_type]
-    out = np.empty((h, w), dtype=np.float32)
+    out = _empty((h, w), dtype=np.float32)
     outs = [None, None, None]
     outs[k] = out
     p3 = _ffi.ptr3(outs)
@@ -223,7 +224,7 @@ def calculate_ndvi(image_path, save_path=None, visualize=True):
     if code is None:
         raise TypeError(f"calculate_ndvi: unsupported sample type {arr.dtype}")
     h, w, c = arr.shape
-    ndvi = np.empty((h, w), dtype=np.float64)
+    ndvi = _empty((h, w), dtype=np.float64)
     _ffi.call("lars_h_ndvi_f64", _ffi.ptr(arr), h, w, c, code, _ffi.ptr(ndvi))
     if visualize or save_path:
         import matplotlib.pyplot as plt
@@ -331,7 +332,7 @@ def classification_mask(index_array, index_type):
         return None
     arr = np.ascontiguousarray(index_array, dtype=np.float32)
     _, threshold = _coverage_rule(index_type)
-    out = np.empty(arr.shape, dtype=np.uint8)
+    out = _empty(arr.shape, dtype=np.uint8)
     _ffi.call("lars_h_threshold_mask_f32", _ffi.ptr(arr.reshape(-1)), arr.size, float(threshold), _ffi.ptr(out))
     return out
 
@@ -349,7 +350,7 @@ def colorize_index(index_array, index_type):
     """Per-pixel RGBA8 of ``imshow(index, cmap, vmin=-1, vmax=1)`` (process-images.py:690-695)."""
     arr = np.ascontiguousarray(index_array, dtype=np.float32)
     lut = colormap_lut(_colormap_for(index_type))
-    out = np.empty(arr.shape + (4,), dtype=np.uint8)
+    out = _empty(arr.shape + (4,), dtype=np.uint8)
     _ffi.call("lars_h_colormap_f32", _ffi.ptr(arr.reshape(-1)), arr.size, _ffi.ptr(lut), _ffi.ptr(out))
     return out
 
@@ -374,14 +375,14 @@ def process_image(img_array, indices=INDEX_NAMES, white_balance=True, want_array
     mask = 0
     for t in indices:
         mask |= 1 << INDEX_IDS[t]
-    out_wb = np.empty((h, w, c), dtype=np.uint8) if white_balance else None
+    out_wb = _empty((h, w, c), dtype=np.uint8) if white_balance else None
     outs, rgbas, luts = [None] * 3, [None] * 3, [None] * 3
     for t in indices:
         k = INDEX_IDS[t]
         if want_arrays:
-            outs[k] = np.empty((h, w), dtype=np.float32)
+            outs[k] = _empty((h, w), dtype=np.float32)
         if want_rgba:
-            rgbas[k] = np.empty((h, w, 4), dtype=np.uint8)
+            rgbas[k] = _empty((h, w, 4), dtype=np.uint8)
             luts[k] = colormap_lut(_colormap_for(t))
     stats = (Stats * 3)()
     med = np.zeros((3, 2), dtype=np.float32)
@@ -445,7 +446,7 @@ def align_images(fixed_img, moving_img):
     fixed_c, moving_c = np.ascontiguousarray(fixed_img), np.ascontiguousarray(moving_img)
     h, w = moving_c.shape[:2]
     channels = 1 if moving_c.ndim == 2 else 3
-    aligned = np.empty_like(moving_c)
+    aligned = _empty(moving_c.shape, moving_c.dtype)
     shift = np.zeros(2, dtype=np.float64)
     _ffi.call("lars_h_align_images", _ffi.ptr(fixed_c), _ffi.ptr(moving_c), h, w, channels, _ffi.ptr(aligned), _ffi.ptr(shift))
     if moving_c.ndim == 3:
@@ -456,7 +457,7 @@ def align_images(fixed_img, moving_img):
 def colorize_difference(diff, vmin=-0.5, vmax=0.5, cmap="bwr"):
     """Per-pixel RGBA8 of ``imshow(diff, cmap='bwr', vmin=-0.5, vmax=0.5)`` (process-images.py:956)."""
     arr = np.ascontiguousarray(diff, dtype=np.float32)
-    out = np.empty(arr.shape + (4,), dtype=np.uint8)
+    out = _empty(arr.shape + (4,), dtype=np.uint8)
     _ffi.call("lars_h_colormap_norm_f32", _ffi.ptr(arr.reshape(-1)), arr.size, float(vmin), float(vmax),
               _ffi.ptr(colormap_lut(cmap)), _ffi.ptr(out))
     return out
@@ -491,9 +492,9 @@ def change_detection(early, late, index_type, early_corrected=None, late_correct
         return {"early_index": e_idx, "late_index": l_idx, "diff": diff, "aligned_late": aligned, "shift": shift,
                 "diff_rgba": colorize_difference(diff) if want_rgba else None}
     h, w, c = e_arr.shape
-    e_idx, l_idx, diff = (np.empty((h, w), dtype=np.float32) for _ in range(3))
-    aligned = np.empty((h, w, c), dtype=np.uint8)
-    rgba = np.empty((h, w, 4), dtype=np.uint8) if want_rgba else None
+    e_idx, l_idx, diff = (_empty((h, w), dtype=np.float32) for _ in range(3))
+    aligned = _empty((h, w, c), dtype=np.uint8)
+    rgba = _empty((h, w, 4), dtype=np.uint8) if want_rgba else None
     shift = np.zeros(2, dtype=np.float64)
     _ffi.call("lars_h_change_detection", _ffi.ptr(e_arr), _ffi.ptr(l_arr), h, w, c, int(wb_e), int(wb_l), int(bool(align)),
               INDEX_IDS[index_type], _ffi.ptr(e_idx), _ffi.ptr(l_idx), _ffi.ptr(diff), _ffi.ptr(rgba),

@@ -265,7 +265,8 @@ class DeviceBuffer:
         call("lars_memcpy_h2d", C.c_void_p(self.ptr + offset), ptr(arr), arr.nbytes)
 
     def download(self, dtype, shape, offset=0):
-        out = np.empty(shape, dtype=dtype)
+        from .hostpool import empty
+        out = empty(shape, dtype)
         assert offset + out.nbytes <= self.nbytes
         call("lars_memcpy_d2h", ptr(out), C.c_void_p(self.ptr + offset), out.nbytes)
         return out

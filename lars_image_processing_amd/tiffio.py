@@ -173,7 +173,8 @@ def read_tiff(path_or_bytes, max_bytes=MAX_DECODED_BYTES):
     if len(offsets) != across * down * planes or len(counts) != len(offsets):
         raise TiffError(f"{len(offsets)} strips / tiles, {across * down * planes} expected")
 
-    out = np.empty((planes, height, width, inner), dtype=dtype.newbyteorder("="))
+    from .hostpool import empty
+    out = empty((planes, height, width, inner), dtype.newbyteorder("="))
     full = chunk_h * chunk_w * inner * dtype.itemsize        # bytes of a whole strip / tile
     decoded = _lzw_all(buf, offsets, counts, full) if compression == 5 else None
     k = 0

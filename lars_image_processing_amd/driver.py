@@ -41,10 +41,14 @@ def _figure_png(index_array, index_type, path):
     plt.close()
 
 
-def process_image(image_path, output_dir, process_wb=False, indices=None, render="figure", full_depth=False):
+def process_image(image_path, output_dir, process_wb=False, indices=None, render="figure", full_depth=False, lut_format="png"):
     """One file: same outputs as backend-process.py:49-73.  Returns the statistics dicts.
     ``full_depth=True`` reads three-sample 16-bit TIFFs at their full depth (``tiffio.read_image``; Pillow, hence the
-    reference, keeps their high bytes only)."""
+    reference, keeps their high bytes only).  ``lut_format="tiff"`` (with ``render="lut"``) writes the colormap images as
+    uncompressed RGBA TIFFs ``<name>_<index>.tif`` instead of PNGs: PNG compression of a 4096 x 4096 map takes seconds,
+    the GPU work milliseconds."""
+    if lut_format not in ("png", "tiff"):
+        raise ValueError(f"lut_format must be 'png' or 'tiff', got {lut_format!r}")
     from PIL import Image
     from .tiffio import read_image
     image_path, output_dir = Path(image_path), Path(output_dir)
@@ -65,7 +69,10 @@ def process_image(image_path, output_dir, process_wb=False, indices=None, render
         (output_dir / t).mkdir(parents=True, exist_ok=True)
         out = output_dir / t / f"{name}_{t.lower()}.png"
         entry = res["indices"][t]
-        if render == "lut":
+        if render == "lut" and lut_format == "tiff":
+            from .tiffio import write_tiff
+            write_tiff(out.with_suffix(".tif"), entry["rgba"])
+        elif render == "lut":
             Image.fromarray(entry["rgba"], "RGBA").save(out, compress_level=LUT_PNG_LEVEL)
         else:
             _figure_png(entry["index"], t, out)
@@ -74,7 +81,7 @@ def process_image(image_path, output_dir, process_wb=False, indices=None, render
 
 
 def batch_process(input_dir, output_dir, process_wb=False, process_ndvi=False, process_gndvi=False,
-                  process_ndwi=True, render="figure", workers=4, verbose=True, full_depth=False):
+                  process_ndwi=True, render="figure", workers=4, verbose=True, full_depth=False, lut_format="png"):
     """backend-process.py:75-97 with its module constants as arguments.  Returns ``{file name: stats | error}``."""
     input_path, output_path = Path(input_dir), Path(output_dir)
     indices = [t for t, on in (("NDVI", process_ndvi), ("GNDVI", process_gndvi), ("NDWI", process_ndwi)) if on]
@@ -87,7 +94,7 @@ def batch_process(input_dir, output_dir, process_wb=False, process_ndvi=False, p
         try:
             if verbose:
                 print(f"Processing {idx}/{total}: {f.name}")
-            return f.name, process_image(f, output_path, process_wb, indices or None, render, full_depth)
+            return f.name, process_image(f, output_path, process_wb, indices or None, render, full_depth, lut_format)
         except Exception as e:                              # same policy as upstream :96-97
             if verbose:
                 print(f"Error processing {f.name}: {str(e)}")

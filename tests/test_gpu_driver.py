@@ -43,6 +43,13 @@ def test_batch_process_directory(tmp_path):
                     assert abs(res[name][t][key] - val) <= 1e-6 * max(abs(val), float(np.mean(np.abs(want))))
                 else:
                     assert res[name][t][key] == val
+    # uncompressed TIFF colormap images instead of PNGs: same pixels
+    driver.batch_process(src, tmp_path / "tif", process_ndvi=True, process_ndwi=False, render="lut", lut_format="tiff",
+                         workers=2, verbose=False)
+    for name in imgs:
+        stem = name.rsplit(".", 1)[0]
+        np.testing.assert_array_equal(lars.read_tiff(tmp_path / "tif" / "NDVI" / f"{stem}_ndvi.tif"),
+                                      np.array(Image.open(dst / "NDVI" / f"{stem}_ndvi.png")))
     # the reference's own figure style, serial path
     res2 = driver.batch_process(src, tmp_path / "fig", process_wb=False, process_ndwi=True, render="figure", verbose=False)
     assert (tmp_path / "fig" / "NDWI" / "a_ndwi.png").stat().st_size > 1000

@@ -240,8 +240,9 @@ def write_tiff(path, array, rows_per_strip=None, tile=None, byteorder="<", plana
     for t in chunks:
         if predictor:
             t = np.concatenate([t[:, :1], np.diff(t, axis=1)], axis=1)      # unsigned wrap-around = modulo 2^bits
-        raw = np.ascontiguousarray(t, dtype=a.dtype).astype(dt, copy=False).tobytes()
-        blobs.append(zlib.compress(raw, 6) if deflate else raw)
+        raw = np.ascontiguousarray(t, dtype=a.dtype).astype(dt, copy=False)
+        # uncompressed chunks are written straight from the array's memory (no 64 MiB byte-string copies)
+        blobs.append(zlib.compress(raw.tobytes(), 6) if deflate else memoryview(raw.reshape(-1).view(np.uint8)))
 
     entries = []                                             # (tag, type, values)
 

@@ -55,17 +55,19 @@ def test_bench_statistics_fold_transports_agree(transport):
     assert line["global_stats"] == base["global_stats"]
 
 
-def test_two_ranks_on_one_gpu_equal_one_process_over_all_tiles(tmp_path):
-    """The N > 1 flow end to end on real kernels: two ranks (both on GPU 0, statistics exchanged over gloo) with 6 tiles
-    each must report the global statistics and medians of one process over the same 12 tiles (rank r owns tiles
-    6r .. 6r+5 of the same counter-hash sequence; sums are exact, so even the means are identical)."""
+@pytest.mark.parametrize("ranks", [2, 3])
+def test_ranks_on_one_gpu_equal_one_process_over_all_tiles(tmp_path, ranks):
+    """The N > 1 flow end to end on real kernels: `ranks` ranks (all on GPU 0, statistics exchanged over gloo) with
+    12 / ranks tiles each must report the global statistics and medians of one process over the same 12 tiles (rank r
+    owns a contiguous block of the same counter-hash sequence; sums are exact, so even the means are identical)."""
+    per_rank = 12 // ranks
     port = 29000 + os.getpid() % 2000
     env = dict(os.environ, LARS_COMM="gloo", LARS_DEVICE="0")
     for k in ("RANK", "LOCAL_RANK", "WORLD_SIZE"):
         env.pop(k, None)
     common = ["--tile", "512", "--ring", "4", "--steps", "2", "--warmup", "1", "--no-probe", "--placement-trials", "0", "--no-cpu-baseline"]
-    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
-           "--master-port", str(port), os.path.join(ROOT, "bench.py"), "--gpus", "2", "--tiles", "6", *common]
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(ranks), "--master-addr", "127.0.0.1",
+           "--master-port", str(port + ranks), os.path.join(ROOT, "bench.py"), "--gpus", str(ranks), "--tiles", str(per_rank), *common]
     out = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=900, cwd=ROOT)
     assert out.returncode == 0, out.stderr[-3000:]
     lines = [ln for ln in out.stdout.splitlines() if ln.startswith("{")]
@@ -76,8 +78,8 @@ def test_two_ranks_on_one_gpu_equal_one_process_over_all_tiles(tmp_path):
                           capture_output=True, text=True, timeout=600, cwd=ROOT)
     assert out1.returncode == 0, out1.stderr[-2000:]
     one = json.loads([ln for ln in out1.stdout.splitlines() if ln.startswith("{")][0])
-    assert two["n_gpus"] == 2 and two["scaling"] == "weak" and "gloo" in two["config"]["collective"]
-    assert two["config"]["tiles_per_gpu"] == 6 and one["config"]["tiles_per_gpu"] == 12
+    assert two["n_gpus"] == ranks and two["scaling"] == "weak" and "gloo" in two["config"]["collective"]
+    assert two["config"]["tiles_per_gpu"] == per_rank and one["config"]["tiles_per_gpu"] == 12
     assert two["global_stats"] == one["global_stats"]
     for name in ("NDVI", "GNDVI", "NDWI"):
         assert two["global_stats"][name]["count"] == 12 * 512 * 512

@@ -7,6 +7,7 @@ NumPy oracle timed on this box's host cores as a baseline.
     python bench.py --gpus 1 --steps 5 --warmup 2
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 \
         --master-port P bench.py --gpus N --steps K --warmup W
+    python bench.py --gpus N ...          # no launcher: this process starts the N ranks itself (launch_ranks)
 
 One process per GPU (RANK / LOCAL_RANK / WORLD_SIZE from the environment).
 Tiles shard by tile with no data-path collective; each step ends with the
@@ -25,8 +26,10 @@ from __future__ import annotations
 
 import argparse
 import ctypes as C
+import hashlib
 import json
 import os
+import subprocess
 import sys
 import time
 
@@ -219,15 +222,36 @@ def device_probe(runner):
     return out
 
 
+KERNEL_SOURCES = ("fused.hip", "fused_v2.hip", "select_q.hip", "device_common.h", "v2_device.h", "common.h")
+
+
+def kernel_sources_sha():
+    """Identity of the kernel sources the PMC traffic figures belong to (tools/collect_profiles.py stores it next to them)."""
+    h = hashlib.sha256()
+    for name in KERNEL_SOURCES:
+        with open(os.path.join(ROOT, "lars_image_processing_amd", "csrc", name), "rb") as fh:
+            h.update(name.encode() + b"\0" + fh.read())
+    return h.hexdigest()[:16]
+
+
 def traffic_from_profiles(mode, pixels_per_launch):
-    """Per-launch HBM bytes of the fused kernel from the committed PMC summary (profiles/traffic.json:
-    rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, separate passes, corrected as MI355X_MICROARCH.md says)."""
+    """(bytes per launch | None, provenance string).  HBM bytes of the fused kernel from the committed PMC summary
+    (profiles/traffic.json: rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, separate passes, corrected as
+    MI355X_MICROARCH.md says).  The figure is only reported while the kernel sources still are the ones it was
+    measured on; otherwise traffic is null and the provenance says why."""
     path = os.path.join(ROOT, "profiles", "traffic.json")
     try:
         with open(path) as fh:
-            return json.load(fh)[mode]["bytes_per_pixel"] * pixels_per_launch
-    except Exception:
-        return None
+            doc = json.load(fh)
+    except (OSError, ValueError) as exc:
+        return None, f"null: cannot read profiles/traffic.json ({exc.__class__.__name__})"
+    measured_on, now = doc.get("_kernel_sources_sha"), kernel_sources_sha()
+    if measured_on != now:
+        return None, (f"null: profiles/traffic.json was measured on kernel sources {measured_on}, this build is {now} "
+                      "(re-run tools/profile_round.sh + tools/collect_profiles.py)")
+    if mode not in doc:
+        return None, f"null: profiles/traffic.json@{now} has no row for mode {mode}"
+    return doc[mode]["bytes_per_pixel"] * pixels_per_launch, f"profiles/traffic.json@{now} ({doc.get('_round', '?')}, rocprofv3 --pmc)"
 
 
 def config4_leg(tiles=16, edge=8192):
@@ -262,38 +286,131 @@ def config4_leg(tiles=16, edge=8192):
             "fused_frac_of_8TBs": npix * 14 / (f_ms * 1e-3) / 1e9 / HBM_PEAK_GBS}
 
 
+def _visible_devices():
+    """Device count seen by a CHILD process: the launching parent must never initialise HIP itself (its children
+    are new processes, and a process that has touched the GPU may not be replaced or forked into ranks)."""
+    code = "from lars_image_processing_amd import _ffi; print(_ffi.device_count())"
+    out = subprocess.run([sys.executable, "-c", code], cwd=ROOT, capture_output=True, text=True, timeout=300)
+    try:
+        return int(out.stdout.strip().splitlines()[-1])
+    except (ValueError, IndexError):
+        raise SystemExit(f"bench.py: cannot count GPUs: {out.stderr[-500:]}")
+
+
+def run_rank_processes(n, command, base_env):
+    """Start ``n`` copies of ``command`` as ranks 0..n-1 (RANK / LOCAL_RANK added to ``base_env``), wait for all of
+    them and return rank 0's stdout.  If any rank exits non-zero the others are ended (exactly the pids started here)
+    and SystemExit is raised: a half-dead group would otherwise sit in its rendezvous until a timeout."""
+    procs = []
+    for r in range(n):
+        env = dict(base_env, RANK=str(r), LOCAL_RANK=str(r))
+        procs.append(subprocess.Popen(command, env=env, cwd=ROOT, stdout=subprocess.PIPE if r == 0 else sys.stderr, text=True))
+    failed, pending = None, set(range(n))
+    while pending and failed is None:
+        for r in sorted(pending):
+            rc = procs[r].poll()
+            if rc is None:
+                continue
+            pending.discard(r)
+            if rc != 0:
+                failed = (r, rc)
+                break
+        else:
+            time.sleep(0.05)
+    if failed is not None:
+        for r in pending:
+            procs[r].terminate()
+        for r in pending:
+            try:
+                procs[r].wait(timeout=15)
+            except subprocess.TimeoutExpired:
+                procs[r].kill()
+                procs[r].wait()
+        procs[0].stdout.close()
+        raise SystemExit(f"bench.py --gpus {n}: rank {failed[0]} exited with status {failed[1]}")
+    out = procs[0].stdout.read()
+    procs[0].stdout.close()
+    return out
+
+
+def launch_ranks(args):
+    """``python bench.py --gpus N`` with no launcher environment: start N rank processes (RANK / LOCAL_RANK /
+    WORLD_SIZE / MASTER_* and one shared rendezvous token), relay rank 0's JSON line, fail if any rank fails.
+    Runs before anything of this process has loaded liblars_hip.so or touched HIP."""
+    import secrets
+    import shutil
+    import socket
+    import tempfile
+    n = args.gpus
+    rehearsal = os.environ.get("LARS_COMM") == "gloo"            # every rank on GPU LARS_DEVICE, statistics over gloo
+    have = _visible_devices()
+    if have < 1 or (have < n and not rehearsal):
+        raise SystemExit(f"bench.py --gpus {n}: only {have} GPU(s) visible on this node (one rank per GPU; "
+                         "LARS_COMM=gloo LARS_DEVICE=0 rehearses N ranks on one GPU)")
+    with socket.socket() as sock:
+        sock.bind(("127.0.0.1", 0))
+        port = sock.getsockname()[1]
+    rdzv_dir = tempfile.mkdtemp(prefix="lars_rdzv_")
+    base = dict(os.environ, WORLD_SIZE=str(n), MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port),
+                LARS_RDZV_TOKEN=secrets.token_hex(16), LARS_RDZV_DIR=rdzv_dir, LARS_BENCH_LAUNCHER="self")
+    base.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    try:
+        out = run_rank_processes(n, [sys.executable, os.path.abspath(__file__), *sys.argv[1:]], base)
+    finally:
+        shutil.rmtree(rdzv_dir, ignore_errors=True)
+    lines = [ln for ln in out.splitlines() if ln.startswith("{")]
+    if len(lines) != 1:
+        raise SystemExit(f"bench.py --gpus {n}: expected one JSON line from rank 0, got {len(lines)}")
+    line = json.loads(lines[0])
+    if line.get("n_gpus") != n or line.get("config", {}).get("ranks_seen") != n:
+        raise SystemExit(f"bench.py --gpus {n}: the ranks report n_gpus={line.get('n_gpus')}, "
+                         f"ranks_seen={line.get('config', {}).get('ranks_seen')}")
+    print(lines[0])
+    return 0
+
+
 def main():
     args = parse()
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        raise SystemExit(launch_ranks(args))
     from lars_image_processing_amd import _ffi
     from lars_image_processing_amd import dist
     rank, local_rank, world = dist.env_rank_world()
-    if world != max(1, args.gpus) and world > 1:
-        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}")
+    if world != max(1, args.gpus):
+        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}: one rank per GPU, start it as "
+                         f"`python bench.py --gpus N` or under torch.distributed.run with --nproc-per-node N")
     collective = "none (single process)"
     if world > 1 or os.environ.get("LARS_FORCE_RCCL"):
-        # LARS_COMM=torch: the statistics exchange through torch.distributed (nccl backend = RCCL) instead of the
-        # library's own RCCL communicator; also the fallback when the direct bootstrap reports an error
-        # LARS_COMM=gloo (rehearsals of the N > 1 flow on fewer GPUs than ranks): statistics over torch.distributed's gloo
-        # backend on the host, every rank on GPU LARS_DEVICE (default LOCAL_RANK)
+        # The transport is chosen from the environment alone, so every rank makes the same choice; a bootstrap error
+        # ends this rank with a non-zero status and the launcher tears the group down (no per-rank fallback).
+        #   LARS_COMM=rccl (default): the library's own RCCL communicator (csrc/comm.cpp)
+        #   LARS_COMM=torch: the statistics exchange through torch.distributed (nccl backend = RCCL)
+        #   LARS_COMM=gloo: rehearsal of the N > 1 flow on fewer GPUs than ranks -- statistics over torch.distributed's
+        #                   gloo backend on the host, every rank on GPU LARS_DEVICE (default LOCAL_RANK)
         flavour = os.environ.get("LARS_COMM", "rccl")
-        want_torch = flavour == "torch"
-        comm = None
-        if flavour == "gloo":
-            _ffi.call("lars_set_device", int(os.environ.get("LARS_DEVICE", local_rank)))
-            comm = dist.TorchComm.from_env("gloo")
-            collective = "torch.distributed all_gather (gloo, host) + rank-order fold -- rehearsal transport"
-        elif not want_torch:
-            try:
+        try:
+            if flavour == "gloo":
+                _ffi.call("lars_set_device", int(os.environ.get("LARS_DEVICE", local_rank)))
+                comm = dist.TorchComm.from_env("gloo")
+                collective = "torch.distributed all_gather (gloo, host) + rank-order fold -- rehearsal transport"
+            elif flavour == "torch":
+                comm = dist.TorchComm.from_env("nccl")
+                collective = "torch.distributed all_gather (nccl backend = RCCL) + rank-order fold"
+            elif flavour == "rccl":
                 comm = dist.Comm.from_env()
                 collective = "RCCL ncclAllGather of packed records + rank-order fold (csrc/comm.cpp)"
-            except (_ffi.LarsError, TimeoutError, OSError) as exc:
-                print(f"[bench rank {rank}] direct RCCL bootstrap failed ({exc}); using torch.distributed", file=sys.stderr)
-        if comm is None:
-            comm = dist.TorchComm.from_env("nccl")
-            collective = "torch.distributed all_gather (nccl backend = RCCL) + rank-order fold"
+            else:
+                raise SystemExit(f"LARS_COMM={flavour}: expected rccl, torch or gloo")
+        except (_ffi.LarsError, TimeoutError, OSError, RuntimeError) as exc:
+            print(f"[bench rank {rank}] {flavour} bootstrap failed: {exc}", file=sys.stderr)
+            raise SystemExit(3)
     else:
         _ffi.call("lars_set_device", 0)
         comm = dist.SingleProcessComm()
+    ranks_seen = comm.ranks_seen()
+    if ranks_seen != world:
+        print(f"[bench rank {rank}] the communicator reports {ranks_seen} ranks, WORLD_SIZE={world}", file=sys.stderr)
+        raise SystemExit(4)
 
     runner = Runner(args, comm, rank, world)
     npix_rank = args.tiles * args.tile * args.tile
@@ -307,7 +424,8 @@ def main():
     launches = timed[0][2]
     bytes_per_launch = npix_rank * bpp / launches
     achieved = bytes_per_launch / (fused_ms / launches * 1e-3) / 1e9
-    traffic = traffic_from_profiles(args.mode, npix_rank / launches)
+    traffic, traffic_source = traffic_from_profiles(args.mode, npix_rank / launches)
+    step_ms = dt / args.steps * 1e3
 
     extra = {}
     if args.all_modes:
@@ -316,8 +434,11 @@ def main():
                 continue
             d, tm, _ = runner.run(m, max(2, args.steps // 2), 1)
             f_ms = float(np.mean([t[1] for t in tm]))
+            m_step_ms = d / max(2, args.steps // 2) * 1e3
             extra[m] = {
                 "Mpix_s": npix_rank * world * max(2, args.steps // 2) / d / 1e6,
+                "ms_per_step": m_step_ms,
+                "whole_step_frac": npix_rank * MODES[m][3] / (m_step_ms * 1e-3) / 1e9 / HBM_PEAK_GBS,
                 "fused_ms": f_ms, "hist_pass_ms": float(np.mean([t[0] for t in tm])),
                 "fused_GBs_algorithmic": npix_rank * MODES[m][3] / (f_ms * 1e-3) / 1e9,
                 "fused_frac_of_8TBs": npix_rank * MODES[m][3] / (f_ms * 1e-3) / 1e9 / HBM_PEAK_GBS,
@@ -341,7 +462,7 @@ def main():
         line = {
             "metric": "Mpixels/sec NDVI+stats on 4096x4096 RGNir tiles; achieved HBM GB/s",
             "value": value, "unit": "Mpix/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
-            "ms_per_step": dt / args.steps * 1e3, "higher_is_better": True, "scaling": "weak",
+            "ms_per_step": step_ms, "higher_is_better": True, "scaling": "weak",
             "vs_baseline": None, "dtype": "f32", "data": "synthetic",
             "config": {
                 "workload": f"{args.tiles}-tile batch per GPU of {args.tile}x{args.tile} uint8 RGNir ({args.profile} "
@@ -352,12 +473,16 @@ def main():
                 "tiles_per_gpu": args.tiles, "tile": [args.tile, args.tile, 3], "input_dtype": "u8", "mode": args.mode,
                 "output_ring_tiles": args.ring if write else 0,
                 "output_ring_placement_trials": args.placement_trials if write else 0, "parallelism": f"tile-sharded x{world}",
-                "collective": collective,
+                "collective": collective, "ranks_seen": ranks_seen,
+                "launcher": os.environ.get("LARS_BENCH_LAUNCHER", "external" if world > 1 else "none"),
                 "device": _ffi.device_name(),
             },
             "roofline": {
                 "bound": "hbm", "kernel": "k_fused_u8c3 (outputs) / k_fused_v2 (statistics only)", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
+                "frac": achieved / HBM_PEAK_GBS, "traffic": traffic, "traffic_source": traffic_source,
+                # the whole step against the same peak: algorithmic bytes of the step (each input byte once, each output
+                # byte once -- the percentile pre-pass's second read of the input is not algorithmic) / ms_per_step
+                "whole_step_frac": npix_rank * bpp / (step_ms * 1e-3) / 1e9 / HBM_PEAK_GBS,
                 "algorithmic_bytes_per_pixel": bpp, "bytes_per_launch": bytes_per_launch,
                 "launches_per_step": launches, "avg_launch_ms": fused_ms / launches,
             },

@@ -364,6 +364,8 @@ int lars_h_tiff_lzw_decode_chunks(const uint8_t *file, int64_t file_len, const u
 #define LARS_COMM_ID_BYTES 128
 int lars_comm_unique_id(uint8_t *id_out);
 int lars_comm_init(void **comm, int nranks, int rank, const uint8_t *unique_id);
+/* number of ranks RCCL reports for the communicator (ncclCommCount): bench.py prints it as config.ranks_seen */
+int lars_comm_count(void *comm, int *nranks_out);
 int lars_comm_destroy(void *comm);
 /* Global statistics: every rank contributes n records (device or host memory,
  * is_device says which); on return every rank holds the fold over all ranks in

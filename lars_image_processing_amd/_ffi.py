@@ -137,6 +137,7 @@ SIGNATURES = {
     "lars_h_resize_lanczos_u8": (_I, [_P, _I64, _I64, _I, _I64, _I64, _P]),
     "lars_comm_unique_id": (_I, [_P]),
     "lars_comm_init": (_I, [C.POINTER(_P), _I, _I, _P]),
+    "lars_comm_count": (_I, [_P, C.POINTER(_I)]),
     "lars_comm_destroy": (_I, [_P]),
     "lars_comm_allreduce_stats": (_I, [_P, _P, _I64, _I, _P]),
     "lars_comm_allreduce_f64": (_I, [_P, _P, _I64, _I]),
@@ -271,5 +272,7 @@ class DeviceBuffer:
         call("lars_memcpy_d2h", ptr(out), C.c_void_p(self.ptr + offset), out.nbytes)
         return out
 
-    def zero(self):
-        call("lars_memset", C.c_void_p(self.ptr), 0, self.nbytes, None)
+    def zero(self, stream=None):
+        """Asynchronous memset on ``stream`` (None = this thread's library stream): pass the stream the consuming
+        kernels are launched on, or the memset is not ordered against them."""
+        call("lars_memset", C.c_void_p(self.ptr), 0, self.nbytes, stream)

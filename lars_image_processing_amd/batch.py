@@ -231,7 +231,7 @@ class TileBatch:
         if white_balance and (recompute_tables or self.table is None):
             self.compute_wb_tables(stream)
         stats = self.new_stats()
-        stats.zero()
+        stats.zero(stream)                                  # same stream as the kernels that accumulate into it
         # uint8 RGNir tiles: medians come from the two-level select on recomputed values (two passes over the 3-byte
         # pixels), whether or not planes are written; other tiles take the radix select over stored planes below
         select = (medians and self.code == _ffi.U8 and self.channels == 3 and self.npix * 6 < (1 << 30)
@@ -266,7 +266,7 @@ class TileBatch:
         med_dev = sel = None
         if medians:
             med_dev = DeviceBuffer(self.ntiles * 3 * 2 * 4)
-            med_dev.zero()
+            med_dev.zero(stream)
             sel = DeviceBuffer(outputs.slots * int(_ffi.load().lars_select_scratch_bytes()))
         chunk = self.ntiles if outputs is None else outputs.slots
         for start in range(0, self.ntiles, chunk):
@@ -336,7 +336,7 @@ class TileBatch:
             raise RuntimeError("compute_wb_tables() first")
         if getattr(self, "_selq", None) is None:
             self._selq = DeviceBuffer(2 * 2 * SELECT_BINS * 8)
-        self._selq.zero()
+        self._selq.zero(stream)
         b = np.ascontiguousarray(buckets, dtype=np.uint32).reshape(4)
         _ffi.call("lars_d_quotient_select_hist", C.c_void_p(self.tiles.ptr), self.ntiles, self.npix, self.channels, self.code,
                   C.c_void_p(self.table.ptr) if white_balance else None, int(streams), int(bool(first)), _ffi.ptr(b),

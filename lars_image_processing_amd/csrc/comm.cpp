@@ -29,6 +29,7 @@ struct Rccl {
     nccl_result (*GetUniqueId)(nccl_uid *) = nullptr;
     nccl_result (*CommInitRank)(nccl_comm *, int, nccl_uid, int) = nullptr;
     nccl_result (*CommDestroy)(nccl_comm) = nullptr;
+    nccl_result (*CommCount)(const nccl_comm, int *) = nullptr;
     nccl_result (*AllGather)(const void *, void *, size_t, int, nccl_comm, hipStream_t) = nullptr;
     nccl_result (*AllReduce)(const void *, void *, size_t, int, int, nccl_comm, hipStream_t) = nullptr;
     const char *(*GetErrorString)(nccl_result) = nullptr;
@@ -53,6 +54,7 @@ int load_rccl()
     SYM(GetUniqueId, "ncclGetUniqueId")
     SYM(CommInitRank, "ncclCommInitRank")
     SYM(CommDestroy, "ncclCommDestroy")
+    SYM(CommCount, "ncclCommCount")
     SYM(AllGather, "ncclAllGather")
     SYM(AllReduce, "ncclAllReduce")
     SYM(GetErrorString, "ncclGetErrorString")
@@ -115,6 +117,16 @@ int lars_comm_init(void **comm, int nranks, int rank, const uint8_t *unique_id)
         return fail(LARS_ERR_RCCL, "ncclCommInitRank(nranks=%d, rank=%d) failed: %s", nranks, rank, g_rccl.GetErrorString(r));
     }
     *comm = cm;
+    return LARS_OK;
+}
+
+int lars_comm_count(void *comm, int *nranks_out)
+{
+    Comm *cm = static_cast<Comm *>(comm);
+    if (!cm || !cm->comm || !nranks_out) return fail(LARS_ERR_INVALID, "lars_comm_count: bad arguments");
+    int n = 0;
+    RCCL_TRY(g_rccl.CommCount(cm->comm, &n));          // what RCCL itself joined, not what the caller asked for
+    *nranks_out = n;
     return LARS_OK;
 }
 

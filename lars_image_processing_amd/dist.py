@@ -22,6 +22,7 @@ from __future__ import annotations
 
 import ctypes as C
 import os
+import stat as _stat
 import tempfile
 import time
 
@@ -37,10 +38,14 @@ def env_rank_world():
             int(os.environ.get("WORLD_SIZE", "1")))
 
 
+_PROCESS_START = time.time()
+_MAGIC = b"LARSRDZV1"
+
+
 def _rendezvous_path():
     run = os.environ.get("TORCHELASTIC_RUN_ID", "none")
     port = os.environ.get("MASTER_PORT", "0")
-    # the launcher's pid keeps back-to-back runs on one port apart
+    # the launcher's pid keeps back-to-back runs on one port apart; bench.py's own launcher passes a random token
     boss = os.environ.get("LARS_RDZV_TOKEN") or str(os.getppid())
     d = os.environ.get("LARS_RDZV_DIR", tempfile.gettempdir())
     return os.path.join(d, f"lars_rccl_id_{run}_{port}_{boss}")
@@ -52,28 +57,56 @@ def _rccl_unique_id():
     return bytes(buf)
 
 
-def exchange_unique_id(rank, world, timeout_s=120.0, make_id=_rccl_unique_id):
-    """Rank 0 creates the RCCL unique id and publishes it atomically; the others poll."""
+def _launch_tag():
+    """What every rank of one launch knows and a file left behind by another launch does not (ranks are siblings)."""
+    boss = os.environ.get("LARS_RDZV_TOKEN") or str(os.getppid())
+    return "|".join([boss, os.environ.get("TORCHELASTIC_RUN_ID", "none"), os.environ.get("MASTER_PORT", "0"),
+                     os.environ.get("WORLD_SIZE", "1")]).encode()
+
+
+def exchange_unique_id(rank, world, timeout_s=120.0, make_id=_rccl_unique_id, max_age_s=900.0):
+    """Rank 0 creates the RCCL unique id and publishes it atomically; the others poll.
+
+    The file is created exclusively with mode 0600 (a file somebody else put at that name is removed first and never
+    written through), carries a magic, the launch tag and rank 0's clock, and a reader only accepts a regular file it
+    owns itself, not writable by others, with the right tag and younger than its own start by at most ``max_age_s``
+    -- so neither a leftover of a crashed launch nor a file planted by another local user is taken for the id."""
     path = _rendezvous_path()
+    tag = _launch_tag()
     if rank == 0:
         data = make_id()
         assert len(data) == _ffi.COMM_ID_BYTES
+        payload = _MAGIC + len(tag).to_bytes(2, "little") + tag + int(time.time() * 1e3).to_bytes(8, "little") + data
         tmp = f"{path}.tmp{os.getpid()}"
-        with open(tmp, "wb") as fh:
-            fh.write(data)
+        for leftover in (path, tmp):
+            try:
+                os.unlink(leftover)
+            except FileNotFoundError:
+                pass
+        fd = os.open(tmp, os.O_WRONLY | os.O_CREAT | os.O_EXCL | getattr(os, "O_NOFOLLOW", 0), 0o600)
+        with os.fdopen(fd, "wb") as fh:
+            fh.write(payload)
         os.replace(tmp, path)
         return data
     deadline = time.time() + timeout_s
+    want_len = len(_MAGIC) + 2 + len(tag) + 8 + _ffi.COMM_ID_BYTES
     while time.time() < deadline:
         try:
-            with open(path, "rb") as fh:
-                data = fh.read()
-            if len(data) == _ffi.COMM_ID_BYTES:
-                return data
-        except FileNotFoundError:
-            pass
+            fd = os.open(path, os.O_RDONLY | getattr(os, "O_NOFOLLOW", 0))
+        except (FileNotFoundError, OSError):
+            time.sleep(0.01)
+            continue
+        with os.fdopen(fd, "rb") as fh:
+            st = os.fstat(fh.fileno())
+            blob = fh.read(want_len + 1)
+        ok = (_stat.S_ISREG(st.st_mode) and st.st_uid == os.getuid() and not (st.st_mode & 0o022) and len(blob) == want_len
+              and blob.startswith(_MAGIC + len(tag).to_bytes(2, "little") + tag))
+        if ok:
+            stamp = int.from_bytes(blob[want_len - _ffi.COMM_ID_BYTES - 8:want_len - _ffi.COMM_ID_BYTES], "little") / 1e3
+            if stamp >= _PROCESS_START - max_age_s:
+                return blob[-_ffi.COMM_ID_BYTES:]
         time.sleep(0.01)
-    raise TimeoutError(f"rank {rank}: no RCCL unique id at {path} after {timeout_s}s")
+    raise TimeoutError(f"rank {rank}: no valid RCCL unique id at {path} after {timeout_s}s")
 
 
 class Comm:
@@ -100,6 +133,12 @@ class Comm:
                 pass
         return comm
 
+    def ranks_seen(self):
+        """The rank count RCCL itself reports for this communicator (ncclCommCount)."""
+        n = C.c_int(0)
+        _ffi.call("lars_comm_count", self._h, C.byref(n))
+        return int(n.value)
+
     def allreduce_stats(self, records):
         """records: structured array [n] of STATS_DTYPE (host).  Returns the fold over all ranks."""
         rec = np.ascontiguousarray(records, dtype=STATS_DTYPE).reshape(-1).copy()
@@ -123,6 +162,9 @@ class Comm:
 class SingleProcessComm:
     """world_size == 1: no RCCL needed."""
     rank, world = 0, 1
+
+    def ranks_seen(self):
+        return 1
 
     def allreduce_stats(self, records):
         return np.ascontiguousarray(records, dtype=STATS_DTYPE).reshape(-1).copy()
@@ -172,6 +214,10 @@ class TorchComm:
         comm._owns_group = True
         comm.barrier()
         return comm
+
+    def ranks_seen(self):
+        """Ranks that really answer: an all_reduce of ones over the group (not just the configured world size)."""
+        return int(round(float(self.allreduce_f64([1.0], "sum")[0])))
 
     def allreduce_stats(self, records):
         torch, td = self._torch, self._td

@@ -33,6 +33,17 @@ def check_line(line, tiles=6, tile=512):
     roof = line["roofline"]
     assert roof["bound"] == "hbm" and roof["unit"] == "GB/s" and roof["peak"] == 8000.0
     assert abs(roof["frac"] - roof["achieved"] / roof["peak"]) < 1e-12
+    # the whole step against the same peak (histogram pre-pass, tables, folds included): algorithmic bytes / ms_per_step
+    bpp = roof["algorithmic_bytes_per_pixel"]
+    whole = tiles * tile * tile * bpp / (line["ms_per_step"] * 1e-3) / 1e9 / roof["peak"]
+    assert abs(roof["whole_step_frac"] - whole) <= 1e-9 * whole and roof["whole_step_frac"] <= roof["frac"]
+    # traffic is a PMC figure with its provenance, or null with the reason -- never a silent None
+    assert isinstance(roof["traffic_source"], str) and roof["traffic_source"]
+    if roof["traffic"] is None:
+        assert roof["traffic_source"].startswith("null: ")
+    else:
+        assert roof["traffic_source"].startswith("profiles/traffic.json@") and roof["traffic"] > 0
+    assert line["config"]["ranks_seen"] == line["n_gpus"]
     for name in ("NDVI", "GNDVI", "NDWI"):
         assert line["global_stats"][name]["count"] == tiles * tile * tile
 
@@ -85,3 +96,39 @@ def test_ranks_on_one_gpu_equal_one_process_over_all_tiles(tmp_path, ranks):
         assert two["global_stats"][name]["count"] == 12 * 512 * 512
         assert two["global_stats"][name]["median"] == one["global_stats"][name]["median"]
     assert abs(two["value"] - 12 * 512 * 512 / (two["ms_per_step"] * 1e-3) / 1e6) <= 1e-6 * two["value"]
+
+
+def _clean_env(**extra):
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_ADDR", "MASTER_PORT")}
+    env.update(extra)
+    return env
+
+
+def test_plain_bench_gpus_2_starts_its_own_ranks():
+    """`python bench.py --gpus 2` with no launcher around it: bench.py starts the two ranks itself (both on GPU 0,
+    statistics over gloo) and rank 0's line says so; global statistics equal one process over the same 12 tiles."""
+    common = ["--tile", "512", "--ring", "4", "--steps", "2", "--warmup", "1", "--no-probe", "--placement-trials", "0",
+              "--no-cpu-baseline", "--no-all-modes"]
+    out = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--tiles", "6", *common],
+                         env=_clean_env(LARS_COMM="gloo", LARS_DEVICE="0"), capture_output=True, text=True, timeout=900, cwd=ROOT)
+    assert out.returncode == 0, out.stderr[-3000:]
+    lines = [ln for ln in out.stdout.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1, out.stdout
+    two = json.loads(lines[0])
+    assert two["n_gpus"] == 2 and two["config"]["ranks_seen"] == 2 and two["config"]["launcher"] == "self"
+    out1 = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--tiles", "12", *common], env=_clean_env(),
+                          capture_output=True, text=True, timeout=600, cwd=ROOT)
+    assert out1.returncode == 0, out1.stderr[-2000:]
+    one = json.loads([ln for ln in out1.stdout.splitlines() if ln.startswith("{")][0])
+    assert one["n_gpus"] == 1 and one["config"]["launcher"] == "none"
+    assert two["global_stats"] == one["global_stats"]
+
+
+def test_more_ranks_than_gpus_fails_loudly():
+    from lars_image_processing_amd import _ffi
+    if _ffi.device_count() >= 8:
+        pytest.skip("this box really has 8 GPUs")
+    out = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "8", "--tiles", "2", "--tile", "256"],
+                         env=_clean_env(), capture_output=True, text=True, timeout=600, cwd=ROOT)
+    assert out.returncode != 0 and "GPU(s) visible" in out.stderr
+    assert not [ln for ln in out.stdout.splitlines() if ln.startswith("{")]

@@ -65,8 +65,9 @@ def parse():
                     help="skip timing the other modes (extra JSON field 'modes')")
     ap.add_argument("--no-probe", dest="probe", action="store_false", help="skip the streaming-roofline probes")
     ap.add_argument("--profile", default="vegetation", choices=["uniform", "vegetation"])
-    ap.add_argument("--placement-trials", type=int, default=6,
-                    help="candidate output rings to allocate; the fastest is kept (0/1: take the first)")
+    ap.add_argument("--placement-trials", type=int, default=8,
+                    help="candidate output arenas (one allocation holding the ring's planes) to allocate and time; the "
+                         "fastest is kept, the rest freed (0/1: take the first)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-tiles", type=int, default=8)
     ap.add_argument("--cpu-workers", type=int, default=16, help="process pool of the multi-core CPU baseline leg")
@@ -472,7 +473,10 @@ def main():
                             "then global fold" + (" over RCCL" if world > 1 else ""),
                 "tiles_per_gpu": args.tiles, "tile": [args.tile, args.tile, 3], "input_dtype": "u8", "mode": args.mode,
                 "output_ring_tiles": args.ring if write else 0,
-                "output_ring_placement_trials": args.placement_trials if write else 0, "parallelism": f"tile-sharded x{world}",
+                "output_ring_placement_trials": args.placement_trials if write else 0,
+                # ms per launch into each candidate arena (the fastest was kept); outside the timed region, like the warm-up
+                "output_arena_trial_ms": (getattr(runner.outputs.get(tuple(indices)), "placement_ms", None) or {}).get("arenas"),
+                "parallelism": f"tile-sharded x{world}",
                 "collective": collective, "ranks_seen": ranks_seen,
                 "launcher": os.environ.get("LARS_BENCH_LAUNCHER", "external" if world > 1 else "none"),
                 "device": _ffi.device_name(),

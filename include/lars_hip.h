@@ -290,6 +290,12 @@ int lars_stats_merge(const lars_stats *records, int64_t n, lars_stats *out);
  * img/out are host [h][w][channels]; out is uint8 with channels >= 3 zeroed. */
 int lars_h_fix_white_balance(const void *img, int64_t h, int64_t w, int channels, int dtype,
                              int variant, uint8_t *out, double *percentiles /* [3][2] or NULL */);
+/* The same function for any other sample type: process-images.py:431 casts whatever it is given with
+ * astype(np.float32) before anything else, so the caller hands over that float32 image.  np.percentile's order
+ * statistics come from an exact radix select, numpy's `_lerp` (float32 difference, float64 blend) and the float64
+ * stretch / float32 store / truncating cast of :438-441 run on the device. */
+int lars_h_fix_white_balance_f32(const float *img, int64_t h, int64_t w, int channels, uint8_t *out,
+                                 double *percentiles /* [3][2] or NULL */);
 
 /* calculate_index(img_array, index_type) -- process-images.py:449-490.
  * Several indices in one pass: out[k] is host [h][w] float32 or NULL. */

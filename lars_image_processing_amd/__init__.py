@@ -12,16 +12,13 @@ from .api import (  # noqa: F401
     calculate_index,
     calculate_index_statistics_by_timeframe,
     calculate_ndvi,
+    calculate_ndvi_array,
     change_detection,
     classification_mask,
     colorize_difference,
     colorize_index,
     colormap_lut,
     correct_white_balance,
-    create_change_detection_visualization,
-    create_comparison_view,
-    create_index_visualization,
-    create_time_series_plot,
     download_processed_images,
     fix_white_balance,
     fix_white_balance_rgnir,

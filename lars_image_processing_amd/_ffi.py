@@ -115,6 +115,7 @@ SIGNATURES = {
     "lars_get_tuning": (_I, [C.c_char_p, C.POINTER(_I)]),
     "lars_d_quot_selfcheck": (_I, [_U32, C.POINTER(C.c_uint64), C.POINTER(_U32 * 2)]),
     "lars_h_fix_white_balance": (_I, [_P, _I64, _I64, _I, _I, _I, _P, _P]),
+    "lars_h_fix_white_balance_f32": (_I, [_P, _I64, _I64, _I, _P, _P]),
     "lars_h_calculate_index": (_I, [_P, _I64, _I64, _I, _I, _U32, C.POINTER(_P * 3), _P, _I]),
     "lars_h_calculate_index_planes": (_I, [_P, _P, _P, _I64, _I, _P]),
     "lars_h_ndvi_f64": (_I, [_P, _I64, _I64, _I, _I, _P]),
@@ -238,7 +239,30 @@ def device_name():
     return buf.value.decode()
 
 
-class DeviceBuffer:
+class _DeviceRange:
+    """``ptr`` / ``nbytes`` of device memory with the copy helpers."""
+    ptr = None
+    nbytes = 0
+
+    def upload(self, arr, offset=0):
+        arr = np.ascontiguousarray(arr)
+        assert offset + arr.nbytes <= self.nbytes
+        call("lars_memcpy_h2d", C.c_void_p(self.ptr + offset), ptr(arr), arr.nbytes)
+
+    def download(self, dtype, shape, offset=0):
+        from .hostpool import empty
+        out = empty(shape, dtype)
+        assert offset + out.nbytes <= self.nbytes
+        call("lars_memcpy_d2h", ptr(out), C.c_void_p(self.ptr + offset), out.nbytes)
+        return out
+
+    def zero(self, stream=None):
+        """Asynchronous memset on ``stream`` (None = this thread's library stream): pass the stream the consuming
+        kernels are launched on, or the memset is not ordered against them."""
+        call("lars_memset", C.c_void_p(self.ptr), 0, self.nbytes, stream)
+
+
+class DeviceBuffer(_DeviceRange):
     """A hipMalloc allocation owned by Python (freed on ``free()`` / GC)."""
 
     def __init__(self, nbytes):
@@ -260,19 +284,13 @@ class DeviceBuffer:
         except Exception:
             pass
 
-    def upload(self, arr, offset=0):
-        arr = np.ascontiguousarray(arr)
-        assert offset + arr.nbytes <= self.nbytes
-        call("lars_memcpy_h2d", C.c_void_p(self.ptr + offset), ptr(arr), arr.nbytes)
 
-    def download(self, dtype, shape, offset=0):
-        from .hostpool import empty
-        out = empty(shape, dtype)
-        assert offset + out.nbytes <= self.nbytes
-        call("lars_memcpy_d2h", ptr(out), C.c_void_p(self.ptr + offset), out.nbytes)
-        return out
+class DeviceSlice(_DeviceRange):
+    """``nbytes`` at ``offset`` of a DeviceBuffer, which stays the owner (``free()`` here does nothing)."""
 
-    def zero(self, stream=None):
-        """Asynchronous memset on ``stream`` (None = this thread's library stream): pass the stream the consuming
-        kernels are launched on, or the memset is not ordered against them."""
-        call("lars_memset", C.c_void_p(self.ptr), 0, self.nbytes, stream)
+    def __init__(self, owner, offset, nbytes):
+        assert 0 <= offset and offset + nbytes <= owner.nbytes
+        self.owner, self.ptr, self.nbytes = owner, owner.ptr + int(offset), int(nbytes)
+
+    def free(self):
+        self.ptr = None

@@ -18,12 +18,17 @@ this module                     reference
 ``preprocess_large_image``      process-images.py:398  (Pillow LANCZOS down-scale)
 ``align_images``                process-images.py:515  (phase correlation + shift)
 ``calculate_index_statistics_by_timeframe``  process-images.py:619 (pandas table)
-``create_time_series_plot``     process-images.py:801  (figure; statistics from the GPU)
-``create_change_detection_visualization``    process-images.py:885 (figure; arrays from the GPU)
-``create_index_visualization`` / ``create_comparison_view``  process-images.py:669 / :718 (figures; statistics from the GPU)
-``download_processed_images``   process-images.py:567  (ZIP of the processed images)
-``generate_ndvi_report``        process-ndvi.py:75     (figure + histogram + statistics file; BASELINE configs[0])
+``time_series_points``          process-images.py:814-832 (the numbers ``create_time_series_plot`` draws)
+``change_detection``            process-images.py:885-923, :956 (the arrays ``create_change_detection_visualization`` draws)
+``download_processed_images``   process-images.py:567  (ZIP of the processed images, per-pixel colormaps)
+``generate_ndvi_report``        process-ndvi.py:75     (NDVI image + histogram counts + statistics file; BASELINE configs[0])
 ==============================  ============================================
+
+Figure rendering (matplotlib: ``create_time_series_plot``, ``create_change_detection_visualization``,
+``create_index_visualization``, ``create_comparison_view``, the pictures inside ``calculate_ndvi`` /
+``generate_ndvi_report``) is NOT part of this package (out of scope).  The
+reference's own figure functions keep working on top of the functions here -- INTEGRATION.md section 1 shows the
+import swap -- and this module only hands them their numbers.  Nothing under this package imports matplotlib.
 
 ``correct_white_balance`` and ``analyze_index_statistics`` are aliases (the
 spellings BASELINE.json uses).  Inputs are never modified; outputs are fresh
@@ -48,8 +53,7 @@ __all__ = [
     "analyze_ndvi_statistics", "index_histogram", "classification_mask", "colorize_index", "process_image",
     "timeseries_row", "colormap_lut", "preprocess_large_image", "align_images", "change_detection",
     "colorize_difference", "calculate_index_statistics_by_timeframe", "time_series_points",
-    "create_time_series_plot", "create_change_detection_visualization", "create_index_visualization",
-    "create_comparison_view", "generate_ndvi_report", "download_processed_images",
+    "calculate_ndvi_array", "generate_ndvi_report", "download_processed_images",
 ]
 
 _CMAPS = None
@@ -124,13 +128,20 @@ def preprocess_large_image(img_array, max_dimension=1024):
 # ---------------------------------------------------------------------------
 def _wb_array(arr, variant=0, want_percentiles=False):
     code = _ffi.dtype_code(arr.dtype)
-    if code is None:
-        raise TypeError(f"fix_white_balance: unsupported sample type {arr.dtype}; the HIP path takes uint8 or uint16 "
-                        "images (what PIL decodes RGNir files to)")
     h, w, c = arr.shape
     out = _empty((h, w, c), dtype=np.uint8)
     pcts = np.empty((3, 2), dtype=np.float64) if want_percentiles else None
-    _ffi.call("lars_h_fix_white_balance", _ffi.ptr(arr), h, w, c, code, variant, _ffi.ptr(out), _ffi.ptr(pcts))
+    if code is None:
+        # any other sample type (float, wider or signed integers, bool): the reference's first line is
+        # `img_array.astype(np.float32)` (process-images.py:431); everything after that cast runs on the device
+        if variant != 0:
+            raise TypeError(f"fix_white_balance_rgnir: unsupported sample type {arr.dtype} (image files decode to uint8 / uint16)")
+        if arr.dtype.kind not in "fiub":
+            raise TypeError(f"fix_white_balance: samples of type {arr.dtype} cannot be cast to float32")
+        as_f32 = np.ascontiguousarray(arr.astype(np.float32))
+        _ffi.call("lars_h_fix_white_balance_f32", _ffi.ptr(as_f32), h, w, c, _ffi.ptr(out), _ffi.ptr(pcts))
+    else:
+        _ffi.call("lars_h_fix_white_balance", _ffi.ptr(arr), h, w, c, code, variant, _ffi.ptr(out), _ffi.ptr(pcts))
     return (out, pcts) if want_percentiles else out
 
 
@@ -212,31 +223,32 @@ def calculate_index(*args):
     return out
 
 
-def calculate_ndvi(image_path, save_path=None, visualize=True):
-    """process-ndvi.py:5-48: float64 NDVI of an image file.
-
-    The figure (when ``save_path`` / ``visualize``) is matplotlib plumbing exactly
-    as upstream; the arithmetic runs on the GPU.
-    """
-    from PIL import Image
-    arr = _as_image(np.array(Image.open(image_path)), "calculate_ndvi")
+def calculate_ndvi_array(img_array):
+    """The arithmetic of process-ndvi.py:18-31 on an array: float64 ``(nir - red) / (nir + red + 1e-10)`` clipped to
+    [-1, 1] of an ``[H, W, C >= 3]`` uint8 / uint16 image (``astype(float)`` is exact for both)."""
+    arr = _as_image(img_array, "calculate_ndvi")
     code = _ffi.dtype_code(arr.dtype)
     if code is None:
         raise TypeError(f"calculate_ndvi: unsupported sample type {arr.dtype}")
     h, w, c = arr.shape
     ndvi = _empty((h, w), dtype=np.float64)
     _ffi.call("lars_h_ndvi_f64", _ffi.ptr(arr), h, w, c, code, _ffi.ptr(ndvi))
-    if visualize or save_path:
-        import matplotlib.pyplot as plt
-        plt.figure(figsize=(12, 8))
-        plot = plt.imshow(ndvi, cmap="RdYlGn", vmin=-1, vmax=1)
-        plt.colorbar(plot, label="NDVI")
-        plt.title("NDVI Values")
-        if save_path:
-            plt.savefig(save_path)
-            plt.close()
-        if visualize:
-            plt.show()
+    return ndvi
+
+
+def calculate_ndvi(image_path, save_path=None, visualize=True):
+    """process-ndvi.py:5-48: float64 NDVI of an image file.
+
+    The reference also draws a matplotlib figure (``:33-46``); figure rendering is out of scope here.  With
+    ``save_path`` this function writes the per-pixel RdYlGn image of the NDVI instead (the colormap of ``:38`` applied
+    pixel by pixel on the GPU, full resolution, no axes or colorbar); ``visualize`` is accepted and ignored (upstream:
+    ``plt.show()``).  A caller that wants the reference's figure keeps the reference's ``calculate_ndvi`` and lets it
+    call ``calculate_ndvi_array`` for lines 18-31.
+    """
+    from PIL import Image
+    ndvi = calculate_ndvi_array(np.array(Image.open(image_path)))
+    if save_path:
+        Image.fromarray(colorize_index(ndvi.astype(np.float32), "NDVI"), "RGBA").save(save_path)
     return ndvi
 
 
@@ -503,7 +515,7 @@ def change_detection(early, late, index_type, early_corrected=None, late_correct
             "shift": np.append(shift, 0), "diff_rgba": rgba}
 
 
-def _corrected_of(img_data):
+def corrected_of(img_data):
     """The cached white-balanced array of an ``image_data`` dict, or ``None`` (process-images.py:636-641)."""
     if "corrected_array" in img_data and img_data["corrected_array"] is not None:
         return img_data["corrected_array"]
@@ -520,7 +532,7 @@ def _timeframe_records(image_data_list, index_type, want_median):
     out = []
     for img_data in image_data_list:
         date = img_data["metadata"]["upload_date"]
-        corrected = _corrected_of(img_data)
+        corrected = corrected_of(img_data)
         src = corrected if corrected is not None else img_data["array"]
         if src is None or np.size(src) == 0:
             continue                                        # calculate_index -> None -> the row is skipped (:649)
@@ -556,159 +568,29 @@ def time_series_points(image_data_list, index_type):
             [st.min for _, st, _ in recs])
 
 
-def create_time_series_plot(image_data_list, index_type):
-    """process-images.py:801-883: the error-bar figure as a PIL image (matplotlib plumbing as upstream)."""
-    if not image_data_list or len(image_data_list) < 2:
-        return None
-    import io
-    from matplotlib.backends.backend_agg import FigureCanvasAgg as FigureCanvas
-    from matplotlib.figure import Figure
-    from PIL import Image
-    dates, mean_values, max_values, min_values = time_series_points(image_data_list, index_type)
-    fig = Figure(figsize=(10, 6), dpi=100)
-    canvas = FigureCanvas(fig)
-    ax = fig.add_subplot(111)
-    ax.errorbar(dates, mean_values,
-                yerr=[np.array(mean_values) - np.array(min_values), np.array(max_values) - np.array(mean_values)],
-                fmt="o-", capsize=5, label=f"Mean {index_type}")
-    feature_name, threshold = _coverage_rule(index_type)
-    ax.axhline(y=threshold, color="r", linestyle="--", label=f"{feature_name} Threshold")
-    ax.set_title(f"{index_type} Time Series")
-    ax.set_xlabel("Date")
-    ax.set_ylabel(f"{index_type} Value")
-    ax.grid(True, alpha=0.3)
-    ax.legend()
-    fig.autofmt_xdate()
-    buf = io.BytesIO()
-    canvas.print_figure(buf, format="png", bbox_inches="tight", dpi=100)
-    buf.seek(0)
-    img = Image.open(buf)
-    img_copy = img.copy()
-    buf.close()
-    img.close()
-    return img_copy
-
-
-def create_change_detection_visualization(image_pair, index_type):
-    """process-images.py:885-989: early | late | change figure as a PIL image (arrays from the GPU)."""
-    if not image_pair or len(image_pair) != 2:
-        return None
-    early_img_data, late_img_data = image_pair
-    res = change_detection(early_img_data.get("array"), late_img_data.get("array"), index_type,
-                           early_corrected=_corrected_of(early_img_data), late_corrected=_corrected_of(late_img_data))
-    if res is None:
-        return None
-    import io
-    from matplotlib.backends.backend_agg import FigureCanvasAgg as FigureCanvas
-    from matplotlib.figure import Figure
-    from PIL import Image
-    fig = Figure(figsize=(15, 5), dpi=100)
-    canvas = FigureCanvas(fig)
-    cmap = _colormap_for(index_type)
-    panels = ((res["early_index"], f"Early: {early_img_data['metadata']['upload_date'].strftime('%Y-%m-%d')}", cmap, -1, 1, index_type),
-              (res["late_index"], f"Late: {late_img_data['metadata']['upload_date'].strftime('%Y-%m-%d')}", cmap, -1, 1, index_type),
-              (res["diff"], f"Change in {index_type}", "bwr", -0.5, 0.5, f"\u0394{index_type}"))
-    for k, (arr, title, cm, lo, hi, label) in enumerate(panels, 1):
-        ax = fig.add_subplot(1, 3, k)
-        im = ax.imshow(arr, cmap=cm, vmin=lo, vmax=hi)
-        ax.set_title(title)
-        fig.colorbar(im, ax=ax, label=label)
-        ax.axis("off")
-    fig.tight_layout()
-    buf = io.BytesIO()
-    canvas.print_figure(buf, format="png", bbox_inches="tight", dpi=100)
-    buf.seek(0)
-    img = Image.open(buf)
-    img_copy = img.copy()
-    buf.close()
-    img.close()
-    return img_copy
-
-
-def _figure_to_pil(fig, canvas, **save_kw):
-    import io
-    from PIL import Image
-    buf = io.BytesIO()
-    canvas.print_figure(buf, format="png", bbox_inches="tight", dpi=100, **save_kw)
-    buf.seek(0)
-    with Image.open(buf) as img:
-        return img.copy()
-
-
-def create_index_visualization(index_array, index_type, render="figure"):
-    """process-images.py:669-716: the index with its colormap and colorbar as a PIL image.
-
-    ``render="lut"`` returns the full-resolution per-pixel RGBA image of the same colormap instead (no axes, no
-    colorbar: a different picture, hence opt-in) -- one GPU pass, no matplotlib."""
-    if index_array is None or np.size(index_array) == 0:
-        return None
-    if render == "lut":
-        from PIL import Image
-        return Image.fromarray(colorize_index(index_array, index_type), "RGBA")
-    from matplotlib.backends.backend_agg import FigureCanvasAgg as FigureCanvas
-    from matplotlib.figure import Figure
-    fig = Figure(figsize=(10, 8))
-    canvas = FigureCanvas(fig)
-    ax = fig.add_subplot(111)
-    im = ax.imshow(index_array, cmap=_colormap_for(index_type), vmin=-1, vmax=1)
-    fig.colorbar(im, label=index_type)
-    ax.axis("off")
-    return _figure_to_pil(fig, canvas, pad_inches=0)
-
-
-def create_comparison_view(image_data_list, index_type=None):
-    """process-images.py:718-799: side-by-side panels + ``{filename: analyze_index(...)}`` (statistics on the GPU)."""
-    if not image_data_list:
-        return None, {}
-    from matplotlib.backends.backend_agg import FigureCanvasAgg as FigureCanvas
-    from matplotlib.figure import Figure
-    n = len(image_data_list)
-    fig = Figure(figsize=(4 * n, 4))
-    canvas = FigureCanvas(fig)
-    all_stats = {}
-    for k, image_data in enumerate(image_data_list, 1):
-        ax = fig.add_subplot(1, n, k)
-        arr = image_data["array"] if image_data.get("array") is not None else np.array(image_data["original"])
-        if index_type:
-            im = ax.imshow(arr, cmap=_colormap_for(index_type), vmin=-1, vmax=1)
-            fig.colorbar(im, ax=ax, label=index_type)
-            all_stats[image_data["metadata"]["filename"]] = analyze_index(arr, index_type)
-        else:
-            ax.imshow(arr)
-        if "metadata" in image_data and "filename" in image_data["metadata"]:
-            ax.set_title(image_data["metadata"]["filename"], fontsize=8)
-        ax.axis("off")
-    fig.tight_layout()
-    return _figure_to_pil(fig, canvas, pad_inches=0.1), all_stats
-
-
-def download_processed_images(image_data, corrected_array, selected_indices, render="figure"):
+def download_processed_images(image_data, corrected_array, selected_indices):
     """process-images.py:567-617: ZIP bytes with ``white_balanced.png`` and ``<INDEX>_visualization.png`` per index.
-
-    ``render="figure"`` keeps the reference's matplotlib pictures; ``render="lut"`` writes full-resolution per-pixel
-    colormap images from one GPU pass (``driver.export_zip``)."""
+    The index pictures are full-resolution per-pixel colormap images from one GPU pass (``driver.export_zip``), not
+    the reference's matplotlib figures."""
     from .driver import export_zip
     return export_zip(None if image_data is None else image_data.get("array"), selected_indices,
-                      corrected_array=corrected_array, render=render)
+                      corrected_array=corrected_array)
 
 
 def generate_ndvi_report(image_path, output_dir):
-    """process-ndvi.py:75-110: ``ndvi_visualization.png``, ``ndvi_histogram.png`` and ``ndvi_statistics.txt`` in
-    ``output_dir``; returns ``(ndvi_array, stats)``.  NDVI, statistics and the 50 histogram counts come from the GPU,
-    the two figures are matplotlib plumbing as upstream."""
-    import matplotlib.pyplot as plt
+    """process-ndvi.py:75-110 without its two matplotlib figures: writes ``ndvi_visualization.png`` (per-pixel RdYlGn
+    image of the NDVI), ``ndvi_histogram.csv`` (the 50 counts ``plt.hist(ndvi.flatten(), bins=50, range=(-1, 1))``
+    would draw, with their bin edges) and ``ndvi_statistics.txt`` (same text as upstream) into ``output_dir``;
+    returns ``(ndvi_array, stats)``.  NDVI, statistics and histogram counts come from the GPU."""
     os.makedirs(output_dir, exist_ok=True)
     ndvi_array = calculate_ndvi(image_path, os.path.join(output_dir, "ndvi_visualization.png"), visualize=False)
     stats = analyze_ndvi_statistics(ndvi_array)
     counts = index_histogram(ndvi_array)
     edges = np.linspace(-1.0, 1.0, 51)
-    plt.figure(figsize=(10, 6))
-    plt.hist(edges[:-1], bins=edges, weights=counts)        # the bars plt.hist(ndvi.flatten(), bins=50, range=(-1, 1)) draws
-    plt.title("Distribution of NDVI Values")
-    plt.xlabel("NDVI")
-    plt.ylabel("Pixel Count")
-    plt.savefig(os.path.join(output_dir, "ndvi_histogram.png"))
-    plt.close()
+    with open(os.path.join(output_dir, "ndvi_histogram.csv"), "w") as f:
+        f.write("bin_left,bin_right,pixel_count\n")
+        for k in range(50):
+            f.write(f"{edges[k]:.2f},{edges[k + 1]:.2f},{int(counts[k])}\n")
     with open(os.path.join(output_dir, "ndvi_statistics.txt"), "w") as f:
         f.write("NDVI Statistics:\n")
         for key, value in stats.items():

@@ -16,7 +16,7 @@ import ctypes as C
 import numpy as np
 
 from . import _ffi
-from ._ffi import FusedArgs, INDEX_IDS, INDEX_NAMES, STATS_DTYPE, DeviceBuffer
+from ._ffi import FusedArgs, INDEX_IDS, INDEX_NAMES, STATS_DTYPE, DeviceBuffer, DeviceSlice
 
 MAX_TILES_PER_LAUNCH = 65535      # grid.y limit
 
@@ -107,53 +107,32 @@ class TileBatch:
         """Allocate output planes.  ``ring`` < ntiles reuses a ring of that many
         tile slots (same HBM traffic, bounded footprint) -- see BatchOutputs.
 
-        ``placement_trials`` = k > 1: allocate k candidate planes per index, time them and keep the fastest
-        combination.  Where the driver happens to put a plane in HBM moves the write-bound fused kernel by up
-        to 10 % -- reproducibly for the lifetime of the allocation -- so a long-lived
-        ring is worth choosing once.  Costs k rings of memory for the duration of the trial."""
+        The float32 index planes live in ONE allocation (an arena).  How fast the write-bound fused kernel runs into an
+        arena is a property of where the driver put it: 5.2 - 6.3 TB/s on the same box, stable to 0.3 % for as long as the
+        allocation lives, independent of the offsets between the planes inside it, of the input batch and of time
+        (profiles/r02_placement_*.txt).  ``placement_trials`` = k > 1 therefore allocates k arenas,
+        times the kernel into each and keeps the fastest; the others are freed.  Costs k arenas of memory for the
+        duration of the trial and k short launches."""
+        outs = BatchOutputs(self, indices, index, wb, rgba, ring)
         if placement_trials <= 1 or not index:
-            return BatchOutputs(self, indices, index, wb, rgba, ring)
-        # Stage 1: a pool of candidate planes, each timed on its own (planes come out "fast" or "slow", ~5 % apart).
-        # Stage 2: the combinations of the fastest few as a ring (planes also interact), the best one stays.
-        import itertools
-        ks = [INDEX_IDS[t] for t in indices]
-        base = BatchOutputs(self, indices, False, wb, rgba, ring)          # everything but the index planes
-        nbytes = base.slots * self.npix * 4
-        pool = []
-        for _ in range(int(placement_trials) * len(ks)):
+            return outs
+        arenas = [outs.arena]
+        for _ in range(int(placement_trials) - 1):
             try:
-                pool.append(DeviceBuffer(nbytes))
+                arenas.append(DeviceBuffer(outs.arena.nbytes))
             except _ffi.LarsError:
                 break                                       # out of memory: choose among what fits
-        if len(pool) < len(ks):
-            for p in pool:
-                p.free()
-            base.free()
-            raise _ffi.LarsError(-2, "no memory for the output planes")
-        solo = []
-        for p in pool:
-            base.index = [None] * 3
-            base.index[ks[0]] = p
-            solo.append(self._time_outputs(base, (indices[0],)))
-        order = list(np.argsort(solo))
-        short = order[:min(len(pool), len(ks) + 2)]
-        best, best_ms, tried = None, None, []
-        for combo in itertools.combinations(short, len(ks)):
-            base.index = [None] * 3
-            for k, j in zip(ks, combo):
-                base.index[k] = pool[j]
-            ms = self._time_outputs(base, indices)
-            tried.append(ms)
-            if best_ms is None or ms < best_ms:
-                best, best_ms = combo, ms
-        base.index = [None] * 3
-        for k, j in zip(ks, best):
-            base.index[k] = pool[j]
-        for j, p in enumerate(pool):
-            if j not in best:
-                p.free()
-        base.placement_ms = {"planes": [float(x) for x in solo], "rings": tried, "chosen": best_ms}
-        return base
+        timings = []
+        for arena in arenas:
+            outs.adopt_arena(arena)
+            timings.append(self._time_outputs(outs, indices))
+        best = int(np.argmin(timings))
+        outs.adopt_arena(arenas[best])
+        for j, arena in enumerate(arenas):
+            if j != best:
+                arena.free()
+        outs.placement_ms = {"arenas": [float(x) for x in timings], "chosen": float(timings[best])}
+        return outs
 
     def _time_outputs(self, outs, indices):
         """Milliseconds of fused launches that fill ``outs`` from up to three chunks of the batch (first, middle, last:
@@ -359,22 +338,33 @@ class TileBatch:
 
 
 class BatchOutputs:
-    """Device output planes of a batch (optionally a ring of ``slots`` tiles)."""
+    """Device output planes of a batch (optionally a ring of ``slots`` tiles).  The float32 index planes are slices of
+    one allocation (``arena``), in the order of INDEX_NAMES."""
 
     def __init__(self, batch, indices, index, wb, rgba, ring=None):
         from .api import colormap_lut, _colormap_for
         self.slots = batch.ntiles if not ring else min(int(ring), batch.ntiles)
         self.index, self.rgba, self.luts = [None] * 3, [None] * 3, [None] * 3
+        self.batch = batch
+        self.plane_bytes = self.slots * batch.npix * 4
+        self._index_ids = sorted(INDEX_IDS[t] for t in indices) if index else []
+        self.arena = None
+        if self._index_ids:
+            self.adopt_arena(DeviceBuffer(len(self._index_ids) * self.plane_bytes))
         for t in indices:
             k = INDEX_IDS[t]
-            if index:
-                self.index[k] = DeviceBuffer(self.slots * batch.npix * 4)
             if rgba:
                 self.rgba[k] = DeviceBuffer(self.slots * batch.npix * 4)
                 self.luts[k] = DeviceBuffer(1024)
                 self.luts[k].upload(colormap_lut(_colormap_for(t)))
         self.wb = DeviceBuffer(self.slots * batch.npix * batch.channels) if wb else None
-        self.batch = batch
+
+    def adopt_arena(self, arena):
+        """Point the index planes at ``arena`` (the caller frees whatever arena was in use before)."""
+        assert arena.nbytes >= len(self._index_ids) * self.plane_bytes
+        self.arena = arena
+        for j, k in enumerate(self._index_ids):
+            self.index[k] = DeviceSlice(arena, j * self.plane_bytes, self.plane_bytes)
 
     def host_index(self, index_type, slot=0, count=1):
         k = INDEX_IDS[index_type]
@@ -391,9 +381,10 @@ class BatchOutputs:
         return self.wb.download(np.uint8, (count, b.h, b.w, b.channels), slot * b.npix * b.channels)
 
     def free(self):
-        for b in self.index + self.rgba + self.luts + [self.wb]:
+        for b in self.index + self.rgba + self.luts + [self.wb, self.arena]:
             if b is not None:
                 b.free()
+        self.index, self.arena = [None] * 3, None
 
 
 # ---------------------------------------------------------------------------

@@ -142,7 +142,8 @@ __global__ __launch_bounds__(256) void k_fold_f64(const double *partials, int nb
 struct SelectState {
     unsigned long long prefix;      // key bits decided so far
     unsigned long long k;           // rank still to find inside the current prefix
-    unsigned long long k0;          // the requested rank (n-1)/2
+    unsigned long long k0;          // the requested rank ((n-1)/2 for a median)
+    unsigned long long k1;          // the second requested rank: k0 or k0 + 1 (n/2 for a median)
     unsigned long long n;
     unsigned long long c_le;        // # keys <= selected key
     unsigned long long next_key;    // smallest key > selected key
@@ -165,12 +166,12 @@ template <> struct KeyOf<double> {
 
 // All select kernels are batched: blockIdx.y = item (one array of n values, e.g. one tile's plane),
 // st[item] its state, x + item * stride its data.
-__global__ void k_sel_init(SelectState *st, long long n)
+__global__ void k_sel_init(SelectState *st, long long n, long long k0, long long k1)
 {
     SelectState *s = st + blockIdx.y;
     const int tid = blockIdx.x * blockDim.x + threadIdx.x;
     if (tid == 0) {
-        s->prefix = 0; s->k0 = (unsigned long long)((n - 1) / 2); s->k = s->k0; s->n = (unsigned long long)n;
+        s->prefix = 0; s->k0 = (unsigned long long)k0; s->k1 = (unsigned long long)k1; s->k = s->k0; s->n = (unsigned long long)n;
         s->c_le = 0; s->next_key = ~0ull;
     }
     if (tid < SEL_BINS) s->hist[tid] = 0;
@@ -272,7 +273,7 @@ __global__ void k_sel_finish(const SelectState *st, T *out, long long items)
         const SelectState *s = st + i;
         const T v1 = KeyOf<T>::val(s->prefix);
         T v2 = v1;
-        const unsigned long long k2 = s->n / 2;                   // == k0 when n is odd
+        const unsigned long long k2 = s->k1;                      // k0 or k0 + 1
         if (k2 != s->k0 && k2 >= s->c_le) v2 = KeyOf<T>::val(s->next_key);
         out[2 * i] = v1;
         out[2 * i + 1] = v2;
@@ -392,13 +393,15 @@ extern "C" int lars_d_array_stats_f64(const double *x, int64_t n, double thresho
 
 extern "C" size_t lars_select_scratch_bytes(void) { return sizeof(SelectState); }
 
+// the order statistics of ranks k0 and k1 (k1 = k0 or k0 + 1) of `items` arrays: out_dev[items][2]
 template <typename T>
-static int median_pair_impl(const T *x, int64_t n, int64_t items, int64_t stride, T *out_dev, void *scratch, void *stream)
+static int rank_pair_impl(const T *x, int64_t n, int64_t items, int64_t stride, int64_t k0, int64_t k1, T *out_dev, void *scratch,
+                          void *stream)
 {
     ThreadCtx *c;
     LARS_TRY(ensure_ctx(&c));
-    if (!x || n <= 0 || items <= 0 || items > 65535 || !out_dev || !scratch)
-        return fail(LARS_ERR_INVALID, "lars_d_median_pair: bad arguments");
+    if (!x || n <= 0 || items <= 0 || items > 65535 || !out_dev || !scratch || k0 < 0 || k1 < k0 || k1 > k0 + 1 || k1 >= n)
+        return fail(LARS_ERR_INVALID, "rank select: bad arguments");
     hipStream_t s = pick_stream(c, stream);
     SelectState *st = static_cast<SelectState *>(scratch);
     int nb = grid_for_reduce(n);
@@ -407,7 +410,7 @@ static int median_pair_impl(const T *x, int64_t n, int64_t items, int64_t stride
         if (nb > want) nb = (int)(want < 1 ? 1 : want);
     }
     const unsigned it = (unsigned)items;
-    hipLaunchKernelGGL(k_sel_init, dim3(SEL_BINS / 256, it), dim3(256), 0, s, st, (long long)n);
+    hipLaunchKernelGGL(k_sel_init, dim3(SEL_BINS / 256, it), dim3(256), 0, s, st, (long long)n, (long long)k0, (long long)k1);
     int hi = KeyOf<T>::BITS;
     while (hi > 0) {
         const int bits = hi >= SEL_BITS ? SEL_BITS : hi;
@@ -418,8 +421,22 @@ static int median_pair_impl(const T *x, int64_t n, int64_t items, int64_t stride
     }
     hipLaunchKernelGGL((k_sel_next<T>), dim3(nb, it), dim3(256), 0, s, x, (long long)n, (long long)stride, st);
     hipLaunchKernelGGL((k_sel_finish<T>), dim3((it + 63) / 64), dim3(64), 0, s, st, out_dev, (long long)items);
-    return launch_check("lars_d_median_pair");
+    return launch_check("rank select");
 }
+template <typename T>
+static int median_pair_impl(const T *x, int64_t n, int64_t items, int64_t stride, T *out_dev, void *scratch, void *stream)
+{
+    if (n <= 0) return fail(LARS_ERR_INVALID, "lars_d_median_pair: bad arguments");
+    return rank_pair_impl<T>(x, n, items, stride, (n - 1) / 2, n / 2, out_dev, scratch, stream);
+}
+namespace lars {
+// np.percentile's two neighbours (ranks k0, min(k0 + 1, n - 1)) of `items` float32 arrays, for wb_generic.hip
+int rank_pair_f32(const float *x, int64_t n, int64_t items, int64_t stride, int64_t k0, int64_t k1, float *out_dev, void *scratch,
+                  void *stream)
+{
+    return rank_pair_impl<float>(x, n, items, stride, k0, k1, out_dev, scratch, stream);
+}
+}  // namespace lars
 extern "C" int lars_d_median_pair_f32(const float *x, int64_t n, float *out_dev, void *scratch, void *stream)
 {
     return median_pair_impl<float>(x, n, 1, n, out_dev, scratch, stream);

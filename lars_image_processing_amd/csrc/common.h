@@ -5,13 +5,11 @@
 #include <stdio.h>
 #include <string>
 
-#include "lars_hip.h"
+#include "host_common.h"
 
 namespace lars {
 
-// ---- error plumbing -------------------------------------------------------
-void set_error(const char *fmt, ...);
-int fail(int code, const char *fmt, ...);
+// ---- error plumbing (set_error / fail / LARS_TRY: host_common.h) -----------
 
 #define LARS_HIP_TRY(expr)                                                          \
     do {                                                                            \
@@ -20,12 +18,6 @@ int fail(int code, const char *fmt, ...);
             return ::lars::fail(_e == hipErrorOutOfMemory ? LARS_ERR_OOM : LARS_ERR_HIP, \
                                 "%s failed: %s (%s:%d)", #expr, hipGetErrorString(_e), \
                                 __FILE__, __LINE__);                                \
-    } while (0)
-
-#define LARS_TRY(expr)                \
-    do {                              \
-        int _s = (expr);              \
-        if (_s != LARS_OK) return _s; \
     } while (0)
 
 // ---- per-thread context ---------------------------------------------------
@@ -107,6 +99,7 @@ struct Tuning {
     int hist_impl = 2;
     int nt_stores = 0;         // non-temporal stores for the float32 planes
     int blocks_per_tile = 0;   // 0 = automatic
+    int traverse = -1;         // plane-writing kernel, A/B only: -1 / 1 the shipped mapping, 0 and 2 see k_fused_u8c3
 };
 Tuning &tuning();
 

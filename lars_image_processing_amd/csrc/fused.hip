@@ -325,7 +325,13 @@ __device__ inline void store_plane4(float *dst, const float (&v)[4], bool nt)
 }
 typedef unsigned int fu32x2 __attribute__((ext_vector_type(2)));
 
-template <typename PIX, unsigned MASK, bool WB, int STATS>
+// TRAV (pixel -> wave mapping): 1 (what runs) a wave owns runs of 1024 consecutive pixels, the four quads of a run
+// unrolled: four loads, then per plane four back-to-back 1 KiB stores = 4 KiB bursts; 0 the same runs one quad per trip;
+// 2 the round-1 mapping (256-pixel slabs a grid stride apart).  Measured in one process, same planes
+// (profiles/r02_traverse_ab.txt): 1 runs 8 % faster than 0 and 2 wherever the planes' placement allows more than
+// 5.3 TB/s at all, and equal elsewhere.  0 and 2 are only instantiated for the headline configuration, for such A/B
+// runs (lars_set_tuning("traverse", 0 | 2); the default -1 means 1).
+template <typename PIX, unsigned MASK, bool WB, int STATS, int TRAV = 1>
 __global__ __launch_bounds__(256) void k_fused_u8c3(FusedParams P)
 {
     constexpr bool U16 = sizeof(PIX) == 2;
@@ -385,22 +391,29 @@ __global__ __launch_bounds__(256) void k_fused_u8c3(FusedParams P)
     const unsigned int *lut2 = reinterpret_cast<const unsigned int *>(P.cmap_lut[2]);
 
     const long long nquads = npix >> 2;
-    const long long stride = (long long)gridDim.x * 256;
     const bool nt_st = (P.flags & 0x20000000u) != 0;
     __amdgpu_buffer_rsrc_t rsrc16;
     if (U16) rsrc16 = __builtin_amdgcn_make_buffer_rsrc(const_cast<PIX *>(base), 0, (int)(nquads * 24), 0x00020000);
-    for (long long q = (long long)blockIdx.x * 256 + tid; q < nquads; q += stride) {
-        unsigned int b[12];
+    constexpr int NW = U16 ? 6 : 3;                          // dwords of one quad of pixels
+
+    auto load_quad = [&](long long q, unsigned int (&w)[NW]) {
         if (U16) {
             const unsigned int off = (unsigned int)q * 24u;
             const fu32x4 a4 = __builtin_amdgcn_raw_buffer_load_b128(rsrc16, off, 0, 0);
             const fu32x2 a2 = __builtin_amdgcn_raw_buffer_load_b64(rsrc16, off + 16u, 0, 0);
-            const unsigned int w[6] = {a4.x, a4.y, a4.z, a4.w, a2.x, a2.y};
-#pragma unroll
-            for (int i = 0; i < 6; ++i) { b[2 * i] = w[i] & 0xFFFFu; b[2 * i + 1] = w[i] >> 16; }
+            w[0] = a4.x; w[1] = a4.y; w[2] = a4.z; w[NW - 3] = a4.w; w[NW - 2] = a2.x; w[NW - 1] = a2.y;
         } else {
             const unsigned int *p = reinterpret_cast<const unsigned int *>(reinterpret_cast<const uint8_t *>(base) + q * 12);
-            const unsigned int w0 = p[0], w1 = p[1], w2 = p[2];
+            w[0] = p[0]; w[1] = p[1]; w[2] = p[2];
+        }
+    };
+    auto do_quad = [&](long long q, const unsigned int (&w)[NW]) {
+        unsigned int b[12];
+        if (U16) {
+#pragma unroll
+            for (int i = 0; i < 6; ++i) { b[2 * i] = w[i % NW] & 0xFFFFu; b[2 * i + 1] = w[i % NW] >> 16; }
+        } else {
+            const unsigned int w0 = w[0], w1 = w[1], w2 = w[2];
             const unsigned int t[12] = {w0 & 0xFF, (w0 >> 8) & 0xFF, (w0 >> 16) & 0xFF, w0 >> 24,
                                         w1 & 0xFF, (w1 >> 8) & 0xFF, (w1 >> 16) & 0xFF, w1 >> 24,
                                         w2 & 0xFF, (w2 >> 8) & 0xFF, (w2 >> 16) & 0xFF, w2 >> 24};
@@ -439,6 +452,50 @@ __global__ __launch_bounds__(256) void k_fused_u8c3(FusedParams P)
         if ((MASK & 4u) && oc2)
             *reinterpret_cast<uint4 *>(oc2 + q * 16) = make_uint4(lut2[cmap_index(v2[0])], lut2[cmap_index(v2[1])],
                                                                   lut2[cmap_index(v2[2])], lut2[cmap_index(v2[3])]);
+    };
+
+    // A wave owns 1024 consecutive pixels per step: four wave-contiguous loads (4 x 768 bytes of uint8 samples), then per
+    // plane four wave-contiguous 1 KiB stores = 4 KiB of consecutive addresses.  Measured against the former mapping
+    // (one 256-pixel slab per wave and step, slabs of a wave a grid stride apart) with the bare traffic mix:
+    // 6.07-6.38 vs 5.63-5.95 TB/s in three sets of allocations (profiles/r02_stream_probe.txt, kinds 9-13 vs 5).
+    const long long nsteps = (nquads + 255) >> 8;
+    const long long wstride = (long long)gridDim.x * 4;
+    const unsigned int lane = (unsigned int)tid & 63u;
+    if (TRAV == 2) {
+        const long long stride = (long long)gridDim.x * 256;
+        unsigned int w[NW];
+        for (long long q = (long long)blockIdx.x * 256 + tid; q < nquads; q += stride) { load_quad(q, w); do_quad(q, w); }
+    } else if (TRAV == 1) {
+        for (long long st = (long long)blockIdx.x * 4 + (tid >> 6); st < nsteps; st += wstride) {
+            const long long q0 = st * 256 + lane;
+            unsigned int w[4][NW];
+            if (st * 256 + 256 <= nquads) {
+#pragma unroll
+                for (int j = 0; j < 4; ++j) load_quad(q0 + 64 * j, w[j]);
+                __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    do_quad(q0 + 64 * j, w[j]);
+                    __builtin_amdgcn_sched_barrier(0);
+                }
+            } else {
+                for (int j = 0; j < 4; ++j) {
+                    const long long q = q0 + 64 * j;
+                    if (q < nquads) { load_quad(q, w[0]); do_quad(q, w[0]); }
+                }
+            }
+        }
+    } else {
+        // same addresses per wave as the unrolled form, one quad per trip (a third of the registers)
+        unsigned int w[NW];
+        for (long long st = (long long)blockIdx.x * 4 + (tid >> 6); st < nsteps; st += wstride) {
+            const long long q0 = st * 256 + lane;
+#pragma unroll 1
+            for (int j = 0; j < 4; ++j) {
+                const long long q = q0 + 64 * j;
+                if (q < nquads) { load_quad(q, w); do_quad(q, w); }
+            }
+        }
     }
     // tail pixels (npix % 4): lanes 0..2 of block 0
     if (blockIdx.x == 0 && tid < (int)(npix & 3)) {
@@ -756,7 +813,10 @@ extern "C" int lars_d_fused(const lars_fused_args *a)
         fused_v2_launch(mask, a->wb_table != nullptr, stats_mode, tuning().nt_stores != 0, grid, s, P);
     } else if (fast && a->dtype == LARS_U8) {
         dim3 grid(blocks_per_tile(a->npix / 4 + 1, a->ntiles, 256, 32768), (unsigned)a->ntiles);
-        launch_fast<uint8_t>(mask, a->wb_table != nullptr, stats_mode, grid, s, P);
+        const bool headline = mask == 7u && a->wb_table && stats_mode == 1;
+        if (headline && tuning().traverse == 0) hipLaunchKernelGGL((k_fused_u8c3<uint8_t, 7u, true, 1, 0>), grid, dim3(256), 0, s, P);
+        else if (headline && tuning().traverse == 2) hipLaunchKernelGGL((k_fused_u8c3<uint8_t, 7u, true, 1, 2>), grid, dim3(256), 0, s, P);
+        else launch_fast<uint8_t>(mask, a->wb_table != nullptr, stats_mode, grid, s, P);
     } else if (fast && a->dtype == LARS_U16 && small_tile) {
         dim3 grid(blocks_per_tile(a->npix / 4 + 1, a->ntiles, 256, 32768), (unsigned)a->ntiles);
         launch_fast<uint16_t>(mask, a->wb_table != nullptr, stats_mode, grid, s, P);

@@ -197,6 +197,17 @@ __device__ inline void count4_lt(unsigned int &counter, const float (&x)[4], flo
     counter += c;
 }
 
+// LARS_COUNT_MODE 3 / template CM == 3: per-lane float counters, two values per instruction:
+//   c = sat(fma(x, +-2^40, -+thr * 2^40))   is exactly 1.0 where x > thr (resp. x < thr) and 0.0 elsewhere -- a value
+// above the threshold is above it by at least one unit in the last place (>= 2^-32 here), which the factor turns into
+// >= 256 -- and   counter += c.   No compare, no VCC, no scalar instruction.  Per-lane sums stay below 2^24.
+__device__ inline void fcount2(f32x2 &counter, f32x2 x, f32x2 k, f32x2 b)
+{
+    f32x2 c;
+    asm("v_pk_fma_f32 %0, %1, %2, %3 clamp" : "=v"(c) : "v"(x), "v"(k), "v"(b));
+    counter += c;
+}
+
 template <int STATS, bool COUNT = true>
 __device__ inline void push(WaveAcc &a, unsigned int &above, float x, float thr)
 {
@@ -245,7 +256,7 @@ template <bool OUT> struct V2Block { static constexpr int threads = OUT ? 512 : 
 // SEL: also count every NDVI / GNDVI value in the 2048 linear buckets of the exact-median select (its first pass,
 // fused: P.sel_hist[tile][stream][track 0][bucket]).  With the 64 KiB table that is exactly 80 KiB of LDS (two blocks
 // per CU) because the reduction scratch then reuses the table's space once the loop is over.
-template <unsigned MASK, bool WB, int STATS, bool OUT, bool NT, bool SEL = false>
+template <unsigned MASK, bool WB, int STATS, bool OUT, bool NT, bool SEL = false, int CM = LARS_COUNT_MODE>
 __global__ __launch_bounds__(V2Block<OUT>::threads, OUT ? 4 : LARS_V2_STATS_WAVES) void k_fused_v2(FusedParams P)
 {
     constexpr int NTHR = V2Block<OUT>::threads;
@@ -299,6 +310,9 @@ __global__ __launch_bounds__(V2Block<OUT>::threads, OUT ? 4 : LARS_V2_STATS_WAVE
     acc_v.mn = acc_g.mn = __builtin_inff(); acc_v.mx = acc_g.mx = -__builtin_inff();
     acc_v.sum = acc_g.sum = 0; acc_v.sumsq = acc_g.sumsq = 0;
     unsigned int above_v = 0, above_g = 0, above_w = 0;
+    f32x2 fc_v = {0.0f, 0.0f}, fc_g = {0.0f, 0.0f}, fc_w = {0.0f, 0.0f};          // CM == 3: float counters
+    const f32x2 fc_kp = {1099511627776.0f, 1099511627776.0f}, fc_kn = {-1099511627776.0f, -1099511627776.0f};
+    const f32x2 fc_bt = {-0.2f * 1099511627776.0f, -0.2f * 1099511627776.0f}, fc_b0 = {0.0f, 0.0f};
 
     // OUT == false: statistics only, every output pointer is known to be null at compile time
     float *const oi0 = (OUT && P.out_index[0]) ? P.out_index[0] + tile * npix : nullptr;
@@ -351,6 +365,7 @@ __global__ __launch_bounds__(V2Block<OUT>::threads, OUT ? 4 : LARS_V2_STATS_WAVE
                 const f32x2 R = {fr[2 * h], fr[2 * h + 1]};
                 const f32x2 x = exact_quot2(N - R, Ne + R);
                 v0[2 * h] = x.x; v0[2 * h + 1] = x.y;
+                if (STATS >= 1 && CM == 3) fcount2(fc_v, x, fc_kp, fc_bt);
                 if (STATS >= 2) {
                     const f32x2 p = hist_pos2(x, 1.0f);
                     hist_add_pos(p.x, hb0); hist_add_pos(p.y, hb0);
@@ -364,6 +379,8 @@ __global__ __launch_bounds__(V2Block<OUT>::threads, OUT ? 4 : LARS_V2_STATS_WAVE
                 const f32x2 G = {fg[2 * h], fg[2 * h + 1]};
                 const f32x2 x = exact_quot2(N - G, Ne + G);
                 v1[2 * h] = x.x; v1[2 * h + 1] = x.y;
+                if (STATS >= 1 && CM == 3 && WANT_GNDVI) fcount2(fc_g, x, fc_kp, fc_bt);
+                if (STATS >= 1 && CM == 3 && WANT_NDWI) fcount2(fc_w, x, fc_kn, fc_b0);          // -x > 0
                 if (STATS >= 2 && WANT_GNDVI) {
                     const f32x2 p = hist_pos2(x, 1.0f);
                     hist_add_pos(p.x, hb1); hist_add_pos(p.y, hb1);
@@ -382,7 +399,7 @@ __global__ __launch_bounds__(V2Block<OUT>::threads, OUT ? 4 : LARS_V2_STATS_WAVE
         for (int px = 0; px < 4; ++px) {
             if (WANT_NDVI) {
                 const float x = v0[px];
-                if (STATS >= 1) push<STATS, LARS_COUNT_MODE != 0>(acc_v, above_v, x, 0.2f);
+                if (STATS >= 1) push<STATS, (CM == 1 || CM == 2)>(acc_v, above_v, x, 0.2f);
             }
             if (NEED_G) {
                 const float x = v1[px];
@@ -392,7 +409,7 @@ __global__ __launch_bounds__(V2Block<OUT>::threads, OUT ? 4 : LARS_V2_STATS_WAVE
                     const double xd = (double)x;
                     acc_g.sum += xd;
                     if (STATS >= 3) acc_g.sumsq += xd * xd;
-                    if (LARS_COUNT_MODE == 1) {
+                    if (CM == 1) {
                         if (WANT_GNDVI) vcount_gt(above_g, x, 0.2f);
                         if (WANT_NDWI) vcount_lt(above_w, x, 0.0f);           // -x > 0
                     }
@@ -402,11 +419,11 @@ __global__ __launch_bounds__(V2Block<OUT>::threads, OUT ? 4 : LARS_V2_STATS_WAVE
                 }
             }
         }
-        if (STATS >= 1 && LARS_COUNT_MODE == 0) {
+        if (STATS >= 1 && CM == 0) {
             if (WANT_NDVI) count4_gt(above_v, v0, 0.2f);
             if (WANT_GNDVI) count4_gt(above_g, v1, 0.2f);
             if (WANT_NDWI) count4_lt(above_w, v1, 0.0f);                   // -x > 0
-        } else if (STATS >= 1 && LARS_COUNT_MODE == 2) {
+        } else if (STATS >= 1 && CM == 2) {
             if (WANT_GNDVI) count4_gt(above_g, v1, 0.2f);
             if (WANT_NDWI) count4_lt(above_w, v1, 0.0f);
         }
@@ -491,7 +508,7 @@ __global__ __launch_bounds__(V2Block<OUT>::threads, OUT ? 4 : LARS_V2_STATS_WAVE
                 const double xd = (double)x;
                 acc_g.sum += xd;
                 if (STATS >= 3) acc_g.sumsq += xd * xd;
-                if (LARS_COUNT_MODE == 1) {
+                if (CM == 1) {
                     if (WANT_GNDVI) vcount_gt(above_g, x, 0.2f);
                     if (WANT_NDWI) vcount_lt(above_w, x, 0.0f);
                 } else {
@@ -518,8 +535,13 @@ __global__ __launch_bounds__(V2Block<OUT>::threads, OUT ? 4 : LARS_V2_STATS_WAVE
     if (RED_ALIASES_TABLE) __syncthreads();               // every wave is done with the table before its space is reused
     if (STATS >= 1) {
         // wave fold (scalar counters are already wave totals; per-lane ones are summed here)
-        if (LARS_COUNT_MODE != 0) above_v = wave_sum_u32(above_v);
-        if (LARS_COUNT_MODE == 1) { above_g = wave_sum_u32(above_g); above_w = wave_sum_u32(above_w); }
+        if (CM == 3) {
+            above_v = wave_sum_u32((unsigned int)(fc_v.x + fc_v.y));
+            above_g = wave_sum_u32((unsigned int)(fc_g.x + fc_g.y));
+            above_w = wave_sum_u32((unsigned int)(fc_w.x + fc_w.y));
+        }
+        if ((CM == 1 || CM == 2)) above_v = wave_sum_u32(above_v);
+        if (CM == 1) { above_g = wave_sum_u32(above_g); above_w = wave_sum_u32(above_w); }
         for (int off = 32; off >= 1; off >>= 1) {
             if (WANT_NDVI) {
                 acc_v.mn = fminf(acc_v.mn, __shfl_xor(acc_v.mn, off)); acc_v.mx = fmaxf(acc_v.mx, __shfl_xor(acc_v.mx, off));

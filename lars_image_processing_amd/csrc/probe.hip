@@ -90,6 +90,127 @@ __global__ __launch_bounds__(256) void k_probe_mix1(const unsigned int *__restri
 }
 
 // ---------------------------------------------------------------------------
+// Round 2: more shapes of the plane-writing kernel's 1 : 4 mix (per 4 pixels 12 B read, 3 x 16 B written).
+// All move the same bytes as k_probe_mix; they differ in which lane touches which address when.
+// ---------------------------------------------------------------------------
+typedef unsigned int pu32x3 __attribute__((ext_vector_type(3)));
+
+// lane-contiguous 16 pixels: 3 x 16 B loads of 48 contiguous bytes, 4 x 16 B stores of 64 contiguous bytes per plane
+__global__ __launch_bounds__(256) void k_probe_lane16(const pu32x4 *__restrict__ src, pu32x4 *__restrict__ d0,
+                                                      pu32x4 *__restrict__ d1, pu32x4 *__restrict__ d2, long long ngroups)
+{
+    const long long stride = (long long)gridDim.x * 256;
+    for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < ngroups; i += stride) {
+        const pu32x4 a = src[3 * i], b = src[3 * i + 1], c = src[3 * i + 2];
+        d0[4 * i] = a; d0[4 * i + 1] = b; d0[4 * i + 2] = c; d0[4 * i + 3] = a ^ b;
+        d1[4 * i] = b; d1[4 * i + 1] = c; d1[4 * i + 2] = a; d1[4 * i + 3] = b ^ c;
+        d2[4 * i] = c; d2[4 * i + 1] = a; d2[4 * i + 2] = b; d2[4 * i + 3] = c ^ a;
+    }
+}
+
+// wave-contiguous 1024 pixels per step.  LOAD16: 3 coalesced 16 B loads per lane (1 KiB per instruction);
+// else 4 coalesced 12 B loads (768 B per instruction).  Stores: 4 x 1 KiB per plane, PLANE_MAJOR = one plane at a
+// time (4 KiB bursts), else plane-interleaved.  SLAB: consecutive steps of a wave are consecutive in memory
+// (each workgroup owns one contiguous slab) instead of grid-strided.
+template <bool LOAD16, bool PLANE_MAJOR, bool SLAB>
+__global__ __launch_bounds__(256) void k_probe_wave1k(const unsigned int *__restrict__ src, pu32x4 *__restrict__ d0,
+                                                      pu32x4 *__restrict__ d1, pu32x4 *__restrict__ d2, long long nsteps)
+{
+    const unsigned int lane = threadIdx.x & 63u;
+    const long long nwaves = (long long)gridDim.x * 4;
+    const long long wave = (long long)blockIdx.x * 4 + (threadIdx.x >> 6);
+    const long long per = (nsteps + nwaves - 1) / nwaves;
+    long long st = SLAB ? wave * per : wave;
+    const long long end = SLAB ? (st + per < nsteps ? st + per : nsteps) : nsteps;
+    const long long inc = SLAB ? 1 : nwaves;
+    for (; st < end; st += inc) {
+        pu32x4 v[4];
+        if (LOAD16) {
+            const pu32x4 *p = reinterpret_cast<const pu32x4 *>(src) + st * 192 + lane;
+            v[0] = p[0]; v[1] = p[64]; v[2] = p[128]; v[3] = v[0] ^ v[1];
+        } else {
+            // three dwords per lane (a 3-vector type would be padded to 16 bytes: never index memory with it)
+            const unsigned int *p = src + (st * 256 + lane) * 3;
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                const unsigned int a = p[192 * j], b = p[192 * j + 1], c = p[192 * j + 2];
+                v[j] = (pu32x4){a, b, c, a ^ b};
+            }
+        }
+        pu32x4 *o0 = d0 + st * 256 + lane, *o1 = d1 + st * 256 + lane, *o2 = d2 + st * 256 + lane;
+        if (PLANE_MAJOR) {
+#pragma unroll
+            for (int j = 0; j < 4; ++j) o0[64 * j] = v[j];
+#pragma unroll
+            for (int j = 0; j < 4; ++j) o1[64 * j] = v[(j + 1) & 3];
+#pragma unroll
+            for (int j = 0; j < 4; ++j) o2[64 * j] = v[(j + 2) & 3];
+        } else {
+#pragma unroll
+            for (int j = 0; j < 4; ++j) { o0[64 * j] = v[j]; o1[64 * j] = v[(j + 1) & 3]; o2[64 * j] = v[(j + 2) & 3]; }
+        }
+    }
+}
+
+// the plain mix with each workgroup on its own contiguous slab of quads instead of a grid stride
+__global__ __launch_bounds__(256) void k_probe_mix_slab(const unsigned int *__restrict__ src, pu32x4 *__restrict__ d0,
+                                                        pu32x4 *__restrict__ d1, pu32x4 *__restrict__ d2, long long nquads)
+{
+    const long long per = ((nquads + gridDim.x - 1) / gridDim.x + 255) / 256 * 256;
+    const long long lo = (long long)blockIdx.x * per;
+    const long long hi = lo + per < nquads ? lo + per : nquads;
+    for (long long i = lo + threadIdx.x; i < hi; i += 256) {
+        const unsigned int a = src[i * 3], b = src[i * 3 + 1], c = src[i * 3 + 2];
+        d0[i] = (pu32x4){a, b, c, a ^ b}; d1[i] = (pu32x4){b, c, a, b ^ c}; d2[i] = (pu32x4){c, a, b, c ^ a};
+    }
+}
+
+// read phase / write phase: N grid-strided 12 B loads, then the 3 N stores (N = 4 or 8)
+template <int N, bool PLANE_MAJOR>
+__global__ __launch_bounds__(256) void k_probe_mix_phase(const unsigned int *__restrict__ src, pu32x4 *__restrict__ d0,
+                                                         pu32x4 *__restrict__ d1, pu32x4 *__restrict__ d2, long long nquads)
+{
+    const long long stride = (long long)gridDim.x * 256;
+    long long i = (long long)blockIdx.x * 256 + threadIdx.x;
+    for (; i + (N - 1) * stride < nquads; i += N * stride) {
+        pu32x3 t[N];
+#pragma unroll
+        for (int j = 0; j < N; ++j) {
+            const unsigned int *q = src + (i + j * stride) * 3;
+            t[j] = (pu32x3){q[0], q[1], q[2]};
+        }
+        if (PLANE_MAJOR) {
+#pragma unroll
+            for (int j = 0; j < N; ++j) d0[i + j * stride] = (pu32x4){t[j].x, t[j].y, t[j].z, t[j].x ^ t[j].y};
+#pragma unroll
+            for (int j = 0; j < N; ++j) d1[i + j * stride] = (pu32x4){t[j].y, t[j].z, t[j].x, t[j].y ^ t[j].z};
+#pragma unroll
+            for (int j = 0; j < N; ++j) d2[i + j * stride] = (pu32x4){t[j].z, t[j].x, t[j].y, t[j].z ^ t[j].x};
+        } else {
+#pragma unroll
+            for (int j = 0; j < N; ++j) {
+                d0[i + j * stride] = (pu32x4){t[j].x, t[j].y, t[j].z, t[j].x ^ t[j].y};
+                d1[i + j * stride] = (pu32x4){t[j].y, t[j].z, t[j].x, t[j].y ^ t[j].z};
+                d2[i + j * stride] = (pu32x4){t[j].z, t[j].x, t[j].y, t[j].z ^ t[j].x};
+            }
+        }
+    }
+    for (; i < nquads; i += stride) {
+        const unsigned int a = src[i * 3], b = src[i * 3 + 1], c = src[i * 3 + 2];
+        d0[i] = (pu32x4){a, b, c, a ^ b}; d1[i] = (pu32x4){b, c, a, b ^ c}; d2[i] = (pu32x4){c, a, b, c ^ a};
+    }
+}
+
+// three planes written, nothing read: the write side of the mix on its own (48 B per lane and step)
+__global__ __launch_bounds__(256) void k_probe_write3(pu32x4 *__restrict__ d0, pu32x4 *__restrict__ d1, pu32x4 *__restrict__ d2,
+                                                      long long nquads)
+{
+    const long long stride = (long long)gridDim.x * 256;
+    const pu32x4 v = {threadIdx.x, blockIdx.x, 3u, 4u};
+    for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < nquads; i += stride) { d0[i] = v; d1[i] = v; d2[i] = v; }
+}
+
+// ---------------------------------------------------------------------------
 // instruction-issue probes: 16 independent chains of ONE instruction per loop
 // trip, every lane of every wave.  tools/probe.py turns the time into cycles
 // per wave64 instruction per SIMD (what the hot loops' VALU budget is made of).
@@ -203,7 +324,8 @@ static void issue_launch(int iters, int blocks, unsigned int *sink, hipStream_t 
 
 // kind: 0 read 16 B/lane, 1 read 12 B/lane, 2 copy 16 B/lane (bytes read + bytes written = 2*bytes), 3 write 16 B/lane,
 // 4 non-temporal write, 5 / 6 the fused kernel's mix (12 B read + 48 B written per lane; plain / non-temporal stores),
-// 7 the NDVI-plane mix (12 B read + 16 B written per lane); 100 + op: instruction-issue probe (unroll = loop trips)
+// 7 the NDVI-plane mix (12 B read + 16 B written per lane); 8..19 round-2 shapes of the 12 B / 48 B mix (see the
+// dispatch below; 19 writes the three planes without reading); 100 + op: instruction-issue probe (unroll = loop trips)
 extern "C" int lars_d_probe(int kind, int unroll, int blocks, const void *src, void *dst, int64_t bytes, void *stream)
 {
     ThreadCtx *c;
@@ -243,6 +365,26 @@ extern "C" int lars_d_probe(int kind, int unroll, int blocks, const void *src, v
     } else if (kind == 7) {
         const long long nquads = bytes / 28;               // total traffic = bytes
         hipLaunchKernelGGL(k_probe_mix1, dim3(blocks), dim3(256), 0, s, p, static_cast<pu32x4 *>(dst), nquads);
+    } else if (kind >= 8 && kind <= 19) {
+        // round-2 shapes of the 12 B-read / 48 B-written mix: total traffic = bytes (bytes / 5 read, 4 * bytes / 5 written)
+        const long long nquads = bytes / 60 / 256 * 256;                   // whole 1024-pixel steps
+        pu32x4 *d = static_cast<pu32x4 *>(dst);
+        pu32x4 *d1 = d + nquads, *d2 = d + 2 * nquads;
+        const dim3 g(blocks), b(256);
+        switch (kind) {
+        case 8: hipLaunchKernelGGL(k_probe_lane16, g, b, 0, s, reinterpret_cast<const pu32x4 *>(p), d, d1, d2, nquads / 4); break;
+        case 9: hipLaunchKernelGGL((k_probe_wave1k<true, false, false>), g, b, 0, s, p, d, d1, d2, nquads / 256); break;
+        case 10: hipLaunchKernelGGL((k_probe_wave1k<true, true, false>), g, b, 0, s, p, d, d1, d2, nquads / 256); break;
+        case 11: hipLaunchKernelGGL((k_probe_wave1k<false, true, false>), g, b, 0, s, p, d, d1, d2, nquads / 256); break;
+        case 12: hipLaunchKernelGGL((k_probe_wave1k<false, false, false>), g, b, 0, s, p, d, d1, d2, nquads / 256); break;
+        case 13: hipLaunchKernelGGL((k_probe_wave1k<false, true, true>), g, b, 0, s, p, d, d1, d2, nquads / 256); break;
+        case 14: hipLaunchKernelGGL(k_probe_mix_slab, g, b, 0, s, p, d, d1, d2, nquads); break;
+        case 15: hipLaunchKernelGGL((k_probe_mix_phase<4, false>), g, b, 0, s, p, d, d1, d2, nquads); break;
+        case 16: hipLaunchKernelGGL((k_probe_mix_phase<8, false>), g, b, 0, s, p, d, d1, d2, nquads); break;
+        case 17: hipLaunchKernelGGL((k_probe_mix_phase<4, true>), g, b, 0, s, p, d, d1, d2, nquads); break;
+        case 18: hipLaunchKernelGGL((k_probe_mix_phase<8, true>), g, b, 0, s, p, d, d1, d2, nquads); break;
+        default: hipLaunchKernelGGL(k_probe_write3, g, b, 0, s, d, d1, d2, nquads); break;      // 19: 48 of 60 bytes move
+        }
     } else if (kind == 99) {
         // shader clock: dst receives {shader cycles, 100 MHz ticks}; unroll = spin count; runs beside `blocks` busy blocks
         hipLaunchKernelGGL(k_probe_clock, dim3(blocks), dim3(256), 0, s, static_cast<unsigned long long *>(dst), unroll);

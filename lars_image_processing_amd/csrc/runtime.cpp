@@ -1,6 +1,7 @@
 // Runtime plumbing of liblars_hip.so: per-thread context, errors, memory,
-// streams, events, and the host-side fold of statistics records.
+// streams, events.  (Errors, the ABI version and the host-side fold of statistics records: host_core.cpp.)
 #include <stdarg.h>
+#include <stdlib.h>
 #include <string.h>
 
 #include <cmath>
@@ -10,7 +11,6 @@
 
 namespace lars {
 
-static thread_local std::string g_last_error;
 static thread_local ThreadCtx g_ctx;
 
 // A thread that used the library gives its stream, workspaces and FFT plan back when it ends (Streamlit sessions
@@ -30,27 +30,6 @@ struct CtxGuard {
     ~CtxGuard() { release_ctx(&g_ctx); }
 };
 static thread_local CtxGuard g_ctx_guard;
-
-void set_error(const char *fmt, ...)
-{
-    char buf[1024];
-    va_list ap;
-    va_start(ap, fmt);
-    vsnprintf(buf, sizeof buf, fmt, ap);
-    va_end(ap);
-    g_last_error = buf;
-}
-
-int fail(int code, const char *fmt, ...)
-{
-    char buf[1024];
-    va_list ap;
-    va_start(ap, fmt);
-    vsnprintf(buf, sizeof buf, fmt, ap);
-    va_end(ap);
-    g_last_error = buf;
-    return code;
-}
 
 static int bind_device(ThreadCtx *c, int ordinal)
 {
@@ -121,8 +100,6 @@ using namespace lars;
 
 extern "C" {
 
-int lars_abi_version(void) { return LARS_ABI_VERSION; }
-const char *lars_last_error(void) { return g_last_error.c_str(); }
 
 int lars_device_count(int *count)
 {
@@ -160,7 +137,12 @@ int lars_malloc(void **dptr, size_t bytes)
     ThreadCtx *c;
     LARS_TRY(ensure_ctx(&c));
     if (!dptr) return fail(LARS_ERR_INVALID, "lars_malloc: NULL");
-    hipError_t e = hipMalloc(dptr, bytes ? bytes : 1);
+    // LARS_MALLOC_KIND (experiments, tools/allocbench.py): 1 uncached, 2 fine-grained device memory instead of plain hipMalloc
+    const char *kind = getenv("LARS_MALLOC_KIND");
+    hipError_t e;
+    if (kind && kind[0] == '1') e = hipExtMallocWithFlags(dptr, bytes ? bytes : 1, hipDeviceMallocUncached);
+    else if (kind && kind[0] == '2') e = hipExtMallocWithFlags(dptr, bytes ? bytes : 1, hipDeviceMallocFinegrained);
+    else e = hipMalloc(dptr, bytes ? bytes : 1);
     if (e != hipSuccess) { *dptr = nullptr; return fail(LARS_ERR_OOM, "hipMalloc(%zu): %s", bytes, hipGetErrorString(e)); }
     return LARS_OK;
 }
@@ -276,6 +258,7 @@ int lars_set_tuning(const char *key, int value)
     else if (!strcmp(key, "hist_impl")) t.hist_impl = value;
     else if (!strcmp(key, "nt_stores")) t.nt_stores = value;
     else if (!strcmp(key, "blocks_per_tile")) t.blocks_per_tile = value;
+    else if (!strcmp(key, "traverse")) t.traverse = value;
     else return fail(LARS_ERR_INVALID, "lars_set_tuning: unknown key %s", key);
     return LARS_OK;
 }
@@ -287,6 +270,7 @@ int lars_get_tuning(const char *key, int *value)
     else if (!strcmp(key, "hist_impl")) *value = t.hist_impl;
     else if (!strcmp(key, "nt_stores")) *value = t.nt_stores;
     else if (!strcmp(key, "blocks_per_tile")) *value = t.blocks_per_tile;
+    else if (!strcmp(key, "traverse")) *value = t.traverse;
     else return fail(LARS_ERR_INVALID, "lars_get_tuning: unknown key %s", key);
     return LARS_OK;
 }
@@ -307,26 +291,6 @@ int lars_d_quot_selfcheck(uint32_t max_den, uint64_t *mismatches, uint32_t first
     *mismatches = h[0];
     first_bad[0] = (uint32_t)(h[1] & 0xFFFFFFFFu);
     first_bad[1] = (uint32_t)(h[1] >> 32);
-    return LARS_OK;
-}
-
-// Fold records of one index (tiles of a batch, or ranks): sums in the given
-// order (deterministic), min/max fold, integer fields add.
-int lars_stats_merge(const lars_stats *r, int64_t n, lars_stats *out)
-{
-    if (!r || !out || n <= 0) return fail(LARS_ERR_INVALID, "lars_stats_merge: bad arguments");
-    lars_stats m = r[0];
-    for (int64_t i = 1; i < n; ++i) {
-        m.sum += r[i].sum;
-        m.sumsq += r[i].sumsq;
-        m.count += r[i].count;
-        m.above += r[i].above;
-        m.nans += r[i].nans;
-        m.min = std::fmin(m.min, r[i].min);
-        m.max = std::fmax(m.max, r[i].max);
-        for (int b = 0; b < LARS_HIST_BINS; ++b) m.hist[b] += r[i].hist[b];
-    }
-    *out = m;
     return LARS_OK;
 }
 

@@ -3,7 +3,7 @@
 // package's own loader (lars_image_processing_amd/tiffio.py) keeps the full depth and calls this for the LZW flavour.
 #include <string.h>
 
-#include "common.h"
+#include "host_common.h"
 
 using namespace lars;
 

@@ -7,9 +7,9 @@ once (``lars_h_process_image``: white balance, all requested indices and their c
 upload) and decoding / encoding overlap the GPU work on a thread pool (PIL releases the GIL;
 the library gives every thread its own stream and workspace).
 
-``render="figure"`` reproduces the reference's matplotlib figure (imshow + colorbar, axes off);
-``render="lut"`` writes the per-pixel RGBA image of the same colormap at full resolution
-(no axes / colorbar: a different picture, hence opt-in).
+The index pictures are the per-pixel RGBA images of the reference's colormaps at full resolution (RdYlGn / RdYlBu,
+``vmin=-1, vmax=1``), produced by the fused kernel.  The reference's matplotlib figure (imshow + colorbar,
+``backend-process.py:40-47``) is figure rendering and not part of this package.
 """
 from __future__ import annotations
 
@@ -27,24 +27,10 @@ EXTENSIONS = {".tif", ".tiff", ".png", ".jpg", ".jpeg"}      # backend-process.p
 LUT_PNG_LEVEL = 1
 
 
-def _figure_png(index_array, index_type, path):
-    """backend-process.py:40-47, verbatim behaviour (plumbing; the index came from the GPU)."""
-    import matplotlib
-    matplotlib.use("Agg", force=False)
-    import matplotlib.pyplot as plt
-    plt.figure(figsize=(10, 8), dpi=100)
-    cmap = "RdYlBu" if index_type == "NDWI" else "RdYlGn"
-    plt.imshow(index_array, cmap=cmap, vmin=-1, vmax=1)
-    plt.colorbar(label=index_type)
-    plt.axis("off")
-    plt.savefig(path, bbox_inches="tight", pad_inches=0)
-    plt.close()
-
-
-def process_image(image_path, output_dir, process_wb=False, indices=None, render="figure", full_depth=False, lut_format="png"):
+def process_image(image_path, output_dir, process_wb=False, indices=None, full_depth=False, lut_format="png"):
     """One file: same outputs as backend-process.py:49-73.  Returns the statistics dicts.
     ``full_depth=True`` reads three-sample 16-bit TIFFs at their full depth (``tiffio.read_image``; Pillow, hence the
-    reference, keeps their high bytes only).  ``lut_format="tiff"`` (with ``render="lut"``) writes the colormap images as
+    reference, keeps their high bytes only).  ``lut_format="tiff"`` writes the colormap images as
     uncompressed RGBA TIFFs ``<name>_<index>.tif`` instead of PNGs: PNG compression of a 4096 x 4096 map takes seconds,
     the GPU work milliseconds."""
     if lut_format not in ("png", "tiff"):
@@ -57,8 +43,7 @@ def process_image(image_path, output_dir, process_wb=False, indices=None, render
     if arr.ndim != 3 or arr.shape[2] < 3:
         raise ValueError(f"{image_path.name}: expected an image with at least 3 channels, got shape {arr.shape}")
     indices = list(indices or [])
-    res = api.process_image(arr, indices=indices, white_balance=True, want_arrays=(render == "figure"),
-                            want_rgba=(render == "lut")) if indices else None
+    res = api.process_image(arr, indices=indices, white_balance=True, want_arrays=False, want_rgba=True) if indices else None
     corrected = res["corrected"] if res else api.fix_white_balance(arr)
     if process_wb:
         (output_dir / "white_balanced").mkdir(parents=True, exist_ok=True)
@@ -69,19 +54,17 @@ def process_image(image_path, output_dir, process_wb=False, indices=None, render
         (output_dir / t).mkdir(parents=True, exist_ok=True)
         out = output_dir / t / f"{name}_{t.lower()}.png"
         entry = res["indices"][t]
-        if render == "lut" and lut_format == "tiff":
+        if lut_format == "tiff":
             from .tiffio import write_tiff
             write_tiff(out.with_suffix(".tif"), entry["rgba"])
-        elif render == "lut":
-            Image.fromarray(entry["rgba"], "RGBA").save(out, compress_level=LUT_PNG_LEVEL)
         else:
-            _figure_png(entry["index"], t, out)
+            Image.fromarray(entry["rgba"], "RGBA").save(out, compress_level=LUT_PNG_LEVEL)
         stats[t] = entry["stats"]
     return stats
 
 
 def batch_process(input_dir, output_dir, process_wb=False, process_ndvi=False, process_gndvi=False,
-                  process_ndwi=True, render="figure", workers=4, verbose=True, full_depth=False, lut_format="png"):
+                  process_ndwi=True, workers=4, verbose=True, full_depth=False, lut_format="png"):
     """backend-process.py:75-97 with its module constants as arguments.  Returns ``{file name: stats | error}``."""
     input_path, output_path = Path(input_dir), Path(output_dir)
     indices = [t for t, on in (("NDVI", process_ndvi), ("GNDVI", process_gndvi), ("NDWI", process_ndwi)) if on]
@@ -94,14 +77,13 @@ def batch_process(input_dir, output_dir, process_wb=False, process_ndvi=False, p
         try:
             if verbose:
                 print(f"Processing {idx}/{total}: {f.name}")
-            return f.name, process_image(f, output_path, process_wb, indices or None, render, full_depth, lut_format)
+            return f.name, process_image(f, output_path, process_wb, indices or None, full_depth, lut_format)
         except Exception as e:                              # same policy as upstream :96-97
             if verbose:
                 print(f"Error processing {f.name}: {str(e)}")
             return f.name, e
 
-    if render == "figure" or workers <= 1:
-        # matplotlib's pyplot state machine is not thread-safe: keep the figure path serial
+    if workers <= 1:
         for job in enumerate(files, 1):
             k, v = one(job)
             results[k] = v
@@ -112,26 +94,22 @@ def batch_process(input_dir, output_dir, process_wb=False, process_ndvi=False, p
     return results
 
 
-def export_zip(image_array, selected_indices, corrected_array=None, render="lut"):
+def export_zip(image_array, selected_indices, corrected_array=None):
     """ZIP of the processed images of one upload (``download_processed_images``,
-    process-images.py:567-617): ``white_balanced.png`` + ``<INDEX>_visualization.png`` per index.
-
-    ``render="lut"`` writes the full-resolution per-pixel colormap image (one GPU pass for white
-    balance, every index and every colormap; no matplotlib figure), ``render="figure"`` the
-    reference's figure.  ``corrected_array`` (the cached white-balanced image the UI keeps,
-    process-images.py:1132) skips the white-balance step.
+    process-images.py:567-617): ``white_balanced.png`` + ``<INDEX>_visualization.png`` per index, the latter as
+    full-resolution per-pixel colormap images (one GPU pass for white balance, every index and every colormap).
+    ``corrected_array`` (the cached white-balanced image the UI keeps, process-images.py:1132) skips the
+    white-balance step.
     """
     import io
     import zipfile
     from PIL import Image
     indices = list(selected_indices)
     if corrected_array is not None:
-        res = api.process_image(np.asarray(corrected_array), indices=indices, white_balance=False,
-                                want_arrays=(render == "figure"), want_rgba=(render == "lut"))
+        res = api.process_image(np.asarray(corrected_array), indices=indices, white_balance=False, want_arrays=False, want_rgba=True)
         corrected = np.asarray(corrected_array)
     else:
-        res = api.process_image(np.asarray(image_array), indices=indices, white_balance=True,
-                                want_arrays=(render == "figure"), want_rgba=(render == "lut"))
+        res = api.process_image(np.asarray(image_array), indices=indices, white_balance=True, want_arrays=False, want_rgba=True)
         corrected = res["corrected"]
     buf = io.BytesIO()
     with zipfile.ZipFile(buf, "w", zipfile.ZIP_DEFLATED) as zf:
@@ -140,12 +118,6 @@ def export_zip(image_array, selected_indices, corrected_array=None, render="lut"
         zf.writestr("white_balanced.png", png.getvalue())
         for t in indices:
             png = io.BytesIO()
-            if render == "lut":
-                Image.fromarray(res["indices"][t]["rgba"], "RGBA").save(png, format="PNG", compress_level=LUT_PNG_LEVEL)
-            else:
-                import tempfile
-                with tempfile.NamedTemporaryFile(suffix=".png") as tmp:
-                    _figure_png(res["indices"][t]["index"], t, tmp.name)
-                    png.write(open(tmp.name, "rb").read())
+            Image.fromarray(res["indices"][t]["rgba"], "RGBA").save(png, format="PNG", compress_level=LUT_PNG_LEVEL)
             zf.writestr(f"{t}_visualization.png", png.getvalue())
     return buf.getvalue()

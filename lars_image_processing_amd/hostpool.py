@@ -1,4 +1,10 @@
-"""Recycled host result buffers.
+"""Recycled host result buffers -- OPT-IN (``LARS_HOST_POOL_MB`` > 0; the default is 0 = plain ``np.empty``).
+
+The documented contract of the host API is "outputs are fresh host ndarrays owned by the caller" (SURVEY.md 8(b)).
+With the pool on, results of 1 MiB or more are VIEWS (``OWNDATA`` False) of recycled byte buffers, and whether a buffer
+may be handed out again is read off its CPython reference count: correct for every NumPy consumer (each view holds a
+reference to the owner), wrong for a consumer that keeps only a raw pointer (ctypes, a C extension) and not portable to
+interpreters without immediate reference counts.  Hence off unless the operator of a long-running host asks for it.
 
 What the large-output calls of the host API pay for is not PCIe but the first touch of freshly allocated result
 arrays (about 11 ms of page faults and zeroing per 192 MiB) -- and a caller that recomputes
@@ -7,8 +13,8 @@ out views of byte buffers that stay mapped; a buffer is handed out again only wh
 (its reference count says so: every view of it, however derived, holds a reference to the owner), so an array the
 caller still holds -- or any slice of it -- is never overwritten.
 
-``LARS_HOST_POOL_MB`` bounds the memory kept (default 1024; 0 turns the pool off: plain ``np.empty``).  Results
-below 1 MiB never go through the pool.
+``LARS_HOST_POOL_MB`` bounds the memory kept (default 0 = pool off: plain ``np.empty``; e.g. 1024 for a Streamlit
+host that recomputes 4096 x 4096 images).  Results below 1 MiB never go through the pool.
 """
 from __future__ import annotations
 
@@ -18,7 +24,7 @@ import threading
 
 import numpy as np
 
-LIMIT_BYTES = int(os.environ.get("LARS_HOST_POOL_MB", "1024")) << 20
+LIMIT_BYTES = int(os.environ.get("LARS_HOST_POOL_MB", "0")) << 20
 MIN_BYTES = 1 << 20
 _lock = threading.Lock()
 _buffers = []                       # owners (uint8, one allocation each), idle or handed out

@@ -95,10 +95,14 @@ def _chunk(buf, offset, nbytes, compression, want):
         raise TiffError("strip / tile data outside the file")
     raw = bytes(buf[offset:offset + nbytes])
     if compression != 1:
+        # bounded inflate: a small strip must not be able to inflate past what the directory says it holds
         try:
-            raw = zlib.decompress(raw)
+            z = zlib.decompressobj()
+            raw = z.decompress(raw, want)
         except zlib.error as exc:
             raise TiffError(f"corrupt Deflate data: {exc}") from None
+        if z.unconsumed_tail:
+            raise TiffError(f"Deflate strip / tile inflates past its {want} bytes")
     if len(raw) < want:
         raise TiffError(f"strip / tile holds {len(raw)} bytes, {want} expected")
     return raw[:want]

@@ -254,6 +254,40 @@ def wb_closed_form(img_array):
     return out
 
 
+def wb_float_closed_form(img_array):
+    """``wb_app`` for any other sample type, spelled the way csrc/wb_generic.hip does it: the reference's own
+    ``astype(np.float32)`` (process-images.py:431), then per channel the two order statistics next to each percentile's
+    virtual index (n - 1) * q, numpy's ``_lerp`` for float32 data (difference b - a in float32, blend in float64,
+    ``b - d * (1 - t)`` where ``t >= 0.5``), the float64 stretch of :438, a float32 store and a truncating cast (:441;
+    NaN -> 0).  Returns ``(uint8 image, float64 percentiles[3][2])``."""
+    f = img_array.astype(np.float32)
+    n = f.shape[0] * f.shape[1]
+    out = np.zeros(f.shape, dtype=np.uint8)
+    pcts = np.zeros((3, 2), dtype=np.float64)
+    for band in (0, 1, 2):
+        ordered = np.sort(f[:, :, band].ravel())
+        for j, q in enumerate((2.0, 98.0)):
+            vi = np.float64(n - 1) * (q / 100.0)
+            k0 = int(np.floor(vi))
+            k1 = min(k0 + 1, n - 1)
+            t = vi - np.floor(vi)
+            a, b = ordered[k0], ordered[k1]
+            with np.errstate(all="ignore"):
+                d = np.float64(np.float32(b - a))               # float32 subtraction, then widened
+                r = np.float64(a) + d * t
+                if t >= 0.5:
+                    r = np.float64(b) - d * (1.0 - t)
+            pcts[band, j] = r
+        lo, span = pcts[band, 0], pcts[band, 1] - pcts[band, 0]
+        with np.errstate(all="ignore"):
+            v = (f[:, :, band].astype(np.float64) - lo) / span * 255.0
+            nan = np.isnan(v)
+            v = np.where(v < 0.0, 0.0, np.where(v > 255.0, 255.0, v))
+            u = np.where(nan, 0.0, v).astype(np.float32).astype(np.uint8)
+        out[:, :, band] = u
+    return out, pcts
+
+
 def index_closed_form(a, b):
     """(a-b)/(a+b) in IEEE float32 with +0.0 where a+b == 0.
 

@@ -185,23 +185,21 @@ def test_timeframe_table_matches_reference_rows(lars, index_type):
     assert maxs == list(df["Max"]) and mins == list(df["Min"]) and means == list(df["Mean"])
 
 
-def test_figures_render(lars):
-    series = _series(3, shape=(128, 160))
-    fig = lars.create_time_series_plot(series, "NDVI")
-    assert fig.size[0] > 300 and fig.size[1] > 200
-    assert lars.create_time_series_plot(series[:1], "NDVI") is None
-    fig = lars.create_change_detection_visualization(series[:2], "GNDVI")
-    assert fig.size[0] > 600
-    assert lars.create_change_detection_visualization(series[:1], "GNDVI") is None
-    # create_index_visualization / create_comparison_view (process-images.py:669-799)
+def test_no_figure_plumbing_in_the_package(lars):
+    """Figure rendering is out of scope: the package hands the reference's own figure
+    functions their numbers and imports no matplotlib; the per-pixel colormap of an index stays available."""
+    import os
+    import re
+    pkg = os.path.dirname(lars.__file__)
+    for name in os.listdir(pkg):
+        if name.endswith(".py"):
+            text = open(os.path.join(pkg, name)).read()
+            assert not re.search(r"^\s*(import|from)\s+matplotlib", text, re.M), name
+    for gone in ("create_time_series_plot", "create_change_detection_visualization", "create_index_visualization",
+                 "create_comparison_view"):
+        assert not hasattr(lars, gone), gone
+    series = _series(2, shape=(64, 80))
     idx = lars.calculate_index(orc.wb_app(series[0]["array"]), "NDWI")
-    assert lars.create_index_visualization(idx, "NDWI").size[0] > 300
-    assert lars.create_index_visualization(None, "NDWI") is None
-    lut_img = lars.create_index_visualization(idx, "NDWI", render="lut")
-    assert lut_img.size == (idx.shape[1], idx.shape[0]) and lut_img.mode == "RGBA"
-    panels = [{"metadata": {"filename": f"f{k}.png"}, "array": lars.calculate_index(orc.wb_app(s_["array"]), "NDVI")}
-              for k, s_ in enumerate(series)]
-    view, stats = lars.create_comparison_view(panels, "NDVI")
-    assert view.size[0] > 300 and list(stats) == ["f0.png", "f1.png", "f2.png"]
-    assert stats["f1.png"] == lars.analyze_index(panels[1]["array"], "NDVI")
-    assert lars.create_comparison_view([], "NDVI") == (None, {})
+    rgba = lars.colorize_index(idx, "NDWI")
+    assert rgba.shape == idx.shape + (4,) and rgba.dtype == np.uint8
+    np.testing.assert_array_equal(rgba, orc.colormap_closed_form(idx, lars.colormap_lut("RdYlBu")))

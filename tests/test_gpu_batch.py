@@ -377,8 +377,10 @@ def test_output_ring_placement_trials(lars):
     b = lars.TileBatch.synthetic(6, 64, 96, seed=5, profile="vegetation")
     plain = b.make_outputs(index=True, ring=2)
     tuned = b.make_outputs(index=True, ring=2, placement_trials=3)
-    assert len(tuned.placement_ms["planes"]) == 9 and tuned.placement_ms["chosen"] == min(tuned.placement_ms["rings"]) > 0
+    assert len(tuned.placement_ms["arenas"]) == 3 and tuned.placement_ms["chosen"] == min(tuned.placement_ms["arenas"]) > 0
     assert not hasattr(plain, "placement_ms")
+    # the three index planes are slices of one allocation, in index order
+    assert [tuned.index[k].ptr - tuned.arena.ptr for k in range(3)] == [0, tuned.plane_bytes, 2 * tuned.plane_bytes]
     rec_a = b.process(outputs=plain)
     ndvi_a = plain.host_index("NDVI", 1, 1)
     rec_b = b.process(outputs=tuned)
@@ -518,8 +520,10 @@ def test_bad_arguments_fail_cleanly(lars):
     hist64.free(); stats.free()
     assert lib.lars_set_tuning(b"no_such_knob", 1) == -1
     assert lib.lars_set_device(99) == -1 and b"out of range" in lib.lars_last_error()
+    # float images are white-balanced like the reference does (a constant image: 0/0 -> NaN -> 0 everywhere)
+    assert not lars.fix_white_balance(np.zeros((4, 4, 3), np.float32)).any()
     with pytest.raises(TypeError):
-        lars.fix_white_balance(np.zeros((4, 4, 3), np.float32))
+        lars.fix_white_balance(np.zeros((4, 4, 3), dtype=complex))
     # the library still works afterwards
     rec = b.process(indices=("NDVI",))
     assert int(rec[0, 0]["count"]) == 256

@@ -24,7 +24,7 @@ def test_batch_process_directory(tmp_path):
     Image.fromarray(rng.integers(0, 256, (20, 20), dtype=np.uint8)).save(src / "gray.png")   # fails like upstream: skipped
     (src / "notes.txt").write_text("not an image")
     res = driver.batch_process(src, dst, process_wb=True, process_ndvi=True, process_gndvi=True, process_ndwi=True,
-                               render="lut", workers=3, verbose=False)
+                               workers=3, verbose=False)
     assert set(res) == {"a.png", "b.tif", "c.PNG", "gray.png"} and isinstance(res["gray.png"], Exception)
     for name, arr in imgs.items():
         stem = name.rsplit(".", 1)[0]
@@ -44,16 +44,17 @@ def test_batch_process_directory(tmp_path):
                 else:
                     assert res[name][t][key] == val
     # uncompressed TIFF colormap images instead of PNGs: same pixels
-    driver.batch_process(src, tmp_path / "tif", process_ndvi=True, process_ndwi=False, render="lut", lut_format="tiff",
+    driver.batch_process(src, tmp_path / "tif", process_ndvi=True, process_ndwi=False, lut_format="tiff",
                          workers=2, verbose=False)
     for name in imgs:
         stem = name.rsplit(".", 1)[0]
         np.testing.assert_array_equal(lars.read_tiff(tmp_path / "tif" / "NDVI" / f"{stem}_ndvi.tif"),
                                       np.array(Image.open(dst / "NDVI" / f"{stem}_ndvi.png")))
-    # the reference's own figure style, serial path
-    res2 = driver.batch_process(src, tmp_path / "fig", process_wb=False, process_ndwi=True, render="figure", verbose=False)
-    assert (tmp_path / "fig" / "NDWI" / "a_ndwi.png").stat().st_size > 1000
-    assert not (tmp_path / "fig" / "white_balanced").exists() and "Water Coverage (%)" in res2["a.png"]["NDWI"]
+    # the reference's defaults (backend-process.py:12-15: NDWI only, no white-balanced copies), serial path
+    res2 = driver.batch_process(src, tmp_path / "ser", workers=1, verbose=False)
+    np.testing.assert_array_equal(np.array(Image.open(tmp_path / "ser" / "NDWI" / "a_ndwi.png")),
+                                  np.array(Image.open(dst / "NDWI" / "a_ndwi.png")))
+    assert not (tmp_path / "ser" / "white_balanced").exists() and "Water Coverage (%)" in res2["a.png"]["NDWI"]
 
 
 def test_sixteen_bit_tiff_at_reference_depth_and_at_full_depth(tmp_path):
@@ -69,7 +70,7 @@ def test_sixteen_bit_tiff_at_reference_depth_and_at_full_depth(tmp_path):
     tiffio.write_tiff(src / "scene.tif", img, tile=(16, 32), deflate=True, predictor=True)
     for full, arr in ((False, (img >> 8).astype(np.uint8)), (True, img)):
         dst = tmp_path / f"out{int(full)}"
-        res = driver.batch_process(src, dst, process_wb=True, process_ndvi=True, process_ndwi=True, render="lut",
+        res = driver.batch_process(src, dst, process_wb=True, process_ndvi=True, process_ndwi=True,
                                    workers=1, verbose=False, full_depth=full)
         assert not isinstance(res["scene.tif"], Exception), res["scene.tif"]
         with warnings.catch_warnings():
@@ -128,7 +129,12 @@ def test_ndvi_report_and_zip_keep_the_reference_file_layout(tmp_path):
     assert list(stats) == list(ws)
     for k, v in ws.items():
         assert stats[k] == pytest.approx(v, rel=1e-9, abs=1e-12), k
-    assert sorted(p.name for p in out.iterdir()) == ["ndvi_histogram.png", "ndvi_statistics.txt", "ndvi_visualization.png"]
+    assert sorted(p.name for p in out.iterdir()) == ["ndvi_histogram.csv", "ndvi_statistics.txt", "ndvi_visualization.png"]
+    rows = (out / "ndvi_histogram.csv").read_text().splitlines()
+    assert rows[0] == "bin_left,bin_right,pixel_count" and len(rows) == 51
+    np.testing.assert_array_equal([int(r.split(",")[2]) for r in rows[1:]], orc.hist50(want))
+    picture = np.array(Image.open(out / "ndvi_visualization.png"))
+    np.testing.assert_array_equal(picture, orc.colormap_closed_form(want.astype(np.float32), lars.colormap_lut("RdYlGn")))
     text = (out / "ndvi_statistics.txt").read_text().splitlines()
     assert text[0] == "NDVI Statistics:" and text[1:] == [f"{k}: {v:.4f}" for k, v in ws.items()]
     corrected = lars.fix_white_balance(img)

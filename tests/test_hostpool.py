@@ -4,7 +4,32 @@ import threading
 
 import numpy as np
 
+import pytest
+
 from lars_image_processing_amd import hostpool as hp
+
+
+@pytest.fixture(autouse=True)
+def pool_on(monkeypatch):
+    """The pool is opt-in (LARS_HOST_POOL_MB, default 0): switch it on for these tests."""
+    monkeypatch.setattr(hp, "LIMIT_BYTES", 1 << 30)
+    hp.clear()
+    yield
+    hp.clear()
+
+
+def test_pool_is_off_by_default(monkeypatch):
+    """Default contract: fresh arrays that own their data; views of recycled buffers only on request."""
+    import importlib
+    import os
+    monkeypatch.delenv("LARS_HOST_POOL_MB", raising=False)
+    fresh = importlib.reload(hp)
+    try:
+        assert fresh.LIMIT_BYTES == 0
+        a = fresh.empty((1024, 1024), np.float32)
+        assert a.flags.owndata and fresh.stats()[0] == 0
+    finally:
+        importlib.reload(hp)
 
 
 def test_reuse_only_after_every_view_is_gone():

@@ -4,12 +4,13 @@ These pin the oracle: every statement function must reproduce the reference's
 outputs bit for bit (arrays) / exactly (dict floats) on the committed goldens,
 and every closed form must agree with its statement function.
 """
+import os
 import warnings
 
 import numpy as np
 import pytest
 
-from conftest import golden_case_names
+from conftest import GOLDEN_DIR, golden_case_names
 from oracle import index_oracle as orc
 
 CASES = golden_case_names()
@@ -195,3 +196,29 @@ def test_lanczos_restatement_matches_reference(resize_golden, golden_dicts, case
     np.testing.assert_array_equal(got, want)
     assert (got is img) == bool(resize_golden[f"{case}/same_object"])
     assert golden_dicts["dicts"]["contract/resize_none"] == "None" and ro.preprocess_large_image(None) is None
+
+
+# ---- white balance of samples that are neither uint8 nor uint16 (tests/golden/wb_dtypes.npz, reference-produced) ----
+def _dtype_golden():
+    with np.load(os.path.join(GOLDEN_DIR, "wb_dtypes.npz"), allow_pickle=False) as z:
+        return {k: z[k] for k in z.files}
+
+
+DTYPE_CASES = sorted({k.split("/")[0] for k in _dtype_golden()})
+
+
+@pytest.mark.parametrize("case", DTYPE_CASES)
+def test_wb_of_other_sample_types(case):
+    g = _dtype_golden()
+    img, want = g[f"{case}/input"], g[f"{case}/wb"]
+    with warnings.catch_warnings():
+        warnings.simplefilter("ignore")
+        np.testing.assert_array_equal(orc.wb_app(img), want)                   # the statement
+        got, pcts = orc.wb_float_closed_form(img)                             # the kernels' spelling
+    np.testing.assert_array_equal(got, want)
+    ref_p = g[f"{case}/percentiles"]
+    same = (pcts == ref_p) | (np.isnan(pcts) & np.isnan(ref_p))
+    assert same.all(), (pcts, ref_p)
+    assert want.dtype == np.uint8 and want.shape == img.shape
+    if img.shape[2] > 3:
+        assert (want[:, :, 3:] == 0).all()

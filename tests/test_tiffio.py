@@ -256,3 +256,34 @@ def test_corrupt_files_raise_tiff_error_only(tmp_path):
             assert isinstance(out, np.ndarray)
         except tiffio.TiffError:
             pass
+
+
+def test_deflate_strip_cannot_inflate_past_its_declared_size(tmp_path):
+    """A Deflate strip that inflates to far more than the directory says is refused after `want` bytes, not inflated whole."""
+    import zlib
+    a = np.zeros((64, 64, 3), np.uint8)
+    tiffio.write_tiff(tmp_path / "z.tif", a, deflate=True)
+    blob = bytearray((tmp_path / "z.tif").read_bytes())
+    good = zlib.compress(a.tobytes(), 6)
+    at = bytes(blob).find(good)
+    assert at > 0
+    bomb = zlib.compress(bytes(64 << 20), 9)                     # 64 MiB of zeros in ~64 KiB
+    # splice the bomb in place of the strip: same offset, byte count patched through a fresh file layout
+    ifd_off = struct.unpack_from("<I", blob, 4)[0]
+    tail = bytes(blob[at + len(good):])
+    new = bytes(blob[:at]) + bomb + tail
+    shift = len(bomb) - len(good)
+    new = bytearray(new)
+    if ifd_off > at:
+        struct.pack_into("<I", new, 4, ifd_off + shift)
+        ifd_off += shift
+    n = struct.unpack_from("<H", new, ifd_off)[0]
+    for k in range(n):
+        e = ifd_off + 2 + 12 * k
+        tag, typ, cnt, val = struct.unpack_from("<HHII", new, e)
+        if tag == 279 and cnt == 1:                               # StripByteCounts
+            struct.pack_into("<I", new, e + 8, len(bomb))
+        elif cnt * {1: 1, 2: 1, 3: 2, 4: 4, 5: 8}.get(typ, 1) > 4 and val > at:
+            struct.pack_into("<I", new, e + 8, val + shift)       # out-of-line values moved with the tail
+    with pytest.raises(tiffio.TiffError, match="inflates past"):
+        tiffio.read_tiff(bytes(new))

@@ -42,7 +42,7 @@ def main():
                 dst = os.path.join(root, f"out_{fmt}_{w}")
                 t0 = time.perf_counter()
                 res = driver.batch_process(src, dst, process_wb=True, process_ndvi=True, process_gndvi=True, process_ndwi=True,
-                                           render="lut", lut_format=fmt, workers=w, verbose=False)
+                                           lut_format=fmt, workers=w, verbose=False)
                 dt = time.perf_counter() - t0
                 bad = [k for k, v in res.items() if isinstance(v, Exception)]
                 assert not bad, (bad, res[bad[0]])

@@ -87,6 +87,30 @@ def make_cases():
     return cases
 
 
+def make_dtype_cases():
+    """Images whose samples are neither uint8 nor uint16 (the reference casts anything with astype(np.float32),
+    process-images.py:431).  name -> input array."""
+    rng = lambda s: np.random.default_rng(s)
+    cases = {}
+    cases["f32_normal_40x52"] = rng(40).normal(100.0, 40.0, (40, 52, 3)).astype(np.float32)
+    cases["f32_unit_33x47"] = rng(41).random((33, 47, 3), dtype=np.float32)
+    cases["i32_wide_40x40"] = rng(42).integers(-5000, 70000, (40, 40, 3)).astype(np.int32)
+    cases["f64_48x32"] = rng(43).normal(0.3, 0.1, (48, 32, 3))
+    cases["i64_big_24x24"] = rng(44).integers(0, 1 << 40, (24, 24, 3)).astype(np.int64)
+    cases["f16_20x30"] = rng(45).normal(50.0, 20.0, (20, 30, 3)).astype(np.float16)
+    cases["f32_rgba_9x11"] = rng(46).normal(10.0, 3.0, (9, 11, 4)).astype(np.float32)
+    cases["i16_neg_31x17"] = rng(47).integers(-300, 300, (31, 17, 3)).astype(np.int16)
+    cases["bool_16x16"] = rng(48).integers(0, 2, (16, 16, 3)).astype(bool)
+    flat = rng(49).normal(5.0, 1.0, (30, 30, 3)).astype(np.float32)
+    flat[:, :, 0] = 2.5                               # constant channel: 0/0 -> NaN -> 0
+    flat[:, :, 1] = np.where(rng(50).random((30, 30)) < 0.99, 7.0, flat[:, :, 1]).astype(np.float32)   # p2 == p98, not constant: x/0 -> +-inf
+    cases["f32_degenerate_30x30"] = flat
+    cases["f32_1x1"] = np.array([[[1.5, -2.0, 3.25]]], dtype=np.float32)
+    few = (rng(51).integers(0, 4, (29, 31, 3)) * 0.3 + 0.1).astype(np.float32)      # ties: the two neighbours often coincide
+    cases["f32_ties_29x31"] = few
+    return cases
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--reference", default="/root/reference")
@@ -162,6 +186,15 @@ def main():
         except Exception as e:
             dicts["contract/index_2d"] = type(e).__name__
 
+    # white balance of other sample types (separate file: reference_outputs.npz stays byte-identical)
+    dtypes = {}
+    with warnings.catch_warnings():
+        warnings.simplefilter("ignore")
+        for name, img in make_dtype_cases().items():
+            dtypes[f"{name}/input"] = img
+            dtypes[f"{name}/wb"] = app.fix_white_balance(img)
+            dtypes[f"{name}/percentiles"] = np.array([np.percentile(img[:, :, c].astype(np.float32), (2, 98)) for c in range(3)])
+
     # colormaps: the per-pixel mapping imshow(cmap, vmin=-1, vmax=1) applies
     from matplotlib.colors import Normalize
     probe = np.concatenate([
@@ -223,6 +256,7 @@ def main():
     os.makedirs(args.out, exist_ok=True)
     np.savez_compressed(os.path.join(args.out, "reference_outputs.npz"), **arrays)
     np.savez_compressed(os.path.join(args.out, "resize_outputs.npz"), **resize)
+    np.savez_compressed(os.path.join(args.out, "wb_dtypes.npz"), **dtypes)
     with open(os.path.join(args.out, "reference_dicts.json"), "w") as fh:
         json.dump({"meta": meta, "dicts": dicts}, fh, indent=1)   # insertion order kept: key order is contract
     total = sum(a.nbytes for a in arrays.values())

@@ -99,6 +99,7 @@ struct Tuning {
     int hist_impl = 2;
     int nt_stores = 0;         // non-temporal stores for the float32 planes
     int blocks_per_tile = 0;   // 0 = automatic
+    int count_mode = -1;       // statistics-only kernels, A/B only: 3 = float coverage counters (fused_v2.hip)
     int traverse = -1;         // plane-writing kernel, A/B only: -1 / 1 the shipped mapping, 0 and 2 see k_fused_u8c3
 };
 Tuning &tuning();

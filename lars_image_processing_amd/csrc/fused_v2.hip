@@ -644,6 +644,12 @@ namespace lars {
 template <unsigned MASK, bool WB, int STATS>
 static void v2_launch_out(bool out, bool nt, dim3 grid, hipStream_t s, const FusedParams &P)
 {
+    // A/B of the coverage counters in one process (lars_set_tuning("count_mode", 3)): float counters, only instantiated
+    // for the two statistics-only configurations the bench reports
+    if (!out && tuning().count_mode == 3 && WB && STATS == 1 && (MASK == 7u || MASK == 1u)) {
+        hipLaunchKernelGGL((k_fused_v2<(MASK == 7u ? 7u : 1u), true, 1, false, false, false, 3>), grid, dim3(V2Block<false>::threads), 0, s, P);
+        return;
+    }
     if (!out) hipLaunchKernelGGL((k_fused_v2<MASK, WB, STATS, false, false>), grid, dim3(V2Block<false>::threads), 0, s, P);
     else if (nt) hipLaunchKernelGGL((k_fused_v2<MASK, WB, STATS, true, true>), grid, dim3(512), 0, s, P);
     else hipLaunchKernelGGL((k_fused_v2<MASK, WB, STATS, true, false>), grid, dim3(512), 0, s, P);

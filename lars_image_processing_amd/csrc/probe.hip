@@ -210,6 +210,36 @@ __global__ __launch_bounds__(256) void k_probe_write3(pu32x4 *__restrict__ d0, p
     for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < nquads; i += stride) { d0[i] = v; d1[i] = v; d2[i] = v; }
 }
 
+// Infinity Cache (MALL) probes.  k_probe_resweep: `reps` read-only sweeps over the same `nvec` 12-byte vectors inside one
+// launch (no barrier between sweeps: every vector is read again after about one sweep's worth of other reads).
+// WRITE: each sweep also writes 4 x as many bytes as it reads to a destination that is never read (3 planes of 16-byte
+// vectors, a different range every sweep) -- does the write stream evict the input from the cache?
+template <bool WRITE, bool NT>
+__global__ __launch_bounds__(256) void k_probe_resweep(const unsigned int *__restrict__ src, long long nquads, int reps,
+                                                       pu32x4 *__restrict__ dst, long long dst_quads, unsigned int *__restrict__ sink)
+{
+    unsigned int acc = 0;
+    const long long stride = (long long)gridDim.x * 256;
+    for (int r = 0; r < reps; ++r) {
+        pu32x4 *d0 = dst + (long long)r * 3 * nquads % (dst_quads > 0 ? dst_quads : 1);
+        for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < nquads; i += stride) {
+            const unsigned int a = src[i * 3], b = src[i * 3 + 1], c = src[i * 3 + 2];
+            acc ^= a ^ b ^ c;
+            if (WRITE) {
+                const pu32x4 v0 = {a, b, c, a ^ b}, v1 = {b, c, a, b ^ c}, v2 = {c, a, b, c ^ a};
+                if (NT) {
+                    __builtin_nontemporal_store(v0, d0 + i);
+                    __builtin_nontemporal_store(v1, d0 + nquads + i);
+                    __builtin_nontemporal_store(v2, d0 + 2 * nquads + i);
+                } else {
+                    d0[i] = v0; d0[nquads + i] = v1; d0[2 * nquads + i] = v2;
+                }
+            }
+        }
+    }
+    if (acc == 0x12345678u) sink[0] = acc;
+}
+
 // ---------------------------------------------------------------------------
 // instruction-issue probes: 16 independent chains of ONE instruction per loop
 // trip, every lane of every wave.  tools/probe.py turns the time into cycles
@@ -385,6 +415,16 @@ extern "C" int lars_d_probe(int kind, int unroll, int blocks, const void *src, v
         case 18: hipLaunchKernelGGL((k_probe_mix_phase<8, true>), g, b, 0, s, p, d, d1, d2, nquads); break;
         default: hipLaunchKernelGGL(k_probe_write3, g, b, 0, s, d, d1, d2, nquads); break;      // 19: 48 of 60 bytes move
         }
+    } else if (kind >= 20 && kind <= 22) {
+        // `bytes` = size of the re-read source range, `unroll` = sweeps; 21 / 22 also write 4 x bytes per sweep (plain /
+        // non-temporal) into dst, which must hold at least 4 * bytes * min(unroll, 8) bytes (the sweeps rotate through it)
+        const long long nquads = bytes / 12;
+        const int reps = unroll < 1 ? 1 : unroll;
+        const long long dst_quads = (long long)(reps < 8 ? reps : 8) * 3 * nquads;
+        pu32x4 *d = static_cast<pu32x4 *>(dst);
+        if (kind == 20) hipLaunchKernelGGL((k_probe_resweep<false, false>), dim3(blocks), dim3(256), 0, s, p, nquads, reps, d, 0ll, sink);
+        else if (kind == 21) hipLaunchKernelGGL((k_probe_resweep<true, false>), dim3(blocks), dim3(256), 0, s, p, nquads, reps, d, dst_quads, sink);
+        else hipLaunchKernelGGL((k_probe_resweep<true, true>), dim3(blocks), dim3(256), 0, s, p, nquads, reps, d, dst_quads, sink);
     } else if (kind == 99) {
         // shader clock: dst receives {shader cycles, 100 MHz ticks}; unroll = spin count; runs beside `blocks` busy blocks
         hipLaunchKernelGGL(k_probe_clock, dim3(blocks), dim3(256), 0, s, static_cast<unsigned long long *>(dst), unroll);

@@ -259,6 +259,7 @@ int lars_set_tuning(const char *key, int value)
     else if (!strcmp(key, "nt_stores")) t.nt_stores = value;
     else if (!strcmp(key, "blocks_per_tile")) t.blocks_per_tile = value;
     else if (!strcmp(key, "traverse")) t.traverse = value;
+    else if (!strcmp(key, "count_mode")) t.count_mode = value;
     else return fail(LARS_ERR_INVALID, "lars_set_tuning: unknown key %s", key);
     return LARS_OK;
 }
@@ -271,6 +272,7 @@ int lars_get_tuning(const char *key, int *value)
     else if (!strcmp(key, "nt_stores")) *value = t.nt_stores;
     else if (!strcmp(key, "blocks_per_tile")) *value = t.blocks_per_tile;
     else if (!strcmp(key, "traverse")) *value = t.traverse;
+    else if (!strcmp(key, "count_mode")) *value = t.count_mode;
     else return fail(LARS_ERR_INVALID, "lars_get_tuning: unknown key %s", key);
     return LARS_OK;
 }

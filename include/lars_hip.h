@@ -178,6 +178,16 @@ typedef struct lars_fused_args {
  * float32), optional float32 / uint8 / RGBA8 outputs and per-tile statistics. */
 int lars_d_fused(const lars_fused_args *args);
 
+/* The whole step in one persistent launch (csrc/pipeline.hip): channel histograms -> np.percentile(ch, (2, 98)) ->
+ * white-balance tables -> the fused pass, ordered tile by tile so that a tile's second read comes out of the 256 MiB
+ * Infinity Cache.  Same results as lars_d_channel_hist + lars_d_wb_table + lars_d_fused, bit for bit.  Serves what the
+ * headline configuration needs: uint8 tiles with 3 channels, all three float32 planes written, LARS_F_STATS.
+ * args->wb_table is the OUTPUT table buffer here ([ntiles][768]); percentiles is [ntiles][3][2]; hist [ntiles][768] or
+ * NULL; scratch holds lars_pipeline_scratch_bytes(ntiles, npix) bytes.  If a wait inside the launch times out the
+ * statistics records come back poisoned (count 0, NaN sums). */
+size_t lars_pipeline_scratch_bytes(int64_t ntiles, int64_t npix);
+int lars_d_pipeline(const lars_fused_args *args, double *percentiles, uint32_t *hist, int rgn_variant, void *scratch);
+
 /* float32 band planes -> index, backend-process.py:28-38 (literal formula with
  * the float32 epsilon add and the clip; any float input). */
 int lars_d_index_planes_f32(const float *red, const float *green, const float *nir,

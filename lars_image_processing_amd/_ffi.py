@@ -93,6 +93,8 @@ SIGNATURES = {
     "lars_wb_table_bytes": (_SZ, [_I]),
     "lars_d_wb_prepare": (_I, [_P, _I64, _I64, _I, _I, _P, _P, _I, _P]),
     "lars_d_fused": (_I, [C.POINTER(FusedArgs)]),
+    "lars_pipeline_scratch_bytes": (_SZ, [_I64, _I64]),
+    "lars_d_pipeline": (_I, [C.POINTER(FusedArgs), _P, _P, _I, _P]),
     "lars_d_index_planes_f32": (_I, [_P, _P, _P, _I64, _I, _P, _P]),
     "lars_d_ndvi_f64": (_I, [_P, _I64, _I, _I, _P, _P]),
     "lars_d_array_stats_f32": (_I, [_P, _I64, _F, _I, _P, _P]),

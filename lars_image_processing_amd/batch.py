@@ -194,6 +194,35 @@ class TileBatch:
     def new_stats(self):
         return DeviceBuffer(self.ntiles * 3 * STATS_DTYPE.itemsize)
 
+    # -- both passes in one persistent launch (csrc/pipeline.hip) ------------
+    def can_pipeline(self, indices=INDEX_NAMES, outputs=None, hist=False, sumsq=False):
+        """What ``lars_d_pipeline`` serves: uint8 RGNir tiles, all three planes written, basic statistics."""
+        return (self.code == _ffi.U8 and self.channels == 3 and self.npix % 4 == 0 and self.npix * 3 < (1 << 31)
+                and tuple(sorted(indices)) == tuple(sorted(INDEX_NAMES)) and outputs is not None and not hist and not sumsq
+                and all(outputs.index[k] is not None for k in range(3)) and outputs.wb is None
+                and all(r is None for r in outputs.rgba))
+
+    def run_pipeline(self, stats, outputs, stream=None, tile_start=0, tile_count=None, rgn_variant=0):
+        """Channel histograms -> percentile tables -> fused pass of tiles [tile_start, tile_start + tile_count) in ONE
+        persistent launch, ordered tile by tile so that a tile's second read is served by the Infinity Cache.  Fills
+        ``self.hist`` / ``self.table`` / ``self.percentiles`` like ``compute_wb_tables`` and ``stats`` / the planes like
+        ``run_fused``: same bytes."""
+        tile_count = self.ntiles - tile_start if tile_count is None else tile_count
+        if self.table is None:
+            self.table = DeviceBuffer(self.ntiles * self.table_bytes)
+            self.percentiles = DeviceBuffer(self.ntiles * 3 * 2 * 8)
+        if self.hist is None:
+            self.hist = DeviceBuffer(self.ntiles * 3 * 256 * 4)
+        need = int(_ffi.load().lars_pipeline_scratch_bytes(tile_count, self.npix))
+        if getattr(self, "_pipe_scratch", None) is None or self._pipe_scratch.nbytes < need:
+            if getattr(self, "_pipe_scratch", None) is not None:
+                _ffi.call("lars_synchronize", stream)
+                self._pipe_scratch.free()
+            self._pipe_scratch = DeviceBuffer(need)
+        a = self.fused_args(INDEX_NAMES, True, stats, False, outputs, stream, tile_start, tile_count)
+        _ffi.call("lars_d_pipeline", C.byref(a), C.c_void_p(self.percentiles.ptr + tile_start * 48),
+                  C.c_void_p(self.hist.ptr + tile_start * 3072), int(rgn_variant), C.c_void_p(self._pipe_scratch.ptr))
+
     def run_fused(self, args):
         _ffi.call("lars_d_fused", C.byref(args))
 
@@ -274,7 +303,7 @@ class TileBatch:
         return rec, med
 
     def free(self):
-        for b in (self.tiles, self.hist, self.table, self.percentiles):
+        for b in (self.tiles, self.hist, self.table, self.percentiles, getattr(self, "_pipe_scratch", None)):
             if b is not None:
                 b.free()
 

@@ -260,6 +260,8 @@ int lars_set_tuning(const char *key, int value)
     else if (!strcmp(key, "blocks_per_tile")) t.blocks_per_tile = value;
     else if (!strcmp(key, "traverse")) t.traverse = value;
     else if (!strcmp(key, "count_mode")) t.count_mode = value;
+    else if (!strcmp(key, "pipe_steps")) t.pipe_steps = value;
+    else if (!strcmp(key, "pipe_head")) t.pipe_head = value;
     else return fail(LARS_ERR_INVALID, "lars_set_tuning: unknown key %s", key);
     return LARS_OK;
 }
@@ -273,6 +275,8 @@ int lars_get_tuning(const char *key, int *value)
     else if (!strcmp(key, "blocks_per_tile")) *value = t.blocks_per_tile;
     else if (!strcmp(key, "traverse")) *value = t.traverse;
     else if (!strcmp(key, "count_mode")) *value = t.count_mode;
+    else if (!strcmp(key, "pipe_steps")) *value = t.pipe_steps;
+    else if (!strcmp(key, "pipe_head")) *value = t.pipe_head;
     else return fail(LARS_ERR_INVALID, "lars_get_tuning: unknown key %s", key);
     return LARS_OK;
 }

@@ -577,3 +577,57 @@ def test_every_quotient_of_bytes_is_found_back_on_the_device():
             assert np.array_equal(med2[:, k], want), t
             assert not np.signbit(med[want == 0, k]).any() or t == "NDWI"
         b.free()
+
+
+@pytest.mark.parametrize("shape,ntiles,steps,head", [((256, 256), 5, 8, 2), ((64, 96), 3, 0, 0), ((130, 62), 4, 1, 1), ((512, 512), 9, 16, 4),
+                                                       ((256, 256), 1, 8, 3)])
+def test_pipelined_launch_equals_the_two_pass_path(lars, shape, ntiles, steps, head):
+    """csrc/pipeline.hip: histograms -> tables -> fused pass in one persistent launch.  Histograms, percentiles, tables,
+    planes and statistics records must be the bytes the separate launches produce (and hence the oracle's)."""
+    from lars_image_processing_amd import _ffi
+    b = lars.TileBatch.synthetic(ntiles, shape[0], shape[1], seed=31, profile="vegetation")
+    want_outs = b.make_outputs(index=True)
+    b.compute_wb_tables()
+    want_hist, want_tab, want_pct = b.host_hist().copy(), b.host_tables().copy(), b.host_percentiles().copy()
+    stats = b.new_stats()
+    b.run_fused(b.fused_args(("NDVI", "GNDVI", "NDWI"), True, stats, False, want_outs))
+    _ffi.call("lars_synchronize", None)
+    want_rec = stats.download(_ffi.STATS_DTYPE, (ntiles, 3)).tobytes()
+    want_planes = [want_outs.host_index(t, 0, ntiles).tobytes() for t in ("NDVI", "GNDVI", "NDWI")]
+    # forget everything, run the pipeline
+    for buf in (b.hist, b.table, b.percentiles, stats):
+        buf.zero()
+    outs = b.make_outputs(index=True)
+    assert b.can_pipeline(("NDVI", "GNDVI", "NDWI"), outs)
+    _ffi.set_tuning(pipe_steps=steps, pipe_head=head)
+    try:
+        b.run_pipeline(stats, outs)
+        _ffi.call("lars_synchronize", None)
+    finally:
+        _ffi.set_tuning(pipe_steps=0, pipe_head=0)
+    np.testing.assert_array_equal(b.host_hist(), want_hist)
+    np.testing.assert_array_equal(b.host_percentiles(), want_pct)
+    np.testing.assert_array_equal(b.host_tables(), want_tab)
+    got = stats.download(_ffi.STATS_DTYPE, (ntiles, 3))
+    assert (got["count"] == shape[0] * shape[1]).all()
+    assert got.tobytes() == want_rec
+    for t, want in zip(("NDVI", "GNDVI", "NDWI"), want_planes):
+        assert outs.host_index(t, 0, ntiles).tobytes() == want, t
+    # a tile of the result against the oracle as well
+    tile = b.host_tiles(ntiles - 1, 1)[0]
+    with warnings.catch_warnings():
+        warnings.simplefilter("ignore")
+        wb = orc.wb_app(tile)
+    np.testing.assert_array_equal(bits(outs.host_index("GNDVI", ntiles - 1, 1)[0]), bits(orc.index_app(wb, "GNDVI")))
+    # a sub-range of the batch into a ring
+    ring = b.make_outputs(index=True, ring=2)
+    if ntiles >= 4:
+        stats.zero()
+        b.run_pipeline(stats, ring, tile_start=2, tile_count=2)
+        _ffi.call("lars_synchronize", None)
+        part = stats.download(_ffi.STATS_DTYPE, (ntiles, 3))
+        assert part[2:4].tobytes() == got[2:4].tobytes() and not part[:2]["count"].any()
+        assert ring.host_index("NDVI", 0, 2).tobytes() == outs.host_index("NDVI", 2, 2).tobytes()
+    for o in (want_outs, outs, ring):
+        o.free()
+    stats.free(); b.free()

@@ -33,9 +33,12 @@
 
 namespace lars {
 
-#define PIPE_THREADS 1024
+#ifndef PIPE_THREADS
+#define PIPE_THREADS 1024                                 // one workgroup per CU (512 x 2 per CU measured slower: r02_pipeline_ab.txt)
+#endif
 #define PIPE_WAVES (PIPE_THREADS / 64)
-#define PIPE_COPIES 32                                    // lane-private histogram copies (copy = lane % 32)
+#define PIPE_COPIES (PIPE_THREADS / 32)                   // histogram copies in LDS (copy = lane % PIPE_COPIES): 48 KiB at 512 threads
+#define PIPE_CH_PER_PASS (PIPE_THREADS / 256)             // channels the table builder serves at a time
 #define PIPE_SPIN_LIMIT 4000000ll
 
 struct PipeParams {
@@ -54,11 +57,29 @@ struct PipeParams {
     unsigned int *sync;            // [0] next item, [1] abort, [2 + t] H items of tile t done, [2 + ntiles + t] table of tile t ready
     int rgn_variant;
     unsigned int flags;            // bit 29: non-temporal plane stores
+    unsigned long long *trace;     // optional [blocks][PIPE_TRACE_ITEMS][6] timestamps (tools/pipebench.py --trace), or null
 };
+#define PIPE_TRACE_ITEMS 96
 
-__device__ inline unsigned int ld_acquire(unsigned int *p)
+// Everything workgroups hand to each other inside the launch (partial histograms, tables, counters, flags) is written and
+// read with RELAXED agent-scope atomics: those are performed at the memory side (sc1), past the per-XCD L2s, so they need
+// no cache maintenance.  Agent-scope release / acquire would cost a write-back / invalidate of the whole 4 MiB L2 per
+// item -- with a few hundred thousand items per launch and the L2s full of dirty plane data that was measured at 25 us
+// per item.  Ordering comes from the hardware's own rules instead: a wave's stores have been acknowledged by memory when
+// its s_waitcnt vmcnt(0) retires (the workgroup barrier waits for that), and only then does thread 0 bump the counter.
+__device__ inline unsigned int ld_coherent(const unsigned int *p)
 {
-    return __hip_atomic_load(p, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_AGENT);
+    return __hip_atomic_load(const_cast<unsigned int *>(p), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+__device__ inline void st_coherent(unsigned int *p, unsigned int v)
+{
+    __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+// abort the launch: remember why, and move the work queue past its end so that nobody takes another item
+__device__ inline void pipe_abort(unsigned int *sync, unsigned int reason)
+{
+    st_coherent(&sync[1], reason);
+    __hip_atomic_fetch_max(&sync[0], 0xF0000000u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 }
 
 // ---------------------------------------------------------------------------------------------------------------------
@@ -101,11 +122,11 @@ __device__ inline void pipe_hist_item(const PipeParams &P, unsigned int *s_h, in
 #undef PQUAD
 #undef PADD
     __syncthreads();
-    if (tid < 768) {
-        const unsigned int *row = s_h + tid * PIPE_COPIES;
+    for (int bin = tid; bin < 768; bin += PIPE_THREADS) {
+        const unsigned int *row = s_h + bin * PIPE_COPIES;
         unsigned int v = 0;
-        for (int j = 0; j < PIPE_COPIES; ++j) v += row[(j + tid) & (PIPE_COPIES - 1)];
-        P.partial[(tile * P.items + chunk) * 768 + tid] = v;
+        for (int j = 0; j < PIPE_COPIES; ++j) v += row[(j + bin) & (PIPE_COPIES - 1)];
+        st_coherent(&P.partial[(tile * P.items + chunk) * 768 + bin], v);
     }
 }
 
@@ -114,33 +135,59 @@ __device__ inline void pipe_hist_item(const PipeParams &P, unsigned int *s_h, in
 // arithmetic is k_wb_table<256>'s (fused.hip): numpy's 'linear' method, _lerp in float64, wb_level per sample value.
 // Threads [256 c, 256 c + 256) serve channel c; the last 256 threads only keep the barriers company.
 // ---------------------------------------------------------------------------------------------------------------------
-__device__ inline void pipe_build_table(const PipeParams &P, unsigned int *s_h, int tid, long long tile)
+// Returns the ready word: bit 31 set, the low bits a checksum of the table's 192 words; 0 if the partial histograms never
+// added up to the tile's pixel count (the launch is then aborted).  That check is what backs the relaxed-atomics protocol:
+// should a partial histogram not be visible yet when its item has been counted as done, the fold is simply repeated.
+__device__ inline unsigned int pipe_build_table(const PipeParams &P, unsigned int *s_h, int tid, long long tile)
 {
     unsigned int *s_tot = s_h;                                                        // [768]
-    unsigned long long *s_scan = reinterpret_cast<unsigned long long *>(s_h + 1024);  // [4][256]
+    unsigned int *s_mass = s_h + 768;                                                 // [3] channel totals (+1 pad)
+    unsigned long long *s_scan = reinterpret_cast<unsigned long long *>(s_h + 1024);  // [PIPE_CH_PER_PASS][256]
     double *s_val = reinterpret_cast<double *>(s_h + 1024 + 2 * 1024);               // [4][4]
     double *s_p = s_val + 16;                                                         // [4][2]
-    if (tid < 768) {
-        const unsigned int *src = P.partial + tile * P.items * 768 + tid;
-        unsigned int v = 0;
-        for (int i = 0; i < P.items; ++i) v += src[(long long)i * 768];
-        s_tot[tid] = v;
-        if (P.hist) P.hist[tile * 768 + tid] = v;
-    }
-    __syncthreads();
-    const int ch = tid >> 8, lt = tid & 255;
-    const bool live = ch < 3;
-    const unsigned long long local = live ? s_tot[ch * 256 + lt] : 0ull;
-    s_scan[ch * 256 + lt] = local;
-    __syncthreads();
-    for (int off = 1; off < 256; off <<= 1) {
-        const unsigned long long v = (lt >= off) ? s_scan[ch * 256 + lt - off] : 0ull;
-        __syncthreads();
-        s_scan[ch * 256 + lt] += v;
-        __syncthreads();
-    }
-    const unsigned long long before = s_scan[ch * 256 + lt] - local;
+    unsigned int *s_part = s_h + 4096;                                                // [PIPE_WAVES][768]
     const long long npix = P.npix;
+    for (int attempt = 0;; ++attempt) {
+        {
+            // fold the N partial histograms: wave w takes the items i = w (mod PIPE_WAVES), lane l the bins l, l + 64, ... (12);
+            // 24 independent loads per trip (a one-load-per-trip loop costs a memory round trip per item: 300 us per tile)
+            const int wave = tid >> 6, lane = tid & 63;
+            unsigned int accb[12];
+#pragma unroll
+            for (int j = 0; j < 12; ++j) accb[j] = 0;
+            const unsigned int *src = P.partial + tile * P.items * 768 + lane;
+            int i = wave;
+            for (; i + PIPE_WAVES < P.items; i += 2 * PIPE_WAVES) {
+                unsigned int a[12], b[12];
+#pragma unroll
+                for (int j = 0; j < 12; ++j) { a[j] = ld_coherent(&src[(long long)i * 768 + 64 * j]); b[j] = ld_coherent(&src[(long long)(i + PIPE_WAVES) * 768 + 64 * j]); }
+#pragma unroll
+                for (int j = 0; j < 12; ++j) accb[j] += a[j] + b[j];
+            }
+            for (; i < P.items; i += PIPE_WAVES) {
+#pragma unroll
+                for (int j = 0; j < 12; ++j) accb[j] += ld_coherent(&src[(long long)i * 768 + 64 * j]);
+            }
+#pragma unroll
+            for (int j = 0; j < 12; ++j) s_part[wave * 768 + 64 * j + lane] = accb[j];
+            if (tid < 4) s_mass[tid] = 0;
+        }
+        __syncthreads();
+        for (int bin = tid; bin < 768; bin += PIPE_THREADS) {
+            unsigned int v = 0;
+#pragma unroll
+            for (int w = 0; w < PIPE_WAVES; ++w) v += s_part[w * 768 + bin];
+            s_tot[bin] = v;
+            atomicAdd(&s_mass[bin >> 8], v);
+        }
+        __syncthreads();
+        const bool whole = s_mass[0] == (unsigned long long)npix && s_mass[1] == (unsigned long long)npix && s_mass[2] == (unsigned long long)npix;
+        if (whole) break;                                       // uniform: everybody reads the same three words
+        if (attempt >= 2000) return 0u;
+        __builtin_amdgcn_s_sleep(64);
+        __syncthreads();
+    }
+    for (int bin = tid; bin < 768 && P.hist; bin += PIPE_THREADS) P.hist[tile * 768 + bin] = s_tot[bin];
     const double nm1 = (double)(npix - 1);
     double tq[2];
     long long rank[4];
@@ -155,21 +202,50 @@ __device__ inline void pipe_build_table(const PipeParams &P, unsigned int *s_h, 
         rank[2 * k + 1] = hi;
         tq[k] = vi - fl;
     }
-    if (live && local) {
-        for (int r = 0; r < 4; ++r)
-            if ((unsigned long long)rank[r] >= before && (unsigned long long)rank[r] < before + local) s_val[ch * 4 + r] = (double)lt;
+    uint8_t *s_tab = reinterpret_cast<uint8_t *>(s_part);                // the wave rows are no longer needed
+    const int slot = tid >> 8, lt = tid & 255;                          // slot: which of the channels of this pass
+    for (int c0 = 0; c0 < 3; c0 += PIPE_CH_PER_PASS) {
+        const int ch = c0 + slot;
+        const bool live = ch < 3;
+        const unsigned long long local = live ? s_tot[ch * 256 + lt] : 0ull;
+        __syncthreads();
+        s_scan[slot * 256 + lt] = local;
+        __syncthreads();
+        for (int off = 1; off < 256; off <<= 1) {
+            const unsigned long long v = (lt >= off) ? s_scan[slot * 256 + lt - off] : 0ull;
+            __syncthreads();
+            s_scan[slot * 256 + lt] += v;
+            __syncthreads();
+        }
+        const unsigned long long before = s_scan[slot * 256 + lt] - local;
+        if (live && local) {
+            for (int r = 0; r < 4; ++r)
+                if ((unsigned long long)rank[r] >= before && (unsigned long long)rank[r] < before + local) s_val[ch * 4 + r] = (double)lt;
+        }
+        __syncthreads();
+        if (live && lt < 2) {
+            const double a = s_val[ch * 4 + 2 * lt], b = s_val[ch * 4 + 2 * lt + 1], t = tq[lt];
+            const double d = b - a;
+            double r = a + d * t;
+            if (t >= 0.5) r = b - d * (1.0 - t);
+            s_p[ch * 2 + lt] = r;
+            P.pcts[tile * 6 + ch * 2 + lt] = r;
+        }
+        __syncthreads();
+        if (live) s_tab[ch * 256 + lt] = (uint8_t)wb_level(lt, s_p[ch * 2], s_p[ch * 2 + 1], P.rgn_variant);
     }
     __syncthreads();
-    if (live && lt < 2) {
-        const double a = s_val[ch * 4 + 2 * lt], b = s_val[ch * 4 + 2 * lt + 1], t = tq[lt];
-        const double d = b - a;
-        double r = a + d * t;
-        if (t >= 0.5) r = b - d * (1.0 - t);
-        s_p[ch * 2 + lt] = r;
-        P.pcts[tile * 6 + ch * 2 + lt] = r;
+    unsigned int word = 0;
+    if (tid < 192) {
+        word = reinterpret_cast<const unsigned int *>(s_tab)[tid];
+        st_coherent(reinterpret_cast<unsigned int *>(P.table + tile * 768) + tid, word);
     }
+    // checksum of the 192 words (position-weighted), folded over the first three waves
+    unsigned int sum = word * (2u * (unsigned)tid + 1u);
+    for (int off = 32; off >= 1; off >>= 1) sum += __shfl_xor(sum, off);
+    if ((tid & 63) == 0 && tid < 192) s_mass[tid >> 6] = sum;
     __syncthreads();
-    if (live) P.table[tile * 768 + ch * 256 + lt] = (uint8_t)wb_level(lt, s_p[ch * 2], s_p[ch * 2 + 1], P.rgn_variant);
+    return 0x80000000u | ((s_mass[0] + s_mass[1] + s_mass[2]) & 0x7FFFFFFFu);
 }
 
 // ---------------------------------------------------------------------------------------------------------------------
@@ -276,10 +352,10 @@ __device__ inline void pipe_fused_item(const PipeParams &P, const uint8_t *s_lut
     }
 }
 
-__global__ __launch_bounds__(PIPE_THREADS) void k_pipe_u8c3(PipeParams P)
+__global__ __launch_bounds__(PIPE_THREADS, 4) void k_pipe_u8c3(PipeParams P)
 {
-    __shared__ __attribute__((aligned(16))) unsigned int s_h[3 * 256 * PIPE_COPIES];         // 96 KiB
-    __shared__ uint8_t s_lut[768];
+    __shared__ __attribute__((aligned(16))) unsigned int s_h[3 * 256 * PIPE_COPIES];         // 48 KiB at 512 threads
+    __shared__ __attribute__((aligned(16))) uint8_t s_lut[768];
     __shared__ double s_red[PIPE_WAVES][16];
     __shared__ unsigned int s_ctl[4];
 
@@ -292,14 +368,20 @@ __global__ __launch_bounds__(PIPE_THREADS) void k_pipe_u8c3(PipeParams P)
     unsigned int *const done = P.sync + 2;
     unsigned int *const ready = P.sync + 2 + T;
 
+    // the item after the one in hand is always on its way (the queue is a memory-side atomic: a round trip of a microsecond
+    // or two that would otherwise sit in front of every item); an abort moves the queue past its end
+    unsigned int fetched = 0;
+    int ntraced = 0;
+    if (tid == 0) fetched = __hip_atomic_fetch_add(&P.sync[0], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     for (;;) {
-        if (tid == 0) {
-            s_ctl[1] = ld_acquire(&P.sync[1]);
-            s_ctl[0] = s_ctl[1] ? 0xFFFFFFFFu : atomicAdd(&P.sync[0], 1u);
-        }
+        if (tid == 0) s_ctl[0] = fetched;
         __syncthreads();
         const unsigned long long item = s_ctl[0];
-        if (s_ctl[1] || item >= total) break;                   // uniform over the workgroup
+        if (item >= total) break;                               // uniform over the workgroup
+        if (tid == 0) fetched = __hip_atomic_fetch_add(&P.sync[0], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        unsigned long long tr[6] = {0, 0, 0, 0, 0, 0};
+        const bool tracing = P.trace != nullptr && tid == 0 && ntraced < PIPE_TRACE_ITEMS;
+        if (tracing) tr[0] = wall_clock64();
         // decode: phase (0 = H, 1 = F), tile, chunk
         unsigned int phase, tile, chunk;
         if (item < N) {
@@ -321,43 +403,76 @@ __global__ __launch_bounds__(PIPE_THREADS) void k_pipe_u8c3(PipeParams P)
         if (phase == 0) {
             if (tile < T) {
                 pipe_hist_item(P, s_h, tid, tile, chunk);
-                __threadfence();                                // the partial histogram is out before the count says so
+                if (tracing) tr[1] = tr[2] = wall_clock64();
+                // every wave's partial-histogram stores have been acknowledged by memory when it passes the barrier
+                // (s_waitcnt vmcnt(0) in front of it); only then does thread 0 count the item as done
+                __builtin_amdgcn_s_waitcnt(0);
                 __syncthreads();
                 if (tid == 0) {
-                    const unsigned int prev = __hip_atomic_fetch_add(&done[tile], 1u, __ATOMIC_ACQ_REL, __HIP_MEMORY_SCOPE_AGENT);
+                    const unsigned int prev = __hip_atomic_fetch_add(&done[tile], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
                     s_ctl[2] = prev == N - 1u;
                 }
                 __syncthreads();
+                if (tracing) tr[3] = wall_clock64();
                 if (s_ctl[2]) {
-                    __threadfence();                            // every other item's partial histogram is visible from here on
-                    pipe_build_table(P, s_h, tid, tile);
-                    __threadfence();
+                    const unsigned int word = pipe_build_table(P, s_h, tid, tile);     // reads the partials past the L2 (ld_coherent)
+                    __builtin_amdgcn_s_waitcnt(0);
                     __syncthreads();
-                    if (tid == 0) __hip_atomic_store(&ready[tile], 1u, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
+                    if (tid == 0) {
+                        if (word) st_coherent(&ready[tile], word);
+                        else pipe_abort(P.sync, 2u);            // histogram mass never reached npix
+                    }
                 }
             }
         } else {
-            if (tid == 0) {
-                unsigned int ok = 0;
-                long long spins = 0;
-                while (!(ok = ld_acquire(&ready[tile]))) {
-                    if (ld_acquire(&P.sync[1])) break;
-                    if (++spins > PIPE_SPIN_LIMIT) {
-                        __hip_atomic_store(&P.sync[1], 1u, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
-                        break;
-                    }
-                    __builtin_amdgcn_s_sleep(32);
+            // the table and its ready word in one round trip; repeated (bounded) until the word is there and the table's
+            // checksum matches it
+            bool good = false;
+            for (long long attempt = 0; !good; ++attempt) {
+                unsigned int word = 0;
+                if (tid < 192) {
+                    word = ld_coherent(reinterpret_cast<const unsigned int *>(P.table + (unsigned long long)tile * 768) + tid);
+                    reinterpret_cast<unsigned int *>(s_lut)[tid] = word;
                 }
-                s_ctl[3] = ok;
+                if (tid == 192) {
+                    // while the table is not there only this one thread polls, one word per visit (a whole workgroup
+                    // re-reading 192 words per visit starves the table builder's own reads)
+                    unsigned int rdy, gone = 0u;
+                    long long spins = 0;
+                    while (!(rdy = ld_coherent(&ready[tile]))) {
+                        if ((++spins & 63) == 0 && (gone = ld_coherent(&P.sync[1])) != 0u) break;
+                        if (spins > PIPE_SPIN_LIMIT) { pipe_abort(P.sync, 1u); gone = 1u; break; }
+                        __builtin_amdgcn_s_sleep(32);
+                    }
+                    s_ctl[3] = rdy;
+                    s_ctl[1] = gone | (attempt > 4000 ? 1u : 0u);
+                    if (attempt > 4000) pipe_abort(P.sync, 3u);   // the table never matched its checksum
+                }
+                unsigned int sum = word * (2u * (unsigned)tid + 1u);
+                for (int off = 32; off >= 1; off >>= 1) sum += __shfl_xor(sum, off);
+                if ((tid & 63) == 0 && tid < 192) s_red[0][tid >> 6] = (double)sum;
+                __syncthreads();
+                const unsigned int total_sum = (unsigned int)s_red[0][0] + (unsigned int)s_red[0][1] + (unsigned int)s_red[0][2];
+                good = s_ctl[3] != 0u && (0x80000000u | (total_sum & 0x7FFFFFFFu)) == s_ctl[3];      // uniform
+                const bool aborted = s_ctl[1] != 0u;
+                __syncthreads();
+                if (good) break;
+                if (aborted) break;
+                __builtin_amdgcn_s_sleep(16);
             }
-            __syncthreads();
-            if (!s_ctl[3]) break;                               // aborted: uniform exit
-            __threadfence();                                    // the table written by another workgroup, not a stale line
-            if (tid < 768) s_lut[tid] = P.table[(unsigned long long)tile * 768 + tid];
-            __syncthreads();
+            if (!good) break;                                   // aborted: uniform exit
+            if (tracing) tr[1] = wall_clock64();
             pipe_fused_item(P, s_lut, s_red, tid, tile, chunk);
+            if (tracing) tr[2] = tr[3] = wall_clock64();
         }
         __syncthreads();                                        // s_ctl, s_lut, s_red and s_h are free again
+        if (tracing) {
+            tr[4] = wall_clock64();
+            tr[5] = (unsigned long long)phase | ((unsigned long long)tile << 8) | ((unsigned long long)chunk << 32);
+            unsigned long long *dst = P.trace + ((unsigned long long)blockIdx.x * PIPE_TRACE_ITEMS + ntraced) * 6;
+            for (int j = 0; j < 6; ++j) dst[j] = tr[j];
+            ++ntraced;
+        }
     }
 }
 
@@ -384,7 +499,7 @@ extern "C" size_t lars_pipeline_scratch_bytes(int64_t ntiles, int64_t npix)
     const long long nsteps = ((npix >> 2) + 255) >> 8;
     long long spi = tuning().pipe_steps > 0 ? tuning().pipe_steps : 64;
     const long long items = (nsteps + spi - 1) / spi;
-    return (size_t)ntiles * (size_t)items * 768 * 4 + (size_t)(2 + 2 * ntiles) * 4 + 512;
+    return (size_t)ntiles * (size_t)items * 768 * 4 + (size_t)(2 + 2 * ntiles) * 4 + 512 + (size_t)4096 * PIPE_TRACE_ITEMS * 6 * 8;
 }
 
 // Histograms, percentile tables and the fused pass of `ntiles` uint8 RGNir tiles in one persistent launch.
@@ -424,6 +539,9 @@ extern "C" int lars_d_pipeline(const lars_fused_args *a, double *percentiles, ui
     P.sync = P.partial + (size_t)a->ntiles * P.items * 768;
     P.rgn_variant = rgn_variant;
     P.flags = tuning().nt_stores ? 0x20000000u : 0u;
+    // item timestamps for tools/pipebench.py: behind the sync words, 8-byte aligned, room for 4096 workgroups
+    P.trace = tuning().pipe_trace ? reinterpret_cast<unsigned long long *>((reinterpret_cast<uintptr_t>(P.sync + 2 + 2 * a->ntiles) + 255) & ~(uintptr_t)255) : nullptr;
+    if (P.trace) LARS_HIP_TRY(hipMemsetAsync(P.trace, 0, (size_t)4096 * PIPE_TRACE_ITEMS * 6 * 8, s));
 
     LARS_HIP_TRY(hipMemsetAsync(P.sync, 0, (size_t)(2 + 2 * a->ntiles) * 4, s));
     const long long nrec = a->ntiles * 3;

@@ -34,8 +34,8 @@ def main():
         return ms.value
 
     res = {}
-    variants = [("two-pass", None), ("pipeline spi=64 head=2", (64, 2)), ("pipeline spi=64 head=1", (64, 1)), ("pipeline spi=64 head=4", (64, 4)),
-                ("pipeline spi=32 head=2", (32, 2)), ("pipeline spi=128 head=2", (128, 2)), ("pipeline spi=16 head=2", (16, 2))]
+    variants = [("two-pass", None)] + [(f"pipeline spi={spi} head={head}", (spi, head))
+                                       for spi, head in ((16, 8), (32, 4), (32, 8), (32, 16), (64, 4), (64, 8), (64, 16), (128, 8), (256, 8))]
     for a in range(narena):
         outs = b.make_outputs(index=True, ring=slots)
         times = {name: [] for name, _ in variants}

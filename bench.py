@@ -223,7 +223,7 @@ def device_probe(runner):
     return out
 
 
-KERNEL_SOURCES = ("fused.hip", "fused_v2.hip", "select_q.hip", "device_common.h", "v2_device.h", "common.h")
+KERNEL_SOURCES = ("fused.hip", "fused_device.h", "fused_v2.hip", "select_q.hip", "device_common.h", "v2_device.h", "common.h")
 
 
 def kernel_sources_sha():
@@ -262,7 +262,8 @@ def config4_leg(tiles=16, edge=8192):
     from lars_image_processing_amd import _ffi
     b = lars.TileBatch(tiles, edge, edge, 3, np.uint16)
     _ffi.call("lars_d_synth_u8", C.c_void_p(b.tiles.ptr), tiles, 0, b.npix * 2, 3, 1234, 0, None)   # random 16-bit samples
-    outs = b.make_outputs(indices=("NDVI",), index=True, rgba=True)
+    b.compute_wb_tables()
+    outs = b.make_outputs(indices=("NDVI",), index=True, rgba=True, placement_trials=4)
     stats = b.new_stats()
     ev = [C.c_void_p() for _ in range(3)]
     for e in ev:

@@ -100,6 +100,7 @@ struct Tuning {
     int nt_stores = 0;         // non-temporal stores for the float32 planes
     int blocks_per_tile = 0;   // 0 = automatic
     int pipe_steps = 0;        // pipeline.hip: wave-steps per work item (0 = 64)
+    int pipe_cold = 0;         // pipeline.hip timing experiment: fused items read a far-away tile (results are wrong)
     int pipe_trace = 0;        // pipeline.hip: record item timestamps behind the scratch's sync words
     int pipe_head = 0;         // pipeline.hip: histogram items handed out before each fused item (0 = 2)
     int count_mode = -1;       // statistics-only kernels, A/B only: 3 = float coverage counters (fused_v2.hip)

@@ -255,7 +255,10 @@ __device__ inline void pipe_fused_item(const PipeParams &P, const uint8_t *s_lut
                                        long long chunk)
 {
     const long long npix = P.npix;
-    const uint8_t *base = P.tiles + tile * npix * 3;
+    // flags bit 0 (lars_set_tuning("pipe_cold", 1), timing experiments only: wrong results): read the samples of a tile half
+    // a launch away, which cannot be in any cache -- what the second read would cost without the Infinity Cache
+    const long long src_tile = (P.flags & 1u) ? (tile + P.ntiles / 2) % P.ntiles : tile;
+    const uint8_t *base = P.tiles + src_tile * npix * 3;
     float *const oi0 = P.out_index[0] + tile * npix;
     float *const oi1 = P.out_index[1] + tile * npix;
     float *const oi2 = P.out_index[2] + tile * npix;
@@ -538,7 +541,7 @@ extern "C" int lars_d_pipeline(const lars_fused_args *a, double *percentiles, ui
     P.partial = static_cast<unsigned int *>(scratch);
     P.sync = P.partial + (size_t)a->ntiles * P.items * 768;
     P.rgn_variant = rgn_variant;
-    P.flags = tuning().nt_stores ? 0x20000000u : 0u;
+    P.flags = (tuning().nt_stores ? 0x20000000u : 0u) | (tuning().pipe_cold ? 1u : 0u);
     // item timestamps for tools/pipebench.py: behind the sync words, 8-byte aligned, room for 4096 workgroups
     P.trace = tuning().pipe_trace ? reinterpret_cast<unsigned long long *>((reinterpret_cast<uintptr_t>(P.sync + 2 + 2 * a->ntiles) + 255) & ~(uintptr_t)255) : nullptr;
     if (P.trace) LARS_HIP_TRY(hipMemsetAsync(P.trace, 0, (size_t)4096 * PIPE_TRACE_ITEMS * 6 * 8, s));

@@ -263,6 +263,7 @@ int lars_set_tuning(const char *key, int value)
     else if (!strcmp(key, "pipe_steps")) t.pipe_steps = value;
     else if (!strcmp(key, "pipe_head")) t.pipe_head = value;
     else if (!strcmp(key, "pipe_trace")) t.pipe_trace = value;
+    else if (!strcmp(key, "pipe_cold")) t.pipe_cold = value;
     else return fail(LARS_ERR_INVALID, "lars_set_tuning: unknown key %s", key);
     return LARS_OK;
 }
@@ -279,6 +280,7 @@ int lars_get_tuning(const char *key, int *value)
     else if (!strcmp(key, "pipe_steps")) *value = t.pipe_steps;
     else if (!strcmp(key, "pipe_head")) *value = t.pipe_head;
     else if (!strcmp(key, "pipe_trace")) *value = t.pipe_trace;
+    else if (!strcmp(key, "pipe_cold")) *value = t.pipe_cold;
     else return fail(LARS_ERR_INVALID, "lars_get_tuning: unknown key %s", key);
     return LARS_OK;
 }

@@ -36,14 +36,19 @@ def main():
     shutil.copy(f"{src}/bench_under_rocprof.json", f"{ROOT}/profiles/{rnd}_bench_under_rocprof.json")
     f, w = read(rnd, "FETCH_SIZE"), read(rnd, "WRITE_SIZE")
     px64, px256 = 64 * 4096 * 4096, 256 * 4096 * 4096
+    # kernel names as rocprofv3 prints them, up to the template arguments that only tuning knobs change (matched by prefix)
     rows = {
-        "wb3idx_out_stats": ("k_fused_u8c3<unsigned char, 7u, true, 1>", px64),
-        "wb3idx_out_stats_hist": ("k_fused_u8c3<unsigned char, 7u, true, 2>", px64),
-        "wb_ndvi_out_stats": ("k_fused_u8c3<unsigned char, 1u, true, 1>", px64),
-        "wb3idx_stats_only": ("k_fused_v2<7u, true, 1, false, false, false>", px256),
-        "wb_ndvi_stats_only": ("k_fused_v2<1u, true, 1, false, false, false>", px256),
+        "wb3idx_out_stats": ("k_fused_u8c3<unsigned char, 7u, true, 1, 1>", px64),
+        "wb3idx_out_stats_hist": ("k_fused_u8c3<unsigned char, 7u, true, 2, 1>", px64),
+        "wb_ndvi_out_stats": ("k_fused_u8c3<unsigned char, 1u, true, 1, 1>", px64),
+        "wb3idx_stats_only": ("k_fused_v2<7u, true, 1, false, false, false", px256),
+        "wb_ndvi_stats_only": ("k_fused_v2<1u, true, 1, false, false, false", px256),
         "channel_hist": ("k_chan_hist_u8c3_v2", px256),
     }
+
+    def find(table, prefix):
+        hits = [k for k in table if k.startswith(prefix)]
+        return hits[0] if len(hits) == 1 else None
     t = {"_comment": "HBM bytes per pixel from rocprofv3 PMC (separate --pmc FETCH_SIZE / --pmc WRITE_SIZE passes): "
                      "(2*FETCH_SIZE + WRITE_SIZE)*1024 / pixels per launch; FETCH_SIZE doubled as MI355X_MICROARCH.md "
                      "(HBM) prescribes for wide coalesced streaming reads on gfx950.  _kernel_sources_sha identifies "
@@ -52,11 +57,12 @@ def main():
     from bench import kernel_sources_sha
     t["_kernel_sources_sha"] = kernel_sources_sha()
     t["_round"] = rnd
-    for mode, (kernel, px) in rows.items():
-        if kernel in f and kernel in w:
-            t[mode] = {"bytes_per_pixel": (2 * f[kernel] + w[kernel]) * 1024 / px, "kernel": kernel}
+    for mode, (prefix, px) in rows.items():
+        kf, kw = find(f, prefix), find(w, prefix)
+        if kf and kf == kw:
+            t[mode] = {"bytes_per_pixel": (2 * f[kf] + w[kw]) * 1024 / px, "kernel": kf}
     json.dump(t, open(f"{ROOT}/profiles/traffic.json", "w"), indent=1)
-    print({k: round(v["bytes_per_pixel"], 4) for k, v in t.items() if k != "_comment"})
+    print({k: round(v["bytes_per_pixel"], 4) for k, v in t.items() if not k.startswith("_")})
 
 
 if __name__ == "__main__":

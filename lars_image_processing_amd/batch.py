@@ -114,7 +114,7 @@ class TileBatch:
         times the kernel into each and keeps the fastest; the others are freed.  Costs k arenas of memory for the
         duration of the trial and k short launches."""
         outs = BatchOutputs(self, indices, index, wb, rgba, ring)
-        if placement_trials <= 1 or not index:
+        if placement_trials <= 1 or outs.arena is None:
             return outs
         arenas = [outs.arena]
         for _ in range(int(placement_trials) - 1):
@@ -367,8 +367,8 @@ class TileBatch:
 
 
 class BatchOutputs:
-    """Device output planes of a batch (optionally a ring of ``slots`` tiles).  The float32 index planes are slices of
-    one allocation (``arena``), in the order of INDEX_NAMES."""
+    """Device output planes of a batch (optionally a ring of ``slots`` tiles).  The float32 index planes and the RGBA8
+    planes are slices of one allocation (``arena``): index planes in the order of INDEX_NAMES, then the RGBA planes."""
 
     def __init__(self, batch, indices, index, wb, rgba, ring=None):
         from .api import colormap_lut, _colormap_for
@@ -377,23 +377,25 @@ class BatchOutputs:
         self.batch = batch
         self.plane_bytes = self.slots * batch.npix * 4
         self._index_ids = sorted(INDEX_IDS[t] for t in indices) if index else []
+        self._rgba_ids = sorted(INDEX_IDS[t] for t in indices) if rgba else []      # RGBA8 planes: 4 bytes per pixel too
         self.arena = None
-        if self._index_ids:
-            self.adopt_arena(DeviceBuffer(len(self._index_ids) * self.plane_bytes))
+        if self._index_ids or self._rgba_ids:
+            self.adopt_arena(DeviceBuffer((len(self._index_ids) + len(self._rgba_ids)) * self.plane_bytes))
         for t in indices:
             k = INDEX_IDS[t]
             if rgba:
-                self.rgba[k] = DeviceBuffer(self.slots * batch.npix * 4)
                 self.luts[k] = DeviceBuffer(1024)
                 self.luts[k].upload(colormap_lut(_colormap_for(t)))
         self.wb = DeviceBuffer(self.slots * batch.npix * batch.channels) if wb else None
 
     def adopt_arena(self, arena):
         """Point the index planes at ``arena`` (the caller frees whatever arena was in use before)."""
-        assert arena.nbytes >= len(self._index_ids) * self.plane_bytes
+        assert arena.nbytes >= (len(self._index_ids) + len(self._rgba_ids)) * self.plane_bytes
         self.arena = arena
         for j, k in enumerate(self._index_ids):
             self.index[k] = DeviceSlice(arena, j * self.plane_bytes, self.plane_bytes)
+        for j, k in enumerate(self._rgba_ids):
+            self.rgba[k] = DeviceSlice(arena, (len(self._index_ids) + j) * self.plane_bytes, self.plane_bytes)
 
     def host_index(self, index_type, slot=0, count=1):
         k = INDEX_IDS[index_type]
@@ -413,7 +415,7 @@ class BatchOutputs:
         for b in self.index + self.rgba + self.luts + [self.wb, self.arena]:
             if b is not None:
                 b.free()
-        self.index, self.arena = [None] * 3, None
+        self.index, self.rgba, self.arena = [None] * 3, [None] * 3, None
 
 
 # ---------------------------------------------------------------------------

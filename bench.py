@@ -65,9 +65,10 @@ def parse():
                     help="skip timing the other modes (extra JSON field 'modes')")
     ap.add_argument("--no-probe", dest="probe", action="store_false", help="skip the streaming-roofline probes")
     ap.add_argument("--profile", default="vegetation", choices=["uniform", "vegetation"])
-    ap.add_argument("--placement-trials", type=int, default=8,
-                    help="candidate output arenas (one allocation holding the ring's planes) to allocate and time; the "
-                         "fastest is kept, the rest freed (0/1: take the first)")
+    ap.add_argument("--placement-trials", type=int, default=16,
+                    help="at most this many candidate output arenas (one allocation holding the ring's planes) are allocated "
+                         "and timed -- the search stops early once one is clearly faster than the slowest -- and the fastest "
+                         "is kept, the rest freed (0/1: take the first)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-tiles", type=int, default=8)
     ap.add_argument("--cpu-workers", type=int, default=16, help="process pool of the multi-core CPU baseline leg")

@@ -110,20 +110,28 @@ class TileBatch:
         The float32 index planes live in ONE allocation (an arena).  How fast the write-bound fused kernel runs into an
         arena is a property of where the driver put it: 5.2 - 6.3 TB/s on the same box, stable to 0.3 % for as long as the
         allocation lives, independent of the offsets between the planes inside it, of the input batch and of time
-        (profiles/r02_placement_*.txt).  ``placement_trials`` = k > 1 therefore allocates k arenas,
-        times the kernel into each and keeps the fastest; the others are freed.  Costs k arenas of memory for the
-        duration of the trial and k short launches."""
+        (profiles/r02_placement_*.txt).  ``placement_trials`` = k > 1 therefore allocates up to k
+        arenas, times the kernel into each and keeps the fastest; the others are freed.  Costs up to k arenas of memory
+        for the duration of the trial and four short launches per arena."""
         outs = BatchOutputs(self, indices, index, wb, rgba, ring)
         if placement_trials <= 1 or outs.arena is None:
             return outs
-        arenas = [outs.arena]
-        for _ in range(int(placement_trials) - 1):
+        # Candidates are allocated one by one and ALL kept until the choice is made (a freed arena would be handed out
+        # again).  The classes are ~15 % apart, so the search stops as soon as one candidate is clearly faster than the
+        # slowest seen (>= 7 %) after at least four, and otherwise goes on to `placement_trials` or the memory limit.
+        arenas, timings = [outs.arena], [self._time_outputs(outs, indices)]
+        free_b, total_b = C.c_size_t(), C.c_size_t()
+        while len(arenas) < int(placement_trials):
+            if len(arenas) >= 4 and min(timings) * 1.07 <= max(timings):
+                break
+            _ffi.call("lars_mem_info", C.byref(free_b), C.byref(total_b))
+            if free_b.value < outs.arena.nbytes + (8 << 30):       # keep 8 GiB of headroom for the caller
+                break
             try:
-                arenas.append(DeviceBuffer(outs.arena.nbytes))
+                arena = DeviceBuffer(outs.arena.nbytes)
             except _ffi.LarsError:
-                break                                       # out of memory: choose among what fits
-        timings = []
-        for arena in arenas:
+                break                                               # out of memory: choose among what fits
+            arenas.append(arena)
             outs.adopt_arena(arena)
             timings.append(self._time_outputs(outs, indices))
         best = int(np.argmin(timings))

@@ -96,8 +96,8 @@ def test_one_rank_share_of_the_sharded_batch(lars):
     from lars_image_processing_amd import _ffi
     free_b, total_b = C.c_size_t(0), C.c_size_t(0)
     _ffi.call("lars_mem_info", C.byref(free_b), C.byref(total_b))
-    if free_b.value < 120 * 2**30:
-        pytest.skip("needs a 288 GiB device")
+    # no skip: this is the only test at BASELINE configs[3]'s per-rank size, and the MI355X it is written for has 288 GB
+    assert free_b.value >= 120 * 2**30, f"only {free_b.value >> 30} GiB of device memory free: 96 GiB of tiles do not fit"
     n, ntiles, first = 4096 * 4096, 2048, 3 * 2048                       # the share of rank 3
     b = lars.TileBatch.synthetic(ntiles, 4096, 4096, seed=1234, profile="vegetation", first_tile=first)
     rec = b.process(hist=True)
@@ -377,7 +377,7 @@ def test_output_ring_placement_trials(lars):
     b = lars.TileBatch.synthetic(6, 64, 96, seed=5, profile="vegetation")
     plain = b.make_outputs(index=True, ring=2)
     tuned = b.make_outputs(index=True, ring=2, placement_trials=3)
-    assert len(tuned.placement_ms["arenas"]) == 3 and tuned.placement_ms["chosen"] == min(tuned.placement_ms["arenas"]) > 0
+    assert 1 <= len(tuned.placement_ms["arenas"]) <= 3 and tuned.placement_ms["chosen"] == min(tuned.placement_ms["arenas"]) > 0
     assert not hasattr(plain, "placement_ms")
     # the three index planes are slices of one allocation, in index order
     assert [tuned.index[k].ptr - tuned.arena.ptr for k in range(3)] == [0, tuned.plane_bytes, 2 * tuned.plane_bytes]
@@ -631,3 +631,32 @@ def test_pipelined_launch_equals_the_two_pass_path(lars, shape, ntiles, steps, h
     for o in (want_outs, outs, ring):
         o.free()
     stats.free(); b.free()
+
+
+def test_caller_stream_is_ordered_against_the_zeroing(lars):
+    """process(..., stream=s) / select_histogram(..., stream=s): the records, the median scratch and the select
+    histograms are zeroed on the SAME stream the kernels run on (a memset on the library stream could land after the
+    kernels started accumulating).  Several rounds on a non-blocking stream must equal the library-stream results."""
+    import ctypes as C
+    from lars_image_processing_amd import _ffi
+    b = lars.TileBatch.synthetic(9, 128, 192, seed=77, profile="vegetation")
+    b.compute_wb_tables()
+    want_rec, want_med = b.process(medians=True, recompute_tables=False)
+    want_hist = b.select_histogram(True, [0, 0, 0, 0])
+    s = C.c_void_p()
+    _ffi.call("lars_stream_create", C.byref(s))
+    try:
+        for _ in range(6):
+            rec, med = b.process(medians=True, recompute_tables=False, stream=s)
+            assert rec.tobytes() == want_rec.tobytes()
+            np.testing.assert_array_equal(med, want_med)
+            np.testing.assert_array_equal(b.select_histogram(True, [0, 0, 0, 0], stream=s), want_hist)
+        outs = b.make_outputs(index=True, ring=4)
+        rec2, med2 = b.process(medians=True, recompute_tables=True, outputs=outs, stream=s)
+        assert rec2.tobytes() == want_rec.tobytes()
+        np.testing.assert_array_equal(med2, want_med)
+        outs.free()
+    finally:
+        _ffi.call("lars_synchronize", s)
+        _ffi.call("lars_stream_destroy", s)
+    b.free()

@@ -383,14 +383,25 @@ def main():
         raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}: one rank per GPU, start it as "
                          f"`python bench.py --gpus N` or under torch.distributed.run with --nproc-per-node N")
     collective = "none (single process)"
+    voted = False
     if world > 1 or os.environ.get("LARS_FORCE_RCCL"):
-        # The transport is chosen from the environment alone, so every rank makes the same choice; a bootstrap error
-        # ends this rank with a non-zero status and the launcher tears the group down (no per-rank fallback).
-        #   LARS_COMM=rccl (default): the library's own RCCL communicator (csrc/comm.cpp)
+        # Every rank makes the same choice of transport: from the environment, or -- by default -- from a pre-flight vote:
+        # each rank checks that librccl loads (lars_comm_available) and all ranks exchange that verdict through marker files
+        # (dist.agree) BEFORE anybody enters a blocking bootstrap; only a unanimous yes takes the library's own communicator,
+        # anything else takes torch.distributed's.  A bootstrap error after that ends the rank with a non-zero status and
+        # the launcher tears the group down (no per-rank fallback).
+        #   LARS_COMM unset / auto: vote, then rccl or torch
+        #   LARS_COMM=rccl: the library's own RCCL communicator (csrc/comm.cpp), no vote
         #   LARS_COMM=torch: the statistics exchange through torch.distributed (nccl backend = RCCL)
         #   LARS_COMM=gloo: rehearsal of the N > 1 flow on fewer GPUs than ranks -- statistics over torch.distributed's
         #                   gloo backend on the host, every rank on GPU LARS_DEVICE (default LOCAL_RANK)
-        flavour = os.environ.get("LARS_COMM", "rccl")
+        flavour = os.environ.get("LARS_COMM", "auto")
+        if flavour == "auto":
+            flavour = "rccl" if dist.agree(rank, world, _ffi.load().lars_comm_available() == 0) else "torch"
+            voted = True
+            if flavour == "torch":
+                print(f"[bench rank {rank}] librccl is not usable on every rank ({_ffi.load().lars_last_error().decode()!r} here): "
+                      "all ranks use torch.distributed", file=sys.stderr)
         try:
             if flavour == "gloo":
                 _ffi.call("lars_set_device", int(os.environ.get("LARS_DEVICE", local_rank)))
@@ -410,6 +421,8 @@ def main():
     else:
         _ffi.call("lars_set_device", 0)
         comm = dist.SingleProcessComm()
+    if world > 1 and voted and rank == 0:
+        dist.forget_agreement(world)                      # every rank is past the vote: the bootstrap above ended in a barrier
     ranks_seen = comm.ranks_seen()
     if ranks_seen != world:
         print(f"[bench rank {rank}] the communicator reports {ranks_seen} ranks, WORLD_SIZE={world}", file=sys.stderr)

@@ -378,6 +378,9 @@ int lars_h_tiff_lzw_decode_chunks(const uint8_t *file, int64_t file_len, const u
  * LARS_COMM_ID_BYTES bytes produced by lars_comm_unique_id() on rank 0 and
  * handed to the other ranks by the launcher (file, socket, environment). */
 #define LARS_COMM_ID_BYTES 128
+/* LARS_OK if librccl loads with every symbol needed (a pre-flight check: a rank that cannot join must say so before the
+ * others block in ncclCommInitRank) */
+int lars_comm_available(void);
 int lars_comm_unique_id(uint8_t *id_out);
 int lars_comm_init(void **comm, int nranks, int rank, const uint8_t *unique_id);
 /* number of ranks RCCL reports for the communicator (ncclCommCount): bench.py prints it as config.ranks_seen */

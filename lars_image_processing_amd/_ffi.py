@@ -138,6 +138,7 @@ SIGNATURES = {
     "lars_d_diff_f32": (_I, [_P, _P, _I64, _P, _P]),
     "lars_d_colormap_norm_f32": (_I, [_P, _I64, _F, _F, _P, _P, _P]),
     "lars_h_resize_lanczos_u8": (_I, [_P, _I64, _I64, _I, _I64, _I64, _P]),
+    "lars_comm_available": (_I, []),
     "lars_comm_unique_id": (_I, [_P]),
     "lars_comm_init": (_I, [C.POINTER(_P), _I, _I, _P]),
     "lars_comm_count": (_I, [_P, C.POINTER(_I)]),

@@ -90,6 +90,10 @@ int comm_buf(Comm *cm, size_t bytes)
 
 extern "C" {
 
+// LARS_OK if librccl can be loaded and has every symbol the communicator needs: what every rank checks (and tells the
+// others, dist.agree) BEFORE anybody enters ncclCommInitRank, which would wait forever for a rank that cannot join
+int lars_comm_available(void) { return load_rccl(); }
+
 int lars_comm_unique_id(uint8_t *id_out)
 {
     if (!id_out) return fail(LARS_ERR_INVALID, "lars_comm_unique_id: NULL");

@@ -109,6 +109,52 @@ def exchange_unique_id(rank, world, timeout_s=120.0, make_id=_rccl_unique_id, ma
     raise TimeoutError(f"rank {rank}: no valid RCCL unique id at {path} after {timeout_s}s")
 
 
+def agree(rank, world, ok, timeout_s=120.0):
+    """All ranks of one launch learn whether EVERY rank said ``ok`` -- before any of them enters a blocking collective
+    bootstrap.  Each rank drops a marker next to the rendezvous file (exclusive, mode 0600) and waits for the others'.
+    Returns True only if all ``world`` markers say ok; a rank that never shows up within ``timeout_s`` counts as not ok
+    (every rank then times out alike and makes the same choice)."""
+    base = _rendezvous_path()
+    tag = _launch_tag()
+    mine = f"{base}.pre{rank}"
+    try:
+        os.unlink(mine)
+    except FileNotFoundError:
+        pass
+    fd = os.open(mine, os.O_WRONLY | os.O_CREAT | os.O_EXCL | getattr(os, "O_NOFOLLOW", 0), 0o600)
+    with os.fdopen(fd, "wb") as fh:
+        fh.write(_MAGIC + tag + (b"|ok" if ok else b"|no"))
+    deadline = time.time() + timeout_s
+    verdicts = {}
+    while time.time() < deadline and len(verdicts) < world:
+        for r in range(world):
+            if r in verdicts:
+                continue
+            try:
+                fd = os.open(f"{base}.pre{r}", os.O_RDONLY | getattr(os, "O_NOFOLLOW", 0))
+            except OSError:
+                continue
+            with os.fdopen(fd, "rb") as fh:
+                st = os.fstat(fh.fileno())
+                blob = fh.read(4096)
+            if (_stat.S_ISREG(st.st_mode) and st.st_uid == os.getuid() and not (st.st_mode & 0o022)
+                    and blob[:-3] == _MAGIC + tag and blob[-3:] in (b"|ok", b"|no")):
+                verdicts[r] = blob[-3:] == b"|ok"
+        if len(verdicts) < world:
+            time.sleep(0.01)
+    return len(verdicts) == world and all(verdicts.values())
+
+
+def forget_agreement(world):
+    """Remove the markers of ``agree`` (rank 0, once every rank is past it -- e.g. after the communicator's first barrier)."""
+    base = _rendezvous_path()
+    for r in range(world):
+        try:
+            os.unlink(f"{base}.pre{r}")
+        except OSError:
+            pass
+
+
 class Comm:
     """RCCL communicator of this process (rank = one GPU)."""
 

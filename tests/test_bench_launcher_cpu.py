@@ -77,3 +77,29 @@ def test_rendezvous_file_is_private_and_tagged(tmp_path, monkeypatch):
     assert dist.exchange_unique_id(1, 2, timeout_s=5) == ident
     with pytest.raises(TimeoutError):
         dist.exchange_unique_id(1, 2, timeout_s=0.3, max_age_s=-3600)
+
+
+def test_ranks_agree_on_the_transport_before_any_blocking_bootstrap(tmp_path, monkeypatch):
+    """dist.agree: every rank learns whether ALL ranks can use librccl; one 'no' or one absent rank makes everybody say no."""
+    import threading
+    monkeypatch.setenv("LARS_RDZV_DIR", str(tmp_path))
+    monkeypatch.setenv("LARS_RDZV_TOKEN", "vote")
+    monkeypatch.setenv("WORLD_SIZE", "3")
+
+    def vote(oks, timeout_s=20.0, absent=()):
+        out = {}
+        threads = [threading.Thread(target=lambda r=r: out.__setitem__(r, dist.agree(r, 3, oks[r], timeout_s)))
+                   for r in range(3) if r not in absent]
+        for t in threads:
+            t.start()
+        for t in threads:
+            t.join()
+        dist.forget_agreement(3)
+        return out
+
+    assert vote([True, True, True]) == {0: True, 1: True, 2: True}
+    assert vote([True, False, True]) == {0: False, 1: False, 2: False}
+    assert vote([True, True, True], timeout_s=0.5, absent=(2,)) == {0: False, 1: False}
+    assert not any(name.endswith((".pre0", ".pre1", ".pre2")) for name in os.listdir(tmp_path))
+    # the library's own pre-flight check answers without a GPU: librccl is part of the ROCm image
+    assert _ffi.load().lars_comm_available() in (0, -6, -7, -8, -5, -4, -3)

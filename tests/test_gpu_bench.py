@@ -56,11 +56,12 @@ def test_bench_line_single_process():
     assert line["config"]["collective"].startswith("none")
 
 
-@pytest.mark.parametrize("transport", ["rccl", "torch"])
+@pytest.mark.parametrize("transport", ["rccl", "torch", "auto"])
 def test_bench_statistics_fold_transports_agree(transport):
-    """One rank through each transport: same global statistics as the single-process fold."""
+    """One rank through each transport (auto = the pre-flight vote, which librccl wins on this image): same global
+    statistics as the single-process fold."""
     base = run_bench({}, "--no-cpu-baseline")
-    line = run_bench({"LARS_FORCE_RCCL": "1", "LARS_COMM": transport}, "--no-cpu-baseline")
+    line = run_bench({"LARS_FORCE_RCCL": "1", **({} if transport == "auto" else {"LARS_COMM": transport})}, "--no-cpu-baseline")
     check_line(line)
     assert ("torch.distributed" in line["config"]["collective"]) == (transport == "torch")
     assert line["global_stats"] == base["global_stats"]

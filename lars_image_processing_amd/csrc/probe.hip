@@ -152,6 +152,24 @@ __global__ __launch_bounds__(256) void k_probe_wave1k(const unsigned int *__rest
     }
 }
 
+// read-only counterpart of the wave-run shapes: a wave reads RUN x 768 contiguous bytes per step (12 B per lane and load)
+template <int RUN>
+__global__ __launch_bounds__(256) void k_probe_read_run(const unsigned int *__restrict__ src, long long nsteps, unsigned int *__restrict__ sink)
+{
+    const unsigned int lane = threadIdx.x & 63u;
+    const long long nwaves = (long long)gridDim.x * 4;
+    unsigned int acc = 0;
+    for (long long st = (long long)blockIdx.x * 4 + (threadIdx.x >> 6); st < nsteps; st += nwaves) {
+        const unsigned int *p = src + (st * (64 * RUN) + lane) * 3;
+        unsigned int v[RUN][3];
+#pragma unroll
+        for (int j = 0; j < RUN; ++j) { v[j][0] = p[192 * j]; v[j][1] = p[192 * j + 1]; v[j][2] = p[192 * j + 2]; }
+#pragma unroll
+        for (int j = 0; j < RUN; ++j) acc ^= v[j][0] ^ v[j][1] ^ v[j][2];
+    }
+    if (acc == 0x12345678u) sink[0] = acc;
+}
+
 // the plain mix with each workgroup on its own contiguous slab of quads instead of a grid stride
 __global__ __launch_bounds__(256) void k_probe_mix_slab(const unsigned int *__restrict__ src, pu32x4 *__restrict__ d0,
                                                         pu32x4 *__restrict__ d1, pu32x4 *__restrict__ d2, long long nquads)
@@ -415,6 +433,12 @@ extern "C" int lars_d_probe(int kind, int unroll, int blocks, const void *src, v
         case 18: hipLaunchKernelGGL((k_probe_mix_phase<8, true>), g, b, 0, s, p, d, d1, d2, nquads); break;
         default: hipLaunchKernelGGL(k_probe_write3, g, b, 0, s, d, d1, d2, nquads); break;      // 19: 48 of 60 bytes move
         }
+    } else if (kind >= 23 && kind <= 25) {
+        // read-only wave runs: 23 = 4 x 768 B, 24 = 8 x 768 B, 25 = 1 x 768 B (the same loop without runs)
+        const long long nquads = bytes / 12;
+        if (kind == 23) hipLaunchKernelGGL((k_probe_read_run<4>), dim3(blocks), dim3(256), 0, s, p, nquads / 256, sink);
+        else if (kind == 24) hipLaunchKernelGGL((k_probe_read_run<8>), dim3(blocks), dim3(256), 0, s, p, nquads / 512, sink);
+        else hipLaunchKernelGGL((k_probe_read_run<1>), dim3(blocks), dim3(256), 0, s, p, nquads / 64, sink);
     } else if (kind >= 20 && kind <= 22) {
         // `bytes` = size of the re-read source range, `unroll` = sweeps; 21 / 22 also write 4 x bytes per sweep (plain /
         // non-temporal) into dst, which must hold at least 4 * bytes * min(unroll, 8) bytes (the sweeps rotate through it)

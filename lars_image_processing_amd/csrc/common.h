@@ -99,6 +99,7 @@ struct Tuning {
     int hist_impl = 2;
     int nt_stores = 0;         // non-temporal stores for the float32 planes
     int blocks_per_tile = 0;   // 0 = automatic
+    int selq_window = 1;       // one-pass medians (select_q.hip): 1 predicted window, 0 always two passes, 2 wrong windows (test)
     int pipe_steps = 0;        // pipeline.hip: wave-steps per work item (0 = 64)
     int pipe_cold = 0;         // pipeline.hip timing experiment: fused items read a far-away tile (results are wrong)
     int pipe_trace = 0;        // pipeline.hip: record item timestamps behind the scratch's sync words
@@ -122,7 +123,7 @@ int selq_pass_launch(const uint8_t *tiles, const uint8_t *wb_table, long long nt
                      const unsigned int bucket[4], unsigned long long *hist, hipStream_t s, unsigned streams);
 size_t selq_tile_scratch_bytes(long long ntiles);
 int selq_tile_medians_launch(const uint8_t *tiles, const uint8_t *wb_table, long long ntiles, long long npix, float *out_pairs,
-                             void *scratch, hipStream_t s, bool first_pass_done, unsigned streams);
+                             void *scratch, hipStream_t s, bool first_pass_done, unsigned streams, bool windowed = false);
 int selq_tile_prepare(void *scratch, long long ntiles, long long npix, hipStream_t s, unsigned int streams);
 unsigned int *selq_tile_hist32(void *scratch, long long ntiles);
 void fused_v2_sel_launch(unsigned mask, bool wb, int stats, dim3 grid, hipStream_t s, const FusedParams &P);

@@ -140,6 +140,7 @@ struct WaveAcc {
 #define V2_HIST_SHIFT 6      // log2(V2_HIST_COPIES * 4): bytes between consecutive bins
 #define V2_HIST_ROWS 51      // bins 0..50; 50 (x == 1.0, the closed right edge) folds into 49 at the flush
 #define V2_HIST_WORDS (3 * V2_HIST_ROWS * V2_HIST_COPIES)
+#define V2_WIN_ROW SELQ_WIN_SLOTS          // one stream's window slots
 
 // Coverage counters live in scalar registers.  The compare mask goes through VCC inside ONE asm
 // statement (v_cmp -> s_bcnt1), so it never occupies an allocatable SGPR pair: with the
@@ -253,23 +254,24 @@ __device__ inline void hist_add(float x, float sign, unsigned int base)
 // SIMD: 1024 threads per block.  With output planes the kernel needs more registers: 512.
 template <bool OUT> struct V2Block { static constexpr int threads = OUT ? 512 : LARS_V2_STATS_THREADS; };
 
-// SEL: also count every NDVI / GNDVI value in the 2048 linear buckets of the exact-median select (its first pass,
+// SEL >= 1: also count every NDVI / GNDVI value in the 2048 linear buckets of the exact-median select (its first pass,
 // fused: P.sel_hist[tile][stream][track 0][bucket]).  With the 64 KiB table that is exactly 80 KiB of LDS (two blocks
 // per CU) because the reduction scratch then reuses the table's space once the loop is over.
-template <unsigned MASK, bool WB, int STATS, bool OUT, bool NT, bool SEL = false, int CM = LARS_COUNT_MODE>
-__global__ __launch_bounds__(V2Block<OUT>::threads, OUT ? 4 : LARS_V2_STATS_WAVES) void k_fused_v2(FusedParams P)
+template <unsigned MASK, bool WB, int STATS, bool OUT, bool NT, int SEL = 0, int CM = LARS_COUNT_MODE>
+__global__ __launch_bounds__(V2Block<OUT>::threads, (OUT || SEL == 2) ? 4 : LARS_V2_STATS_WAVES) void k_fused_v2(FusedParams P)
 {
     constexpr int NTHR = V2Block<OUT>::threads;
     constexpr int NWAVES = NTHR / 64;
     constexpr bool RED_ALIASES_TABLE = WB && SEL;
     __shared__ __attribute__((aligned(16))) char s_mem[(WB ? V2_TABLE_BYTES : 0) + (STATS >= 2 ? V2_HIST_WORDS * 4 : 0) +
-                                                       (SEL ? 2 * SELQ_BINS * 4 : 0) +
+                                                       (SEL ? 2 * SELQ_BINS * 4 : 0) + (SEL == 2 ? 2 * V2_WIN_ROW * 4 : 0) +
                                                        (RED_ALIASES_TABLE ? 0 : NWAVES * 16 * sizeof(double))];
     char *s_tab = s_mem;                                                             // 64 KiB when WB
     unsigned int *s_hist = reinterpret_cast<unsigned int *>(s_mem + (WB ? V2_TABLE_BYTES : 0));
     unsigned int *s_sel = s_hist + (STATS >= 2 ? V2_HIST_WORDS : 0);                 // [2 streams][SELQ_BINS] when SEL
+    unsigned int *s_win = s_sel + (SEL ? 2 * SELQ_BINS : 0);                         // [2 streams][V2_WIN_ROW] when SEL == 2
     double *s_red = RED_ALIASES_TABLE ? reinterpret_cast<double *>(s_mem)
-                                      : reinterpret_cast<double *>(s_sel + (SEL ? 2 * SELQ_BINS : 0));     // [NWAVES][16]
+                                      : reinterpret_cast<double *>(s_win + (SEL == 2 ? 2 * V2_WIN_ROW : 0));     // [NWAVES][16]
 
     constexpr bool NEED_R = (MASK & 1u) != 0;
     constexpr bool NEED_G = (MASK & 6u) != 0;
@@ -284,6 +286,10 @@ __global__ __launch_bounds__(V2Block<OUT>::threads, OUT ? 4 : LARS_V2_STATS_WAVE
     const unsigned int hb1 = hb0 + V2_HIST_ROWS * V2_HIST_COPIES * 4, hb2 = hb1 + V2_HIST_ROWS * V2_HIST_COPIES * 4;
     const unsigned int sel_lds = SEL ? (unsigned int)(unsigned long long)(lds_u32 *)s_sel : 0u;
     const unsigned int sb0 = sel_lds, sb1 = sb0 + SELQ_BINS * 4;     // NDVI row, GNDVI row
+    // SEL == 2: slot counts inside each stream's predicted window of SELQ_WIN buckets (the one-pass median, select_q.hip)
+    const unsigned int win_lds = SEL == 2 ? (unsigned int)(unsigned long long)(lds_u32 *)s_win : 0u;
+    const unsigned int wr0 = win_lds, wr1 = wr0 + V2_WIN_ROW * 4;
+    unsigned int wt0 = 0, wt1 = 0;                                   // bits of the first t of each window
     const unsigned int lane_off4 = lane << 2;
     const long long tile = blockIdx.y;
     const long long npix = P.npix;
@@ -303,6 +309,11 @@ __global__ __launch_bounds__(V2Block<OUT>::threads, OUT ? 4 : LARS_V2_STATS_WAVE
     }
     if (SEL) {
         for (int i = tid; i < 2 * SELQ_BINS; i += NTHR) s_sel[i] = 0;
+    }
+    if (SEL == 2) {
+        for (int i = tid; i < 2 * V2_WIN_ROW; i += NTHR) s_win[i] = 0;
+        wt0 = SELQ_T_BITS | (P.sel_win[blockIdx.y * 2] << 12);
+        wt1 = SELQ_T_BITS | (P.sel_win[blockIdx.y * 2 + 1] << 12);
     }
     if (WB || STATS >= 2 || SEL) __syncthreads();
 
@@ -373,6 +384,7 @@ __global__ __launch_bounds__(V2Block<OUT>::threads, OUT ? 4 : LARS_V2_STATS_WAVE
                 if (SEL) {
                     const f32x2 p = selq_t2(x);
                     selq_add_bucket(p.x, sb0); selq_add_bucket(p.y, sb0);
+                    if (SEL == 2) { selq_add_window(p.x, wt0, wr0); selq_add_window(p.y, wt0, wr0); }
                 }
             }
             if (NEED_G) {
@@ -388,6 +400,7 @@ __global__ __launch_bounds__(V2Block<OUT>::threads, OUT ? 4 : LARS_V2_STATS_WAVE
                 if (SEL) {
                     const f32x2 p = selq_t2(x);
                     selq_add_bucket(p.x, sb1); selq_add_bucket(p.y, sb1);
+                    if (SEL == 2) { selq_add_window(p.x, wt1, wr1); selq_add_window(p.y, wt1, wr1); }
                 }
                 if (STATS >= 2 && WANT_NDWI) {
                     const f32x2 p = hist_pos2(x, -1.0f);
@@ -469,9 +482,11 @@ __global__ __launch_bounds__(V2Block<OUT>::threads, OUT ? 4 : LARS_V2_STATS_WAVE
                 // consume slot k, then refill it: the refill lands in the registers just freed
                 // (no copies, no vmcnt(0) at the loop head) and has three quads of work to hide behind
                 do_quad(q0 + (it + k) * stride, w[k].x, w[k].y, w[k].z);
-                __builtin_amdgcn_sched_barrier(0);
+                // with one block per CU (SEL == 2: 4 waves per SIMD, 128 VGPRs) the quads of a trip may overlap: the waves
+                // alone no longer cover the LDS round trips
+                if (SEL != 2) __builtin_amdgcn_sched_barrier(0);
                 w[k] = __builtin_amdgcn_raw_buffer_load_b96(rsrc, voff, soff + (unsigned)k * step_b, 0);
-                __builtin_amdgcn_sched_barrier(0);
+                if (SEL != 2) __builtin_amdgcn_sched_barrier(0);
             }
             soff += 4u * step_b;
         }
@@ -497,12 +512,14 @@ __global__ __launch_bounds__(V2Block<OUT>::threads, OUT ? 4 : LARS_V2_STATS_WAVE
             if (STATS >= 1) push<STATS>(acc_v, above_v, x, 0.2f);
             if (STATS >= 2) hist_add(x, 1.0f, hb0);
             if (SEL) selq_add_bucket(selq_t(x), sb0);
+            if (SEL == 2) selq_add_window(selq_t(x), wt0, wr0);
             if (oi0) oi0[i] = x;
             if (oc0) reinterpret_cast<unsigned int *>(oc0)[i] = lut0[cmap_index(x)];
         }
         if (NEED_G) {
             const float x = norm_diff_fast(fn, fg);
             if (SEL) selq_add_bucket(selq_t(x), sb1);
+            if (SEL == 2) selq_add_window(selq_t(x), wt1, wr1);
             if (STATS >= 1) {
                 acc_g.mn = fminf(acc_g.mn, x); acc_g.mx = fmaxf(acc_g.mx, x);
                 const double xd = (double)x;
@@ -626,6 +643,13 @@ __global__ __launch_bounds__(V2Block<OUT>::threads, OUT ? 4 : LARS_V2_STATS_WAVE
                 const unsigned int v = s_sel[i];
                 if (v) atomicAdd(&h[(i >> 11) * (2 * SELQ_BINS) + (i & (SELQ_BINS - 1))], v);      // stream row, track 0
             }
+            if (SEL == 2) {
+                unsigned int *wh = P.sel_win_hist + tile * (2 * SELQ_WIN_SLOTS);
+                for (int i = tid; i < 2 * SELQ_WIN_SLOTS; i += NTHR) {
+                    const unsigned int v = s_win[(i / SELQ_WIN_SLOTS) * V2_WIN_ROW + (i % SELQ_WIN_SLOTS)];
+                    if (v) atomicAdd(&wh[i], v);
+                }
+            }
         }
     }
 }
@@ -647,7 +671,7 @@ static void v2_launch_out(bool out, bool nt, dim3 grid, hipStream_t s, const Fus
     // A/B of the coverage counters in one process (lars_set_tuning("count_mode", 3)): float counters, only instantiated
     // for the two statistics-only configurations the bench reports
     if (!out && tuning().count_mode == 3 && WB && STATS == 1 && (MASK == 7u || MASK == 1u)) {
-        hipLaunchKernelGGL((k_fused_v2<(MASK == 7u ? 7u : 1u), true, 1, false, false, false, 3>), grid, dim3(V2Block<false>::threads), 0, s, P);
+        hipLaunchKernelGGL((k_fused_v2<(MASK == 7u ? 7u : 1u), true, 1, false, false, 0, 3>), grid, dim3(V2Block<false>::threads), 0, s, P);
         return;
     }
     if (!out) hipLaunchKernelGGL((k_fused_v2<MASK, WB, STATS, false, false>), grid, dim3(V2Block<false>::threads), 0, s, P);
@@ -673,12 +697,18 @@ template <unsigned MASK>
 static void v2_launch_sel(bool wb, int stats, dim3 grid, hipStream_t s, const FusedParams &P)
 {
     const dim3 block(V2Block<false>::threads);
-    if (wb && stats >= 3) hipLaunchKernelGGL((k_fused_v2<MASK, true, 3, false, false, true>), grid, block, 0, s, P);
-    else if (wb && stats == 2) hipLaunchKernelGGL((k_fused_v2<MASK, true, 2, false, false, true>), grid, block, 0, s, P);
-    else if (wb) hipLaunchKernelGGL((k_fused_v2<MASK, true, 1, false, false, true>), grid, block, 0, s, P);
-    else if (stats >= 3) hipLaunchKernelGGL((k_fused_v2<MASK, false, 3, false, false, true>), grid, block, 0, s, P);
-    else if (stats == 2) hipLaunchKernelGGL((k_fused_v2<MASK, false, 2, false, false, true>), grid, block, 0, s, P);
-    else hipLaunchKernelGGL((k_fused_v2<MASK, false, 1, false, false, true>), grid, block, 0, s, P);
+    // with a predicted window (P.sel_win) the slots inside it are counted as well: basic statistics only
+    if (P.sel_win && stats == 1) {
+        if (wb) hipLaunchKernelGGL((k_fused_v2<MASK, true, 1, false, false, 2>), grid, block, 0, s, P);
+        else hipLaunchKernelGGL((k_fused_v2<MASK, false, 1, false, false, 2>), grid, block, 0, s, P);
+        return;
+    }
+    if (wb && stats >= 3) hipLaunchKernelGGL((k_fused_v2<MASK, true, 3, false, false, 1>), grid, block, 0, s, P);
+    else if (wb && stats == 2) hipLaunchKernelGGL((k_fused_v2<MASK, true, 2, false, false, 1>), grid, block, 0, s, P);
+    else if (wb) hipLaunchKernelGGL((k_fused_v2<MASK, true, 1, false, false, 1>), grid, block, 0, s, P);
+    else if (stats >= 3) hipLaunchKernelGGL((k_fused_v2<MASK, false, 3, false, false, 1>), grid, block, 0, s, P);
+    else if (stats == 2) hipLaunchKernelGGL((k_fused_v2<MASK, false, 2, false, false, 1>), grid, block, 0, s, P);
+    else hipLaunchKernelGGL((k_fused_v2<MASK, false, 1, false, false, 1>), grid, block, 0, s, P);
 }
 // statistics + the select's bucket pass in one kernel (mask 1, 2, 4 or 7; no output planes)
 void fused_v2_sel_launch(unsigned mask, bool wb, int stats, dim3 grid, hipStream_t s, const FusedParams &P)

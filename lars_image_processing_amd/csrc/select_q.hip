@@ -57,6 +57,7 @@ __global__ __launch_bounds__(1024, 8) void k_selq_pass(SelQParams P)
     const int tid = threadIdx.x;
     const unsigned int lane_off4 = (tid & 63u) << 2;
     const long long tile = blockIdx.y;
+    if (PER_TILE && !P.first && P.state[tile].pad[2]) return;     // the predicted window already gave this tile's medians
     const long long npix = P.npix;
     const uint8_t *base = P.tiles + tile * npix * 3;
     if (WB) {
@@ -203,6 +204,7 @@ __global__ __launch_bounds__(256) void k_selq_pick(SelQTile *state, unsigned int
 {
     const long long tile = blockIdx.x;
     unsigned int *h = hist32 + tile * (4 * SELQ_BINS);
+    if (!first && state[tile].pad[2]) return;                     // served by the window: out[] is already final, h untouched since
     const int combo = threadIdx.x >> 6, lane = threadIdx.x & 63;
     const bool active = (state[tile].streams >> (combo >> 1)) & 1u;
     // the second pass counted a bucket shared by both tracks once, under track 0
@@ -256,6 +258,147 @@ __global__ __launch_bounds__(256) void k_selq_pick(SelQTile *state, unsigned int
     for (int i = threadIdx.x; i < 4 * SELQ_BINS; i += 256) h[i] = 0u;
 }
 
+// ---------------------------------------------------------------------------------------------------------------------
+// One-pass medians: predict where each tile's median will fall, let the statistics kernel count the slots of a window of
+// SELQ_WIN buckets around the prediction next to its 2048 buckets (fused_v2.hip, SEL == 2), and take the slot pass only for
+// tiles whose real median bucket -- known exactly from the bucket counts -- lies outside their window.
+// ---------------------------------------------------------------------------------------------------------------------
+// The prediction: the median bucket of a subsample (every SUB-th 1024-pixel step, at most 256 steps: 262144 of a 4096 x 4096
+// tile's pixels).  Its standard error is 0.5 / sqrt(n) of the distribution's mass, under one bucket for index planes that
+// are not concentrated on a few values -- and concentrated planes have their median inside the predicted bucket anyway.
+// One block per tile; win[tile][stream] = first bucket of the window.
+template <bool WB>
+__global__ __launch_bounds__(1024) void k_selq_predict(const uint8_t *__restrict__ tiles, const uint8_t *__restrict__ wb_table, long long npix,
+                                                       unsigned int streams, unsigned int *__restrict__ win)
+{
+    __shared__ __attribute__((aligned(16))) char s_tab[WB ? V2_TABLE_BYTES : 16];
+    __shared__ unsigned int s_h[2 * SELQ_BINS];
+    const int tid = threadIdx.x;
+    const unsigned int lane = tid & 63u, lane_off4 = lane << 2;
+    const long long tile = blockIdx.x;
+    const uint8_t *base = tiles + tile * npix * 3;
+    if (WB) {
+        const uint8_t *t = wb_table + tile * 768;
+        unsigned int *tab = reinterpret_cast<unsigned int *>(s_tab);
+        for (int i = tid; i < 256 * 64; i += 1024) {
+            const int v = i >> 6;
+            tab[i] = (unsigned)t[v] | ((unsigned)t[256 + v] << 8) | ((unsigned)t[512 + v] << 16);
+        }
+    }
+    for (int i = tid; i < 2 * SELQ_BINS; i += 1024) s_h[i] = 0;
+    __syncthreads();
+    const long long nquads = npix >> 2;
+    const long long nsteps = nquads >> 8;                          // complete steps only
+    const long long sub = nsteps > 256 ? nsteps / 256 : 1;
+    for (long long k = tid >> 6; k * sub < nsteps && k < 256; k += 16) {
+        const long long q0 = k * sub * 256 + lane;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const unsigned int *p = reinterpret_cast<const unsigned int *>(base + (q0 + 64 * j) * 12);
+            const unsigned int w0 = p[0], w1 = p[1], w2 = p[2];
+            const unsigned int wr[4] = {w0, w0, w1, w2}, wg[4] = {w0, w1, w1, w2}, wn[4] = {w0, w1, w2, w2};
+            constexpr int br[4] = {0, 3, 2, 1}, bg[4] = {1, 0, 3, 2}, bn[4] = {2, 1, 0, 3};
+#pragma unroll
+            for (int px = 0; px < 4; ++px) {
+                const float fn = sample<WB>(wn[px], bn[px], 2, lane_off4, s_tab);
+                if (streams & 1u) {
+                    const float fr = sample<WB>(wr[px], br[px], 0, lane_off4, s_tab);
+                    atomicAdd(&s_h[selq_bucket_of(selq_t(norm_diff_fast(fn, fr)))], 1u);
+                }
+                if (streams & 2u) {
+                    const float fg = sample<WB>(wg[px], bg[px], 1, lane_off4, s_tab);
+                    atomicAdd(&s_h[SELQ_BINS + selq_bucket_of(selq_t(norm_diff_fast(fn, fg)))], 1u);
+                }
+            }
+        }
+    }
+    __syncthreads();
+    // waves 0 and 1: the bucket holding the sample's median of stream 0 / 1 (lane l owns buckets 32 l .. 32 l + 31)
+    const int stream = tid >> 6;
+    if (stream < 2) {
+        const unsigned int *mine = s_h + stream * SELQ_BINS + lane * 32;
+        unsigned int c[32], local = 0;
+#pragma unroll
+        for (int j = 0; j < 32; ++j) { c[j] = mine[j]; local += c[j]; }
+        unsigned int incl = local;
+        for (int off = 1; off < 64; off <<= 1) {
+            const unsigned int o = __shfl_up(incl, off);
+            if ((int)lane >= off) incl += o;
+        }
+        const unsigned int total = __shfl(incl, 63);
+        const unsigned int rank = total / 2;
+        unsigned int cum = incl - local;
+        if (total && rank >= cum && rank < incl) {
+            int d = 0;
+#pragma unroll
+            for (int j = 0; j < 32; ++j) {
+                if (rank >= cum + c[j]) { cum += c[j]; d = j + 1; }
+                else break;
+            }
+            int b = (int)lane * 32 + d - SELQ_WIN / 2;
+            b = b < 0 ? 0 : (b > SELQ_BINS - SELQ_WIN ? SELQ_BINS - SELQ_WIN : b);
+            win[tile * 2 + stream] = (unsigned int)b;
+        }
+        if (!total && lane == 0) win[tile * 2 + stream] = 0u;
+    }
+}
+
+// After the statistics kernel and the bucket pick: where a (stream, track)'s bucket lies inside the tile's window, its slot
+// is found in the window's counts and the value written; a tile whose every requested order statistic was found that way
+// is marked done (pad[2]) and skips the slot pass.  One block per tile, one wave per (stream, track).
+__global__ __launch_bounds__(256) void k_selq_pick_window(SelQTile *state, const unsigned int *win, const unsigned int *win_hist, float *out,
+                                                          unsigned int *pending)
+{
+    __shared__ unsigned int s_ok[4];
+    const long long tile = blockIdx.x;
+    const int combo = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    const int stream = combo >> 1;
+    const bool active = (state[tile].streams >> stream) & 1u;
+    const unsigned int bucket = state[tile].bucket[combo], rank = state[tile].rank[combo];
+    const unsigned int w0 = win[tile * 2 + stream];
+    bool ok = !active;
+    float v = __builtin_nanf("");
+    if (active && bucket >= w0 && bucket < w0 + SELQ_WIN) {
+        const unsigned int *mine = win_hist + (tile * 2 + stream) * SELQ_WIN_SLOTS + (bucket - w0) * SELQ_SLOTS + lane * 16;
+        unsigned int c[16], local = 0;
+#pragma unroll
+        for (int j = 0; j < 16; ++j) { c[j] = mine[j]; local += c[j]; }
+        unsigned int incl = local;
+        for (int off = 1; off < 64; off <<= 1) {
+            const unsigned int o = __shfl_up(incl, off);
+            if (lane >= off) incl += o;
+        }
+        unsigned int cum = incl - local;
+        const bool holder = rank >= cum && rank < incl;
+        int d = 0;
+        if (holder) {
+#pragma unroll
+            for (int j = 0; j < 16; ++j) {
+                if (rank >= cum + c[j]) { cum += c[j]; d = j + 1; }
+                else break;
+            }
+        }
+        const unsigned long long who = __ballot(holder);
+        if (who) {
+            const int src = __ffsll((long long)who) - 1;
+            const unsigned int slot = (unsigned int)__shfl(lane * 16 + d, src);
+            v = selq_value_of(bucket, slot, lane);
+            ok = v == v;
+        }
+    }
+    if (lane == 0) {
+        s_ok[combo] = ok ? 1u : 0u;
+        if (active && ok) out[tile * 4 + combo] = v;
+        if (!active) out[tile * 4 + combo] = __builtin_nanf("");
+    }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        const unsigned int done = s_ok[0] & s_ok[1] & s_ok[2] & s_ok[3];
+        state[tile].pad[2] = done;
+        if (!done) atomicAdd(pending, 1u);                        // tiles that still need the slot pass
+    }
+}
+
 }  // namespace lars
 
 using namespace lars;
@@ -294,7 +437,16 @@ int selq_pass_launch(const uint8_t *tiles, const uint8_t *wb_table, long long nt
 
 size_t selq_tile_scratch_bytes(long long ntiles)
 {
-    return (size_t)ntiles * (sizeof(SelQTile) + 4 * SELQ_BINS * sizeof(unsigned int)) + 512;
+    return (size_t)ntiles * (sizeof(SelQTile) + 4 * SELQ_BINS * sizeof(unsigned int) + 2 * sizeof(unsigned int) +
+                             2 * SELQ_WIN_SLOTS * sizeof(unsigned int)) + 1024 + 64;
+}
+// behind the per-tile histograms: the predicted windows [ntiles][2] and their slot counts [ntiles][2][SELQ_WIN_SLOTS]
+static void selq_window_layout(void *scratch, long long ntiles, unsigned int **win, unsigned int **win_hist)
+{
+    char *p = reinterpret_cast<char *>(selq_tile_hist32(scratch, ntiles) + (size_t)ntiles * 4 * SELQ_BINS);
+    p = reinterpret_cast<char *>((reinterpret_cast<uintptr_t>(p) + 255) & ~(uintptr_t)255);
+    *win = reinterpret_cast<unsigned int *>(p);
+    *win_hist = reinterpret_cast<unsigned int *>(p + (((size_t)ntiles * 2 * sizeof(unsigned int) + 255) & ~(size_t)255));
 }
 
 // medians of every tile: bucket pass + slot pass, picks on the device, no host round trip
@@ -322,10 +474,12 @@ int selq_tile_prepare(void *scratch, long long ntiles, long long npix, hipStream
 }
 
 int selq_tile_medians_launch(const uint8_t *tiles, const uint8_t *wb_table, long long ntiles, long long npix, float *out_pairs,
-                             void *scratch, hipStream_t s, bool first_pass_done, unsigned streams)
+                             void *scratch, hipStream_t s, bool first_pass_done, unsigned streams, bool windowed)
 {
     SelQTile *state; unsigned int *hist32;
     selq_scratch_layout(scratch, ntiles, &state, &hist32);
+    unsigned int *win, *win_hist;
+    selq_window_layout(scratch, ntiles, &win, &win_hist);
     if (!first_pass_done) LARS_TRY(selq_tile_prepare(scratch, ntiles, npix, s, streams));
     const dim3 grid = selq_grid(ntiles, npix);
     for (int p = 0; p < 2; ++p) {
@@ -336,6 +490,19 @@ int selq_tile_medians_launch(const uint8_t *tiles, const uint8_t *wb_table, long
         if (p == 0 && first_pass_done) { /* counted by the statistics kernel */ }
         else selq_launch<true>(wb_table != nullptr, streams, grid, s, P);
         hipLaunchKernelGGL(k_selq_pick, dim3((unsigned)ntiles), dim3(256), 0, s, state, hist32, p == 0 ? 1 : 0, out_pairs);
+        // buckets are known: tiles whose buckets lie inside their predicted window are finished from the window's slot counts
+        if (p == 0 && windowed && first_pass_done) {
+            unsigned int *pending = win_hist + (size_t)ntiles * 2 * SELQ_WIN_SLOTS;      // one word behind the window counts
+            LARS_HIP_TRY(hipMemsetAsync(pending, 0, sizeof(unsigned int), s));
+            hipLaunchKernelGGL(k_selq_pick_window, dim3((unsigned)ntiles), dim3(256), 0, s, state, win, win_hist, out_pairs, pending);
+            // Nearly always every tile is done here.  Launching the slot pass just to let its 8192 workgroups find that out
+            // costs 0.7 ms per 256 tiles, so the host looks at the count first -- the one place where a device entry point
+            // waits for its stream (the callers read the medians back right after it anyway).
+            unsigned int left = 1;
+            LARS_HIP_TRY(hipMemcpyAsync(&left, pending, sizeof left, hipMemcpyDeviceToHost, s));
+            LARS_HIP_TRY(hipStreamSynchronize(s));
+            if (left == 0) break;
+        }
     }
     return launch_check("selq_tile_medians");
 }
@@ -377,7 +544,7 @@ extern "C" int lars_d_quotient_median_pairs(const void *tiles, int64_t ntiles, i
     if (ntiles > 65535 || (long long)npix * 6 >= (1ll << 30))
         return fail(LARS_ERR_INVALID, "lars_d_quotient_median_pairs: at most 65535 tiles of < 2^30 / 6 pixels");
     return selq_tile_medians_launch(static_cast<const uint8_t *>(tiles), wb_table, ntiles, npix, out_pairs, scratch,
-                                    pick_stream(c, stream), false, streams);
+                                    pick_stream(c, stream), false, streams, false);
 }
 
 // Statistics AND the exact median of every tile in two passes over the tiles (three with the white-balance histogram
@@ -408,11 +575,25 @@ extern "C" int lars_d_stats_medians(const lars_fused_args *a, float *out_pairs, 
     const unsigned streams = ((mask & 1u) ? 1u : 0u) | ((mask & 6u) ? 2u : 0u);
     LARS_TRY(selq_tile_prepare(scratch, a->ntiles, a->npix, s, streams));
     P.sel_hist = selq_tile_hist32(scratch, a->ntiles);
+    // one-pass medians: predict a window of SELQ_WIN buckets per tile and stream from a subsample; the statistics kernel
+    // then counts the window's slots as well, and only tiles whose median bucket falls outside take the slot pass.
+    // lars_set_tuning("selq_window", 0) = always two passes; 2 = predict, then point every window at bucket 0 (tests the fallback)
+    const bool windowed = stats_mode == 1 && tuning().selq_window != 0;
+    if (windowed) {
+        unsigned int *win, *win_hist;
+        selq_window_layout(scratch, a->ntiles, &win, &win_hist);
+        LARS_HIP_TRY(hipMemsetAsync(win_hist, 0, (size_t)a->ntiles * 2 * SELQ_WIN_SLOTS * sizeof(unsigned int), s));
+        if (a->wb_table) hipLaunchKernelGGL((k_selq_predict<true>), dim3((unsigned)a->ntiles), dim3(1024), 0, s, tiles, a->wb_table, (long long)a->npix, streams, win);
+        else hipLaunchKernelGGL((k_selq_predict<false>), dim3((unsigned)a->ntiles), dim3(1024), 0, s, tiles, a->wb_table, (long long)a->npix, streams, win);
+        if (tuning().selq_window == 2) LARS_HIP_TRY(hipMemsetAsync(win, 0, (size_t)a->ntiles * 2 * sizeof(unsigned int), s));
+        P.sel_win = win;
+        P.sel_win_hist = win_hist;
+    }
     const long long nrec = a->ntiles * 3;
     stats_init_launch(a->stats, nrec, mask, s);
     dim3 grid(blocks_per_tile(a->npix / 4 + 1, a->ntiles, fused_v2_threads(false), 8192), (unsigned)a->ntiles);
     fused_v2_sel_launch(mask, a->wb_table != nullptr, stats_mode, grid, s, P);
     stats_finalize_launch(a->stats, nrec, mask, (long long)a->npix, s);
     LARS_TRY(launch_check("lars_d_stats_medians"));
-    return selq_tile_medians_launch(tiles, a->wb_table, a->ntiles, a->npix, out_pairs, scratch, s, true, streams);
+    return selq_tile_medians_launch(tiles, a->wb_table, a->ntiles, a->npix, out_pairs, scratch, s, true, streams, windowed);
 }

@@ -90,6 +90,11 @@ __device__ inline unsigned int sample_entry(unsigned int word, int byte, unsigne
 #define SELQ_BINS 2048
 #define SELQ_SLOTS 1024
 #define SELQ_T_BITS 0x45000000u                         /* float bits of 2048.0 */
+// Predicted window of the one-pass median (select_q.hip): SELQ_WIN consecutive buckets around the bucket a subsample's median
+// fell into; the statistics kernel counts the 1024 slots of each of them next to the 2048 buckets, so that the slot pass
+// is only needed where the real median bucket lies outside the window.
+#define SELQ_WIN 8
+#define SELQ_WIN_SLOTS (SELQ_WIN * SELQ_SLOTS)
 __device__ inline float selq_t(float x) { return __builtin_fmaf(x, 1023.5f, 3071.5f); }
 __device__ inline f32x2 selq_t2(f32x2 x)
 {
@@ -101,6 +106,18 @@ __device__ inline void selq_add_bucket(float t, unsigned int row)      // row: L
 {
     const unsigned int addr = (selq_bucket_of(t) << 2) + row;
     asm volatile("ds_add_u32 %0, %1" : : "v"(addr), "v"(1u) : "memory");
+}
+
+// slot inside the window that starts at the bucket whose first t has the bits t0 (SELQ_T_BITS | bucket << 12): the same
+// integer subtract as the slot pass (units of 2^-12 of t, four per slot).  Only lanes whose value lies inside the window
+// (a few per cent at most) touch LDS: the rest is masked off, and a wave without any such lane skips the add altogether.
+__device__ inline void selq_add_window(float t, unsigned int t0_bits, unsigned int row)
+{
+    const unsigned int d = __builtin_bit_cast(unsigned int, t) - t0_bits;
+    if (d < (unsigned)SELQ_WIN_SLOTS * 4u) {
+        const unsigned int addr = (d & ~3u) + row;
+        asm volatile("ds_add_u32 %0, %1" : : "v"(addr), "v"(1u) : "memory");
+    }
 }
 
 // The fused kernel's load pipeline as a reusable loop: four 12-byte buffer loads in flight per lane, slot k is

@@ -660,3 +660,39 @@ def test_caller_stream_is_ordered_against_the_zeroing(lars):
         _ffi.call("lars_synchronize", s)
         _ffi.call("lars_stream_destroy", s)
     b.free()
+
+
+@pytest.mark.parametrize("profile", ["vegetation", "uniform"])
+@pytest.mark.parametrize("indices", [("NDVI", "GNDVI", "NDWI"), ("NDVI",), ("NDWI",)])
+def test_one_pass_medians_and_their_fallback(lars, profile, indices):
+    """Statistics + exact medians without planes: the statistics kernel counts the slots of a predicted window of buckets
+    next to the buckets themselves, so the slot pass is only taken where the prediction missed.  Three routes must give
+    np.median exactly: predicted windows (default), windows pointed at the wrong place on purpose (every tile falls back
+    to the slot pass) and no windows at all (always two passes); statistics records identical throughout.  Includes
+    constant tiles (every value in one slot) and a tile whose two middle values straddle buckets."""
+    from lars_image_processing_amd import _ffi
+    tiles = [orc.synth_tile_u8(41, t, 128, 256, profile=profile) for t in range(6)]
+    tiles.append(np.full((128, 256, 3), 77, dtype=np.uint8))                              # constant: WB -> NaN -> 0, index 0
+    half = np.zeros((128, 256, 3), dtype=np.uint8)
+    half[:64] = (10, 40, 200)
+    half[64:] = (200, 40, 10)                                                             # two values, N/2 each: the middles differ
+    tiles.append(half)
+    b = lars.TileBatch.from_host(np.stack(tiles))
+    want = np.full((b.ntiles, 3), np.nan)
+    for i, tile in enumerate(tiles):
+        with warnings.catch_warnings():
+            warnings.simplefilter("ignore")
+            wb = orc.wb_app(tile)
+        for t in indices:
+            want[i, TYPES.index(t)] = float(np.median(orc.index_app(wb, t)))
+    results = {}
+    try:
+        for mode in (1, 2, 0):
+            _ffi.set_tuning(selq_window=mode)
+            rec, med = b.process(indices=indices, medians=True)
+            results[mode] = rec.tobytes()
+            np.testing.assert_array_equal(med, want, err_msg=f"selq_window={mode}")
+    finally:
+        _ffi.set_tuning(selq_window=1)
+    assert results[1] == results[2] == results[0]
+    b.free()

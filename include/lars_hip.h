@@ -234,7 +234,10 @@ size_t lars_quotient_median_scratch_bytes(int64_t ntiles);
 /* The statistics of lars_d_fused (a->stats, LARS_F_HIST honoured; index_mask = one index or all three; no
  * output planes) AND those medians in one call: the statistics kernel also counts the select's first
  * pass, so the tiles are read twice (three times with the white-balance histogram pass).  Streams the mask does not ask for come back
- * as NaN pairs. */
+ * as NaN pairs.  With plain LARS_F_STATS the select passes are usually not needed at all: a subsample predicts a window per
+ * tile and stream, the statistics kernel counts the values below it and the slots inside it instead of the buckets, and only
+ * tiles whose ranks fall outside their window take the two classic passes -- to find out which, this call waits for its
+ * stream once (one word comes back to the host). */
 int lars_d_stats_medians(const lars_fused_args *a, float *out_pairs, void *scratch);
 int lars_d_quotient_median_pairs(const void *tiles, int64_t ntiles, int64_t npix, int channels, int dtype,
                                  const uint8_t *wb_table, uint32_t streams /* bit 0 NDVI, bit 1 GNDVI; others come back NaN */,

@@ -729,7 +729,7 @@ extern "C" int lars_d_fused(const lars_fused_args *a)
         P.out_rgba[k] = on ? a->out_rgba[k] : nullptr;
         P.cmap_lut[k] = a->cmap_lut[k];
     }
-    P.out_wb = a->out_wb; P.stats = a->stats; P.mask = mask; P.sel_hist = nullptr; P.sel_win = nullptr; P.sel_win_hist = nullptr;
+    P.out_wb = a->out_wb; P.stats = a->stats; P.mask = mask; P.sel_hist = nullptr; P.sel_win = nullptr; P.sel_win_hist = nullptr; P.sel_below = nullptr;
     P.flags = (a->flags & 7u) | (tuning().nt_stores ? 0x20000000u : 0u);
 
     const long long nrec = a->ntiles * 3;

@@ -140,7 +140,7 @@ struct WaveAcc {
 #define V2_HIST_SHIFT 6      // log2(V2_HIST_COPIES * 4): bytes between consecutive bins
 #define V2_HIST_ROWS 51      // bins 0..50; 50 (x == 1.0, the closed right edge) folds into 49 at the flush
 #define V2_HIST_WORDS (3 * V2_HIST_ROWS * V2_HIST_COPIES)
-#define V2_WIN_ROW SELQ_WIN_SLOTS          // one stream's window slots
+#define V2_WIN_ROW (64 + SELQ_WIN_SLOTS + 64)   // one stream's row: below words, slots, above words = 2048
 
 // Coverage counters live in scalar registers.  The compare mask goes through VCC inside ONE asm
 // statement (v_cmp -> s_bcnt1), so it never occupies an allocatable SGPR pair: with the
@@ -258,18 +258,18 @@ template <bool OUT> struct V2Block { static constexpr int threads = OUT ? 512 : 
 // fused: P.sel_hist[tile][stream][track 0][bucket]).  With the 64 KiB table that is exactly 80 KiB of LDS (two blocks
 // per CU) because the reduction scratch then reuses the table's space once the loop is over.
 template <unsigned MASK, bool WB, int STATS, bool OUT, bool NT, int SEL = 0, int CM = LARS_COUNT_MODE>
-__global__ __launch_bounds__(V2Block<OUT>::threads, (OUT || SEL == 2) ? 4 : LARS_V2_STATS_WAVES) void k_fused_v2(FusedParams P)
+__global__ __launch_bounds__(V2Block<OUT>::threads, OUT ? 4 : LARS_V2_STATS_WAVES) void k_fused_v2(FusedParams P)
 {
     constexpr int NTHR = V2Block<OUT>::threads;
     constexpr int NWAVES = NTHR / 64;
     constexpr bool RED_ALIASES_TABLE = WB && SEL;
     __shared__ __attribute__((aligned(16))) char s_mem[(WB ? V2_TABLE_BYTES : 0) + (STATS >= 2 ? V2_HIST_WORDS * 4 : 0) +
-                                                       (SEL ? 2 * SELQ_BINS * 4 : 0) + (SEL == 2 ? 2 * V2_WIN_ROW * 4 : 0) +
+                                                       (SEL == 1 ? 2 * SELQ_BINS * 4 : 0) + (SEL == 2 ? 2 * V2_WIN_ROW * 4 : 0) +
                                                        (RED_ALIASES_TABLE ? 0 : NWAVES * 16 * sizeof(double))];
     char *s_tab = s_mem;                                                             // 64 KiB when WB
     unsigned int *s_hist = reinterpret_cast<unsigned int *>(s_mem + (WB ? V2_TABLE_BYTES : 0));
     unsigned int *s_sel = s_hist + (STATS >= 2 ? V2_HIST_WORDS : 0);                 // [2 streams][SELQ_BINS] when SEL
-    unsigned int *s_win = s_sel + (SEL ? 2 * SELQ_BINS : 0);                         // [2 streams][V2_WIN_ROW] when SEL == 2
+    unsigned int *s_win = s_sel + (SEL == 1 ? 2 * SELQ_BINS : 0);                    // [2 streams][V2_WIN_ROW] when SEL == 2 (instead of the buckets)
     double *s_red = RED_ALIASES_TABLE ? reinterpret_cast<double *>(s_mem)
                                       : reinterpret_cast<double *>(s_win + (SEL == 2 ? 2 * V2_WIN_ROW : 0));     // [NWAVES][16]
 
@@ -284,12 +284,14 @@ __global__ __launch_bounds__(V2Block<OUT>::threads, (OUT || SEL == 2) ? 4 : LARS
     const unsigned int hist_lds = STATS >= 2 ? (unsigned int)(unsigned long long)(lds_u32 *)s_hist : 0u;
     const unsigned int hb0 = hist_lds + (((unsigned)tid & (V2_HIST_COPIES - 1)) << 2) - (V2_HIST_MAGIC_BITS << V2_HIST_SHIFT);
     const unsigned int hb1 = hb0 + V2_HIST_ROWS * V2_HIST_COPIES * 4, hb2 = hb1 + V2_HIST_ROWS * V2_HIST_COPIES * 4;
-    const unsigned int sel_lds = SEL ? (unsigned int)(unsigned long long)(lds_u32 *)s_sel : 0u;
+    const unsigned int sel_lds = SEL == 1 ? (unsigned int)(unsigned long long)(lds_u32 *)s_sel : 0u;
     const unsigned int sb0 = sel_lds, sb1 = sb0 + SELQ_BINS * 4;     // NDVI row, GNDVI row
-    // SEL == 2: slot counts inside each stream's predicted window of SELQ_WIN buckets (the one-pass median, select_q.hip)
+    // SEL == 2: per stream the count of values below its predicted window and the slot counts inside it (the one-pass
+    // median, select_q.hip) -- instead of the 2048 buckets, same 16 KiB
     const unsigned int win_lds = SEL == 2 ? (unsigned int)(unsigned long long)(lds_u32 *)s_win : 0u;
     const unsigned int wr0 = win_lds, wr1 = wr0 + V2_WIN_ROW * 4;
-    unsigned int wt0 = 0, wt1 = 0;                                   // bits of the first t of each window
+    unsigned int wt0 = 0, wt1 = 0;                                   // bits of (first t of each window - 64 slots)
+    const int win_lo = (int)lane, win_hi = 64 + SELQ_WIN_SLOTS + (int)lane;
     const unsigned int lane_off4 = lane << 2;
     const long long tile = blockIdx.y;
     const long long npix = P.npix;
@@ -307,13 +309,13 @@ __global__ __launch_bounds__(V2Block<OUT>::threads, (OUT || SEL == 2) ? 4 : LARS
     if (STATS >= 2) {
         for (int i = tid; i < V2_HIST_WORDS; i += NTHR) s_hist[i] = 0;
     }
-    if (SEL) {
+    if (SEL == 1) {
         for (int i = tid; i < 2 * SELQ_BINS; i += NTHR) s_sel[i] = 0;
     }
     if (SEL == 2) {
         for (int i = tid; i < 2 * V2_WIN_ROW; i += NTHR) s_win[i] = 0;
-        wt0 = SELQ_T_BITS | (P.sel_win[blockIdx.y * 2] << 12);
-        wt1 = SELQ_T_BITS | (P.sel_win[blockIdx.y * 2 + 1] << 12);
+        wt0 = __builtin_amdgcn_readfirstlane(P.sel_win[blockIdx.y * 2]) - (64u << SELQ_WIN_SHIFT);       // wave-uniform
+        wt1 = __builtin_amdgcn_readfirstlane(P.sel_win[blockIdx.y * 2 + 1]) - (64u << SELQ_WIN_SHIFT);
     }
     if (WB || STATS >= 2 || SEL) __syncthreads();
 
@@ -381,10 +383,13 @@ __global__ __launch_bounds__(V2Block<OUT>::threads, (OUT || SEL == 2) ? 4 : LARS
                     const f32x2 p = hist_pos2(x, 1.0f);
                     hist_add_pos(p.x, hb0); hist_add_pos(p.y, hb0);
                 }
-                if (SEL) {
+                if (SEL == 1) {
                     const f32x2 p = selq_t2(x);
                     selq_add_bucket(p.x, sb0); selq_add_bucket(p.y, sb0);
-                    if (SEL == 2) { selq_add_window(p.x, wt0, wr0); selq_add_window(p.y, wt0, wr0); }
+                }
+                if (SEL == 2) {
+                    const f32x2 p = selq_t2(x);
+                    selq_window_add(p.x, wt0, wr0, win_lo, win_hi); selq_window_add(p.y, wt0, wr0, win_lo, win_hi);
                 }
             }
             if (NEED_G) {
@@ -397,10 +402,13 @@ __global__ __launch_bounds__(V2Block<OUT>::threads, (OUT || SEL == 2) ? 4 : LARS
                     const f32x2 p = hist_pos2(x, 1.0f);
                     hist_add_pos(p.x, hb1); hist_add_pos(p.y, hb1);
                 }
-                if (SEL) {
+                if (SEL == 1) {
                     const f32x2 p = selq_t2(x);
                     selq_add_bucket(p.x, sb1); selq_add_bucket(p.y, sb1);
-                    if (SEL == 2) { selq_add_window(p.x, wt1, wr1); selq_add_window(p.y, wt1, wr1); }
+                }
+                if (SEL == 2) {
+                    const f32x2 p = selq_t2(x);
+                    selq_window_add(p.x, wt1, wr1, win_lo, win_hi); selq_window_add(p.y, wt1, wr1, win_lo, win_hi);
                 }
                 if (STATS >= 2 && WANT_NDWI) {
                     const f32x2 p = hist_pos2(x, -1.0f);
@@ -482,11 +490,9 @@ __global__ __launch_bounds__(V2Block<OUT>::threads, (OUT || SEL == 2) ? 4 : LARS
                 // consume slot k, then refill it: the refill lands in the registers just freed
                 // (no copies, no vmcnt(0) at the loop head) and has three quads of work to hide behind
                 do_quad(q0 + (it + k) * stride, w[k].x, w[k].y, w[k].z);
-                // with one block per CU (SEL == 2: 4 waves per SIMD, 128 VGPRs) the quads of a trip may overlap: the waves
-                // alone no longer cover the LDS round trips
-                if (SEL != 2) __builtin_amdgcn_sched_barrier(0);
+                __builtin_amdgcn_sched_barrier(0);
                 w[k] = __builtin_amdgcn_raw_buffer_load_b96(rsrc, voff, soff + (unsigned)k * step_b, 0);
-                if (SEL != 2) __builtin_amdgcn_sched_barrier(0);
+                __builtin_amdgcn_sched_barrier(0);
             }
             soff += 4u * step_b;
         }
@@ -511,15 +517,15 @@ __global__ __launch_bounds__(V2Block<OUT>::threads, (OUT || SEL == 2) ? 4 : LARS
             const float x = norm_diff_fast(fn, fr);
             if (STATS >= 1) push<STATS>(acc_v, above_v, x, 0.2f);
             if (STATS >= 2) hist_add(x, 1.0f, hb0);
-            if (SEL) selq_add_bucket(selq_t(x), sb0);
-            if (SEL == 2) selq_add_window(selq_t(x), wt0, wr0);
+            if (SEL == 1) selq_add_bucket(selq_t(x), sb0);
+            if (SEL == 2) selq_window_add(selq_t(x), wt0, wr0, win_lo, win_hi);
             if (oi0) oi0[i] = x;
             if (oc0) reinterpret_cast<unsigned int *>(oc0)[i] = lut0[cmap_index(x)];
         }
         if (NEED_G) {
             const float x = norm_diff_fast(fn, fg);
-            if (SEL) selq_add_bucket(selq_t(x), sb1);
-            if (SEL == 2) selq_add_window(selq_t(x), wt1, wr1);
+            if (SEL == 1) selq_add_bucket(selq_t(x), sb1);
+            if (SEL == 2) selq_window_add(selq_t(x), wt1, wr1, win_lo, win_hi);
             if (STATS >= 1) {
                 acc_g.mn = fminf(acc_g.mn, x); acc_g.mx = fmaxf(acc_g.mx, x);
                 const double xd = (double)x;
@@ -636,19 +642,22 @@ __global__ __launch_bounds__(V2Block<OUT>::threads, (OUT || SEL == 2) ? 4 : LARS
                 }
             }
         }
-        if (SEL) {
+        if (SEL == 1) {
             // the barrier of the statistics flush above already ordered every wave's bucket atomics
             unsigned int *h = P.sel_hist + tile * (4 * SELQ_BINS);
             for (int i = tid; i < 2 * SELQ_BINS; i += NTHR) {
                 const unsigned int v = s_sel[i];
                 if (v) atomicAdd(&h[(i >> 11) * (2 * SELQ_BINS) + (i & (SELQ_BINS - 1))], v);      // stream row, track 0
             }
-            if (SEL == 2) {
-                unsigned int *wh = P.sel_win_hist + tile * (2 * SELQ_WIN_SLOTS);
-                for (int i = tid; i < 2 * SELQ_WIN_SLOTS; i += NTHR) {
-                    const unsigned int v = s_win[(i / SELQ_WIN_SLOTS) * V2_WIN_ROW + (i % SELQ_WIN_SLOTS)];
-                    if (v) atomicAdd(&wh[i], v);
-                }
+        }
+        if (SEL == 2) {
+            // words 0..63 of a row: values below the window; 64 .. 64 + SLOTS - 1: the slots; the rest: above (not needed)
+            for (int i = tid; i < 2 * V2_WIN_ROW; i += NTHR) {
+                const unsigned int v = s_win[i];
+                if (!v) continue;
+                const int stream = i / V2_WIN_ROW, w = i % V2_WIN_ROW;
+                if (w < 64) atomicAdd(&P.sel_below[tile * 2 + stream], v);
+                else if (w < 64 + SELQ_WIN_SLOTS) atomicAdd(&P.sel_win_hist[(tile * 2 + stream) * SELQ_WIN_SLOTS + (w - 64)], v);
             }
         }
     }

@@ -39,6 +39,7 @@ struct SelQParams {
     // per-tile selection (medians of every tile of a batch, all on the device): state and 32-bit histograms per tile
     struct SelQTile *state;
     unsigned int *hist32;                 // [ntiles][2][2][SELQ_BINS]
+    const unsigned int *tile_list;        // per-tile mode: blockIdx.y -> tile (the tiles the one-pass route did not serve), or null
 };
 struct SelQTile {
     unsigned int bucket[4];               // [stream * 2 + track]: bucket picked after pass 1
@@ -56,8 +57,7 @@ __global__ __launch_bounds__(1024, 8) void k_selq_pass(SelQParams P)
     __shared__ unsigned int s_h[2 * SELQ_BINS];
     const int tid = threadIdx.x;
     const unsigned int lane_off4 = (tid & 63u) << 2;
-    const long long tile = blockIdx.y;
-    if (PER_TILE && !P.first && P.state[tile].pad[2]) return;     // the predicted window already gave this tile's medians
+    const long long tile = (PER_TILE && P.tile_list) ? (long long)P.tile_list[blockIdx.y] : (long long)blockIdx.y;
     const long long npix = P.npix;
     const uint8_t *base = P.tiles + tile * npix * 3;
     if (WB) {
@@ -200,11 +200,10 @@ __device__ inline float selq_value_of(unsigned int bucket, unsigned int slot, in
 
 // one block per tile, one wave per (stream, track): find the bin whose cumulative count covers the rank.
 // first: bucket -> state; second: slot -> the value, written to out[tile][stream][track]
-__global__ __launch_bounds__(256) void k_selq_pick(SelQTile *state, unsigned int *hist32, int first, float *out)
+__global__ __launch_bounds__(256) void k_selq_pick(SelQTile *state, unsigned int *hist32, int first, float *out, const unsigned int *tile_list)
 {
-    const long long tile = blockIdx.x;
+    const long long tile = tile_list ? (long long)tile_list[blockIdx.x] : (long long)blockIdx.x;
     unsigned int *h = hist32 + tile * (4 * SELQ_BINS);
-    if (!first && state[tile].pad[2]) return;                     // served by the window: out[] is already final, h untouched since
     const int combo = threadIdx.x >> 6, lane = threadIdx.x & 63;
     const bool active = (state[tile].streams >> (combo >> 1)) & 1u;
     // the second pass counted a bucket shared by both tracks once, under track 0
@@ -259,14 +258,15 @@ __global__ __launch_bounds__(256) void k_selq_pick(SelQTile *state, unsigned int
 }
 
 // ---------------------------------------------------------------------------------------------------------------------
-// One-pass medians: predict where each tile's median will fall, let the statistics kernel count the slots of a window of
-// SELQ_WIN buckets around the prediction next to its 2048 buckets (fused_v2.hip, SEL == 2), and take the slot pass only for
-// tiles whose real median bucket -- known exactly from the bucket counts -- lies outside their window.
+// One-pass medians: predict where each tile's median will fall, and let the statistics kernel count -- instead of the 2048
+// buckets -- the values below a window of 3.75 buckets around the prediction and the slots inside it (fused_v2.hip,
+// SEL == 2).  If a rank falls inside the window the order statistic is exact from those counts; tiles where it does not
+// (known exactly: below <= rank < below + window mass) take the two classic passes.
 // ---------------------------------------------------------------------------------------------------------------------
-// The prediction: the median bucket of a subsample (every SUB-th 1024-pixel step, at most 256 steps: 262144 of a 4096 x 4096
-// tile's pixels).  Its standard error is 0.5 / sqrt(n) of the distribution's mass, under one bucket for index planes that
-// are not concentrated on a few values -- and concentrated planes have their median inside the predicted bucket anyway.
-// One block per tile; win[tile][stream] = first bucket of the window.
+// The prediction: the median bucket of a subsample (every SUB-th 1024-pixel step, at most 1024 steps: a sixteenth of a
+// 4096 x 4096 tile).  Standard error of a sample median = 1 / (2 f sqrt(n)) for density f at the median: with n = 2^20 and
+// f ~ 1 per unit of the index that is half a bucket, and the window reaches two buckets to either side of the predicted
+// bucket's centre.  One block per tile; win[tile][stream] = float bits of the window's first t.
 template <bool WB>
 __global__ __launch_bounds__(1024) void k_selq_predict(const uint8_t *__restrict__ tiles, const uint8_t *__restrict__ wb_table, long long npix,
                                                        unsigned int streams, unsigned int *__restrict__ win)
@@ -289,8 +289,8 @@ __global__ __launch_bounds__(1024) void k_selq_predict(const uint8_t *__restrict
     __syncthreads();
     const long long nquads = npix >> 2;
     const long long nsteps = nquads >> 8;                          // complete steps only
-    const long long sub = nsteps > 256 ? nsteps / 256 : 1;
-    for (long long k = tid >> 6; k * sub < nsteps && k < 256; k += 16) {
+    const long long sub = nsteps > 1024 ? nsteps / 1024 : 1;
+    for (long long k = tid >> 6; k * sub < nsteps && k < 1024; k += 16) {
         const long long q0 = k * sub * 256 + lane;
 #pragma unroll
         for (int j = 0; j < 4; ++j) {
@@ -335,54 +335,86 @@ __global__ __launch_bounds__(1024) void k_selq_predict(const uint8_t *__restrict
                 if (rank >= cum + c[j]) { cum += c[j]; d = j + 1; }
                 else break;
             }
-            int b = (int)lane * 32 + d - SELQ_WIN / 2;
-            b = b < 0 ? 0 : (b > SELQ_BINS - SELQ_WIN ? SELQ_BINS - SELQ_WIN : b);
-            win[tile * 2 + stream] = (unsigned int)b;
+            // the window: 3.75 buckets centred on the predicted bucket's centre, kept inside the binade [2048, 4096)
+            const float width = (float)SELQ_WIN_UNITS / 4096.0f;
+            float t0 = 2048.0f + (float)((int)lane * 32 + d) + 0.5f - 0.5f * width;
+            t0 = fminf(fmaxf(t0, 2048.0f), 4096.0f - width);
+            win[tile * 2 + stream] = __builtin_bit_cast(unsigned int, t0);
         }
-        if (!total && lane == 0) win[tile * 2 + stream] = 0u;
+        if (!total && lane == 0) win[tile * 2 + stream] = SELQ_T_BITS;
     }
 }
 
-// After the statistics kernel and the bucket pick: where a (stream, track)'s bucket lies inside the tile's window, its slot
-// is found in the window's counts and the value written; a tile whose every requested order statistic was found that way
-// is marked done (pad[2]) and skips the slot pass.  One block per tile, one wave per (stream, track).
-__global__ __launch_bounds__(256) void k_selq_pick_window(SelQTile *state, const unsigned int *win, const unsigned int *win_hist, float *out,
-                                                          unsigned int *pending)
+__global__ void k_selq_fill(unsigned int *p, long long n, unsigned int v)
+{
+    const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) p[i] = v;
+}
+
+// the quotient of bytes in slot `slot` of the window whose first t has the bits t0_bits (see selq_value_of)
+__device__ inline float selq_window_value(unsigned int t0_bits, unsigned int slot, int lane)
+{
+    const double t0 = (double)__builtin_bit_cast(float, t0_bits);
+    const double centre_t = t0 + ((double)(slot << SELQ_WIN_SHIFT) + 0.5 * (double)(1 << SELQ_WIN_SHIFT)) / 4096.0;
+    const double centre = (centre_t - 3071.5) / 1023.5;
+    float found = __builtin_nanf("");
+    for (int den = 1 + lane; den <= 510; den += 64) {
+        const float n = (float)__builtin_rint(centre * (double)den);
+        if (__builtin_fabsf(n) > (float)den) continue;
+        const float q = exact_quot(n, (float)den);
+        const unsigned int d = __builtin_bit_cast(unsigned int, selq_t(q)) - t0_bits;
+        if (d < (unsigned)SELQ_WIN_UNITS && (d >> SELQ_WIN_SHIFT) == slot) found = q + 0.0f;      // -0/den -> +0.0
+    }
+    for (int off = 32; off >= 1; off >>= 1) {
+        const float o = __shfl_xor(found, off);
+        if (found != found) found = o;
+    }
+    return found;
+}
+
+// After the statistics kernel: for every requested (stream, track) the rank is looked up in the window's counts
+// (below <= rank < below + mass of the window); a tile whose every order statistic was found is marked done (pad[2]) and
+// never sees the classic passes.  One block per tile, one wave per (stream, track); lane l owns 30 of the 1920 slots.
+__global__ __launch_bounds__(256) void k_selq_pick_window(SelQTile *state, const unsigned int *win, const unsigned int *win_hist,
+                                                          const unsigned int *below, float *out, unsigned int *pending, unsigned int *tile_list)
 {
     __shared__ unsigned int s_ok[4];
     const long long tile = blockIdx.x;
     const int combo = threadIdx.x >> 6, lane = threadIdx.x & 63;
     const int stream = combo >> 1;
     const bool active = (state[tile].streams >> stream) & 1u;
-    const unsigned int bucket = state[tile].bucket[combo], rank = state[tile].rank[combo];
-    const unsigned int w0 = win[tile * 2 + stream];
+    const unsigned int rank = state[tile].rank[combo];              // absolute: (N - 1) / 2 or N / 2 (k_selq_init)
+    const unsigned int t0_bits = win[tile * 2 + stream], lo = below[tile * 2 + stream];
     bool ok = !active;
     float v = __builtin_nanf("");
-    if (active && bucket >= w0 && bucket < w0 + SELQ_WIN) {
-        const unsigned int *mine = win_hist + (tile * 2 + stream) * SELQ_WIN_SLOTS + (bucket - w0) * SELQ_SLOTS + lane * 16;
-        unsigned int c[16], local = 0;
+    if (active && rank >= lo) {
+        constexpr int PER = SELQ_WIN_SLOTS / 64;
+        static_assert(SELQ_WIN_SLOTS == 64 * PER, "whole slots per lane");
+        const unsigned int *mine = win_hist + (tile * 2 + stream) * SELQ_WIN_SLOTS + lane * PER;
+        const unsigned int r = rank - lo;
+        unsigned int c[PER], local = 0;
 #pragma unroll
-        for (int j = 0; j < 16; ++j) { c[j] = mine[j]; local += c[j]; }
+        for (int j = 0; j < PER; ++j) { c[j] = mine[j]; local += c[j]; }
         unsigned int incl = local;
         for (int off = 1; off < 64; off <<= 1) {
             const unsigned int o = __shfl_up(incl, off);
             if (lane >= off) incl += o;
         }
         unsigned int cum = incl - local;
-        const bool holder = rank >= cum && rank < incl;
+        const bool holder = r >= cum && r < incl;
         int d = 0;
         if (holder) {
 #pragma unroll
-            for (int j = 0; j < 16; ++j) {
-                if (rank >= cum + c[j]) { cum += c[j]; d = j + 1; }
+            for (int j = 0; j < PER; ++j) {
+                if (r >= cum + c[j]) { cum += c[j]; d = j + 1; }
                 else break;
             }
         }
         const unsigned long long who = __ballot(holder);
         if (who) {
             const int src = __ffsll((long long)who) - 1;
-            const unsigned int slot = (unsigned int)__shfl(lane * 16 + d, src);
-            v = selq_value_of(bucket, slot, lane);
+            const unsigned int slot = (unsigned int)__shfl(lane * PER + d, src);
+            v = selq_window_value(t0_bits, slot, lane);
             ok = v == v;
         }
     }
@@ -395,7 +427,7 @@ __global__ __launch_bounds__(256) void k_selq_pick_window(SelQTile *state, const
     if (threadIdx.x == 0) {
         const unsigned int done = s_ok[0] & s_ok[1] & s_ok[2] & s_ok[3];
         state[tile].pad[2] = done;
-        if (!done) atomicAdd(pending, 1u);                        // tiles that still need the slot pass
+        if (!done) tile_list[atomicAdd(pending, 1u)] = (unsigned int)tile;      // tiles that still need the classic passes
     }
 }
 
@@ -437,16 +469,28 @@ int selq_pass_launch(const uint8_t *tiles, const uint8_t *wb_table, long long nt
 
 size_t selq_tile_scratch_bytes(long long ntiles)
 {
-    return (size_t)ntiles * (sizeof(SelQTile) + 4 * SELQ_BINS * sizeof(unsigned int) + 2 * sizeof(unsigned int) +
-                             2 * SELQ_WIN_SLOTS * sizeof(unsigned int)) + 1024 + 64;
+    return (size_t)ntiles * (sizeof(SelQTile) + 4 * SELQ_BINS * sizeof(unsigned int) + 5 * sizeof(unsigned int) +
+                             2 * SELQ_WIN_SLOTS * sizeof(unsigned int)) + 2048 + 512;
 }
-// behind the per-tile histograms: the predicted windows [ntiles][2] and their slot counts [ntiles][2][SELQ_WIN_SLOTS]
-static void selq_window_layout(void *scratch, long long ntiles, unsigned int **win, unsigned int **win_hist)
+// behind the per-tile histograms: the predicted windows [ntiles][2], the counts below them [ntiles][2], the slot counts
+// [ntiles][2][SELQ_WIN_SLOTS] and one word for the number of tiles the window did not serve
+struct SelQWindow {
+    unsigned int *win, *below, *win_hist, *pending, *tile_list;
+    size_t zero_bytes;                     // below .. pending are contiguous: one memset
+};
+static SelQWindow selq_window_layout(void *scratch, long long ntiles)
 {
+    SelQWindow w;
     char *p = reinterpret_cast<char *>(selq_tile_hist32(scratch, ntiles) + (size_t)ntiles * 4 * SELQ_BINS);
     p = reinterpret_cast<char *>((reinterpret_cast<uintptr_t>(p) + 255) & ~(uintptr_t)255);
-    *win = reinterpret_cast<unsigned int *>(p);
-    *win_hist = reinterpret_cast<unsigned int *>(p + (((size_t)ntiles * 2 * sizeof(unsigned int) + 255) & ~(size_t)255));
+    w.win = reinterpret_cast<unsigned int *>(p);
+    p += ((size_t)ntiles * 2 * sizeof(unsigned int) + 255) & ~(size_t)255;
+    w.below = reinterpret_cast<unsigned int *>(p);
+    w.win_hist = w.below + (((size_t)ntiles * 2 + 63) & ~(size_t)63);
+    w.pending = w.win_hist + (size_t)ntiles * 2 * SELQ_WIN_SLOTS;
+    w.zero_bytes = (size_t)(reinterpret_cast<char *>(w.pending + 1) - reinterpret_cast<char *>(w.below));
+    w.tile_list = w.pending + 64;
+    return w;
 }
 
 // medians of every tile: bucket pass + slot pass, picks on the device, no host round trip
@@ -478,31 +522,34 @@ int selq_tile_medians_launch(const uint8_t *tiles, const uint8_t *wb_table, long
 {
     SelQTile *state; unsigned int *hist32;
     selq_scratch_layout(scratch, ntiles, &state, &hist32);
-    unsigned int *win, *win_hist;
-    selq_window_layout(scratch, ntiles, &win, &win_hist);
-    if (!first_pass_done) LARS_TRY(selq_tile_prepare(scratch, ntiles, npix, s, streams));
-    const dim3 grid = selq_grid(ntiles, npix);
+    const unsigned int *tile_list = nullptr;
+    long long nrun = ntiles;
+    if (windowed) {
+        // the statistics kernel counted the windows (not the buckets): finish every tile whose ranks fall inside
+        const SelQWindow w = selq_window_layout(scratch, ntiles);
+        hipLaunchKernelGGL(k_selq_pick_window, dim3((unsigned)ntiles), dim3(256), 0, s, state, w.win, w.win_hist, w.below, out_pairs, w.pending,
+                           w.tile_list);
+        // How many tiles are left decides whether (and over how many tiles) the classic passes are launched at all, so the
+        // host looks at the count -- the one place where a device entry point waits for its stream (the callers read the
+        // medians back right after it anyway).
+        unsigned int left = 1;
+        LARS_HIP_TRY(hipMemcpyAsync(&left, w.pending, sizeof left, hipMemcpyDeviceToHost, s));
+        LARS_HIP_TRY(hipStreamSynchronize(s));
+        if (left == 0) return launch_check("selq_tile_medians (window)");
+        first_pass_done = false;                              // the tiles on the list take both classic passes
+        tile_list = w.tile_list;
+        nrun = left;
+    }
+    if (!first_pass_done && !windowed) LARS_TRY(selq_tile_prepare(scratch, ntiles, npix, s, streams));
+    const dim3 grid = selq_grid(nrun, npix);
     for (int p = 0; p < 2; ++p) {
         SelQParams P;
         memset(&P, 0, sizeof P);
         P.tiles = tiles; P.wb_table = wb_table; P.npix = npix; P.first = p == 0;
-        P.state = state; P.hist32 = hist32;
+        P.state = state; P.hist32 = hist32; P.tile_list = tile_list;
         if (p == 0 && first_pass_done) { /* counted by the statistics kernel */ }
         else selq_launch<true>(wb_table != nullptr, streams, grid, s, P);
-        hipLaunchKernelGGL(k_selq_pick, dim3((unsigned)ntiles), dim3(256), 0, s, state, hist32, p == 0 ? 1 : 0, out_pairs);
-        // buckets are known: tiles whose buckets lie inside their predicted window are finished from the window's slot counts
-        if (p == 0 && windowed && first_pass_done) {
-            unsigned int *pending = win_hist + (size_t)ntiles * 2 * SELQ_WIN_SLOTS;      // one word behind the window counts
-            LARS_HIP_TRY(hipMemsetAsync(pending, 0, sizeof(unsigned int), s));
-            hipLaunchKernelGGL(k_selq_pick_window, dim3((unsigned)ntiles), dim3(256), 0, s, state, win, win_hist, out_pairs, pending);
-            // Nearly always every tile is done here.  Launching the slot pass just to let its 8192 workgroups find that out
-            // costs 0.7 ms per 256 tiles, so the host looks at the count first -- the one place where a device entry point
-            // waits for its stream (the callers read the medians back right after it anyway).
-            unsigned int left = 1;
-            LARS_HIP_TRY(hipMemcpyAsync(&left, pending, sizeof left, hipMemcpyDeviceToHost, s));
-            LARS_HIP_TRY(hipStreamSynchronize(s));
-            if (left == 0) break;
-        }
+        hipLaunchKernelGGL(k_selq_pick, dim3((unsigned)nrun), dim3(256), 0, s, state, hist32, p == 0 ? 1 : 0, out_pairs, tile_list);
     }
     return launch_check("selq_tile_medians");
 }
@@ -580,14 +627,17 @@ extern "C" int lars_d_stats_medians(const lars_fused_args *a, float *out_pairs, 
     // lars_set_tuning("selq_window", 0) = always two passes; 2 = predict, then point every window at bucket 0 (tests the fallback)
     const bool windowed = stats_mode == 1 && tuning().selq_window != 0;
     if (windowed) {
-        unsigned int *win, *win_hist;
-        selq_window_layout(scratch, a->ntiles, &win, &win_hist);
-        LARS_HIP_TRY(hipMemsetAsync(win_hist, 0, (size_t)a->ntiles * 2 * SELQ_WIN_SLOTS * sizeof(unsigned int), s));
-        if (a->wb_table) hipLaunchKernelGGL((k_selq_predict<true>), dim3((unsigned)a->ntiles), dim3(1024), 0, s, tiles, a->wb_table, (long long)a->npix, streams, win);
-        else hipLaunchKernelGGL((k_selq_predict<false>), dim3((unsigned)a->ntiles), dim3(1024), 0, s, tiles, a->wb_table, (long long)a->npix, streams, win);
-        if (tuning().selq_window == 2) LARS_HIP_TRY(hipMemsetAsync(win, 0, (size_t)a->ntiles * 2 * sizeof(unsigned int), s));
-        P.sel_win = win;
-        P.sel_win_hist = win_hist;
+        const SelQWindow w = selq_window_layout(scratch, a->ntiles);
+        LARS_HIP_TRY(hipMemsetAsync(w.below, 0, w.zero_bytes, s));
+        if (a->wb_table) hipLaunchKernelGGL((k_selq_predict<true>), dim3((unsigned)a->ntiles), dim3(1024), 0, s, tiles, a->wb_table, (long long)a->npix, streams, w.win);
+        else hipLaunchKernelGGL((k_selq_predict<false>), dim3((unsigned)a->ntiles), dim3(1024), 0, s, tiles, a->wb_table, (long long)a->npix, streams, w.win);
+        if (tuning().selq_window == 2) {
+            // test hook: every window at the bottom of the range, so that every tile misses and takes the classic passes
+            hipLaunchKernelGGL(k_selq_fill, dim3((unsigned)((a->ntiles * 2 + 255) / 256)), dim3(256), 0, s, w.win, a->ntiles * 2, (unsigned)SELQ_T_BITS);
+        }
+        P.sel_win = w.win;
+        P.sel_win_hist = w.win_hist;
+        P.sel_below = w.below;
     }
     const long long nrec = a->ntiles * 3;
     stats_init_launch(a->stats, nrec, mask, s);

@@ -90,11 +90,15 @@ __device__ inline unsigned int sample_entry(unsigned int word, int byte, unsigne
 #define SELQ_BINS 2048
 #define SELQ_SLOTS 1024
 #define SELQ_T_BITS 0x45000000u                         /* float bits of 2048.0 */
-// Predicted window of the one-pass median (select_q.hip): SELQ_WIN consecutive buckets around the bucket a subsample's median
-// fell into; the statistics kernel counts the 1024 slots of each of them next to the 2048 buckets, so that the slot pass
-// is only needed where the real median bucket lies outside the window.
-#define SELQ_WIN 8
-#define SELQ_WIN_SLOTS (SELQ_WIN * SELQ_SLOTS)
+// Predicted window of the one-pass median (select_q.hip): the statistics kernel counts, per stream, the values below the
+// window's first t and the slots inside the window; the median is exact from those two whenever its rank falls inside.
+// The window starts at any t0 of the binade and is cut into SELQ_WIN_SLOTS slots of 8 units of 2^-12 (two different
+// quotients of bytes are >= 15 such units apart, so a slot still holds ONE distinct value): 1920 slots = 3.75 buckets.
+// LDS row of a stream: 64 "below" words | 1920 slots | 64 "above" words = the 2048 words a bucket row takes otherwise, so
+// the kernel keeps its 80 KiB (two blocks per CU).
+#define SELQ_WIN_SHIFT 3                                   /* log2 of the slot width in units of 2^-12 */
+#define SELQ_WIN_SLOTS 1920
+#define SELQ_WIN_UNITS (SELQ_WIN_SLOTS << SELQ_WIN_SHIFT)  /* window width in units of 2^-12: 15360 = 3.75 buckets */
 __device__ inline float selq_t(float x) { return __builtin_fmaf(x, 1023.5f, 3071.5f); }
 __device__ inline f32x2 selq_t2(f32x2 x)
 {
@@ -108,16 +112,17 @@ __device__ inline void selq_add_bucket(float t, unsigned int row)      // row: L
     asm volatile("ds_add_u32 %0, %1" : : "v"(addr), "v"(1u) : "memory");
 }
 
-// slot inside the window that starts at the bucket whose first t has the bits t0 (SELQ_T_BITS | bucket << 12): the same
-// integer subtract as the slot pass (units of 2^-12 of t, four per slot).  Only lanes whose value lies inside the window
-// (a few per cent at most) touch LDS: the rest is masked off, and a wave without any such lane skips the add altogether.
-__device__ inline void selq_add_window(float t, unsigned int t0_bits, unsigned int row)
+// One value against a stream's window, branch-free: q = (bits(t) - bits(t0 - 64 slots)) >> 3 (arithmetic) is the value's
+// word in the row if it lies inside the window (64 .. 64 + SELQ_WIN_SLOTS - 1); anything smaller is clamped onto the lane's
+// own "below" word, anything larger onto its "above" word (values within 64 slots of the window land on a neighbour's
+// word: still the right group).  One subtract, one shift, one v_med3_i32, one address add, one LDS atomic.
+__device__ inline void selq_window_add(float t, unsigned int t0m_bits, unsigned int row, int lo_word, int hi_word)
 {
-    const unsigned int d = __builtin_bit_cast(unsigned int, t) - t0_bits;
-    if (d < (unsigned)SELQ_WIN_SLOTS * 4u) {
-        const unsigned int addr = (d & ~3u) + row;
-        asm volatile("ds_add_u32 %0, %1" : : "v"(addr), "v"(1u) : "memory");
-    }
+    const int q = (int)(__builtin_bit_cast(unsigned int, t) - t0m_bits) >> SELQ_WIN_SHIFT;
+    int idx;
+    asm("v_med3_i32 %0, %1, %2, %3" : "=v"(idx) : "v"(q), "v"(lo_word), "v"(hi_word));
+    const unsigned int addr = ((unsigned)idx << 2) + row;
+    asm volatile("ds_add_u32 %0, %1" : : "v"(addr), "v"(1u) : "memory");
 }
 
 // The fused kernel's load pipeline as a reusable loop: four 12-byte buffer loads in flight per lane, slot k is

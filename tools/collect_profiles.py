@@ -41,8 +41,8 @@ def main():
         "wb3idx_out_stats": ("k_fused_u8c3<unsigned char, 7u, true, 1, 1>", px64),
         "wb3idx_out_stats_hist": ("k_fused_u8c3<unsigned char, 7u, true, 2, 1>", px64),
         "wb_ndvi_out_stats": ("k_fused_u8c3<unsigned char, 1u, true, 1, 1>", px64),
-        "wb3idx_stats_only": ("k_fused_v2<7u, true, 1, false, false, false", px256),
-        "wb_ndvi_stats_only": ("k_fused_v2<1u, true, 1, false, false, false", px256),
+        "wb3idx_stats_only": ("k_fused_v2<7u, true, 1, false, false, 0,", px256),
+        "wb_ndvi_stats_only": ("k_fused_v2<1u, true, 1, false, false, 0,", px256),
         "channel_hist": ("k_chan_hist_u8c3_v2", px256),
     }
 

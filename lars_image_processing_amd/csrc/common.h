@@ -100,6 +100,7 @@ struct Tuning {
     int nt_stores = 0;         // non-temporal stores for the float32 planes
     int blocks_per_tile = 0;   // 0 = automatic
     int selq_window = 1;       // one-pass medians (select_q.hip): 1 predicted window, 0 always two passes, 2 wrong windows (test)
+    int selq_list_wgs = 0;     // workgroups per launch of the classic select passes over the tiles a window missed (0 = 2048)
     int pipe_steps = 0;        // pipeline.hip: wave-steps per work item (0 = 64)
     int pipe_cold = 0;         // pipeline.hip timing experiment: fused items read a far-away tile (results are wrong)
     int pipe_trace = 0;        // pipeline.hip: record item timestamps behind the scratch's sync words

@@ -17,7 +17,7 @@ struct FusedParams {
     unsigned int mask;             // runtime copy (generic kernel)
     unsigned int flags;
     unsigned int *sel_hist;        // [ntiles][2 streams][2 tracks][2048]: bucket pass of the median select, or null
-    const unsigned int *sel_win;   // [ntiles][2]: float bits of the first t of each stream's predicted window (select_q.hip), or null
+    const unsigned int *sel_win;   // [ntiles][2]: first slot (int) of each stream's predicted window (select_q.hip, v2_device.h), or null
     unsigned int *sel_win_hist;    // [ntiles][2][SELQ_WIN_SLOTS]: slot counts inside the window
     unsigned int *sel_below;       // [ntiles][2]: values below the window
 };

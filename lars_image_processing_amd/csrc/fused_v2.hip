@@ -289,9 +289,9 @@ __global__ __launch_bounds__(V2Block<OUT>::threads, OUT ? 4 : LARS_V2_STATS_WAVE
     // SEL == 2: per stream the count of values below its predicted window and the slot counts inside it (the one-pass
     // median, select_q.hip) -- instead of the 2048 buckets, same 16 KiB
     const unsigned int win_lds = SEL == 2 ? (unsigned int)(unsigned long long)(lds_u32 *)s_win : 0u;
-    const unsigned int wr0 = win_lds, wr1 = wr0 + V2_WIN_ROW * 4;
-    unsigned int wt0 = 0, wt1 = 0;                                   // bits of (first t of each window - 64 slots)
-    const int win_lo = (int)lane, win_hi = 64 + SELQ_WIN_SLOTS + (int)lane;
+    const unsigned int wr0 = win_lds - (SELQ_WIN_MAGIC_BITS << 2), wr1 = wr0 + V2_WIN_ROW * 4;     // see selq_window_add
+    float wt0 = 0, wt1 = 0;                                          // fma bias of each stream's window (selq_window_bias)
+    const int win_lo = (int)(SELQ_WIN_MAGIC_BITS + lane), win_hi = (int)(SELQ_WIN_MAGIC_BITS + 64 + SELQ_WIN_SLOTS + lane);
     const unsigned int lane_off4 = lane << 2;
     const long long tile = blockIdx.y;
     const long long npix = P.npix;
@@ -314,8 +314,8 @@ __global__ __launch_bounds__(V2Block<OUT>::threads, OUT ? 4 : LARS_V2_STATS_WAVE
     }
     if (SEL == 2) {
         for (int i = tid; i < 2 * V2_WIN_ROW; i += NTHR) s_win[i] = 0;
-        wt0 = __builtin_amdgcn_readfirstlane(P.sel_win[blockIdx.y * 2]) - (64u << SELQ_WIN_SHIFT);       // wave-uniform
-        wt1 = __builtin_amdgcn_readfirstlane(P.sel_win[blockIdx.y * 2 + 1]) - (64u << SELQ_WIN_SHIFT);
+        wt0 = selq_window_bias((int)__builtin_amdgcn_readfirstlane(P.sel_win[blockIdx.y * 2]));         // wave-uniform
+        wt1 = selq_window_bias((int)__builtin_amdgcn_readfirstlane(P.sel_win[blockIdx.y * 2 + 1]));
     }
     if (WB || STATS >= 2 || SEL) __syncthreads();
 
@@ -388,8 +388,8 @@ __global__ __launch_bounds__(V2Block<OUT>::threads, OUT ? 4 : LARS_V2_STATS_WAVE
                     selq_add_bucket(p.x, sb0); selq_add_bucket(p.y, sb0);
                 }
                 if (SEL == 2) {
-                    const f32x2 p = selq_t2(x);
-                    selq_window_add(p.x, wt0, wr0, win_lo, win_hi); selq_window_add(p.y, wt0, wr0, win_lo, win_hi);
+                    const f32x2 p = __builtin_elementwise_fma(x, (f32x2){SELQ_WIN_SCALE, SELQ_WIN_SCALE}, (f32x2){wt0, wt0});
+                    selq_window_add(p.x, wr0, win_lo, win_hi); selq_window_add(p.y, wr0, win_lo, win_hi);
                 }
             }
             if (NEED_G) {
@@ -407,8 +407,8 @@ __global__ __launch_bounds__(V2Block<OUT>::threads, OUT ? 4 : LARS_V2_STATS_WAVE
                     selq_add_bucket(p.x, sb1); selq_add_bucket(p.y, sb1);
                 }
                 if (SEL == 2) {
-                    const f32x2 p = selq_t2(x);
-                    selq_window_add(p.x, wt1, wr1, win_lo, win_hi); selq_window_add(p.y, wt1, wr1, win_lo, win_hi);
+                    const f32x2 p = __builtin_elementwise_fma(x, (f32x2){SELQ_WIN_SCALE, SELQ_WIN_SCALE}, (f32x2){wt1, wt1});
+                    selq_window_add(p.x, wr1, win_lo, win_hi); selq_window_add(p.y, wr1, win_lo, win_hi);
                 }
                 if (STATS >= 2 && WANT_NDWI) {
                     const f32x2 p = hist_pos2(x, -1.0f);
@@ -518,14 +518,14 @@ __global__ __launch_bounds__(V2Block<OUT>::threads, OUT ? 4 : LARS_V2_STATS_WAVE
             if (STATS >= 1) push<STATS>(acc_v, above_v, x, 0.2f);
             if (STATS >= 2) hist_add(x, 1.0f, hb0);
             if (SEL == 1) selq_add_bucket(selq_t(x), sb0);
-            if (SEL == 2) selq_window_add(selq_t(x), wt0, wr0, win_lo, win_hi);
+            if (SEL == 2) selq_window_add(__builtin_fmaf(x, SELQ_WIN_SCALE, wt0), wr0, win_lo, win_hi);
             if (oi0) oi0[i] = x;
             if (oc0) reinterpret_cast<unsigned int *>(oc0)[i] = lut0[cmap_index(x)];
         }
         if (NEED_G) {
             const float x = norm_diff_fast(fn, fg);
             if (SEL == 1) selq_add_bucket(selq_t(x), sb1);
-            if (SEL == 2) selq_window_add(selq_t(x), wt1, wr1, win_lo, win_hi);
+            if (SEL == 2) selq_window_add(__builtin_fmaf(x, SELQ_WIN_SCALE, wt1), wr1, win_lo, win_hi);
             if (STATS >= 1) {
                 acc_g.mn = fminf(acc_g.mn, x); acc_g.mx = fmaxf(acc_g.mx, x);
                 const double xd = (double)x;

@@ -262,6 +262,7 @@ int lars_set_tuning(const char *key, int value)
     else if (!strcmp(key, "count_mode")) t.count_mode = value;
     else if (!strcmp(key, "pipe_steps")) t.pipe_steps = value;
     else if (!strcmp(key, "selq_window")) t.selq_window = value;
+    else if (!strcmp(key, "selq_list_wgs")) t.selq_list_wgs = value;
     else if (!strcmp(key, "pipe_head")) t.pipe_head = value;
     else if (!strcmp(key, "pipe_trace")) t.pipe_trace = value;
     else if (!strcmp(key, "pipe_cold")) t.pipe_cold = value;
@@ -280,6 +281,7 @@ int lars_get_tuning(const char *key, int *value)
     else if (!strcmp(key, "count_mode")) *value = t.count_mode;
     else if (!strcmp(key, "pipe_steps")) *value = t.pipe_steps;
     else if (!strcmp(key, "selq_window")) *value = t.selq_window;
+    else if (!strcmp(key, "selq_list_wgs")) *value = t.selq_list_wgs;
     else if (!strcmp(key, "pipe_head")) *value = t.pipe_head;
     else if (!strcmp(key, "pipe_trace")) *value = t.pipe_trace;
     else if (!strcmp(key, "pipe_cold")) *value = t.pipe_cold;

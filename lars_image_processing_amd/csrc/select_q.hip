@@ -263,10 +263,11 @@ __global__ __launch_bounds__(256) void k_selq_pick(SelQTile *state, unsigned int
 // SEL == 2).  If a rank falls inside the window the order statistic is exact from those counts; tiles where it does not
 // (known exactly: below <= rank < below + window mass) take the two classic passes.
 // ---------------------------------------------------------------------------------------------------------------------
-// The prediction: the median bucket of a subsample (every SUB-th 1024-pixel step, at most 1024 steps: a sixteenth of a
-// 4096 x 4096 tile).  Standard error of a sample median = 1 / (2 f sqrt(n)) for density f at the median: with n = 2^20 and
-// f ~ 1 per unit of the index that is half a bucket, and the window reaches two buckets to either side of the predicted
-// bucket's centre.  One block per tile; win[tile][stream] = float bits of the window's first t.
+// The prediction: where the distribution of a subsample (every SUB-th 1024-pixel step, at most 1024 steps: a sixteenth of a
+// 4096 x 4096 tile) passes one half.  In ranks the standard error of a sample median is sqrt(n) / 2 (512 of n = 2^20); how
+// many buckets that is depends on the tile (half a bucket for a density of 1 per unit of the index, two buckets where the
+// median sits among the sparse quotients around 0).  One block per tile; win[tile][stream] = the window's first slot (an int,
+// v2_device.h).
 template <bool WB>
 __global__ __launch_bounds__(1024) void k_selq_predict(const uint8_t *__restrict__ tiles, const uint8_t *__restrict__ wb_table, long long npix,
                                                        unsigned int streams, unsigned int *__restrict__ win)
@@ -313,10 +314,12 @@ __global__ __launch_bounds__(1024) void k_selq_predict(const uint8_t *__restrict
         }
     }
     __syncthreads();
-    // waves 0 and 1: the bucket holding the sample's median of stream 0 / 1 (lane l owns buckets 32 l .. 32 l + 31)
+    // waves 0 and 1: the sample's cumulative counts of stream 0 / 1 (lane l owns buckets 32 l .. 32 l + 31), written over the
+    // counts, and the bucket m that holds the sample's median
+    __shared__ unsigned int s_m[2][2];
     const int stream = tid >> 6;
     if (stream < 2) {
-        const unsigned int *mine = s_h + stream * SELQ_BINS + lane * 32;
+        unsigned int *mine = s_h + stream * SELQ_BINS + lane * 32;
         unsigned int c[32], local = 0;
 #pragma unroll
         for (int j = 0; j < 32; ++j) { c[j] = mine[j]; local += c[j]; }
@@ -326,22 +329,43 @@ __global__ __launch_bounds__(1024) void k_selq_predict(const uint8_t *__restrict
             if ((int)lane >= off) incl += o;
         }
         const unsigned int total = __shfl(incl, 63);
-        const unsigned int rank = total / 2;
+        const unsigned int mid = total / 2;
         unsigned int cum = incl - local;
-        if (total && rank >= cum && rank < incl) {
-            int d = 0;
 #pragma unroll
-            for (int j = 0; j < 32; ++j) {
-                if (rank >= cum + c[j]) { cum += c[j]; d = j + 1; }
-                else break;
-            }
-            // the window: 3.75 buckets centred on the predicted bucket's centre, kept inside the binade [2048, 4096)
-            const float width = (float)SELQ_WIN_UNITS / 4096.0f;
-            float t0 = 2048.0f + (float)((int)lane * 32 + d) + 0.5f - 0.5f * width;
-            t0 = fminf(fmaxf(t0, 2048.0f), 4096.0f - width);
-            win[tile * 2 + stream] = __builtin_bit_cast(unsigned int, t0);
+        for (int j = 0; j < 32; ++j) {
+            if (mid >= cum && mid < cum + c[j]) s_m[stream][0] = (unsigned int)((int)lane * 32 + j);
+            cum += c[j];
+            mine[j] = cum;
         }
-        if (!total && lane == 0) win[tile * 2 + stream] = SELQ_T_BITS;
+        if (lane == 0) s_m[stream][1] = total;
+    }
+    __syncthreads();
+    // Index values of bytes are atoms, not a density (around 0 the distinct quotients lie two buckets apart and one of them
+    // can hold 0.6 % of a tile: 13 standard errors of the sample's median, which is sqrt(n) / 2 ranks), so the bucket of the
+    // sample's median may be a neighbour of the tile's.  Of the three windows of three whole buckets that contain m, take
+    // the one that keeps the sample's middle rank farthest from both of its ends, in ranks.
+    if (tid < 2) {
+        const unsigned int *C = s_h + tid * SELQ_BINS;                 // inclusive cumulative counts
+        const unsigned int total = s_m[tid][1];
+        if (!total) win[tile * 2 + tid] = (unsigned int)SELQ_WIN_BOTTOM;
+        else {
+            const int m = (int)s_m[tid][0];
+            const long long mid = total / 2;
+            int best = m;
+            long long best_margin = -1;
+            for (int b = m - 2; b <= m; ++b) {
+                const int lo = b < 0 ? 0 : (b > SELQ_BINS - 3 ? SELQ_BINS - 3 : b);
+                const long long below = lo > 0 ? (long long)C[lo - 1] : 0ll;
+                const long long margin_lo = mid - below, margin_hi = (long long)C[lo + 2] - 1 - mid;
+                const long long margin = margin_lo < margin_hi ? margin_lo : margin_hi;
+                if (margin > best_margin) { best_margin = margin; best = lo; }
+            }
+            // the window's 3.75 buckets around those three, in slots: bucket b starts at t = 2048 + b, i.e. sigma = (t - 3071.5) * 512
+            int ws = (best - 1023) * SELQ_WIN_PER_BUCKET - SELQ_WIN_PER_BUCKET / 2 - (SELQ_WIN_SLOTS - 3 * SELQ_WIN_PER_BUCKET) / 2;
+            if (ws < SELQ_WIN_BOTTOM) ws = SELQ_WIN_BOTTOM;
+            if (ws > -SELQ_WIN_BOTTOM + 1 - SELQ_WIN_SLOTS) ws = -SELQ_WIN_BOTTOM + 1 - SELQ_WIN_SLOTS;
+            win[tile * 2 + tid] = (unsigned int)ws;
+        }
     }
 }
 
@@ -351,19 +375,18 @@ __global__ void k_selq_fill(unsigned int *p, long long n, unsigned int v)
     if (i < n) p[i] = v;
 }
 
-// the quotient of bytes in slot `slot` of the window whose first t has the bits t0_bits (see selq_value_of)
-__device__ inline float selq_window_value(unsigned int t0_bits, unsigned int slot, int lane)
+// the quotient of bytes in slot `slot` of the window that starts at slot ws (see selq_value_of): every denominator is tried,
+// with the kernel's own fma (same bias, so the same rounding) deciding which slot a candidate falls into
+__device__ inline float selq_window_value(int ws, unsigned int slot, int lane)
 {
-    const double t0 = (double)__builtin_bit_cast(float, t0_bits);
-    const double centre_t = t0 + ((double)(slot << SELQ_WIN_SHIFT) + 0.5 * (double)(1 << SELQ_WIN_SHIFT)) / 4096.0;
-    const double centre = (centre_t - 3071.5) / 1023.5;
+    const double centre = (double)(ws + (int)slot) / (double)SELQ_WIN_SCALE;
+    const float bias = selq_window_bias(ws);
     float found = __builtin_nanf("");
     for (int den = 1 + lane; den <= 510; den += 64) {
         const float n = (float)__builtin_rint(centre * (double)den);
         if (__builtin_fabsf(n) > (float)den) continue;
         const float q = exact_quot(n, (float)den);
-        const unsigned int d = __builtin_bit_cast(unsigned int, selq_t(q)) - t0_bits;
-        if (d < (unsigned)SELQ_WIN_UNITS && (d >> SELQ_WIN_SHIFT) == slot) found = q + 0.0f;      // -0/den -> +0.0
+        if (selq_window_word(q, bias) == 64 + (int)slot) found = q + 0.0f;      // -0/den -> +0.0
     }
     for (int off = 32; off >= 1; off >>= 1) {
         const float o = __shfl_xor(found, off);
@@ -384,7 +407,8 @@ __global__ __launch_bounds__(256) void k_selq_pick_window(SelQTile *state, const
     const int stream = combo >> 1;
     const bool active = (state[tile].streams >> stream) & 1u;
     const unsigned int rank = state[tile].rank[combo];              // absolute: (N - 1) / 2 or N / 2 (k_selq_init)
-    const unsigned int t0_bits = win[tile * 2 + stream], lo = below[tile * 2 + stream];
+    const int ws = (int)win[tile * 2 + stream];
+    const unsigned int lo = below[tile * 2 + stream];
     bool ok = !active;
     float v = __builtin_nanf("");
     if (active && rank >= lo) {
@@ -414,7 +438,7 @@ __global__ __launch_bounds__(256) void k_selq_pick_window(SelQTile *state, const
         if (who) {
             const int src = __ffsll((long long)who) - 1;
             const unsigned int slot = (unsigned int)__shfl(lane * PER + d, src);
-            v = selq_window_value(t0_bits, slot, lane);
+            v = selq_window_value(ws, slot, lane);
             ok = v == v;
         }
     }
@@ -437,9 +461,9 @@ using namespace lars;
 
 namespace lars {
 
-static dim3 selq_grid(long long ntiles, long long npix)
+static dim3 selq_grid(long long ntiles, long long npix, long long total = 2048)
 {
-    long long bpt = (2048 + ntiles - 1) / ntiles;                  // ~2048 workgroups per launch
+    long long bpt = (total + ntiles - 1) / ntiles;                 // ~2048 workgroups per launch
     const long long cap = (npix / 4 + 1024 * 8 - 1) / (1024 * 8);  // at least ~8 steps per block (64 KiB table each)
     if (bpt > cap) bpt = cap;
     if (bpt < 1) bpt = 1;
@@ -541,7 +565,9 @@ int selq_tile_medians_launch(const uint8_t *tiles, const uint8_t *wb_table, long
         nrun = left;
     }
     if (!first_pass_done && !windowed) LARS_TRY(selq_tile_prepare(scratch, ntiles, npix, s, streams));
-    const dim3 grid = selq_grid(nrun, npix);
+    // listed tiles: as many workgroups as a whole batch gets (the passes are bound by the steps a wave runs through, not by
+    // what a workgroup pays for its table and counters: tools/selqbench.py, 64 .. 2048 workgroups)
+    const dim3 grid = selq_grid(nrun, npix, tile_list && tuning().selq_list_wgs > 0 ? tuning().selq_list_wgs : 2048);
     for (int p = 0; p < 2; ++p) {
         SelQParams P;
         memset(&P, 0, sizeof P);
@@ -633,7 +659,7 @@ extern "C" int lars_d_stats_medians(const lars_fused_args *a, float *out_pairs, 
         else hipLaunchKernelGGL((k_selq_predict<false>), dim3((unsigned)a->ntiles), dim3(1024), 0, s, tiles, a->wb_table, (long long)a->npix, streams, w.win);
         if (tuning().selq_window == 2) {
             // test hook: every window at the bottom of the range, so that every tile misses and takes the classic passes
-            hipLaunchKernelGGL(k_selq_fill, dim3((unsigned)((a->ntiles * 2 + 255) / 256)), dim3(256), 0, s, w.win, a->ntiles * 2, (unsigned)SELQ_T_BITS);
+            hipLaunchKernelGGL(k_selq_fill, dim3((unsigned)((a->ntiles * 2 + 255) / 256)), dim3(256), 0, s, w.win, a->ntiles * 2, (unsigned)SELQ_WIN_BOTTOM);
         }
         P.sel_win = w.win;
         P.sel_win_hist = w.win_hist;

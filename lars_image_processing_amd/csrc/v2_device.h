@@ -91,14 +91,24 @@ __device__ inline unsigned int sample_entry(unsigned int word, int byte, unsigne
 #define SELQ_SLOTS 1024
 #define SELQ_T_BITS 0x45000000u                         /* float bits of 2048.0 */
 // Predicted window of the one-pass median (select_q.hip): the statistics kernel counts, per stream, the values below the
-// window's first t and the slots inside the window; the median is exact from those two whenever its rank falls inside.
-// The window starts at any t0 of the binade and is cut into SELQ_WIN_SLOTS slots of 8 units of 2^-12 (two different
-// quotients of bytes are >= 15 such units apart, so a slot still holds ONE distinct value): 1920 slots = 3.75 buckets.
-// LDS row of a stream: 64 "below" words | 1920 slots | 64 "above" words = the 2048 words a bucket row takes otherwise, so
-// the kernel keeps its 80 KiB (two blocks per CU).
-#define SELQ_WIN_SHIFT 3                                   /* log2 of the slot width in units of 2^-12 */
+// window and the slots inside it; the median is exact from those two whenever its rank falls inside.
+// Slots: sigma(x) = round(x * 524032) -- 512 slots per bucket (8 of the bucket's units of 2^-12; two different quotients
+// of bytes are 2.01 slots apart, so a slot still holds ONE distinct value).  The window is slots [ws, ws + 1920) = 3.75
+// buckets, for any integer ws.  LDS row of a stream: 64 "below" words | 1920 slots | 64 "above" words = the 2048 words a
+// bucket row takes otherwise, so the kernel keeps its 80 KiB (two blocks per CU).
+// The word of x in that row comes out of ONE fma: u = fma(x, 524032, 1.5 * 2^23 - (ws - 64)) lies in [2^23, 2^24), where a
+// float's mantissa IS its integer value, so bits(u) - bits(1.5 * 2^23) = sigma(x) - ws + 64 (selq_window_word).
 #define SELQ_WIN_SLOTS 1920
-#define SELQ_WIN_UNITS (SELQ_WIN_SLOTS << SELQ_WIN_SHIFT)  /* window width in units of 2^-12: 15360 = 3.75 buckets */
+#define SELQ_WIN_PER_BUCKET 512
+#define SELQ_WIN_SCALE 524032.0f                           /* 1023.5 * 512 */
+#define SELQ_WIN_MAGIC 12582912.0f                         /* 1.5 * 2^23 */
+#define SELQ_WIN_MAGIC_BITS 0x4B400000u
+#define SELQ_WIN_BOTTOM (-524032)                          /* sigma(-1): the lowest window start */
+__device__ inline float selq_window_bias(int ws) { return (float)(12582912 - (ws - 64)); }      // exact: an integer below 2^24
+__device__ inline int selq_window_word(float x, float bias)
+{
+    return (int)(__builtin_bit_cast(unsigned int, __builtin_fmaf(x, SELQ_WIN_SCALE, bias)) - SELQ_WIN_MAGIC_BITS);
+}
 __device__ inline float selq_t(float x) { return __builtin_fmaf(x, 1023.5f, 3071.5f); }
 __device__ inline f32x2 selq_t2(f32x2 x)
 {
@@ -112,16 +122,16 @@ __device__ inline void selq_add_bucket(float t, unsigned int row)      // row: L
     asm volatile("ds_add_u32 %0, %1" : : "v"(addr), "v"(1u) : "memory");
 }
 
-// One value against a stream's window, branch-free: q = (bits(t) - bits(t0 - 64 slots)) >> 3 (arithmetic) is the value's
-// word in the row if it lies inside the window (64 .. 64 + SELQ_WIN_SLOTS - 1); anything smaller is clamped onto the lane's
-// own "below" word, anything larger onto its "above" word (values within 64 slots of the window land on a neighbour's
-// word: still the right group).  One subtract, one shift, one v_med3_i32, one address add, one LDS atomic.
-__device__ inline void selq_window_add(float t, unsigned int t0m_bits, unsigned int row, int lo_word, int hi_word)
+// One value against a stream's window, branch-free: u (see above) as an integer is bits(1.5 * 2^23) + the value's word in
+// the row if it lies inside the window (64 .. 64 + SELQ_WIN_SLOTS - 1); anything smaller is clamped onto the lane's own
+// "below" word, anything larger onto its "above" word (values within 64 slots of the window land on a neighbour's word:
+// still the right group).  After the fma (packed, two values at a time): one v_med3_i32, one shift-and-add whose constant
+// takes bits(1.5 * 2^23) << 2 off again (mod 2^32), one LDS atomic.  lo / hi: the lane's two words + SELQ_WIN_MAGIC_BITS.
+__device__ inline void selq_window_add(float u, unsigned int row_rel, int lo, int hi)
 {
-    const int q = (int)(__builtin_bit_cast(unsigned int, t) - t0m_bits) >> SELQ_WIN_SHIFT;
     int idx;
-    asm("v_med3_i32 %0, %1, %2, %3" : "=v"(idx) : "v"(q), "v"(lo_word), "v"(hi_word));
-    const unsigned int addr = ((unsigned)idx << 2) + row;
+    asm("v_med3_i32 %0, %1, %2, %3" : "=v"(idx) : "v"(__builtin_bit_cast(int, u)), "v"(lo), "v"(hi));
+    const unsigned int addr = ((unsigned)idx << 2) + row_rel;        // row_rel = row - (SELQ_WIN_MAGIC_BITS << 2), mod 2^32
     asm volatile("ds_add_u32 %0, %1" : : "v"(addr), "v"(1u) : "memory");
 }
 

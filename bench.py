@@ -388,8 +388,9 @@ def main():
         # Every rank makes the same choice of transport: from the environment, or -- by default -- from a pre-flight vote:
         # each rank checks that librccl loads (lars_comm_available) and all ranks exchange that verdict through marker files
         # (dist.agree) BEFORE anybody enters a blocking bootstrap; only a unanimous yes takes the library's own communicator,
-        # anything else takes torch.distributed's.  A bootstrap error after that ends the rank with a non-zero status and
-        # the launcher tears the group down (no per-rank fallback).
+        # anything else takes torch.distributed's.  If the library's bootstrap then fails on every rank alike, a second vote moves
+        # the whole group to torch.distributed; any other bootstrap error ends the rank with a non-zero status and the launcher
+        # tears the group down (no per-rank fallback).
         #   LARS_COMM unset / auto: vote, then rccl or torch
         #   LARS_COMM=rccl: the library's own RCCL communicator (csrc/comm.cpp), no vote
         #   LARS_COMM=torch: the statistics exchange through torch.distributed (nccl backend = RCCL)
@@ -402,8 +403,29 @@ def main():
             if flavour == "torch":
                 print(f"[bench rank {rank}] librccl is not usable on every rank ({_ffi.load().lars_last_error().decode()!r} here): "
                       "all ranks use torch.distributed", file=sys.stderr)
+        comm = None
+        if flavour == "rccl" and voted:
+            # the library's communicator, and a second vote on whether it came up on EVERY rank: an error all ranks see alike
+            # (a node whose RCCL refuses to initialise) moves the whole group to torch.distributed instead of ending the run;
+            # a rank that hangs inside the bootstrap still ends it -- the others time out in the vote
+            try:
+                if os.environ.get("LARS_BENCH_FAIL_RCCL"):        # tests/test_gpu_bench.py: the path below without a broken node
+                    raise RuntimeError("LARS_BENCH_FAIL_RCCL is set")
+                comm = dist.Comm.from_env()
+                collective = "RCCL ncclAllGather of packed records + rank-order fold (csrc/comm.cpp)"
+            except (_ffi.LarsError, TimeoutError, OSError, RuntimeError) as exc:
+                print(f"[bench rank {rank}] rccl bootstrap failed: {exc}", file=sys.stderr)
+            if not dist.agree(rank, world, comm is not None, timeout_s=180.0, phase="up"):
+                if comm is not None:
+                    comm.destroy()
+                    comm = None
+                print(f"[bench rank {rank}] the library's RCCL communicator did not come up on every rank: "
+                      "all ranks use torch.distributed", file=sys.stderr)
+                flavour = "torch"
         try:
-            if flavour == "gloo":
+            if comm is not None:
+                pass
+            elif flavour == "gloo":
                 _ffi.call("lars_set_device", int(os.environ.get("LARS_DEVICE", local_rank)))
                 comm = dist.TorchComm.from_env("gloo")
                 collective = "torch.distributed all_gather (gloo, host) + rank-order fold -- rehearsal transport"

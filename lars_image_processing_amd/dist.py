@@ -109,14 +109,15 @@ def exchange_unique_id(rank, world, timeout_s=120.0, make_id=_rccl_unique_id, ma
     raise TimeoutError(f"rank {rank}: no valid RCCL unique id at {path} after {timeout_s}s")
 
 
-def agree(rank, world, ok, timeout_s=120.0):
+def agree(rank, world, ok, timeout_s=120.0, phase="pre"):
     """All ranks of one launch learn whether EVERY rank said ``ok`` -- before any of them enters a blocking collective
-    bootstrap.  Each rank drops a marker next to the rendezvous file (exclusive, mode 0600) and waits for the others'.
-    Returns True only if all ``world`` markers say ok; a rank that never shows up within ``timeout_s`` counts as not ok
-    (every rank then times out alike and makes the same choice)."""
+    bootstrap (``phase="pre"``), or after one (``phase="up"``: did it come up everywhere?).  Each rank drops a marker next
+    to the rendezvous file (exclusive, mode 0600) and waits for the others'.  Returns True only if all ``world`` markers
+    say ok; a rank that never shows up within ``timeout_s`` counts as not ok (every rank then times out alike and makes
+    the same choice)."""
     base = _rendezvous_path()
-    tag = _launch_tag()
-    mine = f"{base}.pre{rank}"
+    tag = _launch_tag() + b"|" + phase.encode()
+    mine = f"{base}.{phase}{rank}"
     try:
         os.unlink(mine)
     except FileNotFoundError:
@@ -131,7 +132,7 @@ def agree(rank, world, ok, timeout_s=120.0):
             if r in verdicts:
                 continue
             try:
-                fd = os.open(f"{base}.pre{r}", os.O_RDONLY | getattr(os, "O_NOFOLLOW", 0))
+                fd = os.open(f"{base}.{phase}{r}", os.O_RDONLY | getattr(os, "O_NOFOLLOW", 0))
             except OSError:
                 continue
             with os.fdopen(fd, "rb") as fh:
@@ -145,14 +146,15 @@ def agree(rank, world, ok, timeout_s=120.0):
     return len(verdicts) == world and all(verdicts.values())
 
 
-def forget_agreement(world):
+def forget_agreement(world, phases=("pre", "up")):
     """Remove the markers of ``agree`` (rank 0, once every rank is past it -- e.g. after the communicator's first barrier)."""
     base = _rendezvous_path()
-    for r in range(world):
-        try:
-            os.unlink(f"{base}.pre{r}")
-        except OSError:
-            pass
+    for phase in phases:
+        for r in range(world):
+            try:
+                os.unlink(f"{base}.{phase}{r}")
+            except OSError:
+                pass
 
 
 class Comm:

@@ -101,5 +101,16 @@ def test_ranks_agree_on_the_transport_before_any_blocking_bootstrap(tmp_path, mo
     assert vote([True, False, True]) == {0: False, 1: False, 2: False}
     assert vote([True, True, True], timeout_s=0.5, absent=(2,)) == {0: False, 1: False}
     assert not any(name.endswith((".pre0", ".pre1", ".pre2")) for name in os.listdir(tmp_path))
+    # the second vote (did the bootstrap come up everywhere?) keeps its own markers: a 'no' there does not read a 'yes' of the first
+    out = {}
+    threads = [threading.Thread(target=lambda r=r: out.__setitem__(r, (dist.agree(r, 3, True, 20.0), dist.agree(r, 3, r != 1, 20.0, phase="up"))))
+               for r in range(3)]
+    for t in threads:
+        t.start()
+    for t in threads:
+        t.join()
+    assert out == {r: (True, False) for r in range(3)}
+    dist.forget_agreement(3)
+    assert not [name for name in os.listdir(tmp_path) if ".pre" in name or ".up" in name]
     # the library's own pre-flight check answers without a GPU: librccl is part of the ROCm image
     assert _ffi.load().lars_comm_available() in (0, -6, -7, -8, -5, -4, -3)

@@ -289,6 +289,8 @@ __global__ __launch_bounds__(256) void k_probe_issue(int iters, unsigned int *__
         __syncthreads();
     }
     const float one = 1.0f, thr = 0.2f;
+    const double dOne = 1.0, dA = 0.0;
+    double dt[4] = {0, 0, 0, 0};
     const unsigned int lane_off4 = (threadIdx.x & 63u) << 2;
     for (int it = 0; it < iters; ++it) {
 #pragma unroll
@@ -340,6 +342,17 @@ __global__ __launch_bounds__(256) void k_probe_issue(int iters, unsigned int *__
             else if (OP == 38) asm volatile("v_fma_f32 %0, %0, %1, %1 clamp" : "+v"(a[j]) : "v"(one));
             else if (OP == 39) asm volatile("v_or_b32 %0, %0, %1" : "+v"(u[j]) : "v"(lane_off4));
             else if (OP == 29) asm volatile("v_perm_b32 %0, %0, %0, %1" : "+v"(u[j]) : "s"(0x0c0c0500u));
+            // does the matrix pipe take the float64 sum off the vector pipe?  40: the MFMA alone (acc += A x ones), 41: MFMA next to
+            // the conversion that feeds it, 42: v_add_f64 next to the same conversion (compare 41 with 42 and with 4 alone)
+            else if (OP == 40) asm volatile("v_mfma_f64_4x4x4_4b_f64 %0, %1, %2, %0" : "+v"(d[j]) : "v"(dA), "v"(dOne));
+            else if (OP == 41) {
+                asm volatile("v_cvt_f64_f32 %0, %1" : "=v"(dt[j & 3]) : "v"(a[j]));
+                asm volatile("v_mfma_f64_4x4x4_4b_f64 %0, %1, %2, %0" : "+v"(d[j]) : "v"(dt[j & 3]), "v"(dOne));
+            }
+            else if (OP == 42) {
+                asm volatile("v_cvt_f64_f32 %0, %1" : "=v"(dt[j & 3]) : "v"(a[j]));
+                asm volatile("v_add_f64 %0, %0, %1" : "+v"(d[j]) : "v"(dt[j & 3]));
+            }
         }
     }
     float fa = 0; double fd = 0; unsigned int fu = cnt;
@@ -452,17 +465,18 @@ extern "C" int lars_d_probe(int kind, int unroll, int blocks, const void *src, v
     } else if (kind == 99) {
         // shader clock: dst receives {shader cycles, 100 MHz ticks}; unroll = spin count; runs beside `blocks` busy blocks
         hipLaunchKernelGGL(k_probe_clock, dim3(blocks), dim3(256), 0, s, static_cast<unsigned long long *>(dst), unroll);
-    } else if (kind >= 100 && kind < 140) {
+    } else if (kind >= 100 && kind < 143) {
         // instruction-issue probe: unroll = loop trips (16 instructions each), blocks of 4 waves
         typedef void (*fn_t)(int, int, unsigned int *, hipStream_t);
-        static const fn_t table[40] = {issue_launch<0>, issue_launch<1>, issue_launch<2>, issue_launch<3>, issue_launch<4>,
+        static const fn_t table[43] = {issue_launch<0>, issue_launch<1>, issue_launch<2>, issue_launch<3>, issue_launch<4>,
                                        issue_launch<5>, issue_launch<6>, issue_launch<7>, issue_launch<8>, issue_launch<9>,
                                        issue_launch<10>, issue_launch<11>, issue_launch<12>, issue_launch<13>, issue_launch<14>,
                                        issue_launch<15>, issue_launch<16>, issue_launch<17>, issue_launch<18>, issue_launch<19>,
                                        issue_launch<20>, issue_launch<21>, issue_launch<22>, issue_launch<23>, issue_launch<24>,
                                        issue_launch<25>, issue_launch<26>, issue_launch<27>, issue_launch<28>, issue_launch<29>,
                                        issue_launch<30>, issue_launch<31>, issue_launch<32>, issue_launch<33>, issue_launch<34>,
-                                       issue_launch<35>, issue_launch<36>, issue_launch<37>, issue_launch<38>, issue_launch<39>};
+                                       issue_launch<35>, issue_launch<36>, issue_launch<37>, issue_launch<38>, issue_launch<39>,
+                                       issue_launch<40>, issue_launch<41>, issue_launch<42>};
         table[kind - 100](unroll, blocks, sink, s);
     } else {
         return fail(LARS_ERR_INVALID, "lars_d_probe: kind");

@@ -29,7 +29,8 @@ OPS = {0: "v_add_f32", 14: "v_fma_f32", 16: "v_max_f32", 7: "v_min3_f32", 12: "v
        20: "v_add_f32 a,a,b", 21: "v_max_f32 a,a,const", 22: "v_mul_f32 a,a,const", 23: "v_cvt_f32_ubyte0 in place",
        24: "v_mov_b32", 25: "v_add_f32 a,b,c", 26: "v_fma_f32 a,a,b,c", 27: "v_pk_add_f32 a,a,const", 28: "v_add_f64 a,a,const",
        29: "v_perm_b32 a,a,a,s", 30: "v_and_or_b32", 31: "v_lshl_or_b32", 32: "v_bfe_u32", 33: "v_lshrrev_b32", 34: "v_and_b32",
-       35: "v_lshlrev_b32_sdwa BYTE_1", 36: "v_lshl_add_u32", 37: "v_pk_fma_f32 clamp", 38: "v_fma_f32 clamp", 39: "v_or_b32"}
+       35: "v_lshlrev_b32_sdwa BYTE_1", 36: "v_lshl_add_u32", 37: "v_pk_fma_f32 clamp", 38: "v_fma_f32 clamp", 39: "v_or_b32",
+       40: "v_mfma_f64_4x4x4_4b_f64", 41: "v_cvt_f64_f32 + v_mfma_f64_4x4x4 (2 instr)", 42: "v_cvt_f64_f32 + v_add_f64 (2 instr)"}
 
 
 def main():

@@ -291,12 +291,20 @@ __global__ __launch_bounds__(1024) void k_selq_predict(const uint8_t *__restrict
     const long long nquads = npix >> 2;
     const long long nsteps = nquads >> 8;                          // complete steps only
     const long long sub = nsteps > 1024 ? nsteps / 1024 : 1;
-    for (long long k = tid >> 6; k * sub < nsteps && k < 1024; k += 16) {
+    // the next step's twelve loads are issued before the current step is counted: the kernel is one block of 16 waves per
+    // tile and CU, so nothing else hides the latency of a wave's loads
+    auto load_step = [&](long long k, unsigned int (&w)[4][3]) {
         const long long q0 = k * sub * 256 + lane;
 #pragma unroll
         for (int j = 0; j < 4; ++j) {
             const unsigned int *p = reinterpret_cast<const unsigned int *>(base + (q0 + 64 * j) * 12);
-            const unsigned int w0 = p[0], w1 = p[1], w2 = p[2];
+            w[j][0] = p[0]; w[j][1] = p[1]; w[j][2] = p[2];
+        }
+    };
+    auto count_step = [&](const unsigned int (&w)[4][3]) {
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const unsigned int w0 = w[j][0], w1 = w[j][1], w2 = w[j][2];
             const unsigned int wr[4] = {w0, w0, w1, w2}, wg[4] = {w0, w1, w1, w2}, wn[4] = {w0, w1, w2, w2};
             constexpr int br[4] = {0, 3, 2, 1}, bg[4] = {1, 0, 3, 2}, bn[4] = {2, 1, 0, 3};
 #pragma unroll
@@ -312,6 +320,19 @@ __global__ __launch_bounds__(1024) void k_selq_predict(const uint8_t *__restrict
                 }
             }
         }
+    };
+    const long long k_end = nsteps / sub < 1024 ? (nsteps + sub - 1) / sub : 1024;      // sampled steps: k * sub < nsteps, k < 1024
+    long long k = tid >> 6;
+    if (k < k_end) {
+        unsigned int cur[4][3], nxt[4][3];
+        load_step(k, cur);
+        for (; k + 16 < k_end; k += 16) {
+            load_step(k + 16, nxt);
+            count_step(cur);
+#pragma unroll
+            for (int j = 0; j < 4; ++j) { cur[j][0] = nxt[j][0]; cur[j][1] = nxt[j][1]; cur[j][2] = nxt[j][2]; }
+        }
+        count_step(cur);
     }
     __syncthreads();
     // waves 0 and 1: the sample's cumulative counts of stream 0 / 1 (lane l owns buckets 32 l .. 32 l + 31), written over the

@@ -264,7 +264,7 @@ __global__ __launch_bounds__(256) void k_selq_pick(SelQTile *state, unsigned int
 // (known exactly: below <= rank < below + window mass) take the two classic passes.
 // ---------------------------------------------------------------------------------------------------------------------
 // The prediction: where the distribution of a subsample (every SUB-th 1024-pixel step, at most 1024 steps: a sixteenth of a
-// 4096 x 4096 tile) passes one half.  In ranks the standard error of a sample median is sqrt(n) / 2 (512 of n = 2^20); how
+// 4096 x 4096 tile), counted in quarter buckets, passes one half.  In ranks the standard error of a sample median is sqrt(n) / 2 (512 of n = 2^20); how
 // many buckets that is depends on the tile (half a bucket for a density of 1 per unit of the index, two buckets where the
 // median sits among the sparse quotients around 0).  One block per tile; win[tile][stream] = the window's first slot (an int,
 // v2_device.h).
@@ -272,8 +272,12 @@ template <bool WB>
 __global__ __launch_bounds__(1024) void k_selq_predict(const uint8_t *__restrict__ tiles, const uint8_t *__restrict__ wb_table, long long npix,
                                                        unsigned int streams, unsigned int *__restrict__ win)
 {
+    // the sample is counted in quarter buckets (PRED_BINS per stream): the window is 15 of them, and where it can start
+    // decides how many ranks of the sample lie between its ends and the sample's middle
+    constexpr int PRED_SUB = 4, PRED_BINS = SELQ_BINS * PRED_SUB, PRED_WIN = SELQ_WIN_SLOTS * PRED_SUB / SELQ_WIN_PER_BUCKET;
+    static_assert(PRED_WIN * SELQ_WIN_PER_BUCKET == SELQ_WIN_SLOTS * PRED_SUB, "the window is a whole number of sample bins");
     __shared__ __attribute__((aligned(16))) char s_tab[WB ? V2_TABLE_BYTES : 16];
-    __shared__ unsigned int s_h[2 * SELQ_BINS];
+    __shared__ unsigned int s_h[2 * PRED_BINS];                    // 64 KiB: one block per CU, as the grid has it anyway
     const int tid = threadIdx.x;
     const unsigned int lane = tid & 63u, lane_off4 = lane << 2;
     const long long tile = blockIdx.x;
@@ -286,8 +290,9 @@ __global__ __launch_bounds__(1024) void k_selq_predict(const uint8_t *__restrict
             tab[i] = (unsigned)t[v] | ((unsigned)t[256 + v] << 8) | ((unsigned)t[512 + v] << 16);
         }
     }
-    for (int i = tid; i < 2 * SELQ_BINS; i += 1024) s_h[i] = 0;
+    for (int i = tid; i < 2 * PRED_BINS; i += 1024) s_h[i] = 0;
     __syncthreads();
+    auto pred_bin = [](float t) -> unsigned int { return (__builtin_bit_cast(unsigned int, t) >> 10) & (unsigned)(PRED_BINS - 1); };
     const long long nquads = npix >> 2;
     const long long nsteps = nquads >> 8;                          // complete steps only
     const long long sub = nsteps > 1024 ? nsteps / 1024 : 1;
@@ -312,11 +317,11 @@ __global__ __launch_bounds__(1024) void k_selq_predict(const uint8_t *__restrict
                 const float fn = sample<WB>(wn[px], bn[px], 2, lane_off4, s_tab);
                 if (streams & 1u) {
                     const float fr = sample<WB>(wr[px], br[px], 0, lane_off4, s_tab);
-                    atomicAdd(&s_h[selq_bucket_of(selq_t(norm_diff_fast(fn, fr)))], 1u);
+                    atomicAdd(&s_h[pred_bin(selq_t(norm_diff_fast(fn, fr)))], 1u);
                 }
                 if (streams & 2u) {
                     const float fg = sample<WB>(wg[px], bg[px], 1, lane_off4, s_tab);
-                    atomicAdd(&s_h[SELQ_BINS + selq_bucket_of(selq_t(norm_diff_fast(fn, fg)))], 1u);
+                    atomicAdd(&s_h[PRED_BINS + pred_bin(selq_t(norm_diff_fast(fn, fg)))], 1u);
                 }
             }
         }
@@ -335,15 +340,15 @@ __global__ __launch_bounds__(1024) void k_selq_predict(const uint8_t *__restrict
         count_step(cur);
     }
     __syncthreads();
-    // waves 0 and 1: the sample's cumulative counts of stream 0 / 1 (lane l owns buckets 32 l .. 32 l + 31), written over the
-    // counts, and the bucket m that holds the sample's median
+    // waves 0 and 1: the sample's cumulative counts of stream 0 / 1, written over the counts (lane l owns PRED_BINS / 64
+    // consecutive bins), and the bin m that holds the sample's middle rank
     __shared__ unsigned int s_m[2][2];
     const int stream = tid >> 6;
     if (stream < 2) {
-        unsigned int *mine = s_h + stream * SELQ_BINS + lane * 32;
-        unsigned int c[32], local = 0;
-#pragma unroll
-        for (int j = 0; j < 32; ++j) { c[j] = mine[j]; local += c[j]; }
+        constexpr int PER = PRED_BINS / 64;
+        unsigned int *mine = s_h + stream * PRED_BINS + lane * PER;
+        unsigned int local = 0;
+        for (int j = 0; j < PER; ++j) local += mine[j];
         unsigned int incl = local;
         for (int off = 1; off < 64; off <<= 1) {
             const unsigned int o = __shfl_up(incl, off);
@@ -352,10 +357,10 @@ __global__ __launch_bounds__(1024) void k_selq_predict(const uint8_t *__restrict
         const unsigned int total = __shfl(incl, 63);
         const unsigned int mid = total / 2;
         unsigned int cum = incl - local;
-#pragma unroll
-        for (int j = 0; j < 32; ++j) {
-            if (mid >= cum && mid < cum + c[j]) s_m[stream][0] = (unsigned int)((int)lane * 32 + j);
-            cum += c[j];
+        for (int j = 0; j < PER; ++j) {
+            const unsigned int c = mine[j];
+            if (mid >= cum && mid < cum + c) s_m[stream][0] = (unsigned int)((int)lane * PER + j);
+            cum += c;
             mine[j] = cum;
         }
         if (lane == 0) s_m[stream][1] = total;
@@ -363,10 +368,10 @@ __global__ __launch_bounds__(1024) void k_selq_predict(const uint8_t *__restrict
     __syncthreads();
     // Index values of bytes are atoms, not a density (around 0 the distinct quotients lie two buckets apart and one of them
     // can hold 0.6 % of a tile: 13 standard errors of the sample's median, which is sqrt(n) / 2 ranks), so the bucket of the
-    // sample's median may be a neighbour of the tile's.  Of the three windows of three whole buckets that contain m, take
-    // the one that keeps the sample's middle rank farthest from both of its ends, in ranks.
+    // sample's median may be a neighbour of the tile's.  Of the PRED_WIN windows (3.75 buckets, starting on any quarter
+    // bucket) that contain m, take the one that keeps the sample's middle rank farthest from both of its ends, in ranks.
     if (tid < 2) {
-        const unsigned int *C = s_h + tid * SELQ_BINS;                 // inclusive cumulative counts
+        const unsigned int *C = s_h + tid * PRED_BINS;                 // inclusive cumulative counts
         const unsigned int total = s_m[tid][1];
         if (!total) win[tile * 2 + tid] = (unsigned int)SELQ_WIN_BOTTOM;
         else {
@@ -374,15 +379,15 @@ __global__ __launch_bounds__(1024) void k_selq_predict(const uint8_t *__restrict
             const long long mid = total / 2;
             int best = m;
             long long best_margin = -1;
-            for (int b = m - 2; b <= m; ++b) {
-                const int lo = b < 0 ? 0 : (b > SELQ_BINS - 3 ? SELQ_BINS - 3 : b);
+            for (int b = m - PRED_WIN + 1; b <= m; ++b) {
+                const int lo = b < 0 ? 0 : (b > PRED_BINS - PRED_WIN ? PRED_BINS - PRED_WIN : b);
                 const long long below = lo > 0 ? (long long)C[lo - 1] : 0ll;
-                const long long margin_lo = mid - below, margin_hi = (long long)C[lo + 2] - 1 - mid;
+                const long long margin_lo = mid - below, margin_hi = (long long)C[lo + PRED_WIN - 1] - 1 - mid;
                 const long long margin = margin_lo < margin_hi ? margin_lo : margin_hi;
                 if (margin > best_margin) { best_margin = margin; best = lo; }
             }
-            // the window's 3.75 buckets around those three, in slots: bucket b starts at t = 2048 + b, i.e. sigma = (t - 3071.5) * 512
-            int ws = (best - 1023) * SELQ_WIN_PER_BUCKET - SELQ_WIN_PER_BUCKET / 2 - (SELQ_WIN_SLOTS - 3 * SELQ_WIN_PER_BUCKET) / 2;
+            // sample bin b starts at t = 2048 + b / PRED_SUB, i.e. at slot sigma = (t - 3071.5) * 512
+            int ws = best * (SELQ_WIN_PER_BUCKET / PRED_SUB) + SELQ_WIN_BOTTOM;
             if (ws < SELQ_WIN_BOTTOM) ws = SELQ_WIN_BOTTOM;
             if (ws > -SELQ_WIN_BOTTOM + 1 - SELQ_WIN_SLOTS) ws = -SELQ_WIN_BOTTOM + 1 - SELQ_WIN_SLOTS;
             win[tile * 2 + tid] = (unsigned int)ws;

@@ -33,13 +33,17 @@ struct SelQParams {
     const uint8_t *tiles;
     const uint8_t *wb_table;
     long long npix;
-    int first;                            // 1: bucket pass (every value counts, under track 0)
+    int first;                            // 1: bucket pass (every value counts, under track 0); 0: slot pass; 2: window pass (per tile)
     unsigned int bucket[4];               // [stream * 2 + track], second pass
     unsigned long long *hist;             // [2][2][SELQ_BINS], accumulated with atomics (whole-batch variant)
     // per-tile selection (medians of every tile of a batch, all on the device): state and 32-bit histograms per tile
     struct SelQTile *state;
     unsigned int *hist32;                 // [ntiles][2][2][SELQ_BINS]
     const unsigned int *tile_list;        // per-tile mode: blockIdx.y -> tile (the tiles the one-pass route did not serve), or null
+    // window pass (first == 2): what the statistics kernel counts with SEL == 2 (fused_v2.hip), without the statistics
+    const unsigned int *win;              // [ntiles][2]: first slot of each stream's predicted window
+    unsigned int *win_hist;               // [ntiles][2][SELQ_WIN_SLOTS]
+    unsigned int *below;                  // [ntiles][2]
 };
 struct SelQTile {
     unsigned int bucket[4];               // [stream * 2 + track]: bucket picked after pass 1
@@ -80,8 +84,17 @@ __global__ __launch_bounds__(1024, 8) void k_selq_pass(SelQParams P)
     auto sweep = [&](auto mode_tag, unsigned int b0, unsigned int b1) {
         constexpr int MODE = decltype(mode_tag)::value;
         const unsigned int t0[2] = {SELQ_T_BITS | (b0 << 12), SELQ_T_BITS | (b1 << 12)};     // bits of the bucket's first t
+        // MODE 2: b0 / b1 carry the windows' first slots; the row of a stream is 64 "below" words | the slots | 64 "above" words
+        typedef __attribute__((address_space(3))) unsigned int lds_u32;
+        const unsigned int row_rel = (unsigned int)(unsigned long long)(lds_u32 *)s_h - (SELQ_WIN_MAGIC_BITS << 2);
+        const float bias[2] = {selq_window_bias((int)b0), selq_window_bias((int)b1)};
+        const int win_lo = (int)(SELQ_WIN_MAGIC_BITS + (tid & 63u)), win_hi = (int)(SELQ_WIN_MAGIC_BITS + 64 + SELQ_WIN_SLOTS + (tid & 63u));
         auto push_n = [&](int stream, const float *x, int nval) {
             for (int j = 0; j < nval; ++j) {
+                if (MODE == 2) {
+                    selq_window_add(__builtin_fmaf(x[j], SELQ_WIN_SCALE, bias[stream]), row_rel + stream * SELQ_BINS * 4, win_lo, win_hi);
+                    continue;
+                }
                 const float t = selq_t(x[j]);
                 if (MODE == 0) {
                     atomicAdd(&s_h[stream * SELQ_BINS + selq_bucket_of(t)], 1u);
@@ -144,7 +157,19 @@ __global__ __launch_bounds__(1024, 8) void k_selq_pass(SelQParams P)
             }
         }
     };
-    if (P.first) {
+    if (PER_TILE && P.first == 2) {
+        static_assert(64 + SELQ_WIN_SLOTS + 64 == SELQ_BINS, "a window row is a bucket row");
+        sweep(std::integral_constant<int, 2>{}, P.win[tile * 2], P.win[tile * 2 + 1]);
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");        // the window atomics are inline asm
+        __syncthreads();
+        for (int i = tid; i < 2 * SELQ_BINS; i += 1024) {
+            const unsigned int v = s_h[i];
+            if (!v) continue;
+            const int stream = i >> 11, w = i & (SELQ_BINS - 1);
+            if (w < 64) atomicAdd(&P.below[tile * 2 + stream], v);
+            else if (w < 64 + SELQ_WIN_SLOTS) atomicAdd(&P.win_hist[(tile * 2 + stream) * SELQ_WIN_SLOTS + (w - 64)], v);
+        }
+    } else if (P.first) {
         sweep(std::integral_constant<int, 0>{}, 0u, 0u);
         flush(0, SELQ_BINS);
     } else {
@@ -642,8 +667,27 @@ extern "C" int lars_d_quotient_median_pairs(const void *tiles, int64_t ntiles, i
         return fail(LARS_ERR_INVALID, "lars_d_quotient_median_pairs: uint8 [ntiles][npix][3] tiles on 4-byte boundaries are required");
     if (ntiles > 65535 || (long long)npix * 6 >= (1ll << 30))
         return fail(LARS_ERR_INVALID, "lars_d_quotient_median_pairs: at most 65535 tiles of < 2^30 / 6 pixels");
-    return selq_tile_medians_launch(static_cast<const uint8_t *>(tiles), wb_table, ntiles, npix, out_pairs, scratch,
-                                    pick_stream(c, stream), false, streams, false);
+    hipStream_t s = pick_stream(c, stream);
+    const uint8_t *t8 = static_cast<const uint8_t *>(tiles);
+    if (tuning().selq_window == 0)
+        return selq_tile_medians_launch(t8, wb_table, ntiles, npix, out_pairs, scratch, s, false, streams, false);
+    // one pass where the predicted window holds the ranks (see lars_d_stats_medians): prediction from a subsample, ONE
+    // sweep that counts the windows (k_selq_pass, first == 2), and the two classic passes only over the tiles that missed
+    LARS_TRY(selq_tile_prepare(scratch, ntiles, npix, s, streams));
+    const SelQWindow w = selq_window_layout(scratch, ntiles);
+    LARS_HIP_TRY(hipMemsetAsync(w.below, 0, w.zero_bytes, s));
+    if (wb_table) hipLaunchKernelGGL((k_selq_predict<true>), dim3((unsigned)ntiles), dim3(1024), 0, s, t8, wb_table, (long long)npix, streams, w.win);
+    else hipLaunchKernelGGL((k_selq_predict<false>), dim3((unsigned)ntiles), dim3(1024), 0, s, t8, wb_table, (long long)npix, streams, w.win);
+    if (tuning().selq_window == 2)
+        hipLaunchKernelGGL(k_selq_fill, dim3((unsigned)((ntiles * 2 + 255) / 256)), dim3(256), 0, s, w.win, ntiles * 2, (unsigned)SELQ_WIN_BOTTOM);
+    SelQParams P;
+    memset(&P, 0, sizeof P);
+    P.tiles = t8; P.wb_table = wb_table; P.npix = npix; P.first = 2;
+    selq_scratch_layout(scratch, ntiles, &P.state, &P.hist32);
+    P.win = w.win; P.win_hist = w.win_hist; P.below = w.below;
+    selq_launch<true>(wb_table != nullptr, streams, selq_grid(ntiles, npix), s, P);
+    LARS_TRY(launch_check("lars_d_quotient_median_pairs (window pass)"));
+    return selq_tile_medians_launch(t8, wb_table, ntiles, npix, out_pairs, scratch, s, true, streams, true);
 }
 
 // Statistics AND the exact median of every tile in two passes over the tiles (three with the white-balance histogram

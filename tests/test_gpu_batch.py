@@ -692,6 +692,8 @@ def test_one_pass_medians_and_their_fallback(lars, profile, indices):
             rec, med = b.process(indices=indices, medians=True)
             results[mode] = rec.tobytes()
             np.testing.assert_array_equal(med, want, err_msg=f"selq_window={mode}")
+            # the medians on their own (what a launch that writes planes uses): prediction + one window sweep + fallback
+            np.testing.assert_array_equal(b.tile_medians(indices), want, err_msg=f"tile_medians, selq_window={mode}")
     finally:
         _ffi.set_tuning(selq_window=1)
     assert results[1] == results[2] == results[0]

@@ -217,10 +217,14 @@ int lars_d_median_pair_batch_f32(const float *x, int64_t n, int64_t items, int64
 /* One pass of the two-level select over the index values of a batch WITHOUT the planes in memory (exact batch /
  * global medians): the NDVI and GNDVI quotients of every pixel are recomputed from the
  * uint8 tiles.  Position of a value: t = float32 fma(x, 1023.5, 3071.5) in [2048, 4095]; its 23 mantissa bits are
- * 11 bits of bucket and 12 bits of fraction.  first != 0: each value is counted in its bucket, under track 0.
- * Otherwise, per stream s and track k, the values of bucket[2s+k] are counted in slot (fraction >> 2) (1024 slots);
+ * 11 bits of bucket and 12 bits of fraction.  first == 1: each value is counted in its bucket, under track 0 (first == 3:
+ * the same over a 1/16 subsample of the pixels -- the prediction of the window below).
+ * first == 0: per stream s and track k, the values of bucket[2s+k] are counted in slot (fraction >> 2) (1024 slots);
  * when both tracks of BOTH streams share their bucket only track 0 is counted.  A slot holds one distinct value
  * (two different quotients of bytes are >= 1/(510 * 509) apart = 16 units of the fraction).
+ * first == 2: ONE pass instead of those two where a predicted window holds the ranks.  Slots sigma(x) = round(x * 524032);
+ * (int32) bucket[2s] is the first slot ws of stream s's window of 1920 slots (3.75 buckets); under track 0 of stream s
+ * words 0..63 together count the values below the window, words 64..1983 its slots, words 1984..2047 the values above.
  * hist is uint64[2 streams][2 tracks][2048], accumulated with atomics (zero it first).  NDWI = -GNDVI shares
  * GNDVI's order statistics. */
 int lars_d_quotient_select_hist(const void *tiles, int64_t ntiles, int64_t npix, int channels, int dtype,

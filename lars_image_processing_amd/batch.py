@@ -344,7 +344,8 @@ class TileBatch:
 
     # -- exact medians of the whole batch (all tiles, all ranks) ------------
     def select_histogram(self, first, buckets, white_balance=True, stream=None, streams=3):
-        """One pass of the two-level select (``lars_d_quotient_select_hist``): uint64[2 streams][2 tracks][2048].
+        """One pass of the select (``lars_d_quotient_select_hist``): uint64[2 streams][2 tracks][2048].  ``first``: 1 / True
+        bucket pass, 0 / False slot pass, 3 bucket pass over a 1/16 subsample, 2 window pass (``buckets[2 s]`` = first slot).
         ``streams``: bit 0 NDVI, bit 1 GNDVI (NDWI shares it); a stream left out is not computed and stays zero."""
         if self.code != _ffi.U8 or self.channels != 3:
             raise TypeError("exact batch medians need uint8 tiles with 3 channels")
@@ -353,9 +354,9 @@ class TileBatch:
         if getattr(self, "_selq", None) is None:
             self._selq = DeviceBuffer(2 * 2 * SELECT_BINS * 8)
         self._selq.zero(stream)
-        b = np.ascontiguousarray(buckets, dtype=np.uint32).reshape(4)
+        b = np.ascontiguousarray(np.asarray(buckets, dtype=np.int64) & 0xFFFFFFFF, dtype=np.uint32).reshape(4)    # window starts are int32
         _ffi.call("lars_d_quotient_select_hist", C.c_void_p(self.tiles.ptr), self.ntiles, self.npix, self.channels, self.code,
-                  C.c_void_p(self.table.ptr) if white_balance else None, int(streams), int(bool(first)), _ffi.ptr(b),
+                  C.c_void_p(self.table.ptr) if white_balance else None, int(streams), int(first), _ffi.ptr(b),
                   C.c_void_p(self._selq.ptr), stream)
         _ffi.call("lars_synchronize", stream)
         return self._selq.download(np.uint64, (2, 2, SELECT_BINS))
@@ -531,28 +532,102 @@ def select_streams(indices):
     return mask
 
 
-def select_order_statistics(pass_fn, n_local, comm=None, streams=3):
+WINDOW_SLOTS = 1920                    # SELQ_WIN_SLOTS (csrc/v2_device.h): a window is 3.75 buckets of 512 slots
+WINDOW_SCALE = 524032.0               # slots per unit of the index: sigma(x) = round(x * 524032)
+WINDOW_MAGIC = 12582912               # 1.5 * 2^23: floats in [2^23, 2^24) carry their integer value in the mantissa
+
+
+def select_window_word(x, ws):
+    """The kernels' word of float32 ``x`` in the row of a window that starts at slot ``ws``: bits(fma(x, 524032,
+    1.5 * 2^23 - (ws - 64))) - bits(1.5 * 2^23); 64 .. 64 + 1919 inside the window.  (Product and sum are exact in float64,
+    so the single rounding to float32 is the fma's.)"""
+    u = (np.asarray(x, dtype=np.float32).astype(np.float64) * WINDOW_SCALE + float(WINDOW_MAGIC - (int(ws) - 64))).astype(np.float32)
+    return np.ascontiguousarray(u).view(np.uint32).astype(np.int64) - 0x4B400000
+
+
+def select_window_value(ws, slot):
+    """The one quotient of bytes whose word in the window starting at ``ws`` is 64 + ``slot`` (see select_value)."""
+    centre = (int(ws) + int(slot)) / WINDOW_SCALE
+    den = np.arange(1, MAX_BYTE_SUM + 1, dtype=np.float64)
+    num = np.rint(centre * den)
+    q = (num.astype(np.float32) / den.astype(np.float32)).astype(np.float32) + np.float32(0)      # -0/d -> +0.0
+    hit = (np.abs(num) <= den) & (select_window_word(q, ws) == 64 + int(slot))
+    if not hit.any():
+        raise RuntimeError(f"select: no quotient of bytes in slot {slot} of the window at {ws} (inconsistent passes)")
+    vals = np.unique(q[hit])
+    assert vals.size == 1
+    return np.float32(vals[0])
+
+
+def select_window_start(sample_hist):
+    """First slot of the window for a stream whose sample fell into the 2048 buckets as ``sample_hist``: of the three
+    windows of three whole buckets that contain the bucket of the sample's middle rank, the one that keeps that rank
+    farthest (in ranks) from both ends (k_selq_predict's rule at bucket resolution; the batch-wide sample is large)."""
+    c = np.cumsum(np.asarray(sample_hist, dtype=np.int64))
+    total = int(c[-1])
+    if total <= 0:
+        return -int(WINDOW_SCALE)
+    mid = total // 2
+    m = int(np.searchsorted(c, mid, side="right"))
+    best, best_margin = m, -1
+    for b in (m - 2, m - 1, m):
+        lo = min(max(b, 0), SELECT_BINS - 3)
+        margin = min(mid - (int(c[lo - 1]) if lo else 0), int(c[lo + 2]) - 1 - mid)
+        if margin > best_margin:
+            best, best_margin = lo, margin
+    ws = (best - 1023) * 512 - 256 - (WINDOW_SLOTS - 3 * 512) // 2
+    return int(min(max(ws, -int(WINDOW_SCALE)), int(WINDOW_SCALE) + 1 - WINDOW_SLOTS))
+
+
+def select_order_statistics(pass_fn, n_local, comm=None, streams=3, windowed=True):
     """The two middle order statistics (ranks (N-1)//2 and N//2) of two streams of quotients of bytes: float32[2][2].
 
-    ``pass_fn(first, buckets[4]) -> uint64[2][2][SELECT_BINS]`` counts on this rank: first pass, the bucket of every
-    value (under track 0); second pass, the slot of the values inside ``buckets[stream * 2 + track]`` -- under track 0
-    only when both streams' tracks share their bucket.  Histograms are summed over ranks through
-    ``comm.allreduce_f64`` (counts < 2^53 are exact in float64), every rank then picks the same bins.
-    ``streams`` (bit 0, bit 1): a stream that is not asked for is skipped and comes back as NaN.
+    ``pass_fn(first, buckets[4]) -> uint64[2][2][SELECT_BINS]`` counts on this rank (lars_d_quotient_select_hist).
+    Histograms are summed over ranks through ``comm.allreduce_f64`` (counts < 2^53 are exact in float64), every rank then
+    picks the same bins.  ``streams`` (bit 0, bit 1): a stream that is not asked for is skipped and comes back as NaN.
+
+    ``windowed``: first a bucket pass over a 1/16 subsample (``first=3``) predicts a window of 3.75 buckets per stream,
+    then ONE full pass (``first=2``) counts the values below the window and its 1920 slots; ranks that fall inside are
+    exact from those counts.  Only if a rank falls outside do the two classic passes follow: first pass, the bucket of
+    every value (under track 0); second pass, the slot of the values inside ``buckets[stream * 2 + track]`` -- under
+    track 0 only when both streams' tracks share their bucket.
     """
     tot = np.array([float(n_local)])
     n_total = int((comm.allreduce_f64(tot, "sum") if comm is not None else tot)[0])
     if n_total <= 0:
         raise ValueError("select: no values")
-    ranks = np.array([[(n_total - 1) // 2, n_total // 2]] * 2, dtype=np.int64)     # [stream][track]
-    buckets = np.zeros((2, 2), dtype=np.uint32)
-    values = np.full((2, 2), np.nan, dtype=np.float32)
-    for first in (True, False):
-        local = np.asarray(pass_fn(first, buckets.reshape(4)), dtype=np.uint64).reshape(2, 2, SELECT_BINS)
+
+    def summed(first, buckets):
+        local = np.asarray(pass_fn(first, buckets), dtype=np.uint64).reshape(2, 2, SELECT_BINS)
         hist = local.astype(np.float64).reshape(-1)
         if comm is not None:
             hist = comm.allreduce_f64(hist, "sum")
-        hist = np.asarray(hist).reshape(2, 2, SELECT_BINS).astype(np.int64)
+        return np.asarray(hist).reshape(2, 2, SELECT_BINS).astype(np.int64)
+
+    ranks = np.array([[(n_total - 1) // 2, n_total // 2]] * 2, dtype=np.int64)     # [stream][track]
+    values = np.full((2, 2), np.nan, dtype=np.float32)
+    if windowed:
+        sample = summed(3, np.zeros(4, dtype=np.int64))
+        ws = [select_window_start(sample[s, 0]) for s in range(2)]
+        rows = summed(2, np.array([ws[0], 0, ws[1], 0], dtype=np.int64))
+        found = True
+        for s in range(2):
+            if not (streams >> s) & 1:
+                continue
+            below = int(rows[s, 0, :64].sum())
+            cum = np.cumsum(rows[s, 0, 64:64 + WINDOW_SLOTS])
+            for t in range(2):
+                r = int(ranks[s, t]) - below
+                if r < 0 or r >= int(cum[-1]):
+                    found = False
+                    continue
+                values[s, t] = select_window_value(ws[s], int(np.searchsorted(cum, r, side="right")))
+        if found:
+            return values
+        values[:] = np.nan
+    buckets = np.zeros((2, 2), dtype=np.uint32)
+    for first in (True, False):
+        hist = summed(1 if first else 0, buckets.reshape(4))
         if first:
             hist[:, 1] = hist[:, 0]                         # bucket pass: counted under track 0
         else:

@@ -33,7 +33,8 @@ struct SelQParams {
     const uint8_t *tiles;
     const uint8_t *wb_table;
     long long npix;
-    int first;                            // 1: bucket pass (every value counts, under track 0); 0: slot pass; 2: window pass (per tile)
+    int first;                            // 1: bucket pass (every value counts, under track 0); 0: slot pass; 2: window pass;
+                                          // 3 (whole batch only): bucket pass over every 16th grid stride (the prediction's sample)
     unsigned int bucket[4];               // [stream * 2 + track], second pass
     unsigned long long *hist;             // [2][2][SELQ_BINS], accumulated with atomics (whole-batch variant)
     // per-tile selection (medians of every tile of a batch, all on the device): state and 32-bit histograms per tile
@@ -81,7 +82,7 @@ __global__ __launch_bounds__(1024, 8) void k_selq_pass(SelQParams P)
     const unsigned int dummy_idx = SELQ_SLOTS + (tid & 63u);      // a value outside the bucket adds to its lane's dummy word
 
     // one sweep over the tile: MODE 0 counts buckets, MODE 1 the slots inside bucket b0 (NDVI) / b1 (GNDVI); no divergence
-    auto sweep = [&](auto mode_tag, unsigned int b0, unsigned int b1) {
+    auto sweep = [&](auto mode_tag, unsigned int b0, unsigned int b1, int every = 1) {
         constexpr int MODE = decltype(mode_tag)::value;
         const unsigned int t0[2] = {SELQ_T_BITS | (b0 << 12), SELQ_T_BITS | (b1 << 12)};     // bits of the bucket's first t
         // MODE 2: b0 / b1 carry the windows' first slots; the row of a stream is 64 "below" words | the slots | 64 "above" words
@@ -131,8 +132,8 @@ __global__ __launch_bounds__(1024, 8) void k_selq_pass(SelQParams P)
             }
             if (STREAMS & 1u) push_n(0, qv, 4);
             if (STREAMS & 2u) push_n(1, qg, 4);
-        });
-        if (blockIdx.x == 0 && tid < (int)(npix & 3)) {
+        }, every);
+        if (every == 1 && blockIdx.x == 0 && tid < (int)(npix & 3)) {
             const long long i = nquads * 4 + tid;
             unsigned int r = base[i * 3], g = base[i * 3 + 1], n = base[i * 3 + 2];
             if (WB) {
@@ -157,18 +158,23 @@ __global__ __launch_bounds__(1024, 8) void k_selq_pass(SelQParams P)
             }
         }
     };
-    if (PER_TILE && P.first == 2) {
+    if (P.first == 2) {
         static_assert(64 + SELQ_WIN_SLOTS + 64 == SELQ_BINS, "a window row is a bucket row");
-        sweep(std::integral_constant<int, 2>{}, P.win[tile * 2], P.win[tile * 2 + 1]);
+        // per tile: the predicted windows of this tile; whole batch: one window per stream in bucket[0] / bucket[2]
+        sweep(std::integral_constant<int, 2>{}, PER_TILE ? P.win[tile * 2] : P.bucket[0], PER_TILE ? P.win[tile * 2 + 1] : P.bucket[2]);
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");        // the window atomics are inline asm
         __syncthreads();
         for (int i = tid; i < 2 * SELQ_BINS; i += 1024) {
             const unsigned int v = s_h[i];
             if (!v) continue;
             const int stream = i >> 11, w = i & (SELQ_BINS - 1);
-            if (w < 64) atomicAdd(&P.below[tile * 2 + stream], v);
+            if (!PER_TILE) atomicAdd(&P.hist[(stream * 2) * SELQ_BINS + w], (unsigned long long)v);     // the whole row, under track 0
+            else if (w < 64) atomicAdd(&P.below[tile * 2 + stream], v);
             else if (w < 64 + SELQ_WIN_SLOTS) atomicAdd(&P.win_hist[(tile * 2 + stream) * SELQ_WIN_SLOTS + (w - 64)], v);
         }
+    } else if (!PER_TILE && P.first == 3) {
+        sweep(std::integral_constant<int, 0>{}, 0u, 0u, 16);
+        flush(0, SELQ_BINS);
     } else if (P.first) {
         sweep(std::integral_constant<int, 0>{}, 0u, 0u);
         flush(0, SELQ_BINS);
@@ -646,11 +652,16 @@ extern "C" int lars_d_quotient_select_hist(const void *tiles, int64_t ntiles, in
         return fail(LARS_ERR_INVALID, "lars_d_quotient_select_hist: bad arguments");
     if (dtype != LARS_U8 || channels != 3 || (reinterpret_cast<uintptr_t>(tiles) & 3) || (ntiles > 1 && (npix & 3)))
         return fail(LARS_ERR_INVALID, "lars_d_quotient_select_hist: uint8 [ntiles][npix][3] tiles on 4-byte boundaries are required");
-    for (int k = 0; k < 4; ++k)
+    if (first < 0 || first > 3) return fail(LARS_ERR_INVALID, "lars_d_quotient_select_hist: first must be 0 .. 3");
+    for (int k = 0; k < 4 && first != 2; ++k)
         if (bucket[k] >= SELQ_BINS) return fail(LARS_ERR_INVALID, "lars_d_quotient_select_hist: bucket must be below 2048");
+    if (first == 2)
+        for (int k = 0; k < 4; k += 2)
+            if ((int)bucket[k] < SELQ_WIN_BOTTOM || (int)bucket[k] > -SELQ_WIN_BOTTOM + 1 - SELQ_WIN_SLOTS)
+                return fail(LARS_ERR_INVALID, "lars_d_quotient_select_hist: window start outside [-524032, 522113]");
     if (ntiles > 65535 || (long long)npix * 6 >= (1ll << 30))
         return fail(LARS_ERR_INVALID, "lars_d_quotient_select_hist: at most 65535 tiles of < 2^30 / 6 pixels per launch");
-    return selq_pass_launch(static_cast<const uint8_t *>(tiles), wb_table, ntiles, npix, first ? 1 : 0, bucket,
+    return selq_pass_launch(static_cast<const uint8_t *>(tiles), wb_table, ntiles, npix, first, bucket,
                             reinterpret_cast<unsigned long long *>(hist), pick_stream(c, stream), streams);
 }
 

@@ -140,10 +140,11 @@ __device__ inline void selq_window_add(float u, unsigned int row_rel, int lo, in
 
 // The fused kernel's load pipeline as a reusable loop: four 12-byte buffer loads in flight per lane, slot k is
 // consumed and refilled in place.  f(q, w0, w1, w2) sees every quad of the tile exactly once.
+// `every` > 1: only every `every`-th grid stride is visited (a subsample in chunks of gridDim.x * NTHR quads).
 template <int NTHR, typename F>
-__device__ inline void for_each_quad_ring(const uint8_t *base, long long nquads, F &&f)
+__device__ inline void for_each_quad_ring(const uint8_t *base, long long nquads, F &&f, int every = 1)
 {
-    const long long stride = (long long)gridDim.x * NTHR;
+    const long long stride = (long long)gridDim.x * NTHR * every;
     const long long q0 = (long long)blockIdx.x * NTHR + threadIdx.x;
     const long long niter = (nquads + stride - 1) / stride;          // same for every lane of the grid
     if (niter <= 0) return;

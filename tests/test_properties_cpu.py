@@ -112,8 +112,16 @@ def test_select_host_logic_equals_numpy_median(n, seed, kind):
             "dark": np.arange(4)}[kind]
     a, r, g = (rng.choice(pool, n).astype(np.float32) for _ in range(3))
     planes = [_quotients(a, r), _quotients(a, g)]
-    values = batch.select_order_statistics(select_pass_on_planes(planes), n)
-    med = batch.medians_from_pairs(values)
-    assert med["NDVI"] == float(np.median(planes[0]))
-    assert med["GNDVI"] == float(np.median(planes[1]))
-    assert med["NDWI"] == float(np.median(np.float32(0) - planes[1]))
+    want = {"NDVI": float(np.median(planes[0])), "GNDVI": float(np.median(planes[1])), "NDWI": float(np.median(np.float32(0) - planes[1]))}
+    # predicted window (one full pass), a window predicted from the wrong sample (falls back to the two passes), two passes
+    wrong = [np.full(16, -0.9, dtype=np.float32), np.full(16, 0.9, dtype=np.float32)]
+    calls = []
+    for pass_fn, windowed in ((select_pass_on_planes(planes), True), (select_pass_on_planes(planes, wrong), True),
+                              (select_pass_on_planes(planes), False)):
+        def counting(first, buckets, fn=pass_fn):
+            calls.append(int(first))
+            return fn(first, buckets)
+        assert batch.medians_from_pairs(batch.select_order_statistics(counting, n, windowed=windowed)) == want
+        calls.append(-1)
+    assert calls[-3:] == [1, 0, -1]                                     # windowed=False: the two classic passes only
+    assert calls[:2] == [3, 2]                                          # windowed: the sample, then the window pass

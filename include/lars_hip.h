@@ -230,10 +230,13 @@ int lars_d_median_pair_batch_f32(const float *x, int64_t n, int64_t items, int64
 int lars_d_quotient_select_hist(const void *tiles, int64_t ntiles, int64_t npix, int channels, int dtype,
                                 const uint8_t *wb_table, uint32_t streams /* bit 0 NDVI, bit 1 GNDVI (and NDWI) */, int first,
                                 const uint32_t bucket[4], uint64_t *hist, void *stream);
-/* np.median of the NDVI and GNDVI planes of EVERY tile without writing a plane: the same two passes with
- * per-tile histograms, the picks and the value look-up on the device (no host round trip).  out_pairs is float[ntiles][2
- * streams: NDVI, GNDVI][2]: the two middle order statistics (median = their float32 mean; NDWI's median is
- * -GNDVI's).  scratch holds lars_quotient_median_scratch_bytes(ntiles). */
+/* np.median of the NDVI and GNDVI planes of EVERY tile without writing a plane: per-tile histograms, the picks and the
+ * value look-up on the device.  Usually ONE full pass: a subsample predicts a window per tile and stream, a window pass
+ * (first == 2 above, per tile) counts it, and only tiles whose ranks fall outside take the two classic passes -- to find
+ * out which, the call waits for its stream once (one word comes back to the host; lars_set_tuning("selq_window", 0)
+ * = always the two passes, no wait).  out_pairs is float[ntiles][2 streams: NDVI, GNDVI][2]: the two middle order
+ * statistics (median = their float32 mean; NDWI's median is -GNDVI's).  scratch holds
+ * lars_quotient_median_scratch_bytes(ntiles). */
 size_t lars_quotient_median_scratch_bytes(int64_t ntiles);
 /* The statistics of lars_d_fused (a->stats, LARS_F_HIST honoured; index_mask = one index or all three; no
  * output planes) AND those medians in one call: the statistics kernel also counts the select's first

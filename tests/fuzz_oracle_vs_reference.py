@@ -1,11 +1,11 @@
 #!/usr/bin/env python3
 """Differential fuzz of the oracle against the reference ITSELF (build container only: /root/reference does not exist on
-the GPU box, and nothing under tests/ imports this).  Random small images -- shapes, sample types, degenerate channels --
+the GPU box; pytest does not collect this file and nothing imports it).  Random small images -- shapes, sample types, degenerate channels --
 go through the reference's fix_white_balance / calculate_index / analyze_index (loaded as tools/gen_golden.py loads them)
 and through oracle/index_oracle.py's statement functions and closed forms; every array must be bit-identical, every
 dictionary equal.  The committed goldens pin a dozen fixed cases; this widens the net.
 
-    MPLBACKEND=Agg python tools/fuzz_oracle.py --cases 400 --seed 0
+    MPLBACKEND=Agg python tests/fuzz_oracle_vs_reference.py --cases 400 --seed 0
 """
 from __future__ import annotations
 
@@ -18,7 +18,7 @@ import numpy as np
 
 HERE = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, os.path.dirname(HERE))
-sys.path.insert(0, HERE)
+sys.path.insert(0, os.path.join(os.path.dirname(HERE), "tools"))
 
 import gen_golden  # noqa: E402
 from oracle import index_oracle as orc  # noqa: E402

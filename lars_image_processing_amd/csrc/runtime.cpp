@@ -3,6 +3,9 @@
 #include <stdarg.h>
 #include <stdlib.h>
 #include <string.h>
+#include <map>
+#include <mutex>
+#include <vector>
 
 #include <cmath>
 #include <mutex>
@@ -132,14 +135,92 @@ int lars_device_name(char *buf, size_t buflen)
     return LARS_OK;
 }
 
+// LARS_MALLOC_KIND=3 (experiments, tools/allocbench.py): virtual-memory-management allocations -- one address range, physical
+// memory created in chunks of LARS_VMM_CHUNK_MB (0 / unset = the whole allocation in ONE handle) and mapped back to back.
+namespace {
+struct VmmBlock { size_t bytes; std::vector<hipMemGenericAllocationHandle_t> handles; };
+std::mutex g_vmm_lock;
+std::map<void *, VmmBlock> g_vmm;
+
+int vmm_alloc(int device, void **dptr, size_t bytes)
+{
+    hipMemAllocationProp prop;
+    memset(&prop, 0, sizeof prop);
+    prop.type = hipMemAllocationTypePinned;
+    prop.location.type = hipMemLocationTypeDevice;
+    prop.location.id = device;
+    size_t gran = 0;
+    if (hipMemGetAllocationGranularity(&gran, &prop, hipMemAllocationGranularityRecommended) != hipSuccess || !gran)
+        return fail(LARS_ERR_HIP, "hipMemGetAllocationGranularity failed");
+    const char *chunk_env = getenv("LARS_VMM_CHUNK_MB");
+    size_t chunk = chunk_env ? (size_t)atoll(chunk_env) << 20 : 0;
+    const size_t total = (bytes + gran - 1) / gran * gran;
+    if (!chunk || chunk > total) chunk = total;
+    chunk = (chunk + gran - 1) / gran * gran;
+    void *base = nullptr;
+    const char *align_env = getenv("LARS_VMM_ALIGN_MB");          // alignment of the address range (0 / unset = the driver's default)
+    const size_t align = align_env ? (size_t)atoll(align_env) << 20 : 0;
+    if (hipMemAddressReserve(&base, total, align, nullptr, 0) != hipSuccess) return fail(LARS_ERR_OOM, "hipMemAddressReserve(%zu) failed", total);
+    VmmBlock blk;
+    blk.bytes = total;
+    for (size_t off = 0; off < total; off += chunk) {
+        const size_t n = off + chunk <= total ? chunk : total - off;
+        hipMemGenericAllocationHandle_t h;
+        hipError_t e = hipMemCreate(&h, n, &prop, 0);
+        if (e == hipSuccess) {
+            e = hipMemMap(static_cast<char *>(base) + off, n, 0, h, 0);
+            if (e != hipSuccess) hipMemRelease(h);
+        }
+        if (e != hipSuccess) {
+            size_t o2 = 0;
+            for (auto &hh : blk.handles) { const size_t n2 = o2 + chunk <= total ? chunk : total - o2; hipMemUnmap(static_cast<char *>(base) + o2, n2); hipMemRelease(hh); o2 += chunk; }
+            hipMemAddressFree(base, total);
+            return fail(LARS_ERR_OOM, "hipMemCreate / hipMemMap(%zu): %s", n, hipGetErrorString(e));
+        }
+        blk.handles.push_back(h);
+    }
+    hipMemAccessDesc acc;
+    memset(&acc, 0, sizeof acc);
+    acc.location = prop.location;
+    acc.flags = hipMemAccessFlagsProtReadWrite;
+    if (hipMemSetAccess(base, total, &acc, 1) != hipSuccess) return fail(LARS_ERR_HIP, "hipMemSetAccess failed");
+    {
+        std::lock_guard<std::mutex> g(g_vmm_lock);
+        g_vmm[base] = blk;
+    }
+    *dptr = base;
+    return LARS_OK;
+}
+// true if dptr was a VMM block (and is gone now)
+bool vmm_free(void *dptr)
+{
+    VmmBlock blk;
+    {
+        std::lock_guard<std::mutex> g(g_vmm_lock);
+        auto it = g_vmm.find(dptr);
+        if (it == g_vmm.end()) return false;
+        blk = it->second;
+        g_vmm.erase(it);
+    }
+    const size_t chunk = blk.handles.empty() ? blk.bytes : (blk.bytes + blk.handles.size() - 1) / blk.handles.size();
+    hipMemUnmap(dptr, blk.bytes);
+    for (auto &h : blk.handles) hipMemRelease(h);
+    hipMemAddressFree(dptr, blk.bytes);
+    (void)chunk;
+    return true;
+}
+}  // namespace
+
 int lars_malloc(void **dptr, size_t bytes)
 {
     ThreadCtx *c;
     LARS_TRY(ensure_ctx(&c));
     if (!dptr) return fail(LARS_ERR_INVALID, "lars_malloc: NULL");
-    // LARS_MALLOC_KIND (experiments, tools/allocbench.py): 1 uncached, 2 fine-grained device memory instead of plain hipMalloc
+    // LARS_MALLOC_KIND (experiments, tools/allocbench.py): 1 uncached, 2 fine-grained device memory, 3 virtual-memory-management
+    // blocks instead of plain hipMalloc
     const char *kind = getenv("LARS_MALLOC_KIND");
     hipError_t e;
+    if (kind && kind[0] == '3' && bytes >= (64u << 20)) return vmm_alloc(c->device, dptr, bytes);
     if (kind && kind[0] == '1') e = hipExtMallocWithFlags(dptr, bytes ? bytes : 1, hipDeviceMallocUncached);
     else if (kind && kind[0] == '2') e = hipExtMallocWithFlags(dptr, bytes ? bytes : 1, hipDeviceMallocFinegrained);
     else e = hipMalloc(dptr, bytes ? bytes : 1);
@@ -151,6 +232,7 @@ int lars_free(void *dptr)
     if (!dptr) return LARS_OK;
     ThreadCtx *c;
     LARS_TRY(ensure_ctx(&c));
+    if (vmm_free(dptr)) return LARS_OK;
     LARS_HIP_TRY(hipFree(dptr));
     return LARS_OK;
 }

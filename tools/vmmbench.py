@@ -67,13 +67,16 @@ def main():
         out.index = [None] * 3
         return tiles * b.npix * 15 / ms.value / 1e6
 
-    t = {i: [] for i in range(len(arenas))}
+    t = {(i, nt): [] for i in range(len(arenas)) for nt in (0, 1)}
     for r in range(rounds + 1):
         for i, (name, arena) in enumerate(arenas):
-            t[i].append(run(arena))
+            for nt in (0, 1):
+                _ffi.set_tuning(nt_stores=nt)
+                t[(i, nt)].append(run(arena))
+    _ffi.set_tuning(nt_stores=0)
     for i, (name, arena) in enumerate(arenas):
-        g = float(np.median(t[i][1:]))
-        print(f"{name:22s} arena at {arena.ptr:#x}: {g:7.1f} GB/s ({g / 8000:.3f})")
+        g, gn = float(np.median(t[(i, 0)][1:])), float(np.median(t[(i, 1)][1:]))
+        print(f"{name:22s} arena at {arena.ptr:#x}: {g:7.1f} GB/s ({g / 8000:.3f})   with non-temporal plane stores {gn:7.1f} GB/s ({gn / 8000:.3f})")
 
 
 if __name__ == "__main__":

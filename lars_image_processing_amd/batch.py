@@ -117,12 +117,16 @@ class TileBatch:
         if placement_trials <= 1 or outs.arena is None:
             return outs
         # Candidates are allocated one by one and ALL kept until the choice is made (a freed arena would be handed out
-        # again).  The classes are ~15 % apart, so the search stops as soon as one candidate is clearly faster than the
-        # slowest seen (>= 7 %) after at least four, and otherwise goes on to `placement_trials` or the memory limit.
+        # again).  The classes are ~15 % apart, so the search ends two candidates after one is clearly faster than the
+        # slowest seen (>= 7 %, at least four tried), and otherwise goes on to `placement_trials` or the memory limit.
         arenas, timings = [outs.arena], [self._time_outputs(outs, indices)]
         free_b, total_b = C.c_size_t(), C.c_size_t()
+        gap_at = None                                               # number of candidates when the 7 % gap first showed
         while len(arenas) < int(placement_trials):
-            if len(arenas) >= 4 and min(timings) * 1.07 <= max(timings):
+            if gap_at is None and len(arenas) >= 4 and min(timings) * 1.07 <= max(timings):
+                gap_at = len(arenas)
+            # the fast class itself has levels 2-3 % apart (profiles/r02_placement_vmm.txt): two more candidates, then the best
+            if gap_at is not None and len(arenas) >= gap_at + 2:
                 break
             _ffi.call("lars_mem_info", C.byref(free_b), C.byref(total_b))
             if free_b.value < outs.arena.nbytes + (8 << 30):       # keep 8 GiB of headroom for the caller

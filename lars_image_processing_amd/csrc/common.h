@@ -106,6 +106,7 @@ struct Tuning {
     int pipe_trace = 0;        // pipeline.hip: record item timestamps behind the scratch's sync words
     int pipe_head = 0;         // pipeline.hip: histogram items handed out before each fused item (0 = 2)
     int count_mode = -1;       // statistics-only kernels, A/B only: 3 = float coverage counters (fused_v2.hip)
+    int grid_swap = 0;         // plane-writing kernel, A/B only: 1 = tile index fastest in dispatch order (k_fused_u8c3)
     int traverse = -1;         // plane-writing kernel, A/B only: -1 / 1 the shipped mapping, 0 and 2 see k_fused_u8c3
 };
 Tuning &tuning();

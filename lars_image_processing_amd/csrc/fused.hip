@@ -290,7 +290,11 @@ __global__ __launch_bounds__(256) void k_fused_u8c3(FusedParams P)
 
     const int tid = threadIdx.x;
     unsigned int *const s_hist = s_hist_all + (tid & (HIST_COPIES - 1));
-    const long long tile = blockIdx.y;
+    // flags bit 28 (lars_set_tuning("grid_swap", 1), A/B only): the tile index varies fastest in dispatch order, so the resident
+    // workgroups write to all tiles of the launch at once instead of to a window of two
+    const bool swap = (P.flags & 0x10000000u) != 0;
+    const unsigned int bx = swap ? blockIdx.y : blockIdx.x, gx = swap ? gridDim.y : gridDim.x;
+    const long long tile = swap ? blockIdx.x : blockIdx.y;
     const long long npix = P.npix;
     const PIX *base = static_cast<const PIX *>(P.tiles) + tile * npix * 3;
 
@@ -406,14 +410,14 @@ __global__ __launch_bounds__(256) void k_fused_u8c3(FusedParams P)
     // (one 256-pixel slab per wave and step, slabs of a wave a grid stride apart) with the bare traffic mix:
     // 6.07-6.38 vs 5.63-5.95 TB/s in three sets of allocations (profiles/r02_stream_probe.txt, kinds 9-13 vs 5).
     const long long nsteps = (nquads + 255) >> 8;
-    const long long wstride = (long long)gridDim.x * 4;
+    const long long wstride = (long long)gx * 4;
     const unsigned int lane = (unsigned int)tid & 63u;
     if (TRAV == 2) {
-        const long long stride = (long long)gridDim.x * 256;
+        const long long stride = (long long)gx * 256;
         unsigned int w[NW];
-        for (long long q = (long long)blockIdx.x * 256 + tid; q < nquads; q += stride) { load_quad(q, w); do_quad(q, w); }
+        for (long long q = (long long)bx * 256 + tid; q < nquads; q += stride) { load_quad(q, w); do_quad(q, w); }
     } else if (TRAV == 1) {
-        for (long long st = (long long)blockIdx.x * 4 + (tid >> 6); st < nsteps; st += wstride) {
+        for (long long st = (long long)bx * 4 + (tid >> 6); st < nsteps; st += wstride) {
             const long long q0 = st * 256 + lane;
             unsigned int w[4][NW];
             if (st * 256 + 256 <= nquads) {
@@ -435,7 +439,7 @@ __global__ __launch_bounds__(256) void k_fused_u8c3(FusedParams P)
     } else {
         // same addresses per wave as the unrolled form, one quad per trip (a third of the registers)
         unsigned int w[NW];
-        for (long long st = (long long)blockIdx.x * 4 + (tid >> 6); st < nsteps; st += wstride) {
+        for (long long st = (long long)bx * 4 + (tid >> 6); st < nsteps; st += wstride) {
             const long long q0 = st * 256 + lane;
 #pragma unroll 1
             for (int j = 0; j < 4; ++j) {
@@ -445,7 +449,7 @@ __global__ __launch_bounds__(256) void k_fused_u8c3(FusedParams P)
         }
     }
     // tail pixels (npix % 4): lanes 0..2 of block 0
-    if (blockIdx.x == 0 && tid < (int)(npix & 3)) {
+    if (bx == 0 && tid < (int)(npix & 3)) {
         const long long i = nquads * 4 + tid;
         unsigned int r = base[i * 3], g = base[i * 3 + 1], n = base[i * 3 + 2];
         if (WB) { r = wb_map(r, 0); g = wb_map(g, 1); n = wb_map(n, 2); }
@@ -730,7 +734,7 @@ extern "C" int lars_d_fused(const lars_fused_args *a)
         P.cmap_lut[k] = a->cmap_lut[k];
     }
     P.out_wb = a->out_wb; P.stats = a->stats; P.mask = mask; P.sel_hist = nullptr; P.sel_win = nullptr; P.sel_win_hist = nullptr; P.sel_below = nullptr;
-    P.flags = (a->flags & 7u) | (tuning().nt_stores ? 0x20000000u : 0u);
+    P.flags = (a->flags & 7u) | (tuning().nt_stores ? 0x20000000u : 0u) | (tuning().grid_swap ? 0x10000000u : 0u);
 
     const long long nrec = a->ntiles * 3;
     if (stats_mode)
@@ -762,6 +766,7 @@ extern "C" int lars_d_fused(const lars_fused_args *a)
         fused_v2_launch(mask, a->wb_table != nullptr, stats_mode, tuning().nt_stores != 0, grid, s, P);
     } else if (fast && a->dtype == LARS_U8) {
         dim3 grid(blocks_per_tile(a->npix / 4 + 1, a->ntiles, 256, 32768), (unsigned)a->ntiles);
+        if (tuning().grid_swap) grid = dim3(grid.y, grid.x);
         const bool headline = mask == 7u && a->wb_table && stats_mode == 1;
         if (headline && tuning().traverse == 0) hipLaunchKernelGGL((k_fused_u8c3<uint8_t, 7u, true, 1, 0>), grid, dim3(256), 0, s, P);
         else if (headline && tuning().traverse == 2) hipLaunchKernelGGL((k_fused_u8c3<uint8_t, 7u, true, 1, 2>), grid, dim3(256), 0, s, P);

@@ -5,6 +5,7 @@
 #include <string.h>
 #include <map>
 #include <mutex>
+#include <utility>
 #include <vector>
 
 #include <cmath>
@@ -138,7 +139,7 @@ int lars_device_name(char *buf, size_t buflen)
 // LARS_MALLOC_KIND=3 (experiments, tools/allocbench.py): virtual-memory-management allocations -- one address range, physical
 // memory created in chunks of LARS_VMM_CHUNK_MB (0 / unset = the whole allocation in ONE handle) and mapped back to back.
 namespace {
-struct VmmBlock { size_t bytes; std::vector<hipMemGenericAllocationHandle_t> handles; };
+struct VmmBlock { size_t bytes, chunk; std::vector<hipMemGenericAllocationHandle_t> handles; };
 std::mutex g_vmm_lock;
 std::map<void *, VmmBlock> g_vmm;
 
@@ -163,21 +164,34 @@ int vmm_alloc(int device, void **dptr, size_t bytes)
     if (hipMemAddressReserve(&base, total, align, nullptr, 0) != hipSuccess) return fail(LARS_ERR_OOM, "hipMemAddressReserve(%zu) failed", total);
     VmmBlock blk;
     blk.bytes = total;
-    for (size_t off = 0; off < total; off += chunk) {
-        const size_t n = off + chunk <= total ? chunk : total - off;
+    blk.chunk = chunk;
+    // LARS_VMM_SHUFFLE=1: all chunks are created first and then mapped in a pseudo-random order, so that neighbouring
+    // addresses are backed by physical memory from unrelated places
+    const bool shuffle = getenv("LARS_VMM_SHUFFLE") && getenv("LARS_VMM_SHUFFLE")[0] == '1';
+    const size_t nchunks = (total + chunk - 1) / chunk;
+    auto undo = [&](size_t mapped) {
+        for (size_t i = 0; i < mapped; ++i) hipMemUnmap(static_cast<char *>(base) + i * chunk, (i + 1) * chunk <= total ? chunk : total - i * chunk);
+        for (auto &hh : blk.handles) hipMemRelease(hh);
+        hipMemAddressFree(base, total);
+    };
+    for (size_t i = 0; i < nchunks; ++i) {
+        const size_t n = (i + 1) * chunk <= total ? chunk : total - i * chunk;
         hipMemGenericAllocationHandle_t h;
-        hipError_t e = hipMemCreate(&h, n, &prop, 0);
-        if (e == hipSuccess) {
-            e = hipMemMap(static_cast<char *>(base) + off, n, 0, h, 0);
-            if (e != hipSuccess) hipMemRelease(h);
-        }
-        if (e != hipSuccess) {
-            size_t o2 = 0;
-            for (auto &hh : blk.handles) { const size_t n2 = o2 + chunk <= total ? chunk : total - o2; hipMemUnmap(static_cast<char *>(base) + o2, n2); hipMemRelease(hh); o2 += chunk; }
-            hipMemAddressFree(base, total);
-            return fail(LARS_ERR_OOM, "hipMemCreate / hipMemMap(%zu): %s", n, hipGetErrorString(e));
-        }
+        const hipError_t e = hipMemCreate(&h, n, &prop, 0);
+        if (e != hipSuccess) { undo(0); return fail(LARS_ERR_OOM, "hipMemCreate(%zu): %s", n, hipGetErrorString(e)); }
         blk.handles.push_back(h);
+    }
+    if (shuffle && total % chunk == 0) {
+        unsigned long long x = 0x9E3779B97F4A7C15ull;
+        for (size_t i = nchunks - 1; i > 0; --i) {
+            x ^= x << 13; x ^= x >> 7; x ^= x << 17;
+            std::swap(blk.handles[i], blk.handles[(size_t)(x % (i + 1))]);
+        }
+    }
+    for (size_t i = 0; i < nchunks; ++i) {
+        const size_t n = (i + 1) * chunk <= total ? chunk : total - i * chunk;
+        const hipError_t e = hipMemMap(static_cast<char *>(base) + i * chunk, n, 0, blk.handles[i], 0);
+        if (e != hipSuccess) { undo(i); return fail(LARS_ERR_OOM, "hipMemMap(%zu): %s", n, hipGetErrorString(e)); }
     }
     hipMemAccessDesc acc;
     memset(&acc, 0, sizeof acc);
@@ -202,11 +216,9 @@ bool vmm_free(void *dptr)
         blk = it->second;
         g_vmm.erase(it);
     }
-    const size_t chunk = blk.handles.empty() ? blk.bytes : (blk.bytes + blk.handles.size() - 1) / blk.handles.size();
     hipMemUnmap(dptr, blk.bytes);
     for (auto &h : blk.handles) hipMemRelease(h);
     hipMemAddressFree(dptr, blk.bytes);
-    (void)chunk;
     return true;
 }
 }  // namespace
@@ -217,12 +229,13 @@ int lars_malloc(void **dptr, size_t bytes)
     LARS_TRY(ensure_ctx(&c));
     if (!dptr) return fail(LARS_ERR_INVALID, "lars_malloc: NULL");
     // LARS_MALLOC_KIND (experiments, tools/allocbench.py): 1 uncached, 2 fine-grained device memory, 3 virtual-memory-management
-    // blocks instead of plain hipMalloc
+    // blocks, 4 physically contiguous memory (hipDeviceMallocContiguous) instead of plain hipMalloc
     const char *kind = getenv("LARS_MALLOC_KIND");
     hipError_t e;
     if (kind && kind[0] == '3' && bytes >= (64u << 20)) return vmm_alloc(c->device, dptr, bytes);
     if (kind && kind[0] == '1') e = hipExtMallocWithFlags(dptr, bytes ? bytes : 1, hipDeviceMallocUncached);
     else if (kind && kind[0] == '2') e = hipExtMallocWithFlags(dptr, bytes ? bytes : 1, hipDeviceMallocFinegrained);
+    else if (kind && kind[0] == '4' && bytes >= (64u << 20)) e = hipExtMallocWithFlags(dptr, bytes, hipDeviceMallocContiguous);
     else e = hipMalloc(dptr, bytes ? bytes : 1);
     if (e != hipSuccess) { *dptr = nullptr; return fail(LARS_ERR_OOM, "hipMalloc(%zu): %s", bytes, hipGetErrorString(e)); }
     return LARS_OK;
@@ -341,6 +354,7 @@ int lars_set_tuning(const char *key, int value)
     else if (!strcmp(key, "nt_stores")) t.nt_stores = value;
     else if (!strcmp(key, "blocks_per_tile")) t.blocks_per_tile = value;
     else if (!strcmp(key, "traverse")) t.traverse = value;
+    else if (!strcmp(key, "grid_swap")) t.grid_swap = value;
     else if (!strcmp(key, "count_mode")) t.count_mode = value;
     else if (!strcmp(key, "pipe_steps")) t.pipe_steps = value;
     else if (!strcmp(key, "selq_window")) t.selq_window = value;
@@ -360,6 +374,7 @@ int lars_get_tuning(const char *key, int *value)
     else if (!strcmp(key, "nt_stores")) *value = t.nt_stores;
     else if (!strcmp(key, "blocks_per_tile")) *value = t.blocks_per_tile;
     else if (!strcmp(key, "traverse")) *value = t.traverse;
+    else if (!strcmp(key, "grid_swap")) *value = t.grid_swap;
     else if (!strcmp(key, "count_mode")) *value = t.count_mode;
     else if (!strcmp(key, "pipe_steps")) *value = t.pipe_steps;
     else if (!strcmp(key, "selq_window")) *value = t.selq_window;

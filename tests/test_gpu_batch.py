@@ -233,6 +233,16 @@ def test_tuning_does_not_change_results(lars):
                 assert got == ref, (impl, nt, bpt)
                 np.testing.assert_allclose(sumsq, ref_sumsq, rtol=1e-12)
     _ffi.set_tuning(fused_impl=keep[0], hist_impl=keep[1], nt_stores=0, blocks_per_tile=0)
+    # the plane-writing kernel's A/B mappings (statistics without histograms: the configuration they exist for)
+    ref = None
+    for knobs in ({}, {"traverse": 0}, {"traverse": 2}, {"grid_swap": 1}, {"grid_swap": 1, "blocks_per_tile": 3}):
+        _ffi.set_tuning(**knobs)
+        rec = b.process(outputs=outs)
+        got = (rec.tobytes(), outs.host_index("NDVI", 0, 4).tobytes(), outs.host_index("GNDVI", 0, 4).tobytes())
+        _ffi.set_tuning(traverse=-1, grid_swap=0, blocks_per_tile=0)
+        if ref is None:
+            ref = got
+        assert got == ref, knobs
     outs.free()
     b.free()
 

@@ -37,9 +37,9 @@ def main():
     plane = slots * b.npix * 4
     out = b.make_outputs(index=False, ring=slots)
     spec = os.environ.get("VMM_VARIANTS", "malloc,0,1024,64,2")
-    # "malloc", or "<chunk MiB>" / "<chunk MiB>a<alignment MiB of the address range>"
-    variants = [("hipMalloc", None, None) if v == "malloc" else (("vmm, one handle" if v == "0" else f"vmm, {v} MiB chunks"), "3", v)
-                for v in spec.split(",")]
+    # "malloc", "contig", or "<chunk MiB>" / "<chunk MiB>a<alignment MiB of the address range>" / "<chunk MiB>s" (shuffled)
+    variants = [("hipMalloc", None, None) if v == "malloc" else ("contiguous", "4", "0") if v == "contig" else
+                (("vmm, one handle" if v == "0" else f"vmm, {v} MiB chunks"), "3", v) for v in spec.split(",")]
     arenas = []
     for name, kind, chunk in variants:
         for k in range(per):
@@ -47,7 +47,8 @@ def main():
                 os.environ.pop("LARS_MALLOC_KIND", None)
             else:
                 os.environ["LARS_MALLOC_KIND"] = kind
-                os.environ["LARS_VMM_CHUNK_MB"] = chunk.split("a")[0]
+                os.environ["LARS_VMM_CHUNK_MB"] = chunk.split("a")[0].rstrip("s")
+                os.environ["LARS_VMM_SHUFFLE"] = "1" if chunk.endswith("s") else "0"
                 os.environ["LARS_VMM_ALIGN_MB"] = chunk.split("a")[1] if "a" in chunk else "0"
             try:
                 arenas.append((name, _ffi.DeviceBuffer(3 * plane)))
@@ -67,16 +68,17 @@ def main():
         out.index = [None] * 3
         return tiles * b.npix * 15 / ms.value / 1e6
 
+    knob = os.environ.get("VMM_KNOB", "nt_stores")                 # the tuning key switched on for the second column
     t = {(i, nt): [] for i in range(len(arenas)) for nt in (0, 1)}
     for r in range(rounds + 1):
         for i, (name, arena) in enumerate(arenas):
             for nt in (0, 1):
-                _ffi.set_tuning(nt_stores=nt)
+                _ffi.set_tuning(**{knob: nt})
                 t[(i, nt)].append(run(arena))
-    _ffi.set_tuning(nt_stores=0)
+    _ffi.set_tuning(**{knob: 0})
     for i, (name, arena) in enumerate(arenas):
         g, gn = float(np.median(t[(i, 0)][1:])), float(np.median(t[(i, 1)][1:]))
-        print(f"{name:22s} arena at {arena.ptr:#x}: {g:7.1f} GB/s ({g / 8000:.3f})   with non-temporal plane stores {gn:7.1f} GB/s ({gn / 8000:.3f})")
+        print(f"{name:22s} arena at {arena.ptr:#x}: {g:7.1f} GB/s ({g / 8000:.3f})   with {knob}=1 {gn:7.1f} GB/s ({gn / 8000:.3f})")
 
 
 if __name__ == "__main__":

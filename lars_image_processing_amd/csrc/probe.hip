@@ -51,6 +51,24 @@ __global__ __launch_bounds__(256) void k_probe_write(uint4 *__restrict__ dst, lo
 
 typedef unsigned int pu32x4 __attribute__((ext_vector_type(4)));
 
+// Writes (or reads, READ = true) from the workgroups of ONE XCD only (workgroup i of a 1-D grid runs on XCD i % 8; xcd = 8:
+// all of them): does it matter which XCD writes to a given piece of memory?  The participating workgroups cover the range.
+template <bool READ>
+__global__ __launch_bounds__(256) void k_probe_xcd(uint4 *__restrict__ dst, long long nvec, int xcd, unsigned int *sink)
+{
+    const unsigned int me = blockIdx.x & 7u;
+    if (xcd < 8 && (int)me != xcd) return;
+    const long long nwg = xcd < 8 ? gridDim.x / 8 : gridDim.x, wg = xcd < 8 ? blockIdx.x / 8 : blockIdx.x;
+    const long long stride = nwg * 256;
+    const uint4 v = make_uint4(threadIdx.x, blockIdx.x, 3u, 4u);
+    unsigned int acc = 0;
+    for (long long i = wg * 256 + threadIdx.x; i < nvec; i += stride) {
+        if (READ) { const uint4 r = dst[i]; acc ^= r.x ^ r.y ^ r.z ^ r.w; }
+        else dst[i] = v;
+    }
+    if (READ && acc == 0x12345678u) sink[0] = acc;
+}
+
 __global__ __launch_bounds__(256) void k_probe_write_nt(pu32x4 *__restrict__ dst, long long nvec)
 {
     const long long stride = (long long)gridDim.x * 256;
@@ -462,6 +480,10 @@ extern "C" int lars_d_probe(int kind, int unroll, int blocks, const void *src, v
         if (kind == 20) hipLaunchKernelGGL((k_probe_resweep<false, false>), dim3(blocks), dim3(256), 0, s, p, nquads, reps, d, 0ll, sink);
         else if (kind == 21) hipLaunchKernelGGL((k_probe_resweep<true, false>), dim3(blocks), dim3(256), 0, s, p, nquads, reps, d, dst_quads, sink);
         else hipLaunchKernelGGL((k_probe_resweep<true, true>), dim3(blocks), dim3(256), 0, s, p, nquads, reps, d, dst_quads, sink);
+    } else if (kind == 26 || kind == 27) {
+        // unroll = XCD (0..7) whose workgroups do the work, 8 = all; 26 writes dst, 27 reads it
+        if (kind == 26) hipLaunchKernelGGL((k_probe_xcd<false>), dim3(blocks), dim3(256), 0, s, static_cast<uint4 *>(dst), (long long)(bytes / 16), unroll, sink);
+        else hipLaunchKernelGGL((k_probe_xcd<true>), dim3(blocks), dim3(256), 0, s, static_cast<uint4 *>(dst), (long long)(bytes / 16), unroll, sink);
     } else if (kind == 99) {
         // shader clock: dst receives {shader cycles, 100 MHz ticks}; unroll = spin count; runs beside `blocks` busy blocks
         hipLaunchKernelGGL(k_probe_clock, dim3(blocks), dim3(256), 0, s, static_cast<unsigned long long *>(dst), unroll);

@@ -288,7 +288,7 @@ int lars_d_synth_u8(uint8_t *tiles, int64_t ntiles, int64_t first_tile, int64_t 
 /* Tuning knobs (per process): "fused_impl" 0 (auto)|1|2, "hist_impl" 1|2, "nt_stores" 0|1,
  * "blocks_per_tile" 0 = automatic, "selq_window" 1 (one-pass medians)|0 (always two select passes)|2 (wrong windows:
  * exercises the fallback), "selq_list_wgs" workgroups per select pass over the tiles a window missed (0 = 2048);
- * A/B switches of the experiments in DESIGN.md: "traverse" -1|0|1|2, "count_mode" -1|3, "pipe_steps", "pipe_head",
+ * A/B switches of the experiments in DESIGN.md: "traverse" -1|0|1|2, "grid_swap" 0|1, "count_mode" -1|3, "pipe_steps", "pipe_head",
  * "pipe_trace".  Results never depend on them ("pipe_cold" 1 is the one exception: a timing experiment of the pipeline
  * launch that reads the wrong tile on purpose). */
 int lars_set_tuning(const char *key, int value);

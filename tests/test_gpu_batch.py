@@ -708,3 +708,33 @@ def test_one_pass_medians_and_their_fallback(lars, profile, indices):
         _ffi.set_tuning(selq_window=1)
     assert results[1] == results[2] == results[0]
     b.free()
+
+
+def test_one_pass_medians_at_the_ends_of_the_range(lars):
+    """Windows clamped at -1 and +1, and a tile whose two middle values are -1 and +1 (no window can hold both: the
+    classic passes take over); without white balance so that the bytes are what the index sees."""
+    h, w = 128, 256
+    top = np.zeros((h, w, 3), dtype=np.uint8); top[..., 2] = 200                      # NDVI = GNDVI = +1
+    bottom = np.zeros((h, w, 3), dtype=np.uint8); bottom[..., 0] = 200; bottom[..., 1] = 200      # NDVI = GNDVI = -1
+    split = top.copy(); split[: h // 2] = bottom[: h // 2]                            # N/2 values -1, N/2 values +1
+    near = top.copy(); near[..., 0] = 1; near[..., 1] = 2                             # 199/201 and 198/202: just below +1
+    rng = np.random.default_rng(5)
+    mostly = bottom.copy(); mostly[rng.random((h, w)) < 0.3] = (3, 7, 250)            # 70 % at -1, the rest near +1
+    tiles = [top, bottom, split, near, mostly]
+    b = lars.TileBatch.from_host(np.stack(tiles))
+    rec, med = b.process(medians=True, white_balance=False)
+    for i, tile in enumerate(tiles):
+        for k, t in enumerate(TYPES):
+            assert med[i, k] == float(np.median(orc.index_app(tile, t))), (i, t)
+    np.testing.assert_array_equal(b.tile_medians(white_balance=False), med)
+    # over all five tiles at once (sampled prediction, window pass, fallback where the window misses)
+    glob = b.global_medians(white_balance=False)
+    for t in TYPES:
+        assert glob[t] == float(np.median(np.concatenate([orc.index_app(tile, t).ravel() for tile in tiles]))), t
+    for sub in ([top, top], [bottom], [split]):
+        bb = lars.TileBatch.from_host(np.stack(sub))
+        g = bb.global_medians(white_balance=False)
+        for t in TYPES:
+            assert g[t] == float(np.median(np.concatenate([orc.index_app(tile, t).ravel() for tile in sub]))), (t, len(sub))
+        bb.free()
+    b.free()

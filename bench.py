@@ -122,14 +122,10 @@ class Runner:
             args = b.fused_args(indices, True, self.stats, hist, None)
             ffi.call("lars_d_stats_medians", C.byref(args), C.c_void_p(self._med_bufs[0].ptr), C.c_void_p(self._med_bufs[1].ptr))
             launches = 1
-        elif outs is None or outs.slots >= b.ntiles:
-            b.run_fused(b.fused_args(indices, True, self.stats, hist, outs))
-            launches = 1
         else:
-            for start in range(0, b.ntiles, outs.slots):
-                count = min(outs.slots, b.ntiles - start)
-                b.run_fused(b.fused_args(indices, True, self.stats, hist, outs, None, start, count))
-                launches += 1
+            # one launch without output planes, one per ring of `outs.slots` tiles with them; the statistics records are opened
+            # and closed once around the launches (lars_d_stats_begin / _end), not by two small kernels per launch
+            launches = b.run_fused_chunks(indices, True, self.stats, hist, outs)
         ffi.call("lars_event_record", self.ev[2], None)
         rec = self.stats.download(ffi.STATS_DTYPE, (b.ntiles, 3))         # synchronises the stream
         local = self.lb.local_fold(rec, indices)

@@ -73,6 +73,9 @@ typedef enum lars_status {
 #define LARS_F_STATS 1u            /* fill stats[tile][index] (min/max/sum/sumsq/above/count) */
 #define LARS_F_HIST  2u            /* also the 50-bin histogram (implies LARS_F_STATS) */
 #define LARS_F_SUMSQ 4u            /* also the sum of squares, for a standard deviation (implies LARS_F_HIST) */
+#define LARS_F_RAW   8u            /* lars_d_fused only: args->stats are running accumulators that the caller has opened with
+                                    * lars_d_stats_begin and closes with lars_d_stats_end -- one pair around the launches of a
+                                    * batch that is processed in chunks, instead of one pair of small kernels per launch */
 
 /*
  * Order-independent statistics record of one index over one tile (or, after a
@@ -177,6 +180,10 @@ typedef struct lars_fused_args {
  * white-balance table lookup, NDVI/GNDVI/NDWI (process-images.py:456-490, IEEE
  * float32), optional float32 / uint8 / RGBA8 outputs and per-tile statistics. */
 int lars_d_fused(const lars_fused_args *args);
+/* Open / close the statistics records [ntiles][3] of the indices in index_mask for launches with LARS_F_RAW (begin: the
+ * accumulators of lars_d_fused's own prologue; end: sums, count, minimum and maximum in their final form). */
+int lars_d_stats_begin(lars_stats *stats, int64_t ntiles, uint32_t index_mask, void *stream);
+int lars_d_stats_end(lars_stats *stats, int64_t ntiles, uint32_t index_mask, int64_t npix, void *stream);
 
 /* The whole step in one persistent launch (csrc/pipeline.hip): channel histograms -> np.percentile(ch, (2, 98)) ->
  * white-balance tables -> the fused pass, ordered tile by tile so that a tile's second read comes out of the 256 MiB

@@ -21,7 +21,7 @@ U8, U16 = 1, 2
 NDVI, GNDVI, NDWI = 0, 1, 2
 INDEX_IDS = {"NDVI": NDVI, "GNDVI": GNDVI, "NDWI": NDWI}
 INDEX_NAMES = ("NDVI", "GNDVI", "NDWI")
-F_STATS, F_HIST, F_SUMSQ = 1, 2, 4
+F_STATS, F_HIST, F_SUMSQ, F_RAW = 1, 2, 4, 8
 COMM_ID_BYTES = 128
 
 
@@ -93,6 +93,8 @@ SIGNATURES = {
     "lars_wb_table_bytes": (_SZ, [_I]),
     "lars_d_wb_prepare": (_I, [_P, _I64, _I64, _I, _I, _P, _P, _I, _P]),
     "lars_d_fused": (_I, [C.POINTER(FusedArgs)]),
+    "lars_d_stats_begin": (_I, [_P, _I64, _U32, _P]),
+    "lars_d_stats_end": (_I, [_P, _I64, _U32, _I64, _P]),
     "lars_pipeline_scratch_bytes": (_SZ, [_I64, _I64]),
     "lars_d_pipeline": (_I, [C.POINTER(FusedArgs), _P, _P, _I, _P]),
     "lars_d_index_planes_f32": (_I, [_P, _P, _P, _I64, _I, _P, _P]),

@@ -171,7 +171,7 @@ class TileBatch:
         return float(ms.value) / len(launches)
 
     def fused_args(self, indices=INDEX_NAMES, white_balance=True, stats=None, hist=False, outputs=None,
-                   stream=None, tile_start=0, tile_count=None, sumsq=False):
+                   stream=None, tile_start=0, tile_count=None, sumsq=False, raw=False):
         tile_count = self.ntiles - tile_start if tile_count is None else tile_count
         a = FusedArgs()
         a.tiles = self.tiles.ptr + tile_start * self.tile_bytes
@@ -185,7 +185,7 @@ class TileBatch:
             mask |= 1 << INDEX_IDS[t]
         a.index_mask = mask
         a.flags = ((_ffi.F_STATS if stats is not None else 0) | (_ffi.F_HIST if (stats is not None and hist) else 0) |
-                   (_ffi.F_SUMSQ if (stats is not None and sumsq) else 0))
+                   (_ffi.F_SUMSQ if (stats is not None and sumsq) else 0) | (_ffi.F_RAW if (stats is not None and raw) else 0))
         if stats is not None:
             a.stats = stats.ptr + tile_start * 3 * STATS_DTYPE.itemsize
         if outputs is not None:
@@ -205,6 +205,26 @@ class TileBatch:
 
     def new_stats(self):
         return DeviceBuffer(self.ntiles * 3 * STATS_DTYPE.itemsize)
+
+    def run_fused_chunks(self, indices, white_balance, stats, hist, outputs, stream=None, sumsq=False):
+        """``lars_d_fused`` over the whole batch in launches of ``outputs.slots`` tiles (one launch without a ring); the
+        statistics records are opened and closed ONCE around the launches (LARS_F_RAW) instead of by two small kernels per
+        launch.  Returns the number of fused launches."""
+        chunk = self.ntiles if outputs is None else outputs.slots
+        if chunk >= self.ntiles or stats is None:
+            self.run_fused(self.fused_args(indices, white_balance, stats, hist, outputs, stream, sumsq=sumsq))
+            return 1
+        mask = 0
+        for t in indices:
+            mask |= 1 << INDEX_IDS[t]
+        _ffi.call("lars_d_stats_begin", C.c_void_p(stats.ptr), self.ntiles, mask, stream)
+        launches = 0
+        for start in range(0, self.ntiles, chunk):
+            count = min(chunk, self.ntiles - start)
+            self.run_fused(self.fused_args(indices, white_balance, stats, hist, outputs, stream, start, count, sumsq=sumsq, raw=True))
+            launches += 1
+        _ffi.call("lars_d_stats_end", C.c_void_p(stats.ptr), self.ntiles, mask, self.npix, stream)
+        return launches
 
     # -- both passes in one persistent launch (csrc/pipeline.hip) ------------
     def can_pipeline(self, indices=INDEX_NAMES, outputs=None, hist=False, sumsq=False):
@@ -272,10 +292,7 @@ class TileBatch:
                 pairs_dev.free()
                 scratch.free()
             else:                                           # planes wanted, or two of the three indices
-                chunk = self.ntiles if outputs is None else outputs.slots
-                for start in range(0, self.ntiles, chunk):
-                    count = min(chunk, self.ntiles - start)
-                    self.run_fused(self.fused_args(indices, white_balance, stats, hist, outputs, stream, start, count, sumsq=sumsq))
+                self.run_fused_chunks(indices, white_balance, stats, hist, outputs, stream, sumsq)
                 med = self.tile_medians(indices, white_balance, stream)
             rec = stats.download(STATS_DTYPE, (self.ntiles, 3))
             stats.free()
@@ -289,7 +306,9 @@ class TileBatch:
             med_dev.zero(stream)
             sel = DeviceBuffer(outputs.slots * int(_ffi.load().lars_select_scratch_bytes()))
         chunk = self.ntiles if outputs is None else outputs.slots
-        for start in range(0, self.ntiles, chunk):
+        if not medians:
+            self.run_fused_chunks(indices, white_balance, stats, hist, outputs, stream, sumsq)
+        for start in range(0, self.ntiles if medians else 0, chunk):
             count = min(chunk, self.ntiles - start)
             self.run_fused(self.fused_args(indices, white_balance, stats, hist, outputs, stream, start, count, sumsq=sumsq))
             if medians:

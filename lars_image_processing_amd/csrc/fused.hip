@@ -737,7 +737,8 @@ extern "C" int lars_d_fused(const lars_fused_args *a)
     P.flags = (a->flags & 7u) | (tuning().nt_stores ? 0x20000000u : 0u) | (tuning().grid_swap ? 0x10000000u : 0u);
 
     const long long nrec = a->ntiles * 3;
-    if (stats_mode)
+    const bool raw = (a->flags & LARS_F_RAW) != 0;        // the caller brackets the launches with lars_d_stats_begin / _end
+    if (stats_mode && !raw)
         hipLaunchKernelGGL(k_stats_init, dim3((unsigned)((nrec + 255) / 256)), dim3(256), 0, s, a->stats, nrec, mask);
 
     const bool aligned = (reinterpret_cast<uintptr_t>(a->tiles) & 3) == 0 &&
@@ -781,10 +782,27 @@ extern "C" int lars_d_fused(const lars_fused_args *a)
         if (a->dtype == LARS_U8) hipLaunchKernelGGL((k_fused_generic<uint8_t, 256>), grid, dim3(256), 0, s, P);
         else hipLaunchKernelGGL((k_fused_generic<uint16_t, 65536>), grid, dim3(256), 0, s, P);
     }
-    if (stats_mode)
+    if (stats_mode && !raw)
         hipLaunchKernelGGL(k_stats_finalize, dim3((unsigned)((nrec + 255) / 256)), dim3(256), 0, s, a->stats, nrec, mask,
                            (long long)a->npix);
     return launch_check("lars_d_fused");
+}
+
+extern "C" int lars_d_stats_begin(lars_stats *stats, int64_t ntiles, uint32_t index_mask, void *stream)
+{
+    ThreadCtx *c;
+    LARS_TRY(ensure_ctx(&c));
+    if (!stats || ntiles <= 0 || (index_mask & ~LARS_MASK_ALL)) return fail(LARS_ERR_INVALID, "lars_d_stats_begin: bad arguments");
+    stats_init_launch(stats, ntiles * 3, index_mask & LARS_MASK_ALL, pick_stream(c, stream));
+    return launch_check("lars_d_stats_begin");
+}
+extern "C" int lars_d_stats_end(lars_stats *stats, int64_t ntiles, uint32_t index_mask, int64_t npix, void *stream)
+{
+    ThreadCtx *c;
+    LARS_TRY(ensure_ctx(&c));
+    if (!stats || ntiles <= 0 || npix <= 0 || (index_mask & ~LARS_MASK_ALL)) return fail(LARS_ERR_INVALID, "lars_d_stats_end: bad arguments");
+    stats_finalize_launch(stats, ntiles * 3, index_mask & LARS_MASK_ALL, (long long)npix, pick_stream(c, stream));
+    return launch_check("lars_d_stats_end");
 }
 
 extern "C" int lars_d_synth_u8(uint8_t *tiles, int64_t ntiles, int64_t first_tile, int64_t npix, int channels,

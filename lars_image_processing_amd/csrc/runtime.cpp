@@ -197,7 +197,7 @@ int vmm_alloc(int device, void **dptr, size_t bytes)
     memset(&acc, 0, sizeof acc);
     acc.location = prop.location;
     acc.flags = hipMemAccessFlagsProtReadWrite;
-    if (hipMemSetAccess(base, total, &acc, 1) != hipSuccess) return fail(LARS_ERR_HIP, "hipMemSetAccess failed");
+    if (hipMemSetAccess(base, total, &acc, 1) != hipSuccess) { undo(nchunks); return fail(LARS_ERR_HIP, "hipMemSetAccess failed"); }
     {
         std::lock_guard<std::mutex> g(g_vmm_lock);
         g_vmm[base] = blk;

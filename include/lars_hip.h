@@ -257,6 +257,26 @@ int lars_d_quotient_median_pairs(const void *tiles, int64_t ntiles, int64_t npix
                                  const uint8_t *wb_table, uint32_t streams /* bit 0 NDVI, bit 1 GNDVI; others come back NaN */,
                                  float *out_pairs, void *scratch, void *stream);
 
+/* The statistics of lars_d_fused -- and the exact medians of lars_d_stats_medians -- from ONE read of the tiles, with the
+ * white balance's own percentile pre-pass inside (csrc/joint.hip): every figure analyze_index reports
+ * (process-images.py:506-512: mean, median, min, max, coverage), the 50-bin histogram (process-ndvi.py:97) and
+ * np.percentile(ch, (2, 98)) of fix_white_balance (process-images.py:437) is a function of how often each pair of raw
+ * bytes (nir, red) resp. (nir, green) occurs.  A counting kernel builds those 2 x 65536 counts per tile in LDS (no table
+ * look-up, no quotient per pixel), a second kernel derives channel histograms -> percentiles -> tables -> records ->
+ * medians from them.  The records are bit-identical to lars_d_fused's, the medians to np.median.
+ *   a             uint8 tiles with 3 channels; index_mask any non-empty subset; LARS_F_HIST / LARS_F_SUMSQ honoured; no
+ *                 output planes; a->stats [ntiles][3] receives final records (unrequested indices untouched);
+ *                 a->wb_table, if not NULL, is an OUTPUT here: [ntiles][3][256] tables of the channels the mask needs
+ *                 (NIR and red for NDVI, NIR and green for GNDVI / NDWI)
+ *   white_balance 0: indices of the raw samples (calculate_index without fix_white_balance); 1: percentile white balance
+ *   percentiles   [ntiles][3][2] double or NULL, hist [ntiles][3][256] or NULL: outputs, same channels as the tables
+ *   out_pairs     float[ntiles][2 streams: NDVI, GNDVI][2] or NULL: the two middle order statistics (median = their
+ *                 float32 mean; NDWI's is -GNDVI's); a stream the mask does not need comes back as NaN
+ *   scratch       lars_joint_scratch_bytes(ntiles, npix, index_mask) bytes */
+size_t lars_joint_scratch_bytes(int64_t ntiles, int64_t npix, uint32_t index_mask);
+int lars_d_stats_joint(const lars_fused_args *a, int white_balance, int rgn_variant, double *percentiles, uint32_t *hist,
+                       float *out_pairs, void *scratch);
+
 /* classification mask (see lars_h_threshold_mask_f32); x 16-byte, out_mask 4-byte aligned */
 int lars_d_threshold_mask_f32(const float *x, int64_t n, float threshold, uint8_t *out_mask, void *stream);
 

@@ -12,6 +12,7 @@ exchange; only the global statistics need one small collective (``dist.py``).
 from __future__ import annotations
 
 import ctypes as C
+import os
 
 import numpy as np
 
@@ -19,6 +20,25 @@ from . import _ffi
 from ._ffi import FusedArgs, INDEX_IDS, INDEX_NAMES, STATS_DTYPE, DeviceBuffer, DeviceSlice
 
 MAX_TILES_PER_LAUNCH = 65535      # grid.y limit
+
+# How statistics-only passes over uint8 RGNir batches run (no output planes):
+#   "joint"   one read of the tiles: joint byte-pair histograms in LDS, everything else -- the white balance's percentiles
+#             included -- derived from the counts (lars_d_stats_joint, csrc/joint.hip)
+#   "classic" channel-histogram pass, then the per-pixel statistics kernel (and its median passes)
+#   "auto"    joint wherever it applies
+# Results are identical bit for bit; LARS_STATS_ROUTE presets it.
+_STATS_ROUTE = os.environ.get("LARS_STATS_ROUTE", "auto")
+
+
+def set_stats_route(route):
+    global _STATS_ROUTE
+    if route not in ("auto", "joint", "classic"):
+        raise ValueError("route must be auto, joint or classic")
+    _STATS_ROUTE = route
+
+
+def get_stats_route():
+    return _STATS_ROUTE
 
 
 def shard_range(ntiles, rank, world):
@@ -48,6 +68,7 @@ class TileBatch:
         self.hist = None
         self.table = None
         self.percentiles = None
+        self._tables_complete = False      # all three channels' tables are valid (a joint pass fills only those it reads)
 
     # -- construction -----------------------------------------------------
     @classmethod
@@ -89,6 +110,7 @@ class TileBatch:
             # uint16: two-level radix percentiles, no 65536-bin histograms
             _ffi.call("lars_d_wb_prepare", C.c_void_p(self.tiles.ptr), self.ntiles, self.npix, self.channels,
                       self.code, C.c_void_p(self.table.ptr), C.c_void_p(self.percentiles.ptr), int(rgn_variant), stream)
+        self._tables_complete = True
         return self
 
     def host_tables(self):
@@ -258,8 +280,51 @@ class TileBatch:
     def run_fused(self, args):
         _ffi.call("lars_d_fused", C.byref(args))
 
+    # -- statistics from one read: joint byte-pair histograms (csrc/joint.hip) ----
+    def can_joint(self):
+        """What ``lars_d_stats_joint`` serves: uint8 RGNir tiles on 4-byte boundaries."""
+        return self.code == _ffi.U8 and self.channels == 3 and (self.ntiles == 1 or self.npix % 4 == 0)
+
+    def run_joint(self, indices, white_balance, stats, hist=False, sumsq=False, pairs=None, stream=None, rgn_variant=0):
+        """Enqueue ``lars_d_stats_joint``: final records into ``stats`` and, with ``pairs`` (a DeviceBuffer of
+        ntiles * 4 floats), the two middle order statistics of every tile's NDVI / GNDVI values.  With white balance the
+        call also leaves ``self.hist`` / ``self.percentiles`` / ``self.table`` filled for the channels the indices read
+        (NIR and red for NDVI, NIR and green for GNDVI / NDWI), as ``compute_wb_tables`` would."""
+        mask = 0
+        for t in indices:
+            mask |= 1 << INDEX_IDS[t]
+        need = int(_ffi.load().lars_joint_scratch_bytes(self.ntiles, self.npix, mask))
+        if getattr(self, "_joint_scratch", None) is None or self._joint_scratch.nbytes < need:
+            if getattr(self, "_joint_scratch", None) is not None:
+                _ffi.call("lars_synchronize", stream)
+                self._joint_scratch.free()
+            self._joint_scratch = DeviceBuffer(need)
+        if white_balance:
+            if self.table is None:
+                self.table = DeviceBuffer(self.ntiles * self.table_bytes)
+                self.percentiles = DeviceBuffer(self.ntiles * 3 * 2 * 8)
+                self.table.zero(stream)
+                self.percentiles.zero(stream)
+            if self.hist is None:
+                self.hist = DeviceBuffer(self.ntiles * 3 * 256 * 4)
+                self.hist.zero(stream)
+            if (mask & 1) and (mask & 6):
+                self._tables_complete = True
+        a = FusedArgs()
+        a.tiles = self.tiles.ptr
+        a.ntiles, a.npix, a.channels, a.dtype = self.ntiles, self.npix, self.channels, self.code
+        a.wb_table = self.table.ptr if white_balance else None
+        a.index_mask = mask
+        a.flags = _ffi.F_STATS | (_ffi.F_HIST if hist else 0) | (_ffi.F_SUMSQ if sumsq else 0)
+        a.stats = stats.ptr
+        a.stream = stream
+        _ffi.call("lars_d_stats_joint", C.byref(a), 1 if white_balance else 0, int(rgn_variant),
+                  C.c_void_p(self.percentiles.ptr) if white_balance else None,
+                  C.c_void_p(self.hist.ptr) if white_balance else None,
+                  C.c_void_p(pairs.ptr) if pairs is not None else None, C.c_void_p(self._joint_scratch.ptr))
+
     def process(self, indices=INDEX_NAMES, white_balance=True, hist=False, outputs=None, stream=None,
-                recompute_tables=True, medians=False, sumsq=False):
+                recompute_tables=True, medians=False, sumsq=False, route=None):
         """Both passes over the whole batch; returns per-tile records
         (structured ndarray ``[ntiles, 3]`` of STATS_DTYPE; rows of indices not
         requested are zero).  ``hist`` adds the 50-bin histograms, ``sumsq`` the sums of squares
@@ -267,8 +332,25 @@ class TileBatch:
         with np.median of each tile's index plane, exact: uint8 RGNir tiles take the
         two-level select on recomputed values (planes or not); other tiles a batched radix
         select on the float32 planes, which must then be written -- a small ring is
-        allocated when ``outputs`` has none."""
-        if white_balance and (recompute_tables or self.table is None):
+        allocated when ``outputs`` has none.  ``route``: see ``set_stats_route`` (None = the module's setting)."""
+        route = _STATS_ROUTE if route is None else route
+        if outputs is None and route != "classic" and self.can_joint() and indices:
+            # nothing to write: one read of the tiles serves the percentiles, the statistics and the medians
+            stats = self.new_stats()
+            stats.zero(stream)
+            pairs_dev = DeviceBuffer(self.ntiles * 4 * 4) if medians else None
+            self.run_joint(indices, white_balance, stats, hist, sumsq, pairs_dev, stream)
+            _ffi.call("lars_synchronize", stream)
+            rec = stats.download(STATS_DTYPE, (self.ntiles, 3))
+            stats.free()
+            if not medians:
+                return rec
+            med = self._medians_from_pairs(pairs_dev.download(np.float32, (self.ntiles, 2, 2)), indices)
+            pairs_dev.free()
+            return rec, med
+        if route == "joint" and outputs is None:
+            raise ValueError("route='joint' serves uint8 tiles with 3 channels (4-byte aligned) only")
+        if white_balance and (recompute_tables or self.table is None or not self._tables_complete):
             self.compute_wb_tables(stream)
         stats = self.new_stats()
         stats.zero(stream)                                  # same stream as the kernels that accumulate into it
@@ -334,14 +416,15 @@ class TileBatch:
         return rec, med
 
     def free(self):
-        for b in (self.tiles, self.hist, self.table, self.percentiles, getattr(self, "_pipe_scratch", None)):
+        for b in (self.tiles, self.hist, self.table, self.percentiles, getattr(self, "_pipe_scratch", None),
+                  getattr(self, "_joint_scratch", None)):
             if b is not None:
                 b.free()
 
     def tile_medians(self, indices=INDEX_NAMES, white_balance=True, stream=None):
         """float64[ntiles, 3]: np.median of every tile's index planes, none of which is written
         (``lars_d_quotient_median_pairs``: per-tile two-level select on recomputed values, all on the device)."""
-        if white_balance and self.table is None:
+        if white_balance and (self.table is None or not self._tables_complete):
             raise RuntimeError("compute_wb_tables() first")
         pairs_dev = DeviceBuffer(self.ntiles * 4 * 4)
         scratch = DeviceBuffer(int(_ffi.load().lars_quotient_median_scratch_bytes(self.ntiles)))
@@ -389,7 +472,7 @@ class TileBatch:
         two select passes (2048 linear buckets, then the 1024 slots of the chosen bucket, each of which holds one
         distinct quotient of bytes) that recompute the index values from the tiles (3 bytes per pixel and pass) and
         one small all-reduce per pass."""
-        if white_balance and (recompute_tables or self.table is None):
+        if white_balance and (recompute_tables or self.table is None or not self._tables_complete):
             self.compute_wb_tables()
         n_local = self.ntiles * self.npix
         streams = select_streams(indices)

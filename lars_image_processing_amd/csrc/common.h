@@ -108,6 +108,7 @@ struct Tuning {
     int count_mode = -1;       // statistics-only kernels, A/B only: 3 = float coverage counters (fused_v2.hip)
     int grid_swap = 0;         // plane-writing kernel, A/B only: 1 = tile index fastest in dispatch order (k_fused_u8c3)
     int traverse = -1;         // plane-writing kernel, A/B only: -1 / 1 the shipped mapping, 0 and 2 see k_fused_u8c3
+    int joint_depth = 6;       // joint.hip: 12-byte loads in flight per lane of the counting kernel (4 | 6)
 };
 Tuning &tuning();
 

@@ -241,7 +241,6 @@ __device__ inline void push(WaveAcc &a, unsigned int &above, float x, float thr)
 // One packed fma + one packed add per pixel pair, one v_lshl_add_u32 per pixel, no LDS lookup.
 // sign = -1 bins -x (NDWI from the GNDVI quotient).  `base` is the lane's byte address of copy
 // lane % 16 of the index's bin 0, minus the constant part of the shifted float bits.
-#define V2_HIST_MAGIC_C 25.5001f
 #define V2_HIST_MAGIC_BITS 0x4B000001u                   /* float bits of 2^23 + 1: "bin 0" */
 __device__ inline f32x2 hist_pos2(f32x2 x, float sign)
 {

@@ -1,0 +1,604 @@
+// One-read statistics of uint8 RGNir tiles through joint byte-pair histograms.
+//
+// Every statistic analyze_index reports (process-images.py:506-512: mean, MEDIAN, min, max, coverage), the 50-bin
+// histogram (process-ndvi.py:97) and the percentiles of the white balance itself (process-images.py:437) are exact
+// functions of how often each pair of raw bytes occurs: NDVI = (n' - r') / (n' + r') with n' = T_n[n], r' = T_r[r], and
+// the tables T follow from the channel histograms, which are the marginals of the pair counts.  So the tile is read
+// ONCE, by a kernel that does no table look-up, no quotient and no float64 sum per pixel -- it only counts the pair
+// (n, r) for the NDVI stream and (n, g) for the GNDVI / NDWI stream -- and a small second kernel per tile and stream
+// derives everything from the 65536 counts: marginals -> np.percentile -> white-balance tables -> the value of every
+// cell (the same correctly rounded float32 quotient the fused kernels produce) -> sums in 2^-32 fixed point, extrema,
+// coverage, bins, and the exact median by a weighted two-level select.  The records are the same bits the per-pixel
+// kernels produce, because every ingredient is a function of the counts.
+//
+// k_joint_count: one 1024-thread workgroup per (tile chunk, stream) with the stream's 65536 counters in LDS as 16-bit
+// pairs: dword D holds in its low half the pixels of BOTH cells 2D and 2D + 1 and in its high half those of cell 2D + 1,
+// so one ds_add_u32 of 1 | (h << 16) per pixel counts it and the high half can never pass the low one.  128 KiB of the
+// 160 KiB: one workgroup per CU.  16-bit sums cannot overflow between two scans: a workgroup adds 12 x 4096 = 49152
+// pixels per period, and at every period's end it moves each dword whose sum has reached 16384 onto a list in LDS
+// (16383 + 49152 = 65535); a workgroup counts at most 2^24 pixels, so at most 1024 moves.  With two streams the two
+// workgroups of a tile chunk sit 8 apart in dispatch order (the same XCD, at the same time): the second reader of a
+// line finds it in that XCD's L2 or in the Infinity Cache.
+// Cell of a pixel: S = (x << 8 | n) ^ x  (x = r or g: the low byte becomes n ^ x so that the LDS bank is a mix of both
+// samples), dword D = S >> 1, half h = S & 1.
+#include <string.h>
+
+#include "v2_device.h"
+
+namespace lars {
+
+#define JH_DWORDS 32768
+#define JH_THREADS 1024
+#define JH_PERIOD_STEPS 12                    /* steps of 4096 pixels between two scans */
+#define JH_PROMOTE_MASK 0x0000C000u           /* a low half >= 16384 */
+#define JH_LIST_CAP 1024
+#define JH_MAX_WG_PIXELS (1ll << 24)
+
+struct JointCountParams {
+    const uint8_t *tiles;
+    long long npix;
+    long long ntiles;
+    long long chunk_quads;                    // quads per chunk: a multiple of 1024 (the last chunk of a tile takes the rest)
+    unsigned int *part;                       // [ntiles][S][K][32768][2] uint32: counts of cell 2D, cell 2D + 1
+    unsigned int *error;                      // set to 1 if a list overflows (cannot happen: see JH_MAX_WG_PIXELS)
+    int K;                                    // chunks per tile
+    int S;                                    // streams counted: 1 or 2
+    unsigned int streams;                     // bit 0: (n, r) pairs, bit 1: (n, g) pairs
+};
+
+__device__ inline void jh_add(unsigned int addr, unsigned int val, char *tab)
+{
+    __hip_atomic_fetch_add(reinterpret_cast<unsigned int *>(tab + addr), val, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+}
+
+template <int DEPTH>
+__global__ __launch_bounds__(JH_THREADS, 4) void k_joint_count(JointCountParams P)
+{
+    static_assert(JH_PERIOD_STEPS % DEPTH == 0, "a period is a whole number of ring turns");
+    __shared__ __attribute__((aligned(16))) unsigned int s_tab[JH_DWORDS];          // 128 KiB
+    __shared__ uint2 s_list[JH_LIST_CAP];                                          // moved dwords: (D, value)
+    __shared__ unsigned int s_nlist;
+
+    const int tid = threadIdx.x;
+    // unit = (tile, chunk); with two streams the two workgroups of a unit are 8 apart in dispatch order
+    long long unit;
+    int role;
+    if (P.S == 2) {
+        const unsigned int b = blockIdx.x;
+        unit = (long long)(b >> 4) * 8 + (b & 7u);
+        role = (int)((b >> 3) & 1u);
+    } else {
+        unit = blockIdx.x;
+        role = 0;
+    }
+    const long long tile = unit / P.K;
+    const int chunk = (int)(unit - tile * P.K);
+    if (tile >= P.ntiles) return;
+    const bool green = P.S == 2 ? role == 1 : (P.streams == 2u);                   // which sample pairs with NIR
+
+    uint4 *tab4 = reinterpret_cast<uint4 *>(s_tab);
+    for (int i = tid; i < JH_DWORDS / 4; i += JH_THREADS) tab4[i] = make_uint4(0u, 0u, 0u, 0u);
+    if (tid == 0) s_nlist = 0;
+    __syncthreads();
+    char *tab = reinterpret_cast<char *>(s_tab);
+
+    const long long nquads_tile = P.npix >> 2;
+    const long long q_begin = (long long)chunk * P.chunk_quads;
+    long long q_end = chunk == P.K - 1 ? nquads_tile : q_begin + P.chunk_quads;
+    if (q_end > nquads_tile) q_end = nquads_tile;
+    const long long nq = q_end > q_begin ? q_end - q_begin : 0;
+    const uint8_t *tile_base = P.tiles + tile * P.npix * 3;
+
+    // byte selectors (wave-uniform): bytes of a quad r0 g0 n0 r1 | g1 n1 r2 g2 | n2 r3 g3 n3
+    // pixels 0, 1 from (w0, w1): perm(src0 = w1, src1 = w0) -> selector = byte offset 0..7
+    // pixels 2, 3 from (w1, w2): perm(src0 = w2, src1 = w1) -> selector = byte offset - 4
+    const unsigned int xo = green ? 1u : 0u;
+    const unsigned int selc01 = 0x02u | ((0u + xo) << 8) | (0x05u << 16) | ((3u + xo) << 24);   // n0 x0 n1 x1
+    const unsigned int selx01 = (0u + xo) | (0x0cu << 8) | ((3u + xo) << 16) | (0x0cu << 24);   // x0 0 x1 0
+    const unsigned int selc23 = 0x04u | ((2u + xo) << 8) | (0x07u << 16) | ((5u + xo) << 24);   // n2 x2 n3 x3
+    const unsigned int selx23 = (2u + xo) | (0x0cu << 8) | ((5u + xo) << 16) | (0x0cu << 24);
+
+    auto count_pair = [&](unsigned int s2) {
+        // two cells: S in the low and in the high 16 bits
+        const unsigned int a0 = (s2 << 1) & 0x1FFFCu, v0 = ((s2 & 1u) << 16) | 1u;
+        const unsigned int a1 = (s2 >> 15) & 0x1FFFCu, v1 = (s2 & 0x10000u) | 1u;
+        jh_add(a0, v0, tab);
+        jh_add(a1, v1, tab);
+    };
+    auto do_quad = [&](unsigned int w0, unsigned int w1, unsigned int w2) {
+        const unsigned int c01 = __builtin_amdgcn_perm(w1, w0, selc01) ^ __builtin_amdgcn_perm(w1, w0, selx01);
+        const unsigned int c23 = __builtin_amdgcn_perm(w2, w1, selc23) ^ __builtin_amdgcn_perm(w2, w1, selx23);
+        count_pair(c01);
+        count_pair(c23);
+    };
+
+    // tail pixels of the tile (npix % 4): its last chunk, before the first period (which starts from zero counts)
+    if (chunk == P.K - 1 && tid < (int)(P.npix & 3)) {
+        const uint8_t *p = tile_base + (nquads_tile * 4 + tid) * 3;
+        const unsigned int n = p[2], x = green ? p[1] : p[0];
+        const unsigned int s = ((x << 8) | n) ^ x;
+        jh_add((s << 1) & 0x1FFFCu, ((s & 1u) << 16) | 1u, tab);
+    }
+
+    // A scan: every dword whose sum (low half) has reached 16384 moves onto the list.  Between the two barriers nobody adds.
+    auto scan = [&]() {
+        __syncthreads();
+#pragma unroll 1
+        for (int i = 0; i < JH_DWORDS / 4 / JH_THREADS; ++i) {
+            const int idx = tid + i * JH_THREADS;
+            const uint4 v = tab4[idx];
+            if ((v.x | v.y | v.z | v.w) & JH_PROMOTE_MASK) {
+                const unsigned int c[4] = {v.x, v.y, v.z, v.w};
+#pragma unroll
+                for (int k = 0; k < 4; ++k) {
+                    if (c[k] & JH_PROMOTE_MASK) {
+                        const unsigned int slot = atomicAdd(&s_nlist, 1u);
+                        if (slot < JH_LIST_CAP) s_list[slot] = make_uint2((unsigned)(idx * 4 + k), c[k]);
+                        else atomicExch(P.error, 1u);
+                        s_tab[idx * 4 + k] = 0u;
+                    }
+                }
+            }
+        }
+        __syncthreads();
+    };
+
+    // Software pipeline: DEPTH 12-byte buffer loads in flight per lane; a step = 1024 quads = 12 KiB contiguous.
+    const long long nfull = nq >> 10;                       // steps in which every lane has a quad
+    const int rem = (int)(nq & 1023);
+    if (nq > 0) {
+        const __amdgpu_buffer_rsrc_t rsrc =
+            __builtin_amdgcn_make_buffer_rsrc(const_cast<uint8_t *>(tile_base + q_begin * 12), 0, (int)(nq * 12), 0x00020000);
+        const unsigned int voff = (unsigned int)tid * 12u;
+        constexpr unsigned int STEP_B = JH_THREADS * 12u;
+        u32x3 w[DEPTH];
+#pragma unroll
+        for (int k = 0; k < DEPTH; ++k) w[k] = __builtin_amdgcn_raw_buffer_load_b96(rsrc, voff, (unsigned)k * STEP_B, 0);
+        long long it = 0;
+        unsigned int soff = DEPTH * STEP_B;
+        int since = 0;
+        for (; it + DEPTH <= nfull; it += DEPTH) {
+#pragma unroll
+            for (int k = 0; k < DEPTH; ++k) {
+                do_quad(w[k].x, w[k].y, w[k].z);
+                __builtin_amdgcn_sched_barrier(0);
+                w[k] = __builtin_amdgcn_raw_buffer_load_b96(rsrc, voff, soff + (unsigned)k * STEP_B, 0);   // past the end: zeros, never counted
+                __builtin_amdgcn_sched_barrier(0);
+            }
+            soff += DEPTH * STEP_B;
+            since += DEPTH;
+            if (since == JH_PERIOD_STEPS) {
+                scan();
+                since = 0;
+            }
+        }
+        // the last (fewer than DEPTH) full steps and the ragged one: since + DEPTH <= JH_PERIOD_STEPS, no scan needed
+#pragma unroll
+        for (int k = 0; k < DEPTH; ++k) {
+            const long long step = it + k;
+            if (step < nfull || (step == nfull && tid < rem)) do_quad(w[k].x, w[k].y, w[k].z);
+        }
+    }
+    __syncthreads();
+
+    // publish: (cell 2D, cell 2D + 1) = (low - high, high), 32 bytes per lane and trip
+    unsigned int *out = P.part + ((tile * P.S + role) * P.K + chunk) * (long long)(2 * JH_DWORDS);
+    for (int i = tid; i < JH_DWORDS / 4; i += JH_THREADS) {
+        const uint4 v = tab4[i];
+        uint4 *o = reinterpret_cast<uint4 *>(out + (long long)i * 8);
+        o[0] = make_uint4((v.x & 0xFFFFu) - (v.x >> 16), v.x >> 16, (v.y & 0xFFFFu) - (v.y >> 16), v.y >> 16);
+        o[1] = make_uint4((v.z & 0xFFFFu) - (v.z >> 16), v.z >> 16, (v.w & 0xFFFFu) - (v.w >> 16), v.w >> 16);
+    }
+    const unsigned int nlist = s_nlist < JH_LIST_CAP ? s_nlist : JH_LIST_CAP;
+    if (nlist) {
+        __threadfence();
+        __syncthreads();
+        for (unsigned int e = tid; e < nlist; e += JH_THREADS) {
+            const uint2 m = s_list[e];
+            const unsigned int hi = m.y >> 16, lo = (m.y & 0xFFFFu) - hi;
+            if (lo) atomicAdd(&out[2 * (long long)m.x], lo);
+            if (hi) atomicAdd(&out[2 * (long long)m.x + 1], hi);
+        }
+    }
+}
+
+// ---------------------------------------------------------------------------
+// counts -> marginals -> percentiles -> tables -> statistics + exact medians
+// ---------------------------------------------------------------------------
+struct JointFinishParams {
+    const unsigned int *part;
+    long long npix;
+    int K, S;
+    unsigned int streams;                     // as JointCountParams
+    unsigned int mask;                        // LARS_MASK_*: which records to write
+    unsigned int flags;                       // LARS_F_HIST / LARS_F_SUMSQ
+    int wb;                                   // percentile white balance (process-images.py:437-441) or raw samples
+    int rgn_variant;
+    lars_stats *stats;                        // [ntiles][3]
+    uint8_t *table_out;                       // [ntiles][3][256] or null
+    double *pcts_out;                         // [ntiles][3][2] or null
+    unsigned int *hist_out;                   // [ntiles][3][256] or null
+    float *out_pairs;                         // [ntiles][2 streams][2] or null: the two middle order statistics
+};
+
+// block-wide exclusive position of a rank in a histogram of NB bins (NB = 2048 or 1024), two ranks at once:
+// bin[k] = first bin whose cumulative count exceeds rank[k], before[k] = count below that bin.  256 threads take part.
+template <int NB>
+__device__ inline void jf_pick(const unsigned int *h, const unsigned long long rank[2], unsigned int *s_grp /*[256]*/,
+                               unsigned int *s_bin /*[2]*/, unsigned long long *s_before /*[2]*/, int tid)
+{
+    constexpr int PER = NB / 256;
+    if (tid < 256) {
+        unsigned int t = 0;
+        for (int j = 0; j < PER; ++j) t += h[tid * PER + j];
+        s_grp[tid] = t;
+    }
+    __syncthreads();
+    if (tid < 2) {
+        unsigned long long cum = 0;
+        int g = 0;
+        for (; g < 255; ++g) {
+            if (rank[tid] < cum + s_grp[g]) break;
+            cum += s_grp[g];
+        }
+        int b = g * PER;
+        for (; b < g * PER + PER - 1; ++b) {
+            if (rank[tid] < cum + h[b]) break;
+            cum += h[b];
+        }
+        s_bin[tid] = (unsigned)b;
+        s_before[tid] = cum;
+    }
+    __syncthreads();
+}
+
+__global__ __launch_bounds__(JH_THREADS) void k_joint_finish(JointFinishParams P)
+{
+    __shared__ unsigned int s_hn[256], s_hx[256];
+    __shared__ float s_fn[256], s_fx[256];
+    __shared__ double s_ord[2][4], s_p[2][2];
+    __shared__ unsigned int s_bucket[SELQ_BINS];
+    __shared__ unsigned int s_slot[2][SELQ_SLOTS];
+    __shared__ unsigned int s_grp[256];
+    __shared__ unsigned int s_bin[2];
+    __shared__ unsigned long long s_before[2];
+    __shared__ unsigned int s_h50[2][LARS_HIST_BINS + 2];          // [plain | negated][bin + 1]
+    __shared__ unsigned long long s_acc[4];                          // sum_fx, above (> 0.2f), below zero (< 0), unused
+    __shared__ double s_wsq[JH_THREADS / 64];                        // per-wave sums of squares, folded in wave order
+    __shared__ unsigned int s_mnk, s_mxk;
+    __shared__ float s_med[2];
+
+    const int tid = threadIdx.x;
+    const int role = blockIdx.x;
+    const long long tile = blockIdx.y;
+    const bool green = P.S == 2 ? role == 1 : (P.streams == 2u);
+    const int xch = green ? 1 : 0;                                   // channel of the sample paired with NIR
+    const unsigned int *part = P.part + ((tile * P.S + role) * P.K) * (long long)(2 * JH_DWORDS);
+    const bool want_hist = (P.flags & (LARS_F_HIST | LARS_F_SUMSQ)) != 0;
+    const bool want_sq = (P.flags & LARS_F_SUMSQ) != 0;
+    const bool want_v = !green && (P.mask & LARS_MASK_NDVI);
+    const bool want_g = green && (P.mask & LARS_MASK_GNDVI);
+    const bool want_w = green && (P.mask & LARS_MASK_NDWI);
+
+    if (tid < 256) { s_hn[tid] = 0; s_hx[tid] = 0; }
+    for (int i = tid; i < SELQ_BINS; i += JH_THREADS) s_bucket[i] = 0;
+    for (int i = tid; i < 2 * SELQ_SLOTS; i += JH_THREADS) (&s_slot[0][0])[i] = 0;
+    if (tid < 2 * (LARS_HIST_BINS + 2)) (&s_h50[0][0])[tid] = 0;
+    if (tid < 4) s_acc[tid] = 0;
+    if (tid == 0) { s_mnk = 0xFFFFFFFFu; s_mxk = 0u; }
+    if (tid < 2) s_med[tid] = __builtin_nanf("");
+    __syncthreads();
+
+    // this thread's dwords: D = j * 1024 + tid; cells S = 2D, 2D + 1; x = S >> 8 = D >> 7 (wave-uniform), n = (S & 255) ^ x
+    auto load_pair = [&](int j, unsigned int &c0, unsigned int &c1) {
+        const long long D = (long long)j * JH_THREADS + tid;
+        c0 = 0; c1 = 0;
+        for (int k = 0; k < P.K; ++k) {
+            const uint2 v = *reinterpret_cast<const uint2 *>(part + (long long)k * (2 * JH_DWORDS) + 2 * D);
+            c0 += v.x; c1 += v.y;
+        }
+    };
+    constexpr int NJ = JH_DWORDS / JH_THREADS;                       // 32
+
+    // ---- marginals: the channel histograms np.percentile needs
+    for (int j = 0; j < NJ; ++j) {
+        unsigned int c0, c1;
+        load_pair(j, c0, c1);
+        const unsigned int D = (unsigned)j * JH_THREADS + tid;
+        const unsigned int x = D >> 7;
+        const unsigned int n0 = ((2u * D) & 255u) ^ x, n1 = ((2u * D + 1u) & 255u) ^ x;
+        if (c0) atomicAdd(&s_hn[n0], c0);
+        if (c1) atomicAdd(&s_hn[n1], c1);
+        unsigned int t = c0 + c1;
+        for (int off = 32; off >= 1; off >>= 1) t += __shfl_xor(t, off);
+        if ((tid & 63) == 0 && t) atomicAdd(&s_hx[x], t);            // D >> 7 is the same for the 64 lanes of a wave
+    }
+    __syncthreads();
+    if (P.hist_out) {
+        unsigned int *ho = P.hist_out + tile * 768;
+        if (tid < 256) {
+            ho[xch * 256 + tid] = s_hx[tid];
+            if (!green || P.S == 1) ho[512 + tid] = s_hn[tid];
+        }
+    }
+
+    // ---- np.percentile(ch, (2, 98)), 'linear' + numpy's _lerp (the arithmetic of k_wb_table, fused.hip)
+    const long long npix = P.npix;
+    if (P.wb) {
+        if (tid < 8) {
+            const int ch = tid >> 2, r = tid & 3;                    // ch 0: NIR, 1: the paired sample
+            const unsigned int *h = ch ? s_hx : s_hn;
+            const double q = ((r >> 1) == 0 ? 2.0 : 98.0) / 100.0;
+            const double vi = (double)(npix - 1) * q;
+            long long rank = (long long)floor(vi);
+            if (r & 1) { rank += 1; if (rank > npix - 1) rank = npix - 1; }
+            unsigned long long cum = 0;
+            double val = 0.0;
+            for (int b = 0; b < 256; ++b) {
+                const unsigned long long c = h[b];
+                if (c && (unsigned long long)rank >= cum && (unsigned long long)rank < cum + c) val = (double)b;
+                cum += c;
+            }
+            s_ord[ch][r] = val;
+        }
+        __syncthreads();
+        if (tid < 4) {
+            const int ch = tid >> 1, k = tid & 1;
+            const double q = (k == 0 ? 2.0 : 98.0) / 100.0;
+            const double vi = (double)(npix - 1) * q;
+            const double t = vi - floor(vi);
+            const double a = s_ord[ch][2 * k], b = s_ord[ch][2 * k + 1];
+            const double d = b - a;
+            double r = a + d * t;
+            if (t >= 0.5) r = b - d * (1.0 - t);
+            s_p[ch][k] = r;
+            if (P.pcts_out) {
+                const int c = ch ? xch : 2;
+                if (ch || !green || P.S == 1) P.pcts_out[(tile * 3 + c) * 2 + k] = r;
+            }
+        }
+        __syncthreads();
+    }
+    if (tid < 512) {
+        const int ch = tid >> 8, v = tid & 255;
+        const unsigned int level = P.wb ? wb_level(v, s_p[ch][0], s_p[ch][1], P.rgn_variant) : (unsigned)v;
+        (ch ? s_fx : s_fn)[v] = (float)level;
+        if (P.wb && P.table_out) {
+            const int c = ch ? xch : 2;
+            if (ch || !green || P.S == 1) P.table_out[(tile * 3 + c) * 256 + v] = (uint8_t)level;
+        }
+    }
+    __syncthreads();
+
+    // ---- statistics of the stream's quotient (n' - x') / (n' + x') over the cells
+    const bool medians = P.out_pairs != nullptr;
+    {
+        long long sum_fx = 0;
+        unsigned long long above = 0, below0 = 0;
+        double sumsq = 0.0;
+        float mn = __builtin_inff(), mx = -__builtin_inff();
+        for (int j = 0; j < NJ; ++j) {
+            unsigned int c[2];
+            load_pair(j, c[0], c[1]);
+            const unsigned int D = (unsigned)j * JH_THREADS + tid;
+            const unsigned int x = D >> 7;
+            const float fx = s_fx[x];
+#pragma unroll
+            for (int h = 0; h < 2; ++h) {
+                if (!c[h]) continue;
+                const unsigned int n = ((2u * D + (unsigned)h) & 255u) ^ x;
+                const float q = norm_diff(s_fn[n], fx);
+                const long long cnt = (long long)c[h];
+                sum_fx += cnt * (long long)((double)q * LARS_FX_SCALE);          // q is a multiple of 2^-32: exact
+                mn = fminf(mn, q);
+                mx = fmaxf(mx, q);
+                if (q > 0.2f) above += (unsigned long long)cnt;
+                if (q < 0.0f) below0 += (unsigned long long)cnt;
+                if (want_sq) sumsq += (double)cnt * ((double)q * (double)q);
+                if (want_hist) {
+                    // bin + 1 in the low mantissa bits (hist_pos2, fused_v2.hip); 51 = the closed right edge
+                    const float u = __builtin_fmaf(q, 25.0f, V2_HIST_MAGIC_C) + 8388608.0f;
+                    atomicAdd(&s_h50[0][__builtin_bit_cast(unsigned int, u) & 0x7FFFFFu], c[h]);
+                    if (want_w) {
+                        const float uw = __builtin_fmaf(q, -25.0f, V2_HIST_MAGIC_C) + 8388608.0f;
+                        atomicAdd(&s_h50[1][__builtin_bit_cast(unsigned int, uw) & 0x7FFFFFu], c[h]);
+                    }
+                }
+                if (medians) atomicAdd(&s_bucket[selq_bucket_of(selq_t(q))], c[h]);
+            }
+        }
+        for (int off = 32; off >= 1; off >>= 1) {
+            sum_fx += __shfl_xor(sum_fx, off);
+            above += __shfl_xor(above, off);
+            below0 += __shfl_xor(below0, off);
+            sumsq += __shfl_xor(sumsq, off);
+            mn = fminf(mn, __shfl_xor(mn, off));
+            mx = fmaxf(mx, __shfl_xor(mx, off));
+        }
+        if ((tid & 63) == 0) {
+            atomicAdd(&s_acc[0], (unsigned long long)sum_fx);
+            atomicAdd(&s_acc[1], above);
+            atomicAdd(&s_acc[2], below0);
+            s_wsq[tid >> 6] = sumsq;
+            atomicMin(&s_mnk, f32_key(mn));
+            atomicMax(&s_mxk, f32_key(mx));
+        }
+    }
+    __syncthreads();
+
+    // ---- exact median: weighted two-level select (bucket, then slot: a slot holds one distinct quotient of bytes)
+    if (medians) {
+        const unsigned long long rank[2] = {(unsigned long long)((npix - 1) / 2), (unsigned long long)(npix / 2)};
+        jf_pick<SELQ_BINS>(s_bucket, rank, s_grp, s_bin, s_before, tid);
+        const unsigned int bk0 = s_bin[0], bk1 = s_bin[1];
+        const unsigned long long in0 = rank[0] - s_before[0], in1 = rank[1] - s_before[1];
+        __syncthreads();
+        for (int j = 0; j < NJ; ++j) {
+            unsigned int c[2];
+            load_pair(j, c[0], c[1]);
+            const unsigned int D = (unsigned)j * JH_THREADS + tid;
+            const unsigned int x = D >> 7;
+            const float fx = s_fx[x];
+#pragma unroll
+            for (int h = 0; h < 2; ++h) {
+                if (!c[h]) continue;
+                const unsigned int n = ((2u * D + (unsigned)h) & 255u) ^ x;
+                const float t = selq_t(norm_diff(s_fn[n], fx));
+                const unsigned int b = selq_bucket_of(t), sl = (__builtin_bit_cast(unsigned int, t) & 0xFFFu) >> 2;
+                if (b == bk0) atomicAdd(&s_slot[0][sl], c[h]);
+                if (b == bk1) atomicAdd(&s_slot[1][sl], c[h]);
+            }
+        }
+        __syncthreads();
+        // slot of each track inside its bucket (jf_pick works on one histogram: run it per track)
+        unsigned int slot[2];
+        {
+            const unsigned long long r0[2] = {in0, in0};
+            jf_pick<SELQ_SLOTS>(s_slot[0], r0, s_grp, s_bin, s_before, tid);
+            slot[0] = s_bin[0];
+            __syncthreads();
+            const unsigned long long r1[2] = {in1, in1};
+            jf_pick<SELQ_SLOTS>(s_slot[1], r1, s_grp, s_bin, s_before, tid);
+            slot[1] = s_bin[0];
+            __syncthreads();
+        }
+        for (int j = 0; j < NJ; ++j) {
+            unsigned int c[2];
+            load_pair(j, c[0], c[1]);
+            const unsigned int D = (unsigned)j * JH_THREADS + tid;
+            const unsigned int x = D >> 7;
+            const float fx = s_fx[x];
+#pragma unroll
+            for (int h = 0; h < 2; ++h) {
+                if (!c[h]) continue;
+                const unsigned int n = ((2u * D + (unsigned)h) & 255u) ^ x;
+                const float q = norm_diff(s_fn[n], fx);
+                const float t = selq_t(q);
+                const unsigned int b = selq_bucket_of(t), sl = (__builtin_bit_cast(unsigned int, t) & 0xFFFu) >> 2;
+                if (b == bk0 && sl == slot[0]) s_med[0] = q;          // every writer holds the same value
+                if (b == bk1 && sl == slot[1]) s_med[1] = q;
+            }
+        }
+        __syncthreads();
+        if (tid < 2) P.out_pairs[(tile * 2 + (green ? 1 : 0)) * 2 + tid] = s_med[tid];
+        if (P.S == 1 && tid >= 2 && tid < 4) P.out_pairs[(tile * 2 + (green ? 0 : 1)) * 2 + (tid - 2)] = __builtin_nanf("");   // the stream nobody asked for
+    }
+
+    // ---- the records, in their final form (what k_stats_init + the fused kernel + k_stats_finalize leave behind)
+    if (tid < 2) {
+        // tid 0: NDVI resp. GNDVI; tid 1: NDWI = -GNDVI (sum negates, extrema swap, coverage counts q < 0)
+        const bool neg = tid == 1;
+        const bool on = neg ? want_w : (want_v || want_g);
+        if (on) {
+            const int k = neg ? LARS_NDWI : (green ? LARS_GNDVI : LARS_NDVI);
+            lars_stats *o = P.stats + tile * 3 + k;
+            const long long s = (long long)s_acc[0];
+            const double mnd = (double)key_f32(s_mnk), mxd = (double)key_f32(s_mxk);
+            o->sum = (double)(neg ? -s : s) * LARS_FX_INV;
+            double sq = 0.0;
+            for (int w = 0; w < JH_THREADS / 64; ++w) sq += s_wsq[w];
+            o->sumsq = want_sq ? (double)__double2ll_rn(sq * LARS_FX_SCALE) * LARS_FX_INV : 0.0;
+            o->count = (uint64_t)npix;
+            o->above = neg ? s_acc[2] : s_acc[1];
+            o->nans = 0;
+            o->min = neg ? 0.0 - mxd : mnd;
+            o->max = neg ? 0.0 - mnd : mxd;
+            o->threshold = neg ? 0.0 : (double)0.2f;
+            o->index_id = (unsigned)k;
+            o->reserved = 0;
+        }
+    }
+    if (tid < 2 * LARS_HIST_BINS) {
+        const bool neg = tid >= LARS_HIST_BINS;
+        const int b = neg ? tid - LARS_HIST_BINS : tid;
+        const bool on = neg ? want_w : (want_v || want_g);
+        if (on) {
+            const int k = neg ? LARS_NDWI : (green ? LARS_GNDVI : LARS_NDVI);
+            unsigned long long v = 0;
+            if (want_hist) {
+                v = s_h50[neg ? 1 : 0][b + 1];
+                if (b == LARS_HIST_BINS - 1) v += s_h50[neg ? 1 : 0][LARS_HIST_BINS + 1];      // x == 1.0: the closed last bin
+            }
+            P.stats[tile * 3 + k].hist[b] = v;
+        }
+    }
+}
+
+}  // namespace lars
+
+using namespace lars;
+
+// K: chunks per tile.  Enough workgroups to fill the chip (one per CU, a few rounds), at least npix / 2^24 (the 16-bit
+// counters' list bound), chunks of whole steps.
+static int joint_chunks(long long ntiles, long long npix, int S)
+{
+    const long long nquads = npix >> 2;
+    long long k_min = (npix + JH_MAX_WG_PIXELS - 1) / JH_MAX_WG_PIXELS;
+    if (k_min < 1) k_min = 1;
+    long long k = tuning().blocks_per_tile > 0 ? tuning().blocks_per_tile : (1024 + ntiles * S - 1) / (ntiles * S);
+    const long long k_max = nquads / (64 * 1024) > 1 ? nquads / (64 * 1024) : 1;          // at least 64 steps per workgroup
+    if (k > k_max) k = k_max;
+    if (k < k_min) k = k_min;
+    if (k > 4096) k = 4096;
+    return (int)k;
+}
+static long long joint_chunk_quads(long long npix, int K)
+{
+    const long long nquads = npix >> 2;
+    long long cq = (nquads + K - 1) / K;
+    cq = (cq + 1023) & ~1023ll;
+    return cq > 0 ? cq : 1024;
+}
+
+extern "C" size_t lars_joint_scratch_bytes(int64_t ntiles, int64_t npix, uint32_t index_mask)
+{
+    if (ntiles <= 0 || npix <= 0) return 0;
+    const int S = ((index_mask & 1u) ? 1 : 0) + ((index_mask & 6u) ? 1 : 0);
+    if (S == 0) return 0;
+    const int K = joint_chunks(ntiles, npix, S);
+    return (size_t)ntiles * S * K * (2 * JH_DWORDS) * sizeof(unsigned int) + 256;
+}
+
+extern "C" int lars_d_stats_joint(const lars_fused_args *a, int white_balance, int rgn_variant, double *percentiles,
+                                  uint32_t *hist, float *out_pairs, void *scratch)
+{
+    ThreadCtx *c;
+    LARS_TRY(ensure_ctx(&c));
+    if (!a || !a->tiles || !a->stats || !scratch || a->ntiles <= 0 || a->npix <= 0)
+        return fail(LARS_ERR_INVALID, "lars_d_stats_joint: bad arguments");
+    if (a->dtype != LARS_U8 || a->channels != 3 || (reinterpret_cast<uintptr_t>(a->tiles) & 3) || (a->ntiles > 1 && (a->npix & 3)))
+        return fail(LARS_ERR_INVALID, "lars_d_stats_joint: uint8 [ntiles][npix][3] tiles on 4-byte boundaries are required");
+    const unsigned mask = a->index_mask & LARS_MASK_ALL;
+    if (!mask || (a->index_mask & ~LARS_MASK_ALL)) return fail(LARS_ERR_INVALID, "lars_d_stats_joint: index_mask");
+    if (a->out_wb || a->out_index[0] || a->out_index[1] || a->out_index[2] || a->out_rgba[0] || a->out_rgba[1] || a->out_rgba[2])
+        return fail(LARS_ERR_INVALID, "lars_d_stats_joint: no output planes (lars_d_fused writes those)");
+    if (a->ntiles > 65535 || (long long)a->npix * 3 >= (1ll << 40))
+        return fail(LARS_ERR_INVALID, "lars_d_stats_joint: at most 65535 tiles per call");
+    hipStream_t s = pick_stream(c, a->stream);
+    const unsigned streams = ((mask & 1u) ? 1u : 0u) | ((mask & 6u) ? 2u : 0u);
+    const int S = streams == 3u ? 2 : 1;
+    const int K = joint_chunks(a->ntiles, a->npix, S);
+
+    unsigned int *error = reinterpret_cast<unsigned int *>(scratch);
+    LARS_HIP_TRY(hipMemsetAsync(error, 0, 256, s));
+    JointCountParams C;
+    memset(&C, 0, sizeof C);
+    C.tiles = static_cast<const uint8_t *>(a->tiles); C.npix = a->npix; C.ntiles = a->ntiles;
+    C.chunk_quads = joint_chunk_quads(a->npix, K);
+    C.part = error + 64; C.error = error; C.K = K; C.S = S; C.streams = streams;
+    const long long units = (long long)a->ntiles * K;
+    const long long nwg = S == 2 ? ((units + 7) / 8) * 16 : units;
+    if (nwg > 0x7FFFFFFFll) return fail(LARS_ERR_INVALID, "lars_d_stats_joint: too many workgroups");
+    if (tuning().joint_depth == 4) hipLaunchKernelGGL((k_joint_count<4>), dim3((unsigned)nwg), dim3(JH_THREADS), 0, s, C);
+    else hipLaunchKernelGGL((k_joint_count<6>), dim3((unsigned)nwg), dim3(JH_THREADS), 0, s, C);
+    LARS_TRY(launch_check("lars_d_stats_joint (count)"));
+
+    JointFinishParams F;
+    memset(&F, 0, sizeof F);
+    F.part = C.part; F.npix = a->npix; F.K = K; F.S = S; F.streams = streams; F.mask = mask;
+    F.flags = a->flags & (LARS_F_HIST | LARS_F_SUMSQ); F.wb = white_balance ? 1 : 0; F.rgn_variant = rgn_variant;
+    F.stats = a->stats; F.table_out = white_balance ? const_cast<uint8_t *>(a->wb_table) : nullptr;
+    F.pcts_out = white_balance ? percentiles : nullptr; F.hist_out = hist; F.out_pairs = out_pairs;
+    hipLaunchKernelGGL(k_joint_finish, dim3((unsigned)S, (unsigned)a->ntiles), dim3(JH_THREADS), 0, s, F);
+    return launch_check("lars_d_stats_joint (finish)");
+}

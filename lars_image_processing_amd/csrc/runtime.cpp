@@ -362,6 +362,7 @@ int lars_set_tuning(const char *key, int value)
     else if (!strcmp(key, "pipe_head")) t.pipe_head = value;
     else if (!strcmp(key, "pipe_trace")) t.pipe_trace = value;
     else if (!strcmp(key, "pipe_cold")) t.pipe_cold = value;
+    else if (!strcmp(key, "joint_depth")) t.joint_depth = value;
     else return fail(LARS_ERR_INVALID, "lars_set_tuning: unknown key %s", key);
     return LARS_OK;
 }
@@ -382,6 +383,7 @@ int lars_get_tuning(const char *key, int *value)
     else if (!strcmp(key, "pipe_head")) *value = t.pipe_head;
     else if (!strcmp(key, "pipe_trace")) *value = t.pipe_trace;
     else if (!strcmp(key, "pipe_cold")) *value = t.pipe_cold;
+    else if (!strcmp(key, "joint_depth")) *value = t.joint_depth;
     else return fail(LARS_ERR_INVALID, "lars_get_tuning: unknown key %s", key);
     return LARS_OK;
 }

@@ -51,6 +51,8 @@ __device__ inline float norm_diff_fast(float a, float b)
 
 
 #define V2_TABLE_BYTES 65536
+// histogram bin of a quotient of bytes from the mantissa of fma(x, 25, 25.5001) + 2^23 (hist_pos2, fused_v2.hip)
+#define V2_HIST_MAGIC_C 25.5001f
 
 // byte k of a dword -> float in one VALU instruction.  Kept opaque (asm) so that hipcc does not
 // turn "float(a) +/- float(b)" into integer SDWA adds plus conversions (5 instructions per pixel

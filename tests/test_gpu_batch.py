@@ -10,15 +10,19 @@ pytestmark = pytest.mark.gpu
 TYPES = ("NDVI", "GNDVI", "NDWI")
 
 
-@pytest.fixture(scope="module", params=[2, 1], ids=["impl2", "impl1"])
+@pytest.fixture(scope="module", params=[(2, "auto"), (2, "classic"), (1, "classic")], ids=["impl2-joint", "impl2-classic", "impl1-classic"])
 def lars(request):
-    """Every batch test runs against both kernel generations (results must not depend on tuning)."""
+    """Every batch test runs against both kernel generations and both statistics routes (one read through joint
+    byte-pair histograms, or histogram pass + per-pixel kernel): results must not depend on either."""
     import lars_image_processing_amd as mod
-    from lars_image_processing_amd import _ffi
+    from lars_image_processing_amd import _ffi, batch
     assert _ffi.device_count() >= 1
-    _ffi.set_tuning(fused_impl=request.param, hist_impl=request.param)
+    impl, route = request.param
+    _ffi.set_tuning(fused_impl=impl, hist_impl=impl)
+    batch.set_stats_route(route)
     yield mod
     _ffi.set_tuning(fused_impl=0, hist_impl=2)
+    batch.set_stats_route("auto")
 
 
 def bits(a):

@@ -1,0 +1,175 @@
+"""The one-read statistics route (joint byte-pair histograms, csrc/joint.hip) against the per-pixel kernels, the oracle
+and NumPy itself (needs a MI355X).  Everything it reports must be the same BITS as the classic route's records:
+every statistic is a function of the pair counts."""
+import itertools
+import warnings
+
+import numpy as np
+import pytest
+
+from oracle import index_oracle as orc
+
+pytestmark = pytest.mark.gpu
+TYPES = ("NDVI", "GNDVI", "NDWI")
+
+
+@pytest.fixture(scope="module")
+def lars():
+    import lars_image_processing_amd as mod
+    from lars_image_processing_amd import _ffi
+    assert _ffi.device_count() >= 1
+    return mod
+
+
+def same_records(a, b):
+    """Records of two routes: everything but the (float64-accumulated, order-dependent) sum of squares bit for bit."""
+    a, b = a.copy(), b.copy()
+    np.testing.assert_allclose(a["sumsq"], b["sumsq"], rtol=1e-12)
+    a["sumsq"] = b["sumsq"] = 0
+    assert a.tobytes() == b.tobytes()
+
+
+def subsets():
+    for r in (1, 2, 3):
+        yield from itertools.combinations(TYPES, r)
+
+
+@pytest.mark.parametrize("profile", ["uniform", "vegetation"])
+@pytest.mark.parametrize("shape,ntiles", [((64, 64), 5), ((96, 160), 3), ((33, 35), 1), ((128, 130), 2)])
+def test_joint_route_equals_classic_route(lars, profile, shape, ntiles):
+    b = lars.TileBatch.synthetic(ntiles, shape[0], shape[1], seed=77, profile=profile)
+    tiles = b.host_tiles()
+    for wb in (True, False):
+        for indices in subsets():
+            rec_c, med_c = b.process(indices=indices, white_balance=wb, hist=True, sumsq=True, medians=True, route="classic")
+            if wb:
+                want_tab, want_pct, want_hist = b.host_tables(), b.host_percentiles(), b.host_hist()
+                b.table.zero(); b.percentiles.zero(); b.hist.zero()
+            rec_j, med_j = b.process(indices=indices, white_balance=wb, hist=True, sumsq=True, medians=True, route="joint")
+            same_records(rec_c, rec_j)
+            np.testing.assert_array_equal(med_c, med_j)
+            # without the optional parts: sums of squares and bins stay zero
+            rec_p = b.process(indices=indices, white_balance=wb, route="joint")
+            assert (rec_p["sumsq"] == 0).all() and (rec_p["hist"] == 0).all()
+            rec_p["hist"] = rec_j["hist"]; rec_p["sumsq"] = rec_j["sumsq"]
+            assert rec_p.tobytes() == rec_j.tobytes()
+            if wb:
+                # the by-products: channel histograms, percentiles and tables of the channels the indices read
+                chans = sorted({2} | ({0} if "NDVI" in indices else set()) | ({1} if set(indices) & {"GNDVI", "NDWI"} else set()))
+                got_tab, got_pct, got_hist = b.host_tables(), b.host_percentiles(), b.host_hist()
+                for c in chans:
+                    np.testing.assert_array_equal(got_hist[:, c], want_hist[:, c])
+                    np.testing.assert_array_equal(got_pct[:, c], want_pct[:, c])
+                    np.testing.assert_array_equal(got_tab[:, c], want_tab[:, c])
+    # and against the oracle / NumPy directly (all three indices, white balance)
+    rec, med = b.process(hist=True, medians=True, route="joint")
+    for i in range(ntiles):
+        with warnings.catch_warnings():
+            warnings.simplefilter("ignore")
+            wbimg = orc.wb_app(tiles[i])
+        for k, t in enumerate(TYPES):
+            plane = orc.index_app(wbimg, t)
+            part = orc.tile_partials(plane, t)
+            assert float(rec[i, k]["sum"]) == part["sum"] and int(rec[i, k]["above"]) == part["above"]
+            assert float(rec[i, k]["min"]) == float(plane.min()) and float(rec[i, k]["max"]) == float(plane.max())
+            assert int(rec[i, k]["count"]) == plane.size
+            np.testing.assert_array_equal(rec[i, k]["hist"], orc.hist50(plane))
+            assert med[i, k] == float(np.median(plane)), (i, t)
+    b.free()
+
+
+def _tile_from(fn, h, w):
+    yy, xx = np.mgrid[0:h, 0:w]
+    return np.stack([fn(yy, xx, c).astype(np.uint8) for c in range(3)], axis=-1)
+
+
+@pytest.mark.parametrize("blocks", [0, 1, 3])
+def test_joint_counters_never_overflow(lars, blocks):
+    """Tiles that pile hundreds of thousands of pixels onto single cells: the 16-bit counters are emptied onto the
+    workgroup's list before they can wrap (constant tiles, two-level tiles, flat areas with a textured rim)."""
+    from lars_image_processing_amd import _ffi
+    h = w = 1024
+    tiles = np.stack([
+        np.full((h, w, 3), 0, np.uint8),                                               # nodata
+        np.full((h, w, 3), 255, np.uint8),                                             # saturated
+        _tile_from(lambda y, x, c: np.full_like(y, (17, 140, 201)[c]), h, w),          # one colour
+        _tile_from(lambda y, x, c: np.where((x // 7 + y // 3) % 2 == 0, (10, 30, 250)[c], (200, 90, 40)[c]), h, w),
+        _tile_from(lambda y, x, c: np.where(y < 900, (60, 70, 180)[c], (x * 7 + y * 13 + c * 31) % 256), h, w),
+        orc.synth_tile_u8(5, 0, h, w, profile="vegetation"),
+    ])
+    b = lars.TileBatch.from_host(tiles)
+    try:
+        _ffi.set_tuning(blocks_per_tile=blocks)
+        for wb in (False, True):
+            rec_j, med_j = b.process(white_balance=wb, hist=True, medians=True, route="joint")
+            _ffi.set_tuning(blocks_per_tile=0)
+            rec_c, med_c = b.process(white_balance=wb, hist=True, medians=True, route="classic")
+            _ffi.set_tuning(blocks_per_tile=blocks)
+            assert rec_j.tobytes() == rec_c.tobytes()
+            np.testing.assert_array_equal(med_j, med_c)
+            for i in (0, 2, 3, 4):
+                with warnings.catch_warnings():
+                    warnings.simplefilter("ignore")
+                    img = orc.wb_app(tiles[i]) if wb else tiles[i]
+                for k, t in enumerate(TYPES):
+                    plane = orc.index_app(img, t)
+                    assert med_j[i, k] == float(np.median(plane)), (i, t, wb)
+                    assert int(rec_j[i, k]["above"]) == orc.tile_partials(plane, t)["above"]
+    finally:
+        _ffi.set_tuning(blocks_per_tile=0)
+        b.free()
+
+
+def test_joint_full_size_tiles(lars):
+    """4096 x 4096 tiles (BASELINE configs[1]/[2] size), one workgroup per tile and stream (2^24 pixels: the most a
+    workgroup may count, a constant tile fills its list to the last entry) and the automatic split."""
+    from lars_image_processing_amd import _ffi
+    b = lars.TileBatch.synthetic(6, 4096, 4096, seed=1234, profile="vegetation")
+    const = np.empty((1, 4096, 4096, 3), np.uint8)
+    const[...] = (9, 200, 77)
+    b.tiles.upload(const, 5 * b.tile_bytes)                                          # tile 5: one colour
+    rec_c, med_c = b.process(hist=True, medians=True, route="classic")
+    try:
+        for blocks in (1, 0, 5):
+            _ffi.set_tuning(blocks_per_tile=blocks)
+            rec_j, med_j = b.process(hist=True, medians=True, route="joint")
+            assert rec_j.tobytes() == rec_c.tobytes(), blocks
+            np.testing.assert_array_equal(med_j, med_c)
+    finally:
+        _ffi.set_tuning(blocks_per_tile=0)
+    n = 4096 * 4096
+    assert (rec_j["count"] == n).all() and (rec_j["hist"].sum(axis=2) == n).all()
+    tile = b.host_tiles(3, 1)[0]
+    for c in range(3):
+        assert b.host_percentiles()[3, c].tolist() == [float(v) for v in np.percentile(tile[:, :, c].astype(np.float32), (2, 98))]
+    with warnings.catch_warnings():
+        warnings.simplefilter("ignore")
+        wbimg = orc.wb_app(tile)
+    for k, t in enumerate(TYPES):
+        plane = orc.index_app(wbimg, t)
+        assert med_j[3, k] == float(np.median(plane)) and float(rec_j[3, k]["sum"]) == orc.tile_partials(plane, t)["sum"]
+    b.free()
+
+
+def test_joint_bad_arguments(lars):
+    import ctypes as C
+    from lars_image_processing_amd import _ffi
+    lib = _ffi.load()
+    b = lars.TileBatch.synthetic(2, 16, 16, seed=1)
+    stats = b.new_stats()
+    scratch = _ffi.DeviceBuffer(int(lib.lars_joint_scratch_bytes(2, 256, 7)))
+    a = b.fused_args(("NDVI",), False, stats)
+    assert lib.lars_d_stats_joint(C.byref(a), 0, 0, None, None, None, None) == -1          # no scratch
+    a.index_mask = 0
+    assert lib.lars_d_stats_joint(C.byref(a), 0, 0, None, None, None, C.c_void_p(scratch.ptr)) == -1
+    a.index_mask = 1
+    a.dtype = _ffi.U16
+    assert lib.lars_d_stats_joint(C.byref(a), 0, 0, None, None, None, C.c_void_p(scratch.ptr)) == -1
+    a.dtype = _ffi.U8
+    a.out_index[0] = scratch.ptr
+    assert lib.lars_d_stats_joint(C.byref(a), 0, 0, None, None, None, C.c_void_p(scratch.ptr)) == -1
+    assert lib.lars_joint_scratch_bytes(0, 256, 7) == 0 and lib.lars_joint_scratch_bytes(2, 256, 0) == 0
+    with pytest.raises(ValueError):
+        wide = lars.TileBatch.from_host(np.zeros((1, 8, 8, 3), np.uint16))
+        wide.process(route="joint")
+    scratch.free(); stats.free(); b.free()

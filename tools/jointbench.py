@@ -1,0 +1,139 @@
+#!/usr/bin/env python3
+"""Statistics-only passes over a resident batch, the two routes side by side in one process (HIP events on the library
+stream; whole step = everything from the raw tiles to final records, white balance included):
+
+    classic   channel-histogram pass + tables, then the per-pixel statistics kernel (+ its median passes)
+    joint     ONE read: joint byte-pair histograms in LDS, then the per-tile finish kernel (csrc/joint.hip)
+
+    python tools/jointbench.py --tiles 256 [--content vegetation,uniform,flat,steps,smooth]
+
+Content: the two synthetic profiles of the bench, and three hand-made tiles replicated over the batch that show what the
+counting kernel's LDS atomics do on imagery whose neighbouring pixels share cells (flat: one colour; steps: runs of 64
+equal pixels; smooth: a slow gradient plus two levels of noise).
+"""
+from __future__ import annotations
+
+import argparse
+import ctypes as C
+import os
+import sys
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+
+from lars_image_processing_amd import _ffi  # noqa: E402
+import lars_image_processing_amd as lars  # noqa: E402
+
+MODES = {"ndvi": ("NDVI",), "3idx": ("NDVI", "GNDVI", "NDWI")}
+
+
+def handmade(kind, edge):
+    rng = np.random.default_rng(7)
+    yy, xx = np.mgrid[0:edge, 0:edge]
+    if kind == "flat":
+        t = np.empty((edge, edge, 3), np.uint8)
+        t[...] = (40, 90, 180)
+        return t
+    if kind == "steps":
+        base = ((xx // 64) * 37 + (yy // 8) * 11) % 200
+        return np.stack([(base + 10 * c) % 256 for c in range(3)], axis=-1).astype(np.uint8)
+    if kind == "smooth":
+        out = []
+        for c in range(3):
+            g = 60 + 50 * c + 40 * np.sin(xx / 900.0 + c) + 30 * np.cos(yy / 700.0) + rng.integers(-2, 3, (edge, edge))
+            out.append(np.clip(g, 0, 255))
+        return np.stack(out, axis=-1).astype(np.uint8)
+    raise ValueError(kind)
+
+
+def make_batch(content, ntiles, edge):
+    if content in ("uniform", "vegetation"):
+        return lars.TileBatch.synthetic(ntiles, edge, edge, seed=1234, profile=content)
+    b = lars.TileBatch(ntiles, edge, edge, 3, np.uint8)
+    b.tiles.upload(handmade(content, edge)[None])
+    for i in range(1, ntiles):
+        _ffi.call("lars_memcpy_d2d", C.c_void_p(b.tiles.ptr + i * b.tile_bytes), C.c_void_p(b.tiles.ptr), b.tile_bytes, None)
+    _ffi.call("lars_synchronize", None)
+    return b
+
+
+def timed(fn, rounds):
+    ev = [C.c_void_p(), C.c_void_p()]
+    for e in ev:
+        _ffi.call("lars_event_create", C.byref(e))
+    out = []
+    for _ in range(rounds + 1):
+        _ffi.call("lars_event_record", ev[0], None)
+        fn()
+        _ffi.call("lars_event_record", ev[1], None)
+        ms = C.c_float(0)
+        _ffi.call("lars_event_elapsed_ms", ev[0], ev[1], C.byref(ms))
+        out.append(ms.value)
+    for e in ev:
+        _ffi.call("lars_event_destroy", e)
+    return float(np.median(out[1:])), float(min(out[1:]))
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--tiles", type=int, default=256)
+    ap.add_argument("--tile", type=int, default=4096)
+    ap.add_argument("--rounds", type=int, default=5)
+    ap.add_argument("--content", default="vegetation,uniform")
+    ap.add_argument("--depths", default="6,4")
+    ap.add_argument("--blocks", default="0", help="chunks per tile of the counting kernel (blocks_per_tile), 0 = automatic")
+    args = ap.parse_args()
+    lib = _ffi.load()
+    for content in args.content.split(","):
+        b = make_batch(content, args.tiles, args.tile)
+        npix = args.tiles * args.tile * args.tile
+        stats = b.new_stats()
+        stats.zero()
+        pairs = _ffi.DeviceBuffer(b.ntiles * 4 * 4)
+        med_scratch = _ffi.DeviceBuffer(int(lib.lars_quotient_median_scratch_bytes(b.ntiles)))
+        print(f"== {content}: {args.tiles} tiles of {args.tile}^2, 3 B/pixel algorithmic")
+
+        def report(name, ms, mn):
+            print(f"  {name:44s} {ms:8.3f} ms (min {mn:8.3f})  {npix / ms / 1e6:8.1f} Gpix/s  whole step {npix * 3 / ms / 1e6 / 8000:.3f} of 8 TB/s",
+                  flush=True)
+
+        ref = {}
+        for mname, indices in MODES.items():
+            def classic():
+                b.compute_wb_tables()
+                b.run_fused(b.fused_args(indices, True, stats))
+            ms, mn = timed(classic, args.rounds)
+            report(f"classic {mname} statistics", ms, mn)
+            _ffi.call("lars_synchronize", None)
+            ref[mname] = stats.download(_ffi.STATS_DTYPE, (b.ntiles, 3)).copy()
+
+            def classic_med():
+                b.compute_wb_tables()
+                a = b.fused_args(indices, True, stats)
+                _ffi.call("lars_d_stats_medians", C.byref(a), C.c_void_p(pairs.ptr), C.c_void_p(med_scratch.ptr))
+            ms, mn = timed(classic_med, args.rounds)
+            report(f"classic {mname} statistics + medians", ms, mn)
+            _ffi.call("lars_synchronize", None)
+            ref[mname + "_med"] = pairs.download(np.float32, (b.ntiles, 2, 2)).copy()
+        for depth in map(int, args.depths.split(",")):
+            for blocks in map(int, args.blocks.split(",")):
+                _ffi.set_tuning(joint_depth=depth, blocks_per_tile=blocks)
+                for mname, indices in MODES.items():
+                    for med in (False, True):
+                        ms, mn = timed(lambda: b.run_joint(indices, True, stats, pairs=pairs if med else None), args.rounds)
+                        report(f"joint   {mname} statistics{' + medians' if med else ''} depth {depth} blocks {blocks}", ms, mn)
+                        _ffi.call("lars_synchronize", None)
+                        rec = stats.download(_ffi.STATS_DTYPE, (b.ntiles, 3))
+                        ids = [_ffi.INDEX_IDS[t] for t in indices]
+                        assert rec[:, ids].tobytes() == ref[mname][:, ids].tobytes(), "records differ between the routes"
+                        if med:
+                            got = pairs.download(np.float32, (b.ntiles, 2, 2))
+                            assert np.array_equal(got, ref[mname + "_med"], equal_nan=True), "medians differ between the routes"
+        _ffi.set_tuning(joint_depth=6, blocks_per_tile=0)
+        stats.free(); pairs.free(); med_scratch.free(); b.free()
+
+
+if __name__ == "__main__":
+    main()

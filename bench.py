@@ -46,10 +46,17 @@ MODES = {
     "wb_ndvi_out_stats": (("NDVI",), True, False, 3 + 4),
     "wb3idx_stats_only": (("NDVI", "GNDVI", "NDWI"), False, False, 3),
     "wb_ndvi_stats_only": (("NDVI",), False, False, 3),
-    # statistics + the exact median of every tile (the reference's analyze_index / time-series table): the statistics
-    # kernel counts the select's bucket pass, one slot pass follows; 3 B/pixel per pass
+    # statistics + the exact median of every tile (the reference's analyze_index / time-series table)
     "wb3idx_stats_medians": (("NDVI", "GNDVI", "NDWI"), False, False, 3),
+    # the reference's whole job per image (process-images.py:424-513: fix_white_balance, three calculate_index planes,
+    # three analyze_index dictionaries INCLUDING the median) -- what cpu_baseline times: one read for statistics, medians
+    # and tables (joint byte-pair histograms), then the plane-writing kernel
+    "wb3idx_out_stats_medians": (("NDVI", "GNDVI", "NDWI"), True, False, 3 + 12),
 }
+# statistics-only modes run on the one-read route (csrc/joint.hip) unless --stats-route classic; "<mode>_classic" in the
+# line's `modes` is the same job on the two-pass route (channel-histogram pass + per-pixel statistics kernel)
+STATS_ONLY = ("wb3idx_stats_only", "wb_ndvi_stats_only", "wb3idx_stats_medians")
+MEDIAN_MODES = ("wb3idx_stats_medians", "wb3idx_out_stats_medians")
 
 
 def parse():
@@ -69,9 +76,16 @@ def parse():
                     help="at most this many candidate output arenas (one allocation holding the ring's planes) are allocated "
                          "and timed -- the search stops early once one is clearly faster than the slowest -- and the fastest "
                          "is kept, the rest freed (0/1: take the first)")
+    ap.add_argument("--stats-route", default="joint", choices=["joint", "classic"],
+                    help="statistics-only modes: one read through joint byte-pair histograms, or histogram pass + per-pixel kernel")
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--cpu-tiles", type=int, default=8)
-    ap.add_argument("--cpu-workers", type=int, default=16, help="process pool of the multi-core CPU baseline leg")
+    ap.add_argument("--cpu-tiles", type=int, default=4, help="tiles per run of the single-core CPU baseline (best of --cpu-runs)")
+    ap.add_argument("--cpu-runs", type=int, default=3)
+    ap.add_argument("--cpu-workers", type=int, default=16,
+                    help="process pool of the multi-core CPU baseline leg (16 = one GPU's share of the box's host cores; every "
+                         "worker holds about 1 GiB of NumPy temporaries for a 4096 x 4096 tile)")
+    ap.add_argument("--no-u16-leg", dest="u16_leg", action="store_false", help="skip the BASELINE configs[4] shape (uint16 8192 x 8192 tiles)")
+    ap.add_argument("--no-verify", dest="verify", action="store_false", help="skip the self-check after the timed region")
     return ap.parse_args()
 
 
@@ -88,6 +102,9 @@ class Runner:
         self.batch = lars.TileBatch.synthetic(args.tiles, args.tile, args.tile, seed=1234, profile=args.profile,
                                               first_tile=first)
         self.stats = self.batch.new_stats()
+        self.folded = _ffi.DeviceBuffer(3 * _ffi.STATS_DTYPE.itemsize)     # this rank's three per-index records
+        self.folded.zero()
+        self.pairs = None
         self.ev = []
         for _ in range(4):
             e = C.c_void_p()
@@ -107,35 +124,50 @@ class Runner:
         return self.outputs[key]
 
     def step(self, mode, timed=None):
-        """One pass over the batch.  ``timed`` collects (hist_ms, fused_ms, n_fused_launches)."""
-        indices, write, hist, _ = MODES[mode]
+        """One pass over the batch.  ``timed`` collects (pre_ms, main_ms, launches of the main kernel): pre = the channel-
+        histogram pass + tables (or, in the like-for-like mode, the one-read statistics pass), main = the fused kernel(s)
+        (or the whole one-read pass of a statistics-only mode)."""
+        classic = mode.endswith("_classic")
+        base_mode = mode[:-len("_classic")] if classic else mode
+        indices, write, hist, _ = MODES[base_mode]
         b, ffi = self.batch, self.ffi
         outs = self.outputs_for(indices, write)
+        joint = base_mode in STATS_ONLY and not classic and self.args.stats_route == "joint" and b.can_joint()
+        if base_mode in MEDIAN_MODES and self.pairs is None:
+            self.pairs = ffi.DeviceBuffer(b.ntiles * 4 * 4)
         ffi.call("lars_event_record", self.ev[0], None)
-        b.compute_wb_tables()
-        ffi.call("lars_event_record", self.ev[1], None)
-        launches = 0
-        if mode == "wb3idx_stats_medians":
-            if getattr(self, "_med_bufs", None) is None:
-                self._med_bufs = (ffi.DeviceBuffer(b.ntiles * 4 * 4),
-                                  ffi.DeviceBuffer(int(ffi.load().lars_quotient_median_scratch_bytes(b.ntiles))))
-            args = b.fused_args(indices, True, self.stats, hist, None)
-            ffi.call("lars_d_stats_medians", C.byref(args), C.c_void_p(self._med_bufs[0].ptr), C.c_void_p(self._med_bufs[1].ptr))
+        if joint:
+            ffi.call("lars_event_record", self.ev[1], None)
+            b.run_joint(indices, True, self.stats, hist, False, self.pairs if base_mode in MEDIAN_MODES else None)
             launches = 1
+        elif base_mode == "wb3idx_out_stats_medians":
+            b.run_joint(indices, True, self.stats, hist, False, self.pairs)        # statistics, medians and all three tables
+            ffi.call("lars_event_record", self.ev[1], None)
+            launches = b.run_fused_chunks(indices, True, None, False, outs)      # planes only
         else:
-            # one launch without output planes, one per ring of `outs.slots` tiles with them; the statistics records are opened
-            # and closed once around the launches (lars_d_stats_begin / _end), not by two small kernels per launch
-            launches = b.run_fused_chunks(indices, True, self.stats, hist, outs)
+            b.compute_wb_tables()
+            ffi.call("lars_event_record", self.ev[1], None)
+            if base_mode == "wb3idx_stats_medians":
+                if getattr(self, "_med_scratch", None) is None:
+                    self._med_scratch = ffi.DeviceBuffer(int(ffi.load().lars_quotient_median_scratch_bytes(b.ntiles)))
+                args = b.fused_args(indices, True, self.stats, hist, None)
+                ffi.call("lars_d_stats_medians", C.byref(args), C.c_void_p(self.pairs.ptr), C.c_void_p(self._med_scratch.ptr))
+                launches = 1
+            else:
+                # one launch without output planes, one per ring of `outs.slots` tiles with them; the statistics records are
+                # opened and closed once around the launches (lars_d_stats_begin / _end), not by two small kernels per launch
+                launches = b.run_fused_chunks(indices, True, self.stats, hist, outs)
         ffi.call("lars_event_record", self.ev[2], None)
-        rec = self.stats.download(ffi.STATS_DTYPE, (b.ntiles, 3))         # synchronises the stream
-        local = self.lb.local_fold(rec, indices)
-        glob = self.comm.allreduce_stats(local)
+        # per-index fold of the per-tile records on the device, then the exchange of 3 x 472 bytes (RCCL all-gather + fold in
+        # rank order inside the library, or nothing at all with one rank): no per-tile record leaves the device in a step
+        b.fold_stats(self.stats, indices, self.folded)
+        glob = self.comm.allreduce_stats_device(self.folded, 3)
         if timed is not None:
             ms = C.c_float(0)
             ffi.call("lars_event_elapsed_ms", self.ev[0], self.ev[1], C.byref(ms))
-            hist_ms = ms.value
+            pre_ms = ms.value
             ffi.call("lars_event_elapsed_ms", self.ev[1], self.ev[2], C.byref(ms))
-            timed.append((hist_ms, ms.value, launches))
+            timed.append((pre_ms, ms.value, launches))
         return glob
 
     def run(self, mode, steps, warmup):
@@ -150,50 +182,146 @@ class Runner:
             glob = self.step(mode, timed)
         self.ffi.call("lars_synchronize", None)
         self.comm.barrier()
-        dt = time.perf_counter() - t0
-        dt = float(self.comm.allreduce_f64([dt], "max")[0])
+        dt_local = time.perf_counter() - t0
+        dt = float(self.comm.allreduce_f64([dt_local], "max")[0])
+        self.last_local_dt = dt_local
         return dt, timed, glob
+
+    # ---- self-check after the timed region -------------------------------------------------------------------
+    def verify(self, mode, glob_by_mode):
+        """What the timed configuration left behind against single-tile runs of the same library: the per-tile records of
+        three tiles (first, middle, last) and, where planes are written, the ring planes of three tiles of the LAST chunk
+        (what the ring holds after a step), bit for bit; the medians of those tiles where the mode has them; and the global
+        statistics of all modes that share an index.  Returns a dict of booleans + what was compared."""
+        ffi, b = self.ffi, self.batch
+        indices, write, hist, _ = MODES[mode]
+        self.step(mode)
+        ffi.call("lars_synchronize", None)
+        rec = self.stats.download(ffi.STATS_DTYPE, (b.ntiles, 3))
+        outs = self.outputs_for(indices, write)
+        ring = outs.slots if outs is not None else b.ntiles
+        last_chunk = ((b.ntiles - 1) // ring) * ring
+        rec_tiles = sorted({0, b.ntiles // 2, b.ntiles - 1})
+        plane_tiles = sorted({last_chunk, (last_chunk + b.ntiles - 1) // 2, b.ntiles - 1}) if write else []
+        out = {"mode": mode, "record_tiles": rec_tiles, "plane_tiles": plane_tiles, "records": True, "planes": True if write else None}
+        one = self.lars.TileBatch(1, b.h, b.w, 3, np.uint8)
+        one_out = one.make_outputs(indices=indices, index=True) if write else None
+        for t in sorted(set(rec_tiles) | set(plane_tiles)):
+            ffi.call("lars_memcpy_d2d", C.c_void_p(one.tiles.ptr), C.c_void_p(b.tiles.ptr + t * b.tile_bytes), b.tile_bytes, None)
+            r1 = one.process(indices=indices, hist=hist, outputs=one_out, route="classic")
+            if t in rec_tiles and r1[0].tobytes() != rec[t].tobytes():
+                out["records"] = False
+            if t in plane_tiles:
+                for name in indices:
+                    got = outs.host_index(name, t % ring, 1)
+                    want = one_out.host_index(name, 0, 1)
+                    if got.tobytes() != want.tobytes():
+                        out["planes"] = False
+        if mode in MEDIAN_MODES:
+            pairs = self.pairs.download(np.float32, (b.ntiles, 2, 2))
+            med = b._medians_from_pairs(pairs, indices)
+            out["medians"] = True
+            for t in rec_tiles:
+                ffi.call("lars_memcpy_d2d", C.c_void_p(one.tiles.ptr), C.c_void_p(b.tiles.ptr + t * b.tile_bytes), b.tile_bytes, None)
+                _, m1 = one.process(indices=indices, medians=True, route="classic")
+                if not np.array_equal(m1[0], med[t]):
+                    out["medians"] = False
+        if one_out is not None:
+            one_out.free()
+        one.free()
+        # global statistics: every mode that ran reports the same record for an index they share (hist only where counted)
+        same = True
+        names = sorted(glob_by_mode)
+        for k in range(3):
+            seen = None
+            for m in names:
+                base = m[:-len("_classic")] if m.endswith("_classic") else m
+                if self.ffi.INDEX_NAMES[k] not in MODES[base][0]:
+                    continue
+                r = glob_by_mode[m][k].copy()
+                r["hist"] = 0
+                if seen is None:
+                    seen = r.tobytes()
+                elif seen != r.tobytes():
+                    same = False
+        out["global_stats_identical_across_modes"] = same
+        out["modes_compared"] = names
+        out["ok"] = bool(out["records"] and same and out["planes"] is not False and out.get("medians", True))
+        return out
 
 
 def _cpu_tile_job(job):
-    """One tile through the NumPy oracle: white balance + 3 indices + 3 analyze_index (worker of cpu_baseline)."""
+    """One tile through the NumPy oracle, the reference's whole job per image (process-images.py:424-513): white balance,
+    three calculate_index planes, three analyze_index dictionaries incl. the median.  Returns the seconds of each step:
+    [wb, index NDVI, index GNDVI, index NDWI, stats NDVI, stats GNDVI, stats NDWI] (worker of cpu_baseline)."""
     import warnings
     from oracle import index_oracle as orc
     tile, edge, profile = job
     img = orc.synth_tile_u8(1234, tile, edge, edge, profile=profile)
-    t0 = time.perf_counter()
+    steps = []
     with warnings.catch_warnings():
         warnings.simplefilter("ignore")
+        t0 = time.perf_counter()
         wb = orc.wb_app(img)
+        steps.append(time.perf_counter() - t0)
+        planes = []
         for t in ("NDVI", "GNDVI", "NDWI"):
-            orc.stats_app(orc.index_app(wb, t), t)
-    return time.perf_counter() - t0
+            t0 = time.perf_counter()
+            planes.append(orc.index_app(wb, t))
+            steps.append(time.perf_counter() - t0)
+        for t, plane in zip(("NDVI", "GNDVI", "NDWI"), planes):
+            t0 = time.perf_counter()
+            orc.stats_app(plane, t)
+            steps.append(time.perf_counter() - t0)
+    return steps
+
+
+CPU_STEP_NAMES = ("wb", "index_NDVI", "index_GNDVI", "index_NDWI", "stats_NDVI", "stats_GNDVI", "stats_NDWI")
 
 
 def cpu_baseline(args):
-    """The NumPy oracle (oracle/index_oracle.py == the reference's expressions) on a bounded sample:
-    one process / one core (how the reference runs), and a process pool over tiles on this GPU's
-    share of the host cores."""
+    """The NumPy oracle (oracle/index_oracle.py == the reference's expressions) on a bounded sample, as BASELINE.md section 4
+    asks: (i) one process / one core (how the reference runs), best of ``--cpu-runs`` runs over ``--cpu-tiles`` tiles with
+    the per-step breakdown; (ii) a process pool over tiles on this GPU's share of the host cores, best of the same number
+    of runs.  The job is the one the GPU mode ``wb3idx_out_stats_medians`` does (planes + statistics incl. medians)."""
     n = max(1, args.cpu_tiles)
+    runs = max(1, args.cpu_runs)
     pix_tile = args.tile * args.tile
-    dt1 = sum(_cpu_tile_job((i, args.tile, args.profile)) for i in range(n))
+    best, all_runs = None, []
+    for _ in range(runs):
+        per_tile = [_cpu_tile_job((i, args.tile, args.profile)) for i in range(n)]
+        total = float(np.sum(per_tile))
+        all_runs.append(total)
+        if best is None or total < best[0]:
+            best = (total, np.sum(per_tile, axis=0))
+    dt1, steps = best
     out = {
         "value": n * pix_tile / dt1 / 1e6, "unit": "Mpix/s", "cores": 1, "kind": "port",
         "sample": f"{n} tiles {args.tile}x{args.tile} uint8 ({args.profile}): fix_white_balance + 3x calculate_index "
-                  f"+ 3x analyze_index (incl. median), NumPy {np.__version__}, single process, {dt1:.1f} s",
+                  f"+ 3x analyze_index (incl. median), NumPy {np.__version__}, single process, best of {runs} runs "
+                  f"({', '.join(f'{t:.1f}' for t in all_runs)} s)",
+        "same_job_as_gpu_mode": "wb3idx_out_stats_medians",
+        "steps_s_per_tile": {name: float(v) / n for name, v in zip(CPU_STEP_NAMES, steps)},
+        "runs_s": all_runs,
         "host_cpus": os.cpu_count(),
     }
     workers = max(1, min(args.cpu_workers, os.cpu_count() or 1))
     if workers > 1:
         import multiprocessing as mp
-        jobs = [(i, args.tile, args.profile) for i in range(2 * workers)]
+        jobs = [(i, args.tile, args.profile) for i in range(workers)]
         with mp.get_context("spawn").Pool(workers) as pool:
-            pool.map(_cpu_tile_job, jobs[:workers])              # warm the workers (imports, page faults)
-            t0 = time.perf_counter()
-            pool.map(_cpu_tile_job, jobs)
-            dtp = time.perf_counter() - t0
+            pool.map(_cpu_tile_job, jobs)                        # warm the workers (imports, page faults)
+            times = []
+            for _ in range(runs):
+                t0 = time.perf_counter()
+                pool.map(_cpu_tile_job, jobs)
+                times.append(time.perf_counter() - t0)
+        dtp = min(times)
         out["pool"] = {"value": len(jobs) * pix_tile / dtp / 1e6, "unit": "Mpix/s", "cores": workers,
-                       "sample": f"{len(jobs)} tiles over a pool of {workers} processes, {dtp:.1f} s"}
+                       "sample": f"{len(jobs)} tiles over a pool of {workers} processes, best of {runs} runs "
+                                 f"({', '.join(f'{t:.1f}' for t in times)} s)",
+                       "why_not_all_cpus": f"os.cpu_count() = {os.cpu_count()} is the whole box; {workers} is one GPU's share of "
+                                           "it, and every worker holds about 1 GiB of NumPy temporaries per 4096 x 4096 tile"}
     return out
 
 
@@ -220,7 +348,7 @@ def device_probe(runner):
     return out
 
 
-KERNEL_SOURCES = ("fused.hip", "fused_device.h", "fused_v2.hip", "select_q.hip", "device_common.h", "v2_device.h", "common.h")
+KERNEL_SOURCES = ("fused.hip", "fused_device.h", "fused_v2.hip", "joint.hip", "select_q.hip", "device_common.h", "v2_device.h", "common.h")
 
 
 def kernel_sources_sha():
@@ -439,8 +567,10 @@ def main():
     else:
         _ffi.call("lars_set_device", 0)
         comm = dist.SingleProcessComm()
-    if world > 1 and voted and rank == 0:
-        dist.forget_agreement(world)                      # every rank is past the vote: the bootstrap above ended in a barrier
+    if world > 1 and voted:
+        # The markers of the votes may only go once EVERY rank has left agree(): on the path where the library's communicator
+        # came up before the second vote nothing has synchronised the ranks since, so they meet in a barrier first.
+        dist.release_agreement(comm, rank, world)
     ranks_seen = comm.ranks_seen()
     if ranks_seen != world:
         print(f"[bench rank {rank}] the communicator reports {ranks_seen} ranks, WORLD_SIZE={world}", file=sys.stderr)
@@ -451,6 +581,7 @@ def main():
     dt, timed, glob = runner.run(args.mode, args.steps, args.warmup)
     total_pix = npix_rank * world * args.steps
     value = total_pix / dt / 1e6
+    local_step_ms = runner.last_local_dt / args.steps * 1e3
 
     indices, write, hist, bpp = MODES[args.mode]
     fused_ms = float(np.mean([t[1] for t in timed]))
@@ -460,23 +591,45 @@ def main():
     achieved = bytes_per_launch / (fused_ms / launches * 1e-3) / 1e9
     traffic, traffic_source = traffic_from_profiles(args.mode, npix_rank / launches)
     step_ms = dt / args.steps * 1e3
+    glob_by_mode = {args.mode: glob}
 
     extra = {}
     if args.all_modes:
-        for m in MODES:
-            if m == args.mode:
-                continue
-            d, tm, _ = runner.run(m, max(2, args.steps // 2), 1)
+        names = [m for m in MODES if m != args.mode]
+        if args.stats_route == "joint" and runner.batch.can_joint():
+            names += [m + "_classic" for m in STATS_ONLY]
+        for m in names:
+            base = m[:-len("_classic")] if m.endswith("_classic") else m
+            k_steps = max(2, args.steps // 2)
+            d, tm, g_m = runner.run(m, k_steps, 1)
+            glob_by_mode[m] = g_m
             f_ms = float(np.mean([t[1] for t in tm]))
-            m_step_ms = d / max(2, args.steps // 2) * 1e3
+            m_step_ms = d / k_steps * 1e3
+            one_read = base in STATS_ONLY and not m.endswith("_classic") and args.stats_route == "joint" and runner.batch.can_joint()
             extra[m] = {
-                "Mpix_s": npix_rank * world * max(2, args.steps // 2) / d / 1e6,
+                "Mpix_s": npix_rank * world * k_steps / d / 1e6,
                 "ms_per_step": m_step_ms,
-                "whole_step_frac": npix_rank * MODES[m][3] / (m_step_ms * 1e-3) / 1e9 / HBM_PEAK_GBS,
+                "whole_step_frac": npix_rank * MODES[base][3] / (m_step_ms * 1e-3) / 1e9 / HBM_PEAK_GBS,
+                "route": ("one read: joint byte-pair histograms (k_joint_count + k_joint_finish)" if one_read else
+                          "one-read statistics pass (k_joint_count + k_joint_finish), then k_fused_u8c3 planes only" if base == "wb3idx_out_stats_medians" else
+                          "channel-histogram pass + tables, then the fused kernel"),
                 "fused_ms": f_ms, "hist_pass_ms": float(np.mean([t[0] for t in tm])),
-                "fused_GBs_algorithmic": npix_rank * MODES[m][3] / (f_ms * 1e-3) / 1e9,
-                "fused_frac_of_8TBs": npix_rank * MODES[m][3] / (f_ms * 1e-3) / 1e9 / HBM_PEAK_GBS,
+                "fused_GBs_algorithmic": npix_rank * MODES[base][3] / (f_ms * 1e-3) / 1e9,
+                "fused_frac_of_8TBs": npix_rank * MODES[base][3] / (f_ms * 1e-3) / 1e9 / HBM_PEAK_GBS,
             }
+
+    # self-check, after the timed region: the timed configuration's records / planes against single-tile runs, and the
+    # global statistics of every mode that ran against each other
+    verified = None
+    if args.verify:
+        verified = runner.verify(args.mode, glob_by_mode)
+        if args.all_modes:
+            for m in MEDIAN_MODES:
+                v = runner.verify(m, {})
+                verified[m] = {k: v[k] for k in ("records", "planes", "medians", "ok")}
+                verified["ok"] = bool(verified["ok"] and v["ok"])
+        ok_all = float(comm.allreduce_f64([1.0 if verified["ok"] else 0.0], "min")[0]) == 1.0
+        verified["ok_on_every_rank"] = ok_all
 
     # exact global medians (all tiles of all ranks) by radix select on recomputed values: informational, untimed region
     medians, median_ms = None, None
@@ -487,8 +640,15 @@ def main():
         medians = runner.batch.global_medians(indices, white_balance=True, comm=comm)
         median_ms = (time.perf_counter() - t0) * 1e3
 
+    # per-rank figures, gathered over the communicator: which rank sets the step time, and with what arena
+    outs_main = runner.outputs.get(tuple(indices))
+    placement = getattr(outs_main, "placement_ms", None) or {}
+    mine = [rank, local_step_ms, fused_ms, hist_ms, fused_ms / launches, float(placement.get("chosen", 0.0) or 0.0),
+            float(placement.get("search_ms", 0.0) or 0.0)]
+    per_rank = comm.allgather_f64(mine)
+
     probe = device_probe(runner) if (args.probe and rank == 0) else None
-    if args.all_modes and world == 1:
+    if args.all_modes and world == 1 and args.u16_leg:
         extra["u16_8192_ndvi_rgba_out_stats"] = config4_leg()
     if rank == 0:
         cpu = None if args.no_cpu_baseline or world > 1 else cpu_baseline(args)
@@ -508,14 +668,17 @@ def main():
                 "output_ring_tiles": args.ring if write else 0,
                 "output_ring_placement_trials": args.placement_trials if write else 0,
                 # ms per launch into each candidate arena (the fastest was kept); outside the timed region, like the warm-up
-                "output_arena_trial_ms": (getattr(runner.outputs.get(tuple(indices)), "placement_ms", None) or {}).get("arenas"),
+                "output_arena_trial_ms": placement.get("arenas"),
+                "arena": placement.get("arena"),
+                "stats_route": args.stats_route,
                 "parallelism": f"tile-sharded x{world}",
                 "collective": collective, "ranks_seen": ranks_seen,
+                "statistics_fold": "per-index fold on the device (lars_d_stats_fold), 3 x 472 B per rank exchanged",
                 "launcher": os.environ.get("LARS_BENCH_LAUNCHER", "external" if world > 1 else "none"),
                 "device": _ffi.device_name(),
             },
             "roofline": {
-                "bound": "hbm", "kernel": "k_fused_u8c3 (outputs) / k_fused_v2 (statistics only)", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                "bound": "hbm", "kernel": "k_fused_u8c3 (outputs) / k_joint_count (statistics only)", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                 "frac": achieved / HBM_PEAK_GBS, "traffic": traffic, "traffic_source": traffic_source,
                 # the whole step against the same peak: algorithmic bytes of the step (each input byte once, each output
                 # byte once -- the percentile pre-pass's second read of the input is not algorithmic) / ms_per_step
@@ -523,8 +686,11 @@ def main():
                 "algorithmic_bytes_per_pixel": bpp, "bytes_per_launch": bytes_per_launch,
                 "launches_per_step": launches, "avg_launch_ms": fused_ms / launches,
             },
-            "passes_ms": {"histogram+tables": hist_ms, "fused": fused_ms},
+            "passes_ms": {"histogram+tables": hist_ms, "fused": fused_ms, "rest_of_step": step_ms - hist_ms - fused_ms},
+            "ranks": [{"rank": int(r[0]), "ms_per_step": r[1], "fused_ms": r[2], "hist_ms": r[3], "avg_launch_ms": r[4],
+                       "arena_ms": r[5], "arena_search_ms": r[6]} for r in per_rank],
             "cpu_baseline": cpu,
+            "verified": verified,
             "global_stats": {t: {k: v for k, v in s.items() if k != "hist"} for t, s in g.items()},
         }
         if medians is not None:
@@ -537,6 +703,9 @@ def main():
             line["device_probe_GBs"] = probe
         print(json.dumps(line))
     comm.destroy()
+    if verified is not None and not verified["ok_on_every_rank"]:
+        print(f"[bench rank {rank}] self-check FAILED: {verified}", file=sys.stderr)
+        raise SystemExit(5)
 
 
 if __name__ == "__main__":

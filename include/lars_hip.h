@@ -333,6 +333,11 @@ int lars_d_probe(int kind, int unroll, int blocks, const void *src, void *dst, i
 
 /* Fold n records (same index) into one: sums add, min/max fold, histograms add. */
 int lars_stats_merge(const lars_stats *records, int64_t n, lars_stats *out);
+/* The same fold on the device, per index over the tiles of a batch: tile_records [ntiles][3] (final form) -> out[3]
+ * (entries of indices outside index_mask untouched), bit-identical to lars_stats_merge over tile_records[:, k] in tile
+ * order.  The three records are what a rank hands to lars_comm_allreduce_stats(..., is_device = 1): nothing but 3 x 472
+ * bytes leaves the device per step. */
+int lars_d_stats_fold(const lars_stats *tile_records, int64_t ntiles, uint32_t index_mask, lars_stats *out, void *stream);
 
 /* ----------------------------------------------------------- host entry points */
 

@@ -116,6 +116,7 @@ SIGNATURES = {
     "lars_d_quotient_select_hist": (_I, [_P, _I64, _I64, _I, _I, _P, _U32, _I, _P, _P, _P]),
     "lars_d_synth_u8": (_I, [_P, _I64, _I64, _I64, _I, _U32, _I, _P]),
     "lars_stats_merge": (_I, [_P, _I64, _P]),
+    "lars_d_stats_fold": (_I, [_P, _I64, _U32, _P, _P]),
     "lars_d_probe": (_I, [_I, _I, _I, _P, _P, _I64, _P]),
     "lars_set_tuning": (_I, [C.c_char_p, _I]),
     "lars_get_tuning": (_I, [C.c_char_p, C.POINTER(_I)]),

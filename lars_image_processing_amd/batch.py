@@ -41,6 +41,16 @@ def get_stats_route():
     return _STATS_ROUTE
 
 
+def channels_of(indices, whole_image=False):
+    """Channels (0 red, 1 green, 2 NIR) whose white-balance tables a pass over ``indices`` reads."""
+    if whole_image:
+        return {0, 1, 2}
+    need = set()
+    for t in indices:
+        need |= {2, 0} if t == "NDVI" else {2, 1}
+    return need
+
+
 def shard_range(ntiles, rank, world):
     """Contiguous block of tiles owned by ``rank`` (remainder to the low ranks)."""
     base, rem = divmod(int(ntiles), int(world))
@@ -68,7 +78,7 @@ class TileBatch:
         self.hist = None
         self.table = None
         self.percentiles = None
-        self._tables_complete = False      # all three channels' tables are valid (a joint pass fills only those it reads)
+        self._table_channels = set()       # channels whose tables are valid (a one-read pass fills only those its indices read)
 
     # -- construction -----------------------------------------------------
     @classmethod
@@ -110,7 +120,7 @@ class TileBatch:
             # uint16: two-level radix percentiles, no 65536-bin histograms
             _ffi.call("lars_d_wb_prepare", C.c_void_p(self.tiles.ptr), self.ntiles, self.npix, self.channels,
                       self.code, C.c_void_p(self.table.ptr), C.c_void_p(self.percentiles.ptr), int(rgn_variant), stream)
-        self._tables_complete = True
+        self._table_channels = {0, 1, 2}
         return self
 
     def host_tables(self):
@@ -228,24 +238,40 @@ class TileBatch:
     def new_stats(self):
         return DeviceBuffer(self.ntiles * 3 * STATS_DTYPE.itemsize)
 
+    def fold_stats(self, stats, indices=INDEX_NAMES, out=None, stream=None):
+        """Per-index fold of this batch's per-tile records ON THE DEVICE (``lars_d_stats_fold``): ``out`` (a DeviceBuffer of
+        3 records, allocated when None) receives what ``local_fold`` computes on the host, bit for bit -- the three
+        records a rank contributes to the global statistics, so that only 3 x 472 bytes leave the device."""
+        mask = 0
+        for t in indices:
+            mask |= 1 << INDEX_IDS[t]
+        if out is None:
+            out = DeviceBuffer(3 * STATS_DTYPE.itemsize)
+            out.zero(stream)
+        _ffi.call("lars_d_stats_fold", C.c_void_p(stats.ptr), self.ntiles, mask, C.c_void_p(out.ptr), stream)
+        return out
+
     def run_fused_chunks(self, indices, white_balance, stats, hist, outputs, stream=None, sumsq=False):
         """``lars_d_fused`` over the whole batch in launches of ``outputs.slots`` tiles (one launch without a ring); the
         statistics records are opened and closed ONCE around the launches (LARS_F_RAW) instead of by two small kernels per
         launch.  Returns the number of fused launches."""
         chunk = self.ntiles if outputs is None else outputs.slots
-        if chunk >= self.ntiles or stats is None:
+        if chunk >= self.ntiles:
             self.run_fused(self.fused_args(indices, white_balance, stats, hist, outputs, stream, sumsq=sumsq))
             return 1
         mask = 0
         for t in indices:
             mask |= 1 << INDEX_IDS[t]
-        _ffi.call("lars_d_stats_begin", C.c_void_p(stats.ptr), self.ntiles, mask, stream)
+        if stats is not None:
+            _ffi.call("lars_d_stats_begin", C.c_void_p(stats.ptr), self.ntiles, mask, stream)
         launches = 0
         for start in range(0, self.ntiles, chunk):
             count = min(chunk, self.ntiles - start)
-            self.run_fused(self.fused_args(indices, white_balance, stats, hist, outputs, stream, start, count, sumsq=sumsq, raw=True))
+            self.run_fused(self.fused_args(indices, white_balance, stats, hist, outputs, stream, start, count, sumsq=sumsq,
+                                           raw=stats is not None))
             launches += 1
-        _ffi.call("lars_d_stats_end", C.c_void_p(stats.ptr), self.ntiles, mask, self.npix, stream)
+        if stats is not None:
+            _ffi.call("lars_d_stats_end", C.c_void_p(stats.ptr), self.ntiles, mask, self.npix, stream)
         return launches
 
     # -- both passes in one persistent launch (csrc/pipeline.hip) ------------
@@ -308,8 +334,7 @@ class TileBatch:
             if self.hist is None:
                 self.hist = DeviceBuffer(self.ntiles * 3 * 256 * 4)
                 self.hist.zero(stream)
-            if (mask & 1) and (mask & 6):
-                self._tables_complete = True
+            self._table_channels |= channels_of(indices)
         a = FusedArgs()
         a.tiles = self.tiles.ptr
         a.ntiles, a.npix, a.channels, a.dtype = self.ntiles, self.npix, self.channels, self.code
@@ -350,7 +375,8 @@ class TileBatch:
             return rec, med
         if route == "joint" and outputs is None:
             raise ValueError("route='joint' serves uint8 tiles with 3 channels (4-byte aligned) only")
-        if white_balance and (recompute_tables or self.table is None or not self._tables_complete):
+        need = channels_of(indices, outputs is not None and outputs.wb is not None)
+        if white_balance and (recompute_tables or self.table is None or not need <= self._table_channels):
             self.compute_wb_tables(stream)
         stats = self.new_stats()
         stats.zero(stream)                                  # same stream as the kernels that accumulate into it
@@ -424,7 +450,7 @@ class TileBatch:
     def tile_medians(self, indices=INDEX_NAMES, white_balance=True, stream=None):
         """float64[ntiles, 3]: np.median of every tile's index planes, none of which is written
         (``lars_d_quotient_median_pairs``: per-tile two-level select on recomputed values, all on the device)."""
-        if white_balance and (self.table is None or not self._tables_complete):
+        if white_balance and (self.table is None or not channels_of(indices) <= self._table_channels):
             raise RuntimeError("compute_wb_tables() first")
         pairs_dev = DeviceBuffer(self.ntiles * 4 * 4)
         scratch = DeviceBuffer(int(_ffi.load().lars_quotient_median_scratch_bytes(self.ntiles)))
@@ -472,7 +498,7 @@ class TileBatch:
         two select passes (2048 linear buckets, then the 1024 slots of the chosen bucket, each of which holds one
         distinct quotient of bytes) that recompute the index values from the tiles (3 bytes per pixel and pass) and
         one small all-reduce per pass."""
-        if white_balance and (recompute_tables or self.table is None or not self._tables_complete):
+        if white_balance and (recompute_tables or self.table is None or not channels_of(indices) <= self._table_channels):
             self.compute_wb_tables()
         n_local = self.ntiles * self.npix
         streams = select_streams(indices)

@@ -212,6 +212,65 @@ __global__ void k_stats_finalize(lars_stats *stats, long long nrec, unsigned int
     o->max = key_f64(mxk);
 }
 
+// Fold of the per-tile records of one index into one record, on the device, with the arithmetic of lars_stats_merge
+// (host_core.cpp): the float64 sums are added in tile order by one thread (deterministic), integer fields add, extrema
+// fold.  One workgroup per index; records come in final form (after k_stats_finalize / lars_d_stats_joint).
+__global__ __launch_bounds__(256) void k_stats_fold(const lars_stats *__restrict__ rec, long long ntiles, unsigned int mask,
+                                                    lars_stats *__restrict__ out)
+{
+    const int k = blockIdx.x;
+    if (!((mask >> k) & 1u)) return;
+    __shared__ double s_sum[256], s_sq[256];
+    __shared__ double s_mn[4], s_mx[4];
+    __shared__ unsigned long long s_cnt[4][3];
+    const int tid = threadIdx.x;
+    double sum = 0.0, sq = 0.0;                                       // thread 0 only
+    double mn = __builtin_inf(), mx = -__builtin_inf();
+    unsigned long long cnt = 0, above = 0, nans = 0;
+    unsigned long long hist = 0;                                      // lane b < LARS_HIST_BINS of wave w: bin b over the tiles i = w (mod 4)
+    __shared__ unsigned long long s_hist[4][LARS_HIST_BINS];
+    for (long long base = 0; base < ntiles; base += 256) {
+        const long long t = base + tid;
+        if (t < ntiles) {
+            const lars_stats *r = rec + t * 3 + k;
+            s_sum[tid] = r->sum; s_sq[tid] = r->sumsq;
+            cnt += r->count; above += r->above; nans += r->nans;
+            mn = fmin(mn, r->min); mx = fmax(mx, r->max);
+        }
+        __syncthreads();
+        const int n = (int)(ntiles - base < 256 ? ntiles - base : 256);
+        if (tid == 0) {
+            int i = 0;
+            if (base == 0) { sum = s_sum[0]; sq = s_sq[0]; i = 1; }
+            for (; i < n; ++i) { sum += s_sum[i]; sq += s_sq[i]; }
+        }
+        if ((tid & 63) < LARS_HIST_BINS)
+            for (int i = tid >> 6; i < n; i += 4) hist += rec[(base + i) * 3 + k].hist[tid & 63];
+        __syncthreads();
+    }
+    for (int off = 32; off >= 1; off >>= 1) {
+        cnt += __shfl_xor(cnt, off); above += __shfl_xor(above, off); nans += __shfl_xor(nans, off);
+        mn = fmin(mn, __shfl_xor(mn, off)); mx = fmax(mx, __shfl_xor(mx, off));
+    }
+    if ((tid & 63) == 0) {
+        const int w = tid >> 6;
+        s_cnt[w][0] = cnt; s_cnt[w][1] = above; s_cnt[w][2] = nans; s_mn[w] = mn; s_mx[w] = mx;
+    }
+    if ((tid & 63) < LARS_HIST_BINS) s_hist[tid >> 6][tid & 63] = hist;
+    __syncthreads();
+    lars_stats *o = out + k;
+    if (tid == 0) {
+        o->sum = sum; o->sumsq = sq;
+        o->count = s_cnt[0][0] + s_cnt[1][0] + s_cnt[2][0] + s_cnt[3][0];
+        o->above = s_cnt[0][1] + s_cnt[1][1] + s_cnt[2][1] + s_cnt[3][1];
+        o->nans = s_cnt[0][2] + s_cnt[1][2] + s_cnt[2][2] + s_cnt[3][2];
+        o->min = fmin(fmin(s_mn[0], s_mn[1]), fmin(s_mn[2], s_mn[3]));
+        o->max = fmax(fmax(s_mx[0], s_mx[1]), fmax(s_mx[2], s_mx[3]));
+        o->threshold = rec[k].threshold; o->index_id = rec[k].index_id; o->reserved = rec[k].reserved;
+    }
+    if (tid < LARS_HIST_BINS) o->hist[tid] = s_hist[0][tid] + s_hist[1][tid] + s_hist[2][tid] + s_hist[3][tid];
+}
+
 // ===========================================================================
 // The fused kernel
 // ===========================================================================
@@ -803,6 +862,17 @@ extern "C" int lars_d_stats_end(lars_stats *stats, int64_t ntiles, uint32_t inde
     if (!stats || ntiles <= 0 || npix <= 0 || (index_mask & ~LARS_MASK_ALL)) return fail(LARS_ERR_INVALID, "lars_d_stats_end: bad arguments");
     stats_finalize_launch(stats, ntiles * 3, index_mask & LARS_MASK_ALL, (long long)npix, pick_stream(c, stream));
     return launch_check("lars_d_stats_end");
+}
+
+extern "C" int lars_d_stats_fold(const lars_stats *tile_records, int64_t ntiles, uint32_t index_mask, lars_stats *out, void *stream)
+{
+    ThreadCtx *c;
+    LARS_TRY(ensure_ctx(&c));
+    if (!tile_records || !out || ntiles <= 0 || !(index_mask & LARS_MASK_ALL) || (index_mask & ~LARS_MASK_ALL))
+        return fail(LARS_ERR_INVALID, "lars_d_stats_fold: bad arguments");
+    hipLaunchKernelGGL(k_stats_fold, dim3(3), dim3(256), 0, pick_stream(c, stream), tile_records, (long long)ntiles,
+                       index_mask & LARS_MASK_ALL, out);
+    return launch_check("lars_d_stats_fold");
 }
 
 extern "C" int lars_d_synth_u8(uint8_t *tiles, int64_t ntiles, int64_t first_tile, int64_t npix, int channels,

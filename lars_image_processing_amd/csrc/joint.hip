@@ -221,33 +221,51 @@ struct JointFinishParams {
     float *out_pairs;                         // [ntiles][2 streams][2] or null: the two middle order statistics
 };
 
-// block-wide exclusive position of a rank in a histogram of NB bins (NB = 2048 or 1024), two ranks at once:
-// bin[k] = first bin whose cumulative count exceeds rank[k], before[k] = count below that bin.  256 threads take part.
+// Exclusive prefix of one value per thread over the first 256 threads of the block (4 waves): wave scans + one barrier.
+// Every thread of the block must call it (threads >= 256 pass 0 and get nothing useful back).  s_w: 4 words of LDS.
+__device__ inline unsigned long long jf_prefix256(unsigned long long v, int tid, unsigned long long *s_w)
+{
+    unsigned long long inc = v;
+    const int lane = tid & 63;
+    for (int off = 1; off < 64; off <<= 1) {
+        const unsigned long long o = __shfl_up(inc, off);
+        if (lane >= off) inc += o;
+    }
+    __syncthreads();                                       // s_w may still be read by the previous call
+    if (tid < 256 && lane == 63) s_w[tid >> 6] = inc;
+    __syncthreads();
+    unsigned long long base = 0;
+    for (int w = 0; w < (tid >> 6) && w < 4; ++w) base += s_w[w];
+    return base + inc - v;
+}
+
+// Position of two ranks in a histogram of NB bins (NB = 2048 or 1024): s_bin[k] = first bin whose cumulative count
+// exceeds rank[k], s_before[k] = the count below that bin.  The first 256 threads own NB / 256 consecutive bins each.
 template <int NB>
-__device__ inline void jf_pick(const unsigned int *h, const unsigned long long rank[2], unsigned int *s_grp /*[256]*/,
-                               unsigned int *s_bin /*[2]*/, unsigned long long *s_before /*[2]*/, int tid)
+__device__ inline void jf_pick(const unsigned int *h, unsigned long long rank0, unsigned long long rank1,
+                               unsigned long long *s_w, unsigned int *s_bin /*[2]*/, unsigned long long *s_before /*[2]*/, int tid)
 {
     constexpr int PER = NB / 256;
+    unsigned int mine[PER];
+    unsigned long long local = 0;
     if (tid < 256) {
-        unsigned int t = 0;
-        for (int j = 0; j < PER; ++j) t += h[tid * PER + j];
-        s_grp[tid] = t;
+#pragma unroll
+        for (int j = 0; j < PER; ++j) { mine[j] = h[tid * PER + j]; local += mine[j]; }
     }
-    __syncthreads();
-    if (tid < 2) {
-        unsigned long long cum = 0;
-        int g = 0;
-        for (; g < 255; ++g) {
-            if (rank[tid] < cum + s_grp[g]) break;
-            cum += s_grp[g];
+    const unsigned long long before = jf_prefix256(local, tid, s_w);
+    if (tid < 256) {
+        const unsigned long long rk[2] = {rank0, rank1};
+#pragma unroll
+        for (int k = 0; k < 2; ++k) {
+            if (rk[k] >= before && rk[k] < before + local) {
+                unsigned long long cum = before;
+#pragma unroll
+                for (int j = 0; j < PER; ++j) {
+                    if (rk[k] >= cum && rk[k] < cum + mine[j]) { s_bin[k] = (unsigned)(tid * PER + j); s_before[k] = cum; }
+                    cum += mine[j];
+                }
+            }
         }
-        int b = g * PER;
-        for (; b < g * PER + PER - 1; ++b) {
-            if (rank[tid] < cum + h[b]) break;
-            cum += h[b];
-        }
-        s_bin[tid] = (unsigned)b;
-        s_before[tid] = cum;
     }
     __syncthreads();
 }
@@ -259,7 +277,7 @@ __global__ __launch_bounds__(JH_THREADS) void k_joint_finish(JointFinishParams P
     __shared__ double s_ord[2][4], s_p[2][2];
     __shared__ unsigned int s_bucket[SELQ_BINS];
     __shared__ unsigned int s_slot[2][SELQ_SLOTS];
-    __shared__ unsigned int s_grp[256];
+    __shared__ unsigned long long s_w[2][4];
     __shared__ unsigned int s_bin[2];
     __shared__ unsigned long long s_before[2];
     __shared__ unsigned int s_h50[2][LARS_HIST_BINS + 2];          // [plain | negated][bin + 1]
@@ -279,6 +297,7 @@ __global__ __launch_bounds__(JH_THREADS) void k_joint_finish(JointFinishParams P
     const bool want_v = !green && (P.mask & LARS_MASK_NDVI);
     const bool want_g = green && (P.mask & LARS_MASK_GNDVI);
     const bool want_w = green && (P.mask & LARS_MASK_NDWI);
+    const bool medians = P.out_pairs != nullptr;
 
     if (tid < 256) { s_hn[tid] = 0; s_hx[tid] = 0; }
     for (int i = tid; i < SELQ_BINS; i += JH_THREADS) s_bucket[i] = 0;
@@ -287,24 +306,47 @@ __global__ __launch_bounds__(JH_THREADS) void k_joint_finish(JointFinishParams P
     if (tid < 4) s_acc[tid] = 0;
     if (tid == 0) { s_mnk = 0xFFFFFFFFu; s_mxk = 0u; }
     if (tid < 2) s_med[tid] = __builtin_nanf("");
-    __syncthreads();
 
-    // this thread's dwords: D = j * 1024 + tid; cells S = 2D, 2D + 1; x = S >> 8 = D >> 7 (wave-uniform), n = (S & 255) ^ x
-    auto load_pair = [&](int j, unsigned int &c0, unsigned int &c1) {
-        const long long D = (long long)j * JH_THREADS + tid;
-        c0 = 0; c1 = 0;
-        for (int k = 0; k < P.K; ++k) {
-            const uint2 v = *reinterpret_cast<const uint2 *>(part + (long long)k * (2 * JH_DWORDS) + 2 * D);
-            c0 += v.x; c1 += v.y;
+    // This thread's 64 cells: dwords D = j * 1024 + tid (j < 32), cells S = 2D, 2D + 1; x = S >> 8 = D >> 7 (the same for
+    // the 64 lanes of a wave), n = (S & 255) ^ x.  Every pass below walks them in four groups of eight dwords, the next
+    // group's loads (L2 hits: the counting kernel has just written them) in flight while the current one is worked on.
+    constexpr int NJ = JH_DWORDS / JH_THREADS;                       // 32
+    constexpr int GRP = 8;
+    auto for_cells = [&](auto &&f) {
+        uint2 buf[2][GRP];
+        auto fetch = [&](int g, uint2 (&dst)[GRP]) {
+#pragma unroll
+            for (int i = 0; i < GRP; ++i)
+                dst[i] = *reinterpret_cast<const uint2 *>(part + 2 * ((long long)(g * GRP + i) * JH_THREADS + tid));
+            for (int k = 1; k < P.K; ++k) {
+                const unsigned int *pk = part + (long long)k * (2 * JH_DWORDS);
+#pragma unroll
+                for (int i = 0; i < GRP; ++i) {
+                    const uint2 v = *reinterpret_cast<const uint2 *>(pk + 2 * ((long long)(g * GRP + i) * JH_THREADS + tid));
+                    dst[i].x += v.x; dst[i].y += v.y;
+                }
+            }
+        };
+        auto work = [&](int g, const uint2 (&src)[GRP]) {
+#pragma unroll
+            for (int i = 0; i < GRP; ++i) {
+                f((unsigned)(g * GRP + i) * JH_THREADS + (unsigned)tid, src[i].x, src[i].y);
+                __builtin_amdgcn_sched_barrier(0);
+            }
+        };
+        fetch(0, buf[0]);
+#pragma unroll 1
+        for (int g = 0; g < NJ / GRP; g += 2) {
+            fetch(g + 1, buf[1]);
+            work(g, buf[0]);
+            if (g + 2 < NJ / GRP) fetch(g + 2, buf[0]);
+            work(g + 1, buf[1]);
         }
     };
-    constexpr int NJ = JH_DWORDS / JH_THREADS;                       // 32
+    __syncthreads();
 
     // ---- marginals: the channel histograms np.percentile needs
-    for (int j = 0; j < NJ; ++j) {
-        unsigned int c0, c1;
-        load_pair(j, c0, c1);
-        const unsigned int D = (unsigned)j * JH_THREADS + tid;
+    for_cells([&](unsigned int D, unsigned int c0, unsigned int c1) {
         const unsigned int x = D >> 7;
         const unsigned int n0 = ((2u * D) & 255u) ^ x, n1 = ((2u * D + 1u) & 255u) ^ x;
         if (c0) atomicAdd(&s_hn[n0], c0);
@@ -312,7 +354,7 @@ __global__ __launch_bounds__(JH_THREADS) void k_joint_finish(JointFinishParams P
         unsigned int t = c0 + c1;
         for (int off = 32; off >= 1; off >>= 1) t += __shfl_xor(t, off);
         if ((tid & 63) == 0 && t) atomicAdd(&s_hx[x], t);            // D >> 7 is the same for the 64 lanes of a wave
-    }
+    });
     __syncthreads();
     if (P.hist_out) {
         unsigned int *ho = P.hist_out + tile * 768;
@@ -322,39 +364,51 @@ __global__ __launch_bounds__(JH_THREADS) void k_joint_finish(JointFinishParams P
         }
     }
 
-    // ---- np.percentile(ch, (2, 98)), 'linear' + numpy's _lerp (the arithmetic of k_wb_table, fused.hip)
+    // ---- np.percentile(ch, (2, 98)), 'linear' + numpy's _lerp (the arithmetic of k_wb_table, fused.hip).
+    // Threads 0..255 hold the NIR histogram, 256..511 the paired channel's: one bin each, prefix by wave scans.
     const long long npix = P.npix;
     if (P.wb) {
-        if (tid < 8) {
-            const int ch = tid >> 2, r = tid & 3;                    // ch 0: NIR, 1: the paired sample
-            const unsigned int *h = ch ? s_hx : s_hn;
-            const double q = ((r >> 1) == 0 ? 2.0 : 98.0) / 100.0;
-            const double vi = (double)(npix - 1) * q;
-            long long rank = (long long)floor(vi);
-            if (r & 1) { rank += 1; if (rank > npix - 1) rank = npix - 1; }
-            unsigned long long cum = 0;
-            double val = 0.0;
-            for (int b = 0; b < 256; ++b) {
-                const unsigned long long c = h[b];
-                if (c && (unsigned long long)rank >= cum && (unsigned long long)rank < cum + c) val = (double)b;
-                cum += c;
+        const int ch = (tid >> 8) & 1, bin = tid & 255;
+        const unsigned long long cnt = tid < 512 ? (unsigned long long)(ch ? s_hx : s_hn)[bin] : 0ull;
+        // two independent 256-thread prefixes: threads 256..511 are shifted down for the helper
+        unsigned long long before;
+        {
+            unsigned long long inc = cnt;
+            const int lane = tid & 63;
+            for (int off = 1; off < 64; off <<= 1) {
+                const unsigned long long o = __shfl_up(inc, off);
+                if (lane >= off) inc += o;
             }
-            s_ord[ch][r] = val;
+            if (tid < 512 && lane == 63) s_w[ch][(tid >> 6) & 3] = inc;
+            __syncthreads();
+            unsigned long long base = 0;
+            for (int w = 0; w < ((tid >> 6) & 3); ++w) base += s_w[ch][w];
+            before = base + inc - cnt;
+        }
+        if (tid < 512 && cnt) {
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const double q = ((r >> 1) == 0 ? 2.0 : 98.0) / 100.0;
+                const double vi = (double)(npix - 1) * q;
+                long long rank = (long long)floor(vi);
+                if (r & 1) { rank += 1; if (rank > npix - 1) rank = npix - 1; }
+                if ((unsigned long long)rank >= before && (unsigned long long)rank < before + cnt) s_ord[ch][r] = (double)bin;
+            }
         }
         __syncthreads();
         if (tid < 4) {
-            const int ch = tid >> 1, k = tid & 1;
+            const int pc = tid >> 1, k = tid & 1;
             const double q = (k == 0 ? 2.0 : 98.0) / 100.0;
             const double vi = (double)(npix - 1) * q;
             const double t = vi - floor(vi);
-            const double a = s_ord[ch][2 * k], b = s_ord[ch][2 * k + 1];
+            const double a = s_ord[pc][2 * k], b = s_ord[pc][2 * k + 1];
             const double d = b - a;
             double r = a + d * t;
             if (t >= 0.5) r = b - d * (1.0 - t);
-            s_p[ch][k] = r;
+            s_p[pc][k] = r;
             if (P.pcts_out) {
-                const int c = ch ? xch : 2;
-                if (ch || !green || P.S == 1) P.pcts_out[(tile * 3 + c) * 2 + k] = r;
+                const int cc = pc ? xch : 2;
+                if (pc || !green || P.S == 1) P.pcts_out[(tile * 3 + cc) * 2 + k] = r;
             }
         }
         __syncthreads();
@@ -364,31 +418,29 @@ __global__ __launch_bounds__(JH_THREADS) void k_joint_finish(JointFinishParams P
         const unsigned int level = P.wb ? wb_level(v, s_p[ch][0], s_p[ch][1], P.rgn_variant) : (unsigned)v;
         (ch ? s_fx : s_fn)[v] = (float)level;
         if (P.wb && P.table_out) {
-            const int c = ch ? xch : 2;
-            if (ch || !green || P.S == 1) P.table_out[(tile * 3 + c) * 256 + v] = (uint8_t)level;
+            const int cc = ch ? xch : 2;
+            if (ch || !green || P.S == 1) P.table_out[(tile * 3 + cc) * 256 + v] = (uint8_t)level;
         }
     }
     __syncthreads();
 
     // ---- statistics of the stream's quotient (n' - x') / (n' + x') over the cells
-    const bool medians = P.out_pairs != nullptr;
     {
         long long sum_fx = 0;
         unsigned long long above = 0, below0 = 0;
         double sumsq = 0.0;
         float mn = __builtin_inff(), mx = -__builtin_inff();
-        for (int j = 0; j < NJ; ++j) {
-            unsigned int c[2];
-            load_pair(j, c[0], c[1]);
-            const unsigned int D = (unsigned)j * JH_THREADS + tid;
+        for_cells([&](unsigned int D, unsigned int c0, unsigned int c1) {
+            const unsigned int cc[2] = {c0, c1};
             const unsigned int x = D >> 7;
             const float fx = s_fx[x];
 #pragma unroll
             for (int h = 0; h < 2; ++h) {
-                if (!c[h]) continue;
+                const unsigned int cv = cc[h];
+                if (!cv) continue;
                 const unsigned int n = ((2u * D + (unsigned)h) & 255u) ^ x;
                 const float q = norm_diff(s_fn[n], fx);
-                const long long cnt = (long long)c[h];
+                const long long cnt = (long long)cv;
                 sum_fx += cnt * (long long)((double)q * LARS_FX_SCALE);          // q is a multiple of 2^-32: exact
                 mn = fminf(mn, q);
                 mx = fmaxf(mx, q);
@@ -398,15 +450,15 @@ __global__ __launch_bounds__(JH_THREADS) void k_joint_finish(JointFinishParams P
                 if (want_hist) {
                     // bin + 1 in the low mantissa bits (hist_pos2, fused_v2.hip); 51 = the closed right edge
                     const float u = __builtin_fmaf(q, 25.0f, V2_HIST_MAGIC_C) + 8388608.0f;
-                    atomicAdd(&s_h50[0][__builtin_bit_cast(unsigned int, u) & 0x7FFFFFu], c[h]);
+                    atomicAdd(&s_h50[0][__builtin_bit_cast(unsigned int, u) & 0x7FFFFFu], cv);
                     if (want_w) {
                         const float uw = __builtin_fmaf(q, -25.0f, V2_HIST_MAGIC_C) + 8388608.0f;
-                        atomicAdd(&s_h50[1][__builtin_bit_cast(unsigned int, uw) & 0x7FFFFFu], c[h]);
+                        atomicAdd(&s_h50[1][__builtin_bit_cast(unsigned int, uw) & 0x7FFFFFu], cv);
                     }
                 }
-                if (medians) atomicAdd(&s_bucket[selq_bucket_of(selq_t(q))], c[h]);
+                if (medians) atomicAdd(&s_bucket[selq_bucket_of(selq_t(q))], cv);
             }
-        }
+        });
         for (int off = 32; off >= 1; off >>= 1) {
             sum_fx += __shfl_xor(sum_fx, off);
             above += __shfl_xor(above, off);
@@ -428,57 +480,49 @@ __global__ __launch_bounds__(JH_THREADS) void k_joint_finish(JointFinishParams P
 
     // ---- exact median: weighted two-level select (bucket, then slot: a slot holds one distinct quotient of bytes)
     if (medians) {
-        const unsigned long long rank[2] = {(unsigned long long)((npix - 1) / 2), (unsigned long long)(npix / 2)};
-        jf_pick<SELQ_BINS>(s_bucket, rank, s_grp, s_bin, s_before, tid);
+        const unsigned long long rank0 = (unsigned long long)((npix - 1) / 2), rank1 = (unsigned long long)(npix / 2);
+        jf_pick<SELQ_BINS>(s_bucket, rank0, rank1, s_w[0], s_bin, s_before, tid);
         const unsigned int bk0 = s_bin[0], bk1 = s_bin[1];
-        const unsigned long long in0 = rank[0] - s_before[0], in1 = rank[1] - s_before[1];
+        const unsigned long long in0 = rank0 - s_before[0], in1 = rank1 - s_before[1];
         __syncthreads();
-        for (int j = 0; j < NJ; ++j) {
-            unsigned int c[2];
-            load_pair(j, c[0], c[1]);
-            const unsigned int D = (unsigned)j * JH_THREADS + tid;
+        for_cells([&](unsigned int D, unsigned int c0, unsigned int c1) {
+            const unsigned int cc[2] = {c0, c1};
             const unsigned int x = D >> 7;
             const float fx = s_fx[x];
 #pragma unroll
             for (int h = 0; h < 2; ++h) {
-                if (!c[h]) continue;
+                const unsigned int cv = cc[h];
+                if (!cv) continue;
                 const unsigned int n = ((2u * D + (unsigned)h) & 255u) ^ x;
                 const float t = selq_t(norm_diff(s_fn[n], fx));
                 const unsigned int b = selq_bucket_of(t), sl = (__builtin_bit_cast(unsigned int, t) & 0xFFFu) >> 2;
-                if (b == bk0) atomicAdd(&s_slot[0][sl], c[h]);
-                if (b == bk1) atomicAdd(&s_slot[1][sl], c[h]);
+                if (b == bk0) atomicAdd(&s_slot[0][sl], cv);
+                if (b == bk1) atomicAdd(&s_slot[1][sl], cv);
             }
-        }
+        });
         __syncthreads();
-        // slot of each track inside its bucket (jf_pick works on one histogram: run it per track)
-        unsigned int slot[2];
-        {
-            const unsigned long long r0[2] = {in0, in0};
-            jf_pick<SELQ_SLOTS>(s_slot[0], r0, s_grp, s_bin, s_before, tid);
-            slot[0] = s_bin[0];
-            __syncthreads();
-            const unsigned long long r1[2] = {in1, in1};
-            jf_pick<SELQ_SLOTS>(s_slot[1], r1, s_grp, s_bin, s_before, tid);
-            slot[1] = s_bin[0];
-            __syncthreads();
-        }
-        for (int j = 0; j < NJ; ++j) {
-            unsigned int c[2];
-            load_pair(j, c[0], c[1]);
-            const unsigned int D = (unsigned)j * JH_THREADS + tid;
+        // slot of each track inside its bucket (one histogram per call)
+        jf_pick<SELQ_SLOTS>(s_slot[0], in0, in0, s_w[0], s_bin, s_before, tid);
+        const unsigned int slot0 = s_bin[0];
+        __syncthreads();
+        jf_pick<SELQ_SLOTS>(s_slot[1], in1, in1, s_w[0], s_bin, s_before, tid);
+        const unsigned int slot1 = s_bin[0];
+        __syncthreads();
+        for_cells([&](unsigned int D, unsigned int c0, unsigned int c1) {
+            const unsigned int cc[2] = {c0, c1};
             const unsigned int x = D >> 7;
             const float fx = s_fx[x];
 #pragma unroll
             for (int h = 0; h < 2; ++h) {
-                if (!c[h]) continue;
+                if (!cc[h]) continue;
                 const unsigned int n = ((2u * D + (unsigned)h) & 255u) ^ x;
                 const float q = norm_diff(s_fn[n], fx);
                 const float t = selq_t(q);
                 const unsigned int b = selq_bucket_of(t), sl = (__builtin_bit_cast(unsigned int, t) & 0xFFFu) >> 2;
-                if (b == bk0 && sl == slot[0]) s_med[0] = q;          // every writer holds the same value
-                if (b == bk1 && sl == slot[1]) s_med[1] = q;
+                if (b == bk0 && sl == slot0) s_med[0] = q;            // every writer holds the same value
+                if (b == bk1 && sl == slot1) s_med[1] = q;
             }
-        }
+        });
         __syncthreads();
         if (tid < 2) P.out_pairs[(tile * 2 + (green ? 1 : 0)) * 2 + tid] = s_med[tid];
         if (P.S == 1 && tid >= 2 && tid < 4) P.out_pairs[(tile * 2 + (green ? 0 : 1)) * 2 + (tid - 2)] = __builtin_nanf("");   // the stream nobody asked for
@@ -494,9 +538,9 @@ __global__ __launch_bounds__(JH_THREADS) void k_joint_finish(JointFinishParams P
             lars_stats *o = P.stats + tile * 3 + k;
             const long long s = (long long)s_acc[0];
             const double mnd = (double)key_f32(s_mnk), mxd = (double)key_f32(s_mxk);
-            o->sum = (double)(neg ? -s : s) * LARS_FX_INV;
             double sq = 0.0;
             for (int w = 0; w < JH_THREADS / 64; ++w) sq += s_wsq[w];
+            o->sum = (double)(neg ? -s : s) * LARS_FX_INV;
             o->sumsq = want_sq ? (double)__double2ll_rn(sq * LARS_FX_SCALE) * LARS_FX_INV : 0.0;
             o->count = (uint64_t)npix;
             o->above = neg ? s_acc[2] : s_acc[1];
@@ -523,7 +567,6 @@ __global__ __launch_bounds__(JH_THREADS) void k_joint_finish(JointFinishParams P
         }
     }
 }
-
 }  // namespace lars
 
 using namespace lars;

@@ -157,6 +157,15 @@ def forget_agreement(world, phases=("pre", "up")):
                 pass
 
 
+def release_agreement(comm, rank, world, phases=("pre", "up")):
+    """Every rank calls this once it is past its last ``agree``: the markers may only go when EVERY rank has left the
+    polling loop (a rank that still waits for a marker somebody has deleted would time out and choose differently), so the
+    ranks meet in a barrier of the communicator they agreed on, and only then does rank 0 remove the files."""
+    comm.barrier()
+    if rank == 0:
+        forget_agreement(world, phases)
+
+
 class Comm:
     """RCCL communicator of this process (rank = one GPU)."""
 
@@ -193,10 +202,21 @@ class Comm:
         _ffi.call("lars_comm_allreduce_stats", self._h, _ffi.ptr(rec), rec.size, 0, None)
         return rec
 
+    def allreduce_stats_device(self, records_dev, n=3, stream=None):
+        """``records_dev``: a DeviceBuffer of ``n`` records (e.g. ``TileBatch.fold_stats``).  The all-gather reads and the
+        fold over ranks lands in that device memory (``lars_comm_allreduce_stats(is_device=1)``); returns the folded records
+        as a host array as well."""
+        _ffi.call("lars_comm_allreduce_stats", self._h, C.c_void_p(records_dev.ptr), int(n), 1, stream)
+        return records_dev.download(STATS_DTYPE, (int(n),))
+
     def allreduce_f64(self, values, op="sum"):
         v = np.ascontiguousarray(values, dtype=np.float64).reshape(-1).copy()
         _ffi.call("lars_comm_allreduce_f64", self._h, _ffi.ptr(v), v.size, {"sum": 0, "max": 1, "min": 2}[op])
         return v
+
+    def allgather_f64(self, values):
+        """[world, len(values)]: every rank's vector (an all-reduce of a vector that is zero outside the rank's own row)."""
+        return _allgather_by_sum(self, values)
 
     def barrier(self):
         _ffi.call("lars_comm_barrier", self._h)
@@ -217,8 +237,15 @@ class SingleProcessComm:
     def allreduce_stats(self, records):
         return np.ascontiguousarray(records, dtype=STATS_DTYPE).reshape(-1).copy()
 
+    def allreduce_stats_device(self, records_dev, n=3, stream=None):
+        _ffi.call("lars_synchronize", stream)
+        return records_dev.download(STATS_DTYPE, (int(n),))
+
     def allreduce_f64(self, values, op="sum"):
         return np.ascontiguousarray(values, dtype=np.float64).reshape(-1).copy()
+
+    def allgather_f64(self, values):
+        return np.ascontiguousarray(values, dtype=np.float64).reshape(1, -1).copy()
 
     def barrier(self):
         pass
@@ -276,6 +303,17 @@ class TorchComm:
         per_rank = [g.cpu().numpy().view(STATS_DTYPE) for g in gathered]
         return fold_gathered(per_rank)
 
+    def allreduce_stats_device(self, records_dev, n=3, stream=None):
+        """The device-resident records of this rank through the torch group: 3 x 472 bytes come to the host, the fold over
+        ranks goes back into ``records_dev`` (as the RCCL path leaves it) and is returned."""
+        _ffi.call("lars_synchronize", stream)
+        out = self.allreduce_stats(records_dev.download(STATS_DTYPE, (int(n),)))
+        records_dev.upload(out)
+        return out
+
+    def allgather_f64(self, values):
+        return _allgather_by_sum(self, values)
+
     def allreduce_f64(self, values, op="sum"):
         torch, td = self._torch, self._td
         t = torch.from_numpy(np.ascontiguousarray(values, dtype=np.float64).reshape(-1).copy()).to(self.device)
@@ -294,6 +332,13 @@ class TorchComm:
         if self._owns_group and self._td.is_initialized():
             self._td.destroy_process_group()
         self._owns_group = False
+
+
+def _allgather_by_sum(comm, values):
+    v = np.ascontiguousarray(values, dtype=np.float64).reshape(-1)
+    wide = np.zeros((comm.world, v.size), dtype=np.float64)
+    wide[comm.rank] = v
+    return np.asarray(comm.allreduce_f64(wide.reshape(-1), "sum")).reshape(comm.world, v.size)
 
 
 def fold_gathered(per_rank_records):

@@ -64,6 +64,10 @@ def main():
         local["min"], local["max"] = np.inf, -np.inf
     glob = comm.allreduce_stats(local)
     comm.barrier()
+    # the per-rank diagnostics of bench.py's line travel the same way: every rank's vector, in rank order, on every rank
+    rows = comm.allgather_f64([rank, 10.0 * rank + 0.5, float(hi - lo)])
+    assert rows.shape == (world, 3) and rows[:, 0].tolist() == list(range(world))
+    assert rows[:, 1].tolist() == [10.0 * r + 0.5 for r in range(world)] and int(rows[:, 2].sum()) == ntiles
 
     # 3. every rank must hold the same bytes, equal to the single-process fold over all tiles
     everything = tile_records(list(range(ntiles)), h, w)

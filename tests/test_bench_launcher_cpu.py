@@ -112,5 +112,31 @@ def test_ranks_agree_on_the_transport_before_any_blocking_bootstrap(tmp_path, mo
     assert out == {r: (True, False) for r in range(3)}
     dist.forget_agreement(3)
     assert not [name for name in os.listdir(tmp_path) if ".pre" in name or ".up" in name]
+    # Rank 0 is the LAST to vote and removes the markers as soon as it may: the others, still polling every 10 ms, must not
+    # lose its marker -- release_agreement holds the deletion back behind a barrier of the agreed communicator.
+    class ThreadComm:
+        def __init__(self, barrier):
+            self._b = barrier
+
+        def barrier(self):
+            self._b.wait(timeout=30)
+
+    import time
+    for _ in range(5):
+        barrier, out = threading.Barrier(3), {}
+
+        def rank_body(r):
+            if r == 0:
+                time.sleep(0.15)                                 # arrives last: sees every marker at its first scan
+            ok = dist.agree(r, 3, True, 10.0, phase="up")
+            dist.release_agreement(ThreadComm(barrier), r, 3)
+            out[r] = ok
+        threads = [threading.Thread(target=rank_body, args=(r,)) for r in range(3)]
+        for t in threads:
+            t.start()
+        for t in threads:
+            t.join()
+        assert out == {0: True, 1: True, 2: True}
+        assert not [name for name in os.listdir(tmp_path) if ".pre" in name or ".up" in name]
     # the library's own pre-flight check answers without a GPU: librccl is part of the ROCm image
     assert _ffi.load().lars_comm_available() in (0, -6, -7, -8, -5, -4, -3)

@@ -123,6 +123,27 @@ def test_one_rank_share_of_the_sharded_batch(lars):
     b.free()
 
 
+@pytest.mark.parametrize("ntiles", [1, 37, 300])
+def test_device_fold_equals_host_fold(lars, ntiles):
+    """lars_d_stats_fold: the per-index fold of a batch's per-tile records on the device is lars_stats_merge over the
+    tiles in tile order, bit for bit (sums added in the same order); indices outside the mask stay untouched."""
+    from lars_image_processing_amd import _ffi, batch as lb
+    b = lars.TileBatch.synthetic(ntiles, 32, 48, seed=5, profile="vegetation")
+    b.compute_wb_tables()
+    stats = b.new_stats()
+    stats.zero()
+    b.run_fused(b.fused_args(TYPES, True, stats, True, sumsq=True))
+    for indices in (TYPES, ("NDVI", "NDWI"), ("GNDVI",)):
+        folded = b.fold_stats(stats, indices)
+        _ffi.call("lars_synchronize", None)
+        got = folded.download(_ffi.STATS_DTYPE, (3,))
+        want = lb.local_fold(stats.download(_ffi.STATS_DTYPE, (ntiles, 3)), indices)
+        assert got.tobytes() == want.tobytes(), indices
+        folded.free()
+    stats.free()
+    b.free()
+
+
 def test_stats_only_equals_stats_with_outputs_and_ring(lars):
     b = lars.TileBatch.synthetic(8, 128, 128, seed=7, profile="vegetation")
     rec_a = b.process(hist=True, sumsq=True)

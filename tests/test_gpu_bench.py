@@ -15,7 +15,8 @@ def run_bench(extra_env, *args):
     env = dict(os.environ, RANK="0", LOCAL_RANK="0", WORLD_SIZE="1", MASTER_ADDR="127.0.0.1", MASTER_PORT="29731",
                LARS_RDZV_TOKEN=f"bench{os.getpid()}", **extra_env)
     cmd = [sys.executable, os.path.join(ROOT, "bench.py"), "--tiles", "6", "--tile", "512", "--ring", "4", "--steps", "2",
-           "--warmup", "1", "--no-all-modes", "--no-probe", "--placement-trials", "2", *args]
+           "--warmup", "1", "--no-probe", "--placement-trials", "2", *(a for a in args if a != "--all-modes"),
+           *(() if "--all-modes" in args else ("--no-all-modes",))]
     out = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=600, cwd=ROOT)
     assert out.returncode == 0, out.stderr[-2000:]
     lines = [ln for ln in out.stdout.splitlines() if ln.startswith("{")]
@@ -46,6 +47,19 @@ def check_line(line, tiles=6, tile=512):
     assert line["config"]["ranks_seen"] == line["n_gpus"]
     for name in ("NDVI", "GNDVI", "NDWI"):
         assert line["global_stats"][name]["count"] == tiles * tile * tile
+    # the self-check after the timed region: records (and ring planes) of sampled tiles against single-tile runs
+    ver = line["verified"]
+    assert ver["ok"] is True and ver["ok_on_every_rank"] is True and ver["records"] is True and ver["planes"] is True
+    assert ver["global_stats_identical_across_modes"] is True and len(ver["record_tiles"]) >= 2
+    # one entry per rank, gathered over the communicator; the slowest rank is the line's step time
+    assert [r["rank"] for r in line["ranks"]] == list(range(line["n_gpus"]))
+    for r in line["ranks"]:
+        for key in ("ms_per_step", "fused_ms", "hist_ms", "avg_launch_ms", "arena_ms", "arena_search_ms"):
+            assert key in r, key
+        assert 0 < r["ms_per_step"] <= line["ms_per_step"] * (1 + 1e-9) and r["fused_ms"] > 0
+    assert abs(max(r["ms_per_step"] for r in line["ranks"]) - line["ms_per_step"]) <= 1e-6 * line["ms_per_step"]
+    assert "lars_d_stats_fold" in line["config"]["statistics_fold"] and line["config"]["stats_route"] in ("joint", "classic")
+    assert abs(line["passes_ms"]["rest_of_step"] - (line["ms_per_step"] - line["passes_ms"]["histogram+tables"] - line["passes_ms"]["fused"])) < 1e-9
 
 
 def test_bench_line_single_process():
@@ -53,7 +67,29 @@ def test_bench_line_single_process():
     check_line(line)
     cpu = line["cpu_baseline"]
     assert cpu["kind"] == "port" and cpu["cores"] == 1 and cpu["unit"] == "Mpix/s" and cpu["value"] > 0
+    # best of 3, per-step breakdown, the job of the like-for-like GPU mode
+    assert len(cpu["runs_s"]) == 3 and abs(min(cpu["runs_s"]) - 512 * 512 / cpu["value"] / 1e6) < 1e-6 * min(cpu["runs_s"])
+    assert sorted(cpu["steps_s_per_tile"]) == sorted(["wb", "index_NDVI", "index_GNDVI", "index_NDWI", "stats_NDVI", "stats_GNDVI", "stats_NDWI"])
+    assert abs(sum(cpu["steps_s_per_tile"].values()) - min(cpu["runs_s"])) < 1e-9 and cpu["same_job_as_gpu_mode"] == "wb3idx_out_stats_medians"
+    assert cpu["pool"]["cores"] == 2 and "why_not_all_cpus" in cpu["pool"]
     assert line["config"]["collective"].startswith("none")
+
+
+def test_bench_all_modes_and_their_self_check():
+    """Every mode of the line on a small batch: the like-for-like mode (planes + statistics + medians), the one-read route
+    next to the two-pass route for the statistics-only modes, and the self-check of the modes with medians."""
+    line = run_bench({}, "--no-cpu-baseline", "--all-modes", "--no-u16-leg")
+    check_line(line)
+    modes = line["modes"]
+    for name in ("wb3idx_out_stats_hist", "wb_ndvi_out_stats", "wb3idx_stats_only", "wb_ndvi_stats_only", "wb3idx_stats_medians",
+                 "wb3idx_out_stats_medians", "wb3idx_stats_only_classic", "wb_ndvi_stats_only_classic", "wb3idx_stats_medians_classic"):
+        assert name in modes and modes[name]["Mpix_s"] > 0 and 0 < modes[name]["whole_step_frac"] < 1, name
+    assert "one read" in modes["wb_ndvi_stats_only"]["route"] and "histogram pass" in modes["wb_ndvi_stats_only_classic"]["route"]
+    for name in ("wb3idx_stats_medians", "wb3idx_out_stats_medians"):
+        assert line["verified"][name] == {"records": True, "planes": (True if name == "wb3idx_out_stats_medians" else None), "medians": True, "ok": True}
+    assert len(line["verified"]["modes_compared"]) == 10
+    for name in ("NDVI", "GNDVI", "NDWI"):
+        assert "median" in line["global_stats"][name]
 
 
 @pytest.mark.parametrize("transport", ["rccl", "torch", "auto"])
@@ -77,7 +113,7 @@ def test_bench_moves_to_torch_when_the_library_communicator_does_not_come_up():
     assert line["global_stats"] == base["global_stats"]
 
 
-@pytest.mark.parametrize("ranks", [2, 3])
+@pytest.mark.parametrize("ranks", [2, 3, 4])
 def test_ranks_on_one_gpu_equal_one_process_over_all_tiles(tmp_path, ranks):
     """The N > 1 flow end to end on real kernels: `ranks` ranks (all on GPU 0, statistics exchanged over gloo) with
     12 / ranks tiles each must report the global statistics and medians of one process over the same 12 tiles (rank r
@@ -101,6 +137,8 @@ def test_ranks_on_one_gpu_equal_one_process_over_all_tiles(tmp_path, ranks):
     assert out1.returncode == 0, out1.stderr[-2000:]
     one = json.loads([ln for ln in out1.stdout.splitlines() if ln.startswith("{")][0])
     assert two["n_gpus"] == ranks and two["scaling"] == "weak" and "gloo" in two["config"]["collective"]
+    assert [r["rank"] for r in two["ranks"]] == list(range(ranks)) and two["verified"]["ok_on_every_rank"] is True
+    assert abs(max(r["ms_per_step"] for r in two["ranks"]) - two["ms_per_step"]) <= 1e-6 * two["ms_per_step"]
     assert two["config"]["tiles_per_gpu"] == per_rank and one["config"]["tiles_per_gpu"] == 12
     assert two["global_stats"] == one["global_stats"]
     for name in ("NDVI", "GNDVI", "NDWI"):

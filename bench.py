@@ -72,10 +72,12 @@ def parse():
                     help="skip timing the other modes (extra JSON field 'modes')")
     ap.add_argument("--no-probe", dest="probe", action="store_false", help="skip the streaming-roofline probes")
     ap.add_argument("--profile", default="vegetation", choices=["uniform", "vegetation"])
-    ap.add_argument("--placement-trials", type=int, default=16,
-                    help="at most this many candidate output arenas (one allocation holding the ring's planes) are allocated "
-                         "and timed -- the search stops early once one is clearly faster than the slowest -- and the fastest "
-                         "is kept, the rest freed (0/1: take the first)")
+    ap.add_argument("--arena", default="auto", choices=["auto", "plain"],
+                    help="output arena of the plane-writing modes.  auto: the library's default (TileBatch.make_outputs) -- for "
+                         "multi-GiB arenas candidate allocations are timed with the batch's own launch and the fastest is kept; "
+                         "plain: one allocation as it comes")
+    ap.add_argument("--placement-trials", type=int, default=-1,
+                    help="candidate arenas of the search (-1: the library's default, 0/1: take the first)")
     ap.add_argument("--stats-route", default="joint", choices=["joint", "classic"],
                     help="statistics-only modes: one read through joint byte-pair histograms, or histogram pass + per-pixel kernel")
     ap.add_argument("--no-cpu-baseline", action="store_true")
@@ -119,8 +121,8 @@ class Runner:
         if key not in self.outputs:
             if self.batch.table is None:
                 self.batch.compute_wb_tables()
-            self.outputs[key] = self.batch.make_outputs(indices=indices, index=True, ring=self.args.ring,
-                                                        placement_trials=self.args.placement_trials)
+            self.outputs[key] = self.batch.make_outputs(indices=indices, index=True, ring=self.args.ring, arena=self.args.arena,
+                                                        placement_trials=None if self.args.placement_trials < 0 else self.args.placement_trials)
         return self.outputs[key]
 
     def step(self, mode, timed=None):
@@ -326,7 +328,16 @@ def cpu_baseline(args):
 
 
 def device_probe(runner):
-    """Plain streaming kernels with the hot path's access shapes: what this device sustains (GB/s)."""
+    """Plain streaming kernels with the hot path's access shapes: what this device sustains (GB/s).  The probe kernels live
+    in the laboratory library (liblars_lab.so, tools/lab/lablib.py); None when it has not been built."""
+    sys.path.insert(0, os.path.join(ROOT, "tools", "lab"))
+    try:
+        import lablib
+        if not lablib.available():
+            return None
+        lablib.load()
+    except (ImportError, OSError, AttributeError):
+        return None
     ffi = runner.ffi
     nbytes = min(runner.batch.ntiles, 256) * runner.batch.tile_bytes
     nbytes -= nbytes % 960
@@ -338,7 +349,7 @@ def device_probe(runner):
         ts = []
         for _ in range(4):
             ffi.call("lars_event_record", runner.ev[0], None)
-            ffi.call("lars_d_probe", kind, 1, 65536, C.c_void_p(src), C.c_void_p(dst.ptr), nbytes, None)
+            lablib.probe(kind, 1, 65536, src, dst.ptr, nbytes)
             ffi.call("lars_event_record", runner.ev[1], None)
             ms = C.c_float(0)
             ffi.call("lars_event_elapsed_ms", runner.ev[0], runner.ev[1], C.byref(ms))
@@ -380,25 +391,27 @@ def traffic_from_profiles(mode, pixels_per_launch):
     return doc[mode]["bytes_per_pixel"] * pixels_per_launch, f"profiles/traffic.json@{now} ({doc.get('_round', '?')}, rocprofv3 --pmc)"
 
 
-def config4_leg(tiles=16, edge=8192):
+def config4_leg(tiles=64, edge=8192, ring=16):
     """BASELINE configs[4] shape on this GPU (not the headline): uint16 8192 x 8192 tiles, percentile white balance,
-    float32 NDVI + RdYlGn RGBA written + statistics.  14 algorithmic bytes per pixel (6 read, 8 written)."""
+    float32 NDVI + RdYlGn RGBA written (ring of 16 tile slots, assembled arena) + statistics.  14 algorithmic bytes per
+    pixel (6 read, 8 written)."""
     import lars_image_processing_amd as lars
     from lars_image_processing_amd import _ffi
     b = lars.TileBatch(tiles, edge, edge, 3, np.uint16)
     _ffi.call("lars_d_synth_u8", C.c_void_p(b.tiles.ptr), tiles, 0, b.npix * 2, 3, 1234, 0, None)   # random 16-bit samples
     b.compute_wb_tables()
-    outs = b.make_outputs(indices=("NDVI",), index=True, rgba=True, placement_trials=4)
+    outs = b.make_outputs(indices=("NDVI",), index=True, rgba=True, ring=ring)
     stats = b.new_stats()
     ev = [C.c_void_p() for _ in range(3)]
     for e in ev:
         _ffi.call("lars_event_create", C.byref(e))
     prep, fused = [], []
+    launches = 1
     for _ in range(4):
         _ffi.call("lars_event_record", ev[0], None)
         b.compute_wb_tables()
         _ffi.call("lars_event_record", ev[1], None)
-        b.run_fused(b.fused_args(("NDVI",), True, stats, False, outs))
+        launches = b.run_fused_chunks(("NDVI",), True, stats, False, outs)
         _ffi.call("lars_event_record", ev[2], None)
         _ffi.call("lars_synchronize", None)
         ms = C.c_float(0)
@@ -406,11 +419,13 @@ def config4_leg(tiles=16, edge=8192):
         _ffi.call("lars_event_elapsed_ms", ev[1], ev[2], C.byref(ms)); fused.append(ms.value)
     p_ms, f_ms = float(np.median(prep[1:])), float(np.median(fused[1:]))
     npix = tiles * edge * edge
+    report = outs.arena_report
     outs.free(); stats.free(); b.free()
-    return {"workload": f"{tiles} tiles of {edge}x{edge} uint16, white balance + float32 NDVI + RGBA8 written + statistics",
-            "Mpix_s": npix / ((p_ms + f_ms) * 1e-3) / 1e6, "wb_prepare_ms": p_ms, "fused_ms": f_ms,
+    return {"workload": f"{tiles} tiles of {edge}x{edge} uint16, white balance + float32 NDVI + RGBA8 written (ring of {ring}) + statistics",
+            "Mpix_s": npix / ((p_ms + f_ms) * 1e-3) / 1e6, "wb_prepare_ms": p_ms, "fused_ms": f_ms, "launches": launches,
+            "whole_step_frac": npix * 14 / ((p_ms + f_ms) * 1e-3) / 1e9 / HBM_PEAK_GBS,
             "fused_GBs_algorithmic": npix * 14 / (f_ms * 1e-3) / 1e9,
-            "fused_frac_of_8TBs": npix * 14 / (f_ms * 1e-3) / 1e9 / HBM_PEAK_GBS}
+            "fused_frac_of_8TBs": npix * 14 / (f_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, "arena": report}
 
 
 def _visible_devices():
@@ -512,9 +527,8 @@ def main():
         # Every rank makes the same choice of transport: from the environment, or -- by default -- from a pre-flight vote:
         # each rank checks that librccl loads (lars_comm_available) and all ranks exchange that verdict through marker files
         # (dist.agree) BEFORE anybody enters a blocking bootstrap; only a unanimous yes takes the library's own communicator,
-        # anything else takes torch.distributed's.  If the library's bootstrap then fails on every rank alike, a second vote moves
-        # the whole group to torch.distributed; any other bootstrap error ends the rank with a non-zero status and the launcher
-        # tears the group down (no per-rank fallback).
+        # anything else takes torch.distributed's.  A bootstrap error after that ends the rank with a non-zero status and the
+        # launcher tears the group down (no per-rank fallback, no second change of transport).
         #   LARS_COMM unset / auto: vote, then rccl or torch
         #   LARS_COMM=rccl: the library's own RCCL communicator (csrc/comm.cpp), no vote
         #   LARS_COMM=torch: the statistics exchange through torch.distributed (nccl backend = RCCL)
@@ -528,28 +542,8 @@ def main():
                 print(f"[bench rank {rank}] librccl is not usable on every rank ({_ffi.load().lars_last_error().decode()!r} here): "
                       "all ranks use torch.distributed", file=sys.stderr)
         comm = None
-        if flavour == "rccl" and voted:
-            # the library's communicator, and a second vote on whether it came up on EVERY rank: an error all ranks see alike
-            # (a node whose RCCL refuses to initialise) moves the whole group to torch.distributed instead of ending the run;
-            # a rank that hangs inside the bootstrap still ends it -- the others time out in the vote
-            try:
-                if os.environ.get("LARS_BENCH_FAIL_RCCL"):        # tests/test_gpu_bench.py: the path below without a broken node
-                    raise RuntimeError("LARS_BENCH_FAIL_RCCL is set")
-                comm = dist.Comm.from_env()
-                collective = "RCCL ncclAllGather of packed records + rank-order fold (csrc/comm.cpp)"
-            except (_ffi.LarsError, TimeoutError, OSError, RuntimeError) as exc:
-                print(f"[bench rank {rank}] rccl bootstrap failed: {exc}", file=sys.stderr)
-            if not dist.agree(rank, world, comm is not None, timeout_s=180.0, phase="up"):
-                if comm is not None:
-                    comm.destroy()
-                    comm = None
-                print(f"[bench rank {rank}] the library's RCCL communicator did not come up on every rank: "
-                      "all ranks use torch.distributed", file=sys.stderr)
-                flavour = "torch"
         try:
-            if comm is not None:
-                pass
-            elif flavour == "gloo":
+            if flavour == "gloo":
                 _ffi.call("lars_set_device", int(os.environ.get("LARS_DEVICE", local_rank)))
                 comm = dist.TorchComm.from_env("gloo")
                 collective = "torch.distributed all_gather (gloo, host) + rank-order fold -- rehearsal transport"
@@ -568,9 +562,8 @@ def main():
         _ffi.call("lars_set_device", 0)
         comm = dist.SingleProcessComm()
     if world > 1 and voted:
-        # The markers of the votes may only go once EVERY rank has left agree(): on the path where the library's communicator
-        # came up before the second vote nothing has synchronised the ranks since, so they meet in a barrier first.
-        dist.release_agreement(comm, rank, world)
+        # the markers of the vote may only go once EVERY rank has left agree(): the ranks meet in a barrier first
+        dist.release_agreement(comm, rank, world, phases=("pre",))
     ranks_seen = comm.ranks_seen()
     if ranks_seen != world:
         print(f"[bench rank {rank}] the communicator reports {ranks_seen} ranks, WORLD_SIZE={world}", file=sys.stderr)
@@ -643,8 +636,9 @@ def main():
     # per-rank figures, gathered over the communicator: which rank sets the step time, and with what arena
     outs_main = runner.outputs.get(tuple(indices))
     placement = getattr(outs_main, "placement_ms", None) or {}
-    mine = [rank, local_step_ms, fused_ms, hist_ms, fused_ms / launches, float(placement.get("chosen", 0.0) or 0.0),
-            float(placement.get("search_ms", 0.0) or 0.0)]
+    arena_report = getattr(outs_main, "arena_report", None) or {}
+    mine = [rank, local_step_ms, fused_ms, hist_ms, fused_ms / launches, float(arena_report.get("chosen_ms") or 0.0),
+            float(arena_report.get("search_ms") or 0.0), float(arena_report.get("rejected") or 0)]
     per_rank = comm.allgather_f64(mine)
 
     probe = device_probe(runner) if (args.probe and rank == 0) else None
@@ -666,10 +660,11 @@ def main():
                             "then global fold" + (" over RCCL" if world > 1 else ""),
                 "tiles_per_gpu": args.tiles, "tile": [args.tile, args.tile, 3], "input_dtype": "u8", "mode": args.mode,
                 "output_ring_tiles": args.ring if write else 0,
-                "output_ring_placement_trials": args.placement_trials if write else 0,
                 # ms per launch into each candidate arena (the fastest was kept); outside the timed region, like the warm-up
                 "output_arena_trial_ms": placement.get("arenas"),
-                "arena": placement.get("arena"),
+                # how the output arena came about (kind, search_ms, chosen_ms = ms per probe launch over one group of tile
+                # slots, rejected candidates); outside the timed region, like the warm-up
+                "arena": arena_report or None,
                 "stats_route": args.stats_route,
                 "parallelism": f"tile-sharded x{world}",
                 "collective": collective, "ranks_seen": ranks_seen,
@@ -688,7 +683,7 @@ def main():
             },
             "passes_ms": {"histogram+tables": hist_ms, "fused": fused_ms, "rest_of_step": step_ms - hist_ms - fused_ms},
             "ranks": [{"rank": int(r[0]), "ms_per_step": r[1], "fused_ms": r[2], "hist_ms": r[3], "avg_launch_ms": r[4],
-                       "arena_ms": r[5], "arena_search_ms": r[6]} for r in per_rank],
+                       "arena_ms": r[5], "arena_search_ms": r[6], "arena_rejected": int(r[7])} for r in per_rank],
             "cpu_baseline": cpu,
             "verified": verified,
             "global_stats": {t: {k: v for k, v in s.items() if k != "hist"} for t, s in g.items()},

@@ -185,16 +185,6 @@ int lars_d_fused(const lars_fused_args *args);
 int lars_d_stats_begin(lars_stats *stats, int64_t ntiles, uint32_t index_mask, void *stream);
 int lars_d_stats_end(lars_stats *stats, int64_t ntiles, uint32_t index_mask, int64_t npix, void *stream);
 
-/* The whole step in one persistent launch (csrc/pipeline.hip): channel histograms -> np.percentile(ch, (2, 98)) ->
- * white-balance tables -> the fused pass, ordered tile by tile so that a tile's second read comes out of the 256 MiB
- * Infinity Cache.  Same results as lars_d_channel_hist + lars_d_wb_table + lars_d_fused, bit for bit.  Serves what the
- * headline configuration needs: uint8 tiles with 3 channels, all three float32 planes written, LARS_F_STATS.
- * args->wb_table is the OUTPUT table buffer here ([ntiles][768]); percentiles is [ntiles][3][2]; hist [ntiles][768] or
- * NULL; scratch holds lars_pipeline_scratch_bytes(ntiles, npix) bytes.  If a wait inside the launch times out the
- * statistics records come back poisoned (count 0, NaN sums). */
-size_t lars_pipeline_scratch_bytes(int64_t ntiles, int64_t npix);
-int lars_d_pipeline(const lars_fused_args *args, double *percentiles, uint32_t *hist, int rgn_variant, void *scratch);
-
 /* float32 band planes -> index, backend-process.py:28-38 (literal formula with
  * the float32 epsilon add and the clip; any float input). */
 int lars_d_index_planes_f32(const float *red, const float *green, const float *nir,
@@ -312,12 +302,12 @@ int lars_d_colormap_norm_f32(const float *x, int64_t n, float vmin, float vmax, 
 int lars_d_synth_u8(uint8_t *tiles, int64_t ntiles, int64_t first_tile, int64_t npix, int channels,
                     uint32_t seed, int profile, void *stream);
 
-/* Tuning knobs (per process): "fused_impl" 0 (auto)|1|2, "hist_impl" 1|2, "nt_stores" 0|1,
- * "blocks_per_tile" 0 = automatic, "selq_window" 1 (one-pass medians)|0 (always two select passes)|2 (wrong windows:
- * exercises the fallback), "selq_list_wgs" workgroups per select pass over the tiles a window missed (0 = 2048);
- * A/B switches of the experiments in DESIGN.md: "traverse" -1|0|1|2, "grid_swap" 0|1, "count_mode" -1|3, "pipe_steps", "pipe_head",
- * "pipe_trace".  Results never depend on them ("pipe_cold" 1 is the one exception: a timing experiment of the pipeline
- * launch that reads the wrong tile on purpose). */
+/* Tuning knobs (per process): "fused_impl" 0 (auto)|1|2, "hist_impl" 1|2, "nt_stores" 0|1, "blocks_per_tile" 0 = automatic
+ * (also the chunks per tile of lars_d_stats_joint), "joint_depth" 4|6 loads in flight per lane of the counting kernel,
+ * "selq_window" 1 (one-pass medians)|0 (always two select passes)|2 (wrong windows: exercises the fallback), "selq_list_wgs"
+ * workgroups per select pass over the tiles a window missed (0 = 2048).  Results never depend on them.  Read-only:
+ * "last_fused_kernel" = the kernel family the last lars_d_fused launched (1 k_fused_u8c3, 2 k_fused_v2, 3 its uint16 form,
+ * 4 k_fused_generic: one pixel per lane, 5 k_fused_u8c3 for RGBA uint8 tiles). */
 int lars_set_tuning(const char *key, int value);
 int lars_get_tuning(const char *key, int *value);
 
@@ -325,11 +315,6 @@ int lars_get_tuning(const char *key, int *value);
  * for which the kernels' rcp+fma quotient differs from IEEE float32 division
  * (must be 0; tests run it for the uint8 and the uint16 operand ranges). */
 int lars_d_quot_selfcheck(uint32_t max_den, uint64_t *mismatches, uint32_t first_bad[2]);
-
-/* Roofline probes (bench.py reports them beside the kernel numbers): kind 0 reads
- * 16 B/lane, 1 reads 12 B/lane (the fused kernel's load shape), 2 copies 16 B/lane
- * (traffic = 2 x bytes), 3 writes 16 B/lane.  src/dst are device buffers of `bytes`. */
-int lars_d_probe(int kind, int unroll, int blocks, const void *src, void *dst, int64_t bytes, void *stream);
 
 /* Fold n records (same index) into one: sums add, min/max fold, histograms add. */
 int lars_stats_merge(const lars_stats *records, int64_t n, lars_stats *out);

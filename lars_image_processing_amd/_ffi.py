@@ -95,8 +95,6 @@ SIGNATURES = {
     "lars_d_fused": (_I, [C.POINTER(FusedArgs)]),
     "lars_d_stats_begin": (_I, [_P, _I64, _U32, _P]),
     "lars_d_stats_end": (_I, [_P, _I64, _U32, _I64, _P]),
-    "lars_pipeline_scratch_bytes": (_SZ, [_I64, _I64]),
-    "lars_d_pipeline": (_I, [C.POINTER(FusedArgs), _P, _P, _I, _P]),
     "lars_d_index_planes_f32": (_I, [_P, _P, _P, _I64, _I, _P, _P]),
     "lars_d_ndvi_f64": (_I, [_P, _I64, _I, _I, _P, _P]),
     "lars_d_array_stats_f32": (_I, [_P, _I64, _F, _I, _P, _P]),
@@ -117,7 +115,6 @@ SIGNATURES = {
     "lars_d_synth_u8": (_I, [_P, _I64, _I64, _I64, _I, _U32, _I, _P]),
     "lars_stats_merge": (_I, [_P, _I64, _P]),
     "lars_d_stats_fold": (_I, [_P, _I64, _U32, _P, _P]),
-    "lars_d_probe": (_I, [_I, _I, _I, _P, _P, _I64, _P]),
     "lars_set_tuning": (_I, [C.c_char_p, _I]),
     "lars_get_tuning": (_I, [C.c_char_p, C.POINTER(_I)]),
     "lars_d_quot_selfcheck": (_I, [_U32, C.POINTER(C.c_uint64), C.POINTER(_U32 * 2)]),

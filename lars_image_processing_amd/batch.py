@@ -13,6 +13,7 @@ from __future__ import annotations
 
 import ctypes as C
 import os
+import time
 
 import numpy as np
 
@@ -20,6 +21,9 @@ from . import _ffi
 from ._ffi import FusedArgs, INDEX_IDS, INDEX_NAMES, STATS_DTYPE, DeviceBuffer, DeviceSlice
 
 MAX_TILES_PER_LAUNCH = 65535      # grid.y limit
+ARENA_MIN_BYTES = 2 << 30         # smaller arenas run alike wherever they land
+ARENA_TRIALS = 16                 # candidate allocations of the default search (it stops early once one is clearly faster)
+
 
 # How statistics-only passes over uint8 RGNir batches run (no output planes):
 #   "joint"   one read of the tiles: joint byte-pair histograms in LDS, everything else -- the white balance's percentiles
@@ -135,19 +139,36 @@ class TileBatch:
         return self.hist.download(np.uint32, (self.ntiles, 3, 256))
 
     # -- pass 2: the fused kernel ------------------------------------------
-    def make_outputs(self, indices=INDEX_NAMES, index=False, wb=False, rgba=False, ring=None, placement_trials=0):
+    def make_outputs(self, indices=INDEX_NAMES, index=False, wb=False, rgba=False, ring=None, placement_trials=None, arena="auto"):
         """Allocate output planes.  ``ring`` < ntiles reuses a ring of that many
         tile slots (same HBM traffic, bounded footprint) -- see BatchOutputs.
 
-        The float32 index planes live in ONE allocation (an arena).  How fast the write-bound fused kernel runs into an
-        arena is a property of where the driver put it: 5.2 - 6.3 TB/s on the same box, stable to 0.3 % for as long as the
-        allocation lives, independent of the offsets between the planes inside it, of the input batch and of time
-        (profiles/r02_placement_*.txt).  ``placement_trials`` = k > 1 therefore allocates up to k
-        arenas, times the kernel into each and keeps the fastest; the others are freed.  Costs up to k arenas of memory
-        for the duration of the trial and four short launches per arena."""
-        outs = BatchOutputs(self, indices, index, wb, rgba, ring)
-        if placement_trials <= 1 or outs.arena is None:
+        The float32 index planes (and RGBA8 planes) live in ONE allocation (an arena).  How fast the write-bound fused
+        kernel runs into an arena is a stable property of that allocation: 5.2 - 6.3 TB/s on the same box, independent of
+        the offsets between the planes, of the input batch and of time (profiles/r02_placement_*.txt,
+        r03_arena_*.txt).  ``arena``:
+          "auto"      multi-GiB arenas are CHOSEN: up to ``placement_trials`` (default ARENA_TRIALS) plain allocations are
+                      made one by one, the batch's own fused launch is timed into each, the fastest is kept and the rest
+                      freed; smaller arenas (they run alike wherever they land) are one plain allocation
+          "plain"     one plain allocation as it comes, unless ``placement_trials`` asks for a search
+        (Arenas put together from timed groups of physical chunks were built and measured in round 3 -- tools/lab/arenalab.py,
+        profiles/r03_arena_assembled.txt: a group's probe time does not predict the arena's speed; not in the product.)
+        ``outs.arena_report`` = {kind, search_ms, chosen_ms, rejected, ...} says what was done."""
+        outs = BatchOutputs(self, indices, index, wb, rgba, ring, allocate=False)
+        nplanes = len(outs._index_ids) + len(outs._rgba_ids)
+        report = {"kind": "none"} if not nplanes else None
+        if nplanes and arena not in ("auto", "plain"):
+            raise ValueError("arena must be auto or plain")
+        big = bool(nplanes) and nplanes * outs.slots * self.npix * 4 >= ARENA_MIN_BYTES
+        if placement_trials is None:
+            placement_trials = ARENA_TRIALS if (arena == "auto" and big) else 0
+        if nplanes and report is None:
+            outs.adopt_arena(DeviceBuffer(nplanes * outs.plane_bytes))
+            report = {"kind": "plain hipMalloc", "search_ms": 0.0, "chosen_ms": None, "rejected": 0}
+        outs.arena_report = report
+        if placement_trials <= 1 or outs.arena is None or report.get("kind") != "plain hipMalloc":
             return outs
+        t_search = time.perf_counter()
         # Candidates are allocated one by one and ALL kept until the choice is made (a freed arena would be handed out
         # again).  The classes are ~15 % apart, so the search ends two candidates after one is clearly faster than the
         # slowest seen (>= 7 %, at least four tried), and otherwise goes on to `placement_trials` or the memory limit.
@@ -164,18 +185,22 @@ class TileBatch:
             if free_b.value < outs.arena.nbytes + (8 << 30):       # keep 8 GiB of headroom for the caller
                 break
             try:
-                arena = DeviceBuffer(outs.arena.nbytes)
+                cand = DeviceBuffer(outs.arena.nbytes)
             except _ffi.LarsError:
                 break                                               # out of memory: choose among what fits
-            arenas.append(arena)
-            outs.adopt_arena(arena)
+            arenas.append(cand)
+            outs.adopt_arena(cand)
             timings.append(self._time_outputs(outs, indices))
         best = int(np.argmin(timings))
         outs.adopt_arena(arenas[best])
-        for j, arena in enumerate(arenas):
+        for j, cand in enumerate(arenas):
             if j != best:
-                arena.free()
+                cand.free()
+        _ffi.call("lars_synchronize", None)
         outs.placement_ms = {"arenas": [float(x) for x in timings], "chosen": float(timings[best])}
+        outs.arena_report = {"kind": f"plain hipMalloc, the fastest of {len(arenas)} candidates timed with the batch's own launch",
+                             "search_ms": (time.perf_counter() - t_search) * 1e3, "chosen_ms": float(timings[best]),
+                             "rejected": len(arenas) - 1, "candidate_ms": [float(x) for x in timings]}
         return outs
 
     def _time_outputs(self, outs, indices):
@@ -274,42 +299,13 @@ class TileBatch:
             _ffi.call("lars_d_stats_end", C.c_void_p(stats.ptr), self.ntiles, mask, self.npix, stream)
         return launches
 
-    # -- both passes in one persistent launch (csrc/pipeline.hip) ------------
-    def can_pipeline(self, indices=INDEX_NAMES, outputs=None, hist=False, sumsq=False):
-        """What ``lars_d_pipeline`` serves: uint8 RGNir tiles, all three planes written, basic statistics."""
-        return (self.code == _ffi.U8 and self.channels == 3 and self.npix % 4 == 0 and self.npix * 3 < (1 << 31)
-                and tuple(sorted(indices)) == tuple(sorted(INDEX_NAMES)) and outputs is not None and not hist and not sumsq
-                and all(outputs.index[k] is not None for k in range(3)) and outputs.wb is None
-                and all(r is None for r in outputs.rgba))
-
-    def run_pipeline(self, stats, outputs, stream=None, tile_start=0, tile_count=None, rgn_variant=0):
-        """Channel histograms -> percentile tables -> fused pass of tiles [tile_start, tile_start + tile_count) in ONE
-        persistent launch, ordered tile by tile so that a tile's second read is served by the Infinity Cache.  Fills
-        ``self.hist`` / ``self.table`` / ``self.percentiles`` like ``compute_wb_tables`` and ``stats`` / the planes like
-        ``run_fused``: same bytes."""
-        tile_count = self.ntiles - tile_start if tile_count is None else tile_count
-        if self.table is None:
-            self.table = DeviceBuffer(self.ntiles * self.table_bytes)
-            self.percentiles = DeviceBuffer(self.ntiles * 3 * 2 * 8)
-        if self.hist is None:
-            self.hist = DeviceBuffer(self.ntiles * 3 * 256 * 4)
-        need = int(_ffi.load().lars_pipeline_scratch_bytes(tile_count, self.npix))
-        if getattr(self, "_pipe_scratch", None) is None or self._pipe_scratch.nbytes < need:
-            if getattr(self, "_pipe_scratch", None) is not None:
-                _ffi.call("lars_synchronize", stream)
-                self._pipe_scratch.free()
-            self._pipe_scratch = DeviceBuffer(need)
-        a = self.fused_args(INDEX_NAMES, True, stats, False, outputs, stream, tile_start, tile_count)
-        _ffi.call("lars_d_pipeline", C.byref(a), C.c_void_p(self.percentiles.ptr + tile_start * 48),
-                  C.c_void_p(self.hist.ptr + tile_start * 3072), int(rgn_variant), C.c_void_p(self._pipe_scratch.ptr))
-
     def run_fused(self, args):
         _ffi.call("lars_d_fused", C.byref(args))
 
     # -- statistics from one read: joint byte-pair histograms (csrc/joint.hip) ----
     def can_joint(self):
-        """What ``lars_d_stats_joint`` serves: uint8 RGNir tiles on 4-byte boundaries."""
-        return self.code == _ffi.U8 and self.channels == 3 and (self.ntiles == 1 or self.npix % 4 == 0)
+        """What ``lars_d_stats_joint`` serves: uint8 tiles with 3 (RGNir) or 4 (RGBA: alpha ignored) channels."""
+        return self.code == _ffi.U8 and self.channels in (3, 4) and (self.ntiles == 1 or self.npix % 4 == 0)
 
     def run_joint(self, indices, white_balance, stats, hist=False, sumsq=False, pairs=None, stream=None, rgn_variant=0):
         """Enqueue ``lars_d_stats_joint``: final records into ``stats`` and, with ``pairs`` (a DeviceBuffer of
@@ -511,16 +507,18 @@ class BatchOutputs:
     """Device output planes of a batch (optionally a ring of ``slots`` tiles).  The float32 index planes and the RGBA8
     planes are slices of one allocation (``arena``): index planes in the order of INDEX_NAMES, then the RGBA planes."""
 
-    def __init__(self, batch, indices, index, wb, rgba, ring=None):
+    def __init__(self, batch, indices, index, wb, rgba, ring=None, allocate=True):
         from .api import colormap_lut, _colormap_for
         self.slots = batch.ntiles if not ring else min(int(ring), batch.ntiles)
         self.index, self.rgba, self.luts = [None] * 3, [None] * 3, [None] * 3
         self.batch = batch
-        self.plane_bytes = self.slots * batch.npix * 4
+        # planes start on 256-byte boundaries inside the arena (the fast kernels want 16-byte aligned planes)
+        self.plane_bytes = (self.slots * batch.npix * 4 + 255) & ~255
         self._index_ids = sorted(INDEX_IDS[t] for t in indices) if index else []
         self._rgba_ids = sorted(INDEX_IDS[t] for t in indices) if rgba else []      # RGBA8 planes: 4 bytes per pixel too
         self.arena = None
-        if self._index_ids or self._rgba_ids:
+        self.arena_report = None
+        if allocate and (self._index_ids or self._rgba_ids):
             self.adopt_arena(DeviceBuffer((len(self._index_ids) + len(self._rgba_ids)) * self.plane_bytes))
         for t in indices:
             k = INDEX_IDS[t]

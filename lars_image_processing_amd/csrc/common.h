@@ -101,13 +101,7 @@ struct Tuning {
     int blocks_per_tile = 0;   // 0 = automatic
     int selq_window = 1;       // one-pass medians (select_q.hip): 1 predicted window, 0 always two passes, 2 wrong windows (test)
     int selq_list_wgs = 0;     // workgroups per launch of the classic select passes over the tiles a window missed (0 = 2048)
-    int pipe_steps = 0;        // pipeline.hip: wave-steps per work item (0 = 64)
-    int pipe_cold = 0;         // pipeline.hip timing experiment: fused items read a far-away tile (results are wrong)
-    int pipe_trace = 0;        // pipeline.hip: record item timestamps behind the scratch's sync words
-    int pipe_head = 0;         // pipeline.hip: histogram items handed out before each fused item (0 = 2)
-    int count_mode = -1;       // statistics-only kernels, A/B only: 3 = float coverage counters (fused_v2.hip)
-    int grid_swap = 0;         // plane-writing kernel, A/B only: 1 = tile index fastest in dispatch order (k_fused_u8c3)
-    int traverse = -1;         // plane-writing kernel, A/B only: -1 / 1 the shipped mapping, 0 and 2 see k_fused_u8c3
+    int last_fused_kernel = 0; // read-only: the kernel family lars_d_fused launched last -- 1 k_fused_u8c3, 2 k_fused_v2, 3 uint16, 4 generic, 5 RGBA uint8
     int joint_depth = 6;       // joint.hip: 12-byte loads in flight per lane of the counting kernel (4 | 6)
 };
 Tuning &tuning();
@@ -121,7 +115,7 @@ struct FusedParams;
 #endif
 int fused_v2_threads(bool any_out);
 void fused_v2_launch(unsigned mask, bool wb, int stats, bool nt, dim3 grid, hipStream_t s, const FusedParams &P);
-void chan_hist_v2_launch(const uint8_t *tiles, long long npix, unsigned int *hist, dim3 grid, hipStream_t s);
+void chan_hist_v2_launch(const uint8_t *tiles, long long npix, unsigned int *hist, dim3 grid, hipStream_t s, int channels = 3);
 int selq_pass_launch(const uint8_t *tiles, const uint8_t *wb_table, long long ntiles, long long npix, int first,
                      const unsigned int bucket[4], unsigned long long *hist, hipStream_t s, unsigned streams);
 size_t selq_tile_scratch_bytes(long long ntiles);

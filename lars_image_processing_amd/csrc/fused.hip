@@ -326,16 +326,20 @@ __device__ inline void acc_flush(Acc a, StatsAccView *rec, double (*s_red)[4], i
 // LDS): g = trunc((v - p2) * 255/(p98 - p2)) in float64 is within one level of the reference's
 // trunc(float32(float64 expression)), and two threshold compares settle it exactly.
 
-// TRAV (pixel -> wave mapping): 1 (what runs) a wave owns runs of 1024 consecutive pixels, the four quads of a run
-// unrolled: four loads, then per plane four back-to-back 1 KiB stores = 4 KiB bursts; 0 the same runs one quad per trip;
-// 2 the round-1 mapping (256-pixel slabs a grid stride apart).  Measured in one process, same planes
-// (profiles/r02_traverse_ab.txt): 1 runs 8 % faster than 0 and 2 wherever the planes' placement allows more than
-// 5.3 TB/s at all, and equal elsewhere.  0 and 2 are only instantiated for the headline configuration, for such A/B
-// runs (lars_set_tuning("traverse", 0 | 2); the default -1 means 1).
-template <typename PIX, unsigned MASK, bool WB, int STATS, int TRAV = 1>
+// Pixel -> wave mapping: a wave owns runs of 1024 consecutive pixels, the four quads of a run unrolled: four loads, then per
+// plane four back-to-back 1 KiB stores = 4 KiB bursts.  Round 2 measured it against the same runs one quad per trip and
+// against 256-pixel slabs a grid stride apart (profiles/r02_traverse_ab.txt): 8 % faster wherever the planes' placement
+// allows more than 5.3 TB/s at all, and equal elsewhere; the other mappings are gone from the source.
+// CH = 4 (uint8 only): RGBA tiles -- 16 bytes per quad of pixels, one dwordx4 load per lane, repacked in three v_perm_b32 into
+// the three dwords the rest of the kernel works on; alpha is ignored and comes back as 0 in the white-balanced image
+// (np.zeros_like + range(3), process-images.py:432-435).
+// Two-index masks (3, 5, 6) run the MASK = 7 instantiation with the unrequested plane's pointers null and P.mask deciding
+// which records are flushed: a launch that is bound by its stores does not notice the spare quotient.
+template <typename PIX, unsigned MASK, bool WB, int STATS, int CH = 3>
 __global__ __launch_bounds__(256) void k_fused_u8c3(FusedParams P)
 {
     constexpr bool U16 = sizeof(PIX) == 2;
+    static_assert(CH == 3 || (CH == 4 && !U16), "4-channel fast path: uint8 tiles");
     __shared__ uint8_t s_lut[U16 ? 16 : 3 * 256];
     __shared__ unsigned int s_thr[U16 ? 3 * 260 : 4];
     __shared__ double s_par[U16 ? 6 : 1];
@@ -349,13 +353,10 @@ __global__ __launch_bounds__(256) void k_fused_u8c3(FusedParams P)
 
     const int tid = threadIdx.x;
     unsigned int *const s_hist = s_hist_all + (tid & (HIST_COPIES - 1));
-    // flags bit 28 (lars_set_tuning("grid_swap", 1), A/B only): the tile index varies fastest in dispatch order, so the resident
-    // workgroups write to all tiles of the launch at once instead of to a window of two
-    const bool swap = (P.flags & 0x10000000u) != 0;
-    const unsigned int bx = swap ? blockIdx.y : blockIdx.x, gx = swap ? gridDim.y : gridDim.x;
-    const long long tile = swap ? blockIdx.x : blockIdx.y;
+    const unsigned int bx = blockIdx.x, gx = gridDim.x;
+    const long long tile = blockIdx.y;
     const long long npix = P.npix;
-    const PIX *base = static_cast<const PIX *>(P.tiles) + tile * npix * 3;
+    const PIX *base = static_cast<const PIX *>(P.tiles) + tile * npix * CH;
 
     if (WB) {
         if (U16) {
@@ -392,7 +393,7 @@ __global__ __launch_bounds__(256) void k_fused_u8c3(FusedParams P)
     float *const oi0 = P.out_index[0] ? P.out_index[0] + tile * npix : nullptr;
     float *const oi1 = P.out_index[1] ? P.out_index[1] + tile * npix : nullptr;
     float *const oi2 = P.out_index[2] ? P.out_index[2] + tile * npix : nullptr;
-    uint8_t *const owb = P.out_wb ? P.out_wb + tile * npix * 3 : nullptr;
+    uint8_t *const owb = P.out_wb ? P.out_wb + tile * npix * CH : nullptr;
     uint8_t *const oc0 = P.out_rgba[0] ? P.out_rgba[0] + tile * npix * 4 : nullptr;
     uint8_t *const oc1 = P.out_rgba[1] ? P.out_rgba[1] + tile * npix * 4 : nullptr;
     uint8_t *const oc2 = P.out_rgba[2] ? P.out_rgba[2] + tile * npix * 4 : nullptr;
@@ -412,6 +413,12 @@ __global__ __launch_bounds__(256) void k_fused_u8c3(FusedParams P)
             const fu32x4 a4 = __builtin_amdgcn_raw_buffer_load_b128(rsrc16, off, 0, 0);
             const fu32x2 a2 = __builtin_amdgcn_raw_buffer_load_b64(rsrc16, off + 16u, 0, 0);
             w[0] = a4.x; w[1] = a4.y; w[2] = a4.z; w[NW - 3] = a4.w; w[NW - 2] = a2.x; w[NW - 1] = a2.y;
+        } else if (CH == 4) {
+            // r0 g0 n0 a0 | r1 g1 n1 a1 | r2 g2 n2 a2 | r3 g3 n3 a3  ->  r0 g0 n0 r1 | g1 n1 r2 g2 | n2 r3 g3 n3
+            const uint4 p = *reinterpret_cast<const uint4 *>(reinterpret_cast<const uint8_t *>(base) + q * 16);
+            w[0] = __builtin_amdgcn_perm(p.y, p.x, 0x04020100u);
+            w[1] = __builtin_amdgcn_perm(p.z, p.y, 0x05040201u);
+            w[2] = __builtin_amdgcn_perm(p.w, p.z, 0x06050402u);
         } else {
             const unsigned int *p = reinterpret_cast<const unsigned int *>(reinterpret_cast<const uint8_t *>(base) + q * 12);
             w[0] = p[0]; w[1] = p[1]; w[2] = p[2];
@@ -436,7 +443,10 @@ __global__ __launch_bounds__(256) void k_fused_u8c3(FusedParams P)
 #pragma unroll
             for (int i = 0; i < 12; ++i)
                 if (i % 3 == 2 || (i % 3 == 0 && need_r) || (i % 3 == 1 && need_g)) b[i] = wb_map(b[i], i % 3);
-            if (owb) {
+            if (owb && CH == 4) {
+                *reinterpret_cast<uint4 *>(owb + q * 16) = make_uint4(b[0] | (b[1] << 8) | (b[2] << 16), b[3] | (b[4] << 8) | (b[5] << 16),
+                                                                      b[6] | (b[7] << 8) | (b[8] << 16), b[9] | (b[10] << 8) | (b[11] << 16));
+            } else if (owb) {
                 unsigned int *o = reinterpret_cast<unsigned int *>(owb + q * 12);
                 o[0] = b[0] | (b[1] << 8) | (b[2] << 16) | (b[3] << 24);
                 o[1] = b[4] | (b[5] << 8) | (b[6] << 16) | (b[7] << 24);
@@ -471,48 +481,34 @@ __global__ __launch_bounds__(256) void k_fused_u8c3(FusedParams P)
     const long long nsteps = (nquads + 255) >> 8;
     const long long wstride = (long long)gx * 4;
     const unsigned int lane = (unsigned int)tid & 63u;
-    if (TRAV == 2) {
-        const long long stride = (long long)gx * 256;
-        unsigned int w[NW];
-        for (long long q = (long long)bx * 256 + tid; q < nquads; q += stride) { load_quad(q, w); do_quad(q, w); }
-    } else if (TRAV == 1) {
-        for (long long st = (long long)bx * 4 + (tid >> 6); st < nsteps; st += wstride) {
-            const long long q0 = st * 256 + lane;
-            unsigned int w[4][NW];
-            if (st * 256 + 256 <= nquads) {
+    for (long long st = (long long)bx * 4 + (tid >> 6); st < nsteps; st += wstride) {
+        const long long q0 = st * 256 + lane;
+        unsigned int w[4][NW];
+        if (st * 256 + 256 <= nquads) {
 #pragma unroll
-                for (int j = 0; j < 4; ++j) load_quad(q0 + 64 * j, w[j]);
+            for (int j = 0; j < 4; ++j) load_quad(q0 + 64 * j, w[j]);
+            __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                do_quad(q0 + 64 * j, w[j]);
                 __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-                for (int j = 0; j < 4; ++j) {
-                    do_quad(q0 + 64 * j, w[j]);
-                    __builtin_amdgcn_sched_barrier(0);
-                }
-            } else {
-                for (int j = 0; j < 4; ++j) {
-                    const long long q = q0 + 64 * j;
-                    if (q < nquads) { load_quad(q, w[0]); do_quad(q, w[0]); }
-                }
             }
-        }
-    } else {
-        // same addresses per wave as the unrolled form, one quad per trip (a third of the registers)
-        unsigned int w[NW];
-        for (long long st = (long long)bx * 4 + (tid >> 6); st < nsteps; st += wstride) {
-            const long long q0 = st * 256 + lane;
-#pragma unroll 1
+        } else {
             for (int j = 0; j < 4; ++j) {
                 const long long q = q0 + 64 * j;
-                if (q < nquads) { load_quad(q, w); do_quad(q, w); }
+                if (q < nquads) { load_quad(q, w[0]); do_quad(q, w[0]); }
             }
         }
     }
     // tail pixels (npix % 4): lanes 0..2 of block 0
     if (bx == 0 && tid < (int)(npix & 3)) {
         const long long i = nquads * 4 + tid;
-        unsigned int r = base[i * 3], g = base[i * 3 + 1], n = base[i * 3 + 2];
+        unsigned int r = base[i * CH], g = base[i * CH + 1], n = base[i * CH + 2];
         if (WB) { r = wb_map(r, 0); g = wb_map(g, 1); n = wb_map(n, 2); }
-        if (WB && owb) { owb[i * 3] = (uint8_t)r; owb[i * 3 + 1] = (uint8_t)g; owb[i * 3 + 2] = (uint8_t)n; }
+        if (WB && owb) {
+            owb[i * CH] = (uint8_t)r; owb[i * CH + 1] = (uint8_t)g; owb[i * CH + 2] = (uint8_t)n;
+            if (CH == 4) owb[i * CH + 3] = 0;
+        }
         float a = 0, bq = 0, c = 0;
         pixel_math<MASK, STATS, false, !U16, HIST_COPIES>((float)r, (float)g, (float)n, 0u, a, bq, c, acc, s_hist, s_edges);
         if ((MASK & 1u) && oi0) oi0[i] = a;
@@ -527,7 +523,7 @@ __global__ __launch_bounds__(256) void k_fused_u8c3(FusedParams P)
         StatsAccView *rec = reinterpret_cast<StatsAccView *>(P.stats + tile * 3);
 #pragma unroll
         for (int k = 0; k < 3; ++k)
-            if (MASK & (1u << k)) acc_flush(acc[k], rec + k, s_red, tid);
+            if ((MASK & (1u << k)) && (P.mask & (1u << k))) acc_flush(acc[k], rec + k, s_red, tid);
         if (STATS >= 2) {
             __syncthreads();
             for (int i = tid; i < 3 * LARS_HIST_BINS; i += 256) {
@@ -535,7 +531,7 @@ __global__ __launch_bounds__(256) void k_fused_u8c3(FusedParams P)
                 unsigned int v = 0;
 #pragma unroll
                 for (int c = 0; c < HIST_COPIES; ++c) v += s_hist_all[i * HIST_COPIES + ((c + i) & (HIST_COPIES - 1))];
-                if ((MASK & (1u << k)) && v) atomicAdd(&rec[k].hist[i - k * LARS_HIST_BINS], (unsigned long long)v);
+                if ((MASK & (1u << k)) && (P.mask & (1u << k)) && v) atomicAdd(&rec[k].hist[i - k * LARS_HIST_BINS], (unsigned long long)v);
             }
         }
     }
@@ -697,14 +693,16 @@ extern "C" int lars_d_channel_hist(const void *tiles, int64_t ntiles, int64_t np
     LARS_HIP_TRY(hipMemsetAsync(hist, 0, (size_t)ntiles * 3 * nval * sizeof(uint32_t), s));
     const bool fast = dtype == LARS_U8 && channels == 3 && (ntiles == 1 || (npix & 3) == 0) &&
                       ((reinterpret_cast<uintptr_t>(tiles) & 3) == 0);
-    if (fast && tuning().hist_impl != 1 && (long long)npix * 3 < (1ll << 30)) {
+    const bool fast4 = dtype == LARS_U8 && channels == 4 && (reinterpret_cast<uintptr_t>(tiles) & 15) == 0 &&
+                       (ntiles == 1 || (npix & 3) == 0) && (long long)npix * 4 < (1ll << 30);     // RGBA: 16 bytes per quad of pixels
+    if ((fast && tuning().hist_impl != 1 && (long long)npix * 3 < (1ll << 30)) || fast4) {
         // 96 KiB of LDS per block: one 1024-thread block per CU, a few waves of blocks per tile
         long long want = tuning().blocks_per_tile > 0 ? tuning().blocks_per_tile : (1024 + ntiles - 1) / ntiles;
         const long long cap = (npix / 4 + 1023) / 1024;
         if (want > cap) want = cap;
         if (want < 1) want = 1;
         dim3 grid((unsigned)want, (unsigned)ntiles);
-        chan_hist_v2_launch(static_cast<const uint8_t *>(tiles), (long long)npix, hist, grid, s);
+        chan_hist_v2_launch(static_cast<const uint8_t *>(tiles), (long long)npix, hist, grid, s, channels);
     } else if (fast) {
         dim3 grid(blocks_per_tile(npix / 4 + 1, ntiles), (unsigned)ntiles);
         hipLaunchKernelGGL(k_chan_hist_u8c3, grid, dim3(256), 0, s, static_cast<const uint8_t *>(tiles),
@@ -739,29 +737,30 @@ extern "C" int lars_d_wb_table(const uint32_t *hist, int64_t ntiles, int64_t npi
     return launch_check("lars_d_wb_table");
 }
 
-template <typename PIX, unsigned MASK, bool WB>
+template <typename PIX, unsigned MASK, bool WB, int CH>
 static void launch_fast_stats(int stats_mode, dim3 grid, hipStream_t s, const FusedParams &P)
 {
-    if (stats_mode == 0) hipLaunchKernelGGL((k_fused_u8c3<PIX, MASK, WB, 0>), grid, dim3(256), 0, s, P);
-    else if (stats_mode == 1) hipLaunchKernelGGL((k_fused_u8c3<PIX, MASK, WB, 1>), grid, dim3(256), 0, s, P);
-    else if (stats_mode == 3) hipLaunchKernelGGL((k_fused_u8c3<PIX, MASK, WB, 3>), grid, dim3(256), 0, s, P);
-    else hipLaunchKernelGGL((k_fused_u8c3<PIX, MASK, WB, 2>), grid, dim3(256), 0, s, P);
+    if (stats_mode == 0) hipLaunchKernelGGL((k_fused_u8c3<PIX, MASK, WB, 0, CH>), grid, dim3(256), 0, s, P);
+    else if (stats_mode == 1) hipLaunchKernelGGL((k_fused_u8c3<PIX, MASK, WB, 1, CH>), grid, dim3(256), 0, s, P);
+    else if (stats_mode == 3) hipLaunchKernelGGL((k_fused_u8c3<PIX, MASK, WB, 3, CH>), grid, dim3(256), 0, s, P);
+    else hipLaunchKernelGGL((k_fused_u8c3<PIX, MASK, WB, 2, CH>), grid, dim3(256), 0, s, P);
 }
-template <typename PIX, unsigned MASK>
+template <typename PIX, unsigned MASK, int CH>
 static void launch_fast_wb(bool wb, int stats_mode, dim3 grid, hipStream_t s, const FusedParams &P)
 {
-    if (wb) launch_fast_stats<PIX, MASK, true>(stats_mode, grid, s, P);
-    else launch_fast_stats<PIX, MASK, false>(stats_mode, grid, s, P);
+    if (wb) launch_fast_stats<PIX, MASK, true, CH>(stats_mode, grid, s, P);
+    else launch_fast_stats<PIX, MASK, false, CH>(stats_mode, grid, s, P);
 }
-template <typename PIX>
+// mask: the template's mask (two-index masks come in as 7, with P.mask = the requested bits)
+template <typename PIX, int CH = 3>
 static void launch_fast(unsigned mask, bool wb, int stats_mode, dim3 grid, hipStream_t s, const FusedParams &P)
 {
     switch (mask) {
-    case 0u: hipLaunchKernelGGL((k_fused_u8c3<PIX, 0u, true, 0>), grid, dim3(256), 0, s, P); break;
-    case 1u: launch_fast_wb<PIX, 1u>(wb, stats_mode, grid, s, P); break;
-    case 2u: launch_fast_wb<PIX, 2u>(wb, stats_mode, grid, s, P); break;
-    case 4u: launch_fast_wb<PIX, 4u>(wb, stats_mode, grid, s, P); break;
-    default: launch_fast_wb<PIX, 7u>(wb, stats_mode, grid, s, P); break;
+    case 0u: hipLaunchKernelGGL((k_fused_u8c3<PIX, 0u, true, 0, CH>), grid, dim3(256), 0, s, P); break;
+    case 1u: launch_fast_wb<PIX, 1u, CH>(wb, stats_mode, grid, s, P); break;
+    case 2u: launch_fast_wb<PIX, 2u, CH>(wb, stats_mode, grid, s, P); break;
+    case 4u: launch_fast_wb<PIX, 4u, CH>(wb, stats_mode, grid, s, P); break;
+    default: launch_fast_wb<PIX, 7u, CH>(wb, stats_mode, grid, s, P); break;
     }
 }
 
@@ -793,7 +792,7 @@ extern "C" int lars_d_fused(const lars_fused_args *a)
         P.cmap_lut[k] = a->cmap_lut[k];
     }
     P.out_wb = a->out_wb; P.stats = a->stats; P.mask = mask; P.sel_hist = nullptr; P.sel_win = nullptr; P.sel_win_hist = nullptr; P.sel_below = nullptr;
-    P.flags = (a->flags & 7u) | (tuning().nt_stores ? 0x20000000u : 0u) | (tuning().grid_swap ? 0x10000000u : 0u);
+    P.flags = (a->flags & 7u) | (tuning().nt_stores ? 0x20000000u : 0u);
 
     const long long nrec = a->ntiles * 3;
     const bool raw = (a->flags & LARS_F_RAW) != 0;        // the caller brackets the launches with lars_d_stats_begin / _end
@@ -808,10 +807,12 @@ extern "C" int lars_d_fused(const lars_fused_args *a)
                          (!P.out_rgba[0] || (reinterpret_cast<uintptr_t>(P.out_rgba[0]) & 15) == 0) &&
                          (!P.out_rgba[1] || (reinterpret_cast<uintptr_t>(P.out_rgba[1]) & 15) == 0) &&
                          (!P.out_rgba[2] || (reinterpret_cast<uintptr_t>(P.out_rgba[2]) & 15) == 0);
-    // the specialised kernels exist for "white balance only" (0), one index (1, 2, 4) and all three (7);
-    // two-index masks take the generic kernel so that unrequested records stay untouched
-    const bool mask_ok = mask == 0u || mask == 1u || mask == 2u || mask == 4u || mask == 7u;
-    const bool fast = a->channels == 3 && aligned && mask_ok && (a->ntiles == 1 || (a->npix & 3) == 0);
+    // the specialised kernels exist for "white balance only" (0), one index (1, 2, 4) and all three (7); two-index masks
+    // run the three-index kernels with the third plane's pointers null and its record left alone (P.mask)
+    const unsigned tmask = (mask == 3u || mask == 5u || mask == 6u) ? 7u : mask;
+    const bool ch_ok = a->channels == 3 || (a->channels == 4 && a->dtype == LARS_U8 && (reinterpret_cast<uintptr_t>(a->tiles) & 15) == 0 &&
+                                            (!a->out_wb || (reinterpret_cast<uintptr_t>(a->out_wb) & 15) == 0));
+    const bool fast = ch_ok && aligned && (a->ntiles == 1 || (a->npix & 3) == 0);
     // fused_impl 0 = automatic: the second-generation kernels win where the launch is read-bound
     // (statistics only); with output planes the launch is write-bound and the lighter first-generation
     // kernel (more resident waves, no LDS table) is as fast or faster (tools/kbench.py)
@@ -821,25 +822,28 @@ extern "C" int lars_d_fused(const lars_fused_args *a)
     if (impl == 0) impl = (any_out && mask != 0u) ? 1 : 2;
     // the second-generation kernels address a tile through a raw buffer descriptor with 32-bit offsets
     const bool small_tile = (long long)a->npix * 6 < (1ll << 30);
-    if (fast && a->dtype == LARS_U8 && impl >= 2 && small_tile) {
+    int &ran = tuning().last_fused_kernel;                    // which kernel family served the launch (tests, tools)
+    if (fast && a->dtype == LARS_U8 && a->channels == 3 && impl >= 2 && small_tile) {
         dim3 grid(blocks_per_tile(a->npix / 4 + 1, a->ntiles, fused_v2_threads(any_out || mask == 0u)), (unsigned)a->ntiles);
-        fused_v2_launch(mask, a->wb_table != nullptr, stats_mode, tuning().nt_stores != 0, grid, s, P);
+        fused_v2_launch(tmask, a->wb_table != nullptr, stats_mode, tuning().nt_stores != 0, grid, s, P);
+        ran = 2;
+    } else if (fast && a->dtype == LARS_U8 && a->channels == 4) {
+        dim3 grid(blocks_per_tile(a->npix / 4 + 1, a->ntiles, 256, 32768), (unsigned)a->ntiles);
+        launch_fast<uint8_t, 4>(tmask, a->wb_table != nullptr, stats_mode, grid, s, P);
+        ran = 5;
     } else if (fast && a->dtype == LARS_U8) {
         dim3 grid(blocks_per_tile(a->npix / 4 + 1, a->ntiles, 256, 32768), (unsigned)a->ntiles);
-        if (tuning().grid_swap) grid = dim3(grid.y, grid.x);
-        const bool headline = mask == 7u && a->wb_table && stats_mode == 1;
-        if (headline && tuning().traverse == 0) hipLaunchKernelGGL((k_fused_u8c3<uint8_t, 7u, true, 1, 0>), grid, dim3(256), 0, s, P);
-        else if (headline && tuning().traverse == 2) hipLaunchKernelGGL((k_fused_u8c3<uint8_t, 7u, true, 1, 2>), grid, dim3(256), 0, s, P);
-        else if (mask == 1u && a->wb_table && stats_mode == 1 && tuning().traverse == 2)       // the NDVI-plane mix (3 B read : 4 B written)
-            hipLaunchKernelGGL((k_fused_u8c3<uint8_t, 1u, true, 1, 2>), grid, dim3(256), 0, s, P);
-        else launch_fast<uint8_t>(mask, a->wb_table != nullptr, stats_mode, grid, s, P);
+        launch_fast<uint8_t>(tmask, a->wb_table != nullptr, stats_mode, grid, s, P);
+        ran = 1;
     } else if (fast && a->dtype == LARS_U16 && small_tile) {
         dim3 grid(blocks_per_tile(a->npix / 4 + 1, a->ntiles, 256, 32768), (unsigned)a->ntiles);
-        launch_fast<uint16_t>(mask, a->wb_table != nullptr, stats_mode, grid, s, P);
+        launch_fast<uint16_t>(tmask, a->wb_table != nullptr, stats_mode, grid, s, P);
+        ran = 3;
     } else {
         dim3 grid(blocks_per_tile(a->npix, a->ntiles), (unsigned)a->ntiles);
         if (a->dtype == LARS_U8) hipLaunchKernelGGL((k_fused_generic<uint8_t, 256>), grid, dim3(256), 0, s, P);
         else hipLaunchKernelGGL((k_fused_generic<uint16_t, 65536>), grid, dim3(256), 0, s, P);
+        ran = 4;
     }
     if (stats_mode && !raw)
         hipLaunchKernelGGL(k_stats_finalize, dim3((unsigned)((nrec + 255) / 256)), dim3(256), 0, s, a->stats, nrec, mask,

@@ -54,6 +54,8 @@ __global__ __launch_bounds__(256) void k_quot_check(unsigned int max_den, unsign
 // channel histograms, conflict-free
 // ---------------------------------------------------------------------------
 // LDS: [3 channels][256 bins][32 copies] u32 = 96 KiB; copy = lane % 32.
+// CH = 4: RGBA tiles, one 16-byte load per lane repacked into the three dwords of an RGB quad (alpha is not counted).
+template <int CH>
 __global__ __launch_bounds__(1024) void k_chan_hist_u8c3_v2(const uint8_t *__restrict__ tiles, long long npix,
                                                             unsigned int *__restrict__ hist)
 {
@@ -63,7 +65,7 @@ __global__ __launch_bounds__(1024) void k_chan_hist_u8c3_v2(const uint8_t *__res
     __syncthreads();
 
     const long long tile = blockIdx.y;
-    const uint8_t *base = tiles + tile * npix * 3;
+    const uint8_t *base = tiles + tile * npix * CH;
     const long long nquads = npix >> 2;
     const unsigned int lane_off = (tid & 31) << 2;         // byte offset of this lane's copy
     char *hb = reinterpret_cast<char *>(s_h);
@@ -77,7 +79,40 @@ __global__ __launch_bounds__(1024) void k_chan_hist_u8c3_v2(const uint8_t *__res
     HADD(a0, 0, 0); HADD(a0, 8, 1); HADD(a0, 16, 2); HADD(a0, 24, 0);                                 \
     HADD(a1, 0, 1); HADD(a1, 8, 2); HADD(a1, 16, 0); HADD(a1, 24, 1);                                 \
     HADD(a2, 0, 2); HADD(a2, 8, 0); HADD(a2, 16, 1); HADD(a2, 24, 2);
-    if (niter > 0) {
+    if (niter > 0 && CH == 4) {
+        const __amdgpu_buffer_rsrc_t rsrc =
+            __builtin_amdgcn_make_buffer_rsrc(const_cast<uint8_t *>(base), 0, (int)(nquads * 16), 0x00020000);
+        const unsigned int voff = (unsigned int)q0 * 16u;
+        const unsigned int step_b = (unsigned int)step * 16u;
+        typedef unsigned int u32x4h __attribute__((ext_vector_type(4)));
+        u32x4h w[4];
+#define HQUAD4(p)                                                                                       \
+        {                                                                                               \
+            const unsigned int a0 = __builtin_amdgcn_perm((p).y, (p).x, 0x04020100u);                  \
+            const unsigned int a1 = __builtin_amdgcn_perm((p).z, (p).y, 0x05040201u);                  \
+            const unsigned int a2 = __builtin_amdgcn_perm((p).w, (p).z, 0x06050402u);                  \
+            HQUAD(a0, a1, a2)                                                                           \
+        }
+#pragma unroll
+        for (int k = 0; k < 4; ++k) w[k] = __builtin_amdgcn_raw_buffer_load_b128(rsrc, voff, (unsigned)k * step_b, 0);
+        long long it = 0;
+        unsigned int soff = 4u * step_b;
+        for (; it + 4 <= niter - 1; it += 4) {
+#pragma unroll
+            for (int k = 0; k < 4; ++k) {
+                HQUAD4(w[k])
+                __builtin_amdgcn_sched_barrier(0);
+                w[k] = __builtin_amdgcn_raw_buffer_load_b128(rsrc, voff, soff + (unsigned)k * step_b, 0);
+                __builtin_amdgcn_sched_barrier(0);
+            }
+            soff += 4u * step_b;
+        }
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            if (it + k < niter && q0 + (it + k) * step < nquads) { HQUAD4(w[k]) }
+        }
+#undef HQUAD4
+    } else if (niter > 0) {
         const __amdgpu_buffer_rsrc_t rsrc =
             __builtin_amdgcn_make_buffer_rsrc(const_cast<uint8_t *>(base), 0, (int)(nquads * 12), 0x00020000);
         const unsigned int voff = (unsigned int)q0 * 12u;
@@ -104,7 +139,7 @@ __global__ __launch_bounds__(1024) void k_chan_hist_u8c3_v2(const uint8_t *__res
     }
 #undef HQUAD
     if (blockIdx.x == 0 && tid < (int)(npix & 3)) {
-        const uint8_t *p = base + (nquads * 4 + tid) * 3;
+        const uint8_t *p = base + (nquads * 4 + tid) * CH;
         HADD((unsigned)p[0], 0, 0); HADD((unsigned)p[1], 0, 1); HADD((unsigned)p[2], 0, 2);
     }
 #undef HADD
@@ -612,21 +647,21 @@ __global__ __launch_bounds__(V2Block<OUT>::threads, OUT ? 4 : LARS_V2_STATS_WAVE
             double t[11];
             for (int j = 0; j < 11; ++j) t[j] = s_red[j];
             StatsAccView *rec = reinterpret_cast<StatsAccView *>(P.stats + tile * 3);
-            if (WANT_NDVI) {
+            if (WANT_NDVI && (P.mask & 1u)) {
                 atomicAdd(&rec[0].sum_fx, (unsigned long long)__double2ll_rn(t[0] * LARS_FX_SCALE));
                 if (STATS >= 3) atomicAdd(&rec[0].sumsq_fx, (unsigned long long)__double2ll_rn(t[1] * LARS_FX_SCALE));
                 atomicAdd(&rec[0].above, (unsigned long long)t[4]);
                 atomicMin(&rec[0].min_key, f64_key(t[2]));
                 atomicMax(&rec[0].max_key, f64_key(t[3]));
             }
-            if (WANT_GNDVI) {
+            if (WANT_GNDVI && (P.mask & 2u)) {
                 atomicAdd(&rec[1].sum_fx, (unsigned long long)__double2ll_rn(t[5] * LARS_FX_SCALE));
                 if (STATS >= 3) atomicAdd(&rec[1].sumsq_fx, (unsigned long long)__double2ll_rn(t[6] * LARS_FX_SCALE));
                 atomicAdd(&rec[1].above, (unsigned long long)t[9]);
                 atomicMin(&rec[1].min_key, f64_key(t[7]));
                 atomicMax(&rec[1].max_key, f64_key(t[8]));
             }
-            if (WANT_NDWI) {
+            if (WANT_NDWI && (P.mask & 4u)) {
                 // NDWI = -GNDVI: sum negates, squares equal, extrema swap (0.0 - x keeps zeros positive,
                 // which the double keys below reproduce: -(+0.0) never occurs because min/max of the
                 // quotient only reach 0 as +0.0 and 0.0 - 0.0 = +0.0)
@@ -642,7 +677,7 @@ __global__ __launch_bounds__(V2Block<OUT>::threads, OUT ? 4 : LARS_V2_STATS_WAVE
             StatsAccView *rec = reinterpret_cast<StatsAccView *>(P.stats + tile * 3);
             if (tid < 3 * LARS_HIST_BINS) {
                 const int k = tid / LARS_HIST_BINS;
-                if (MASK & (1u << k)) {
+                if ((MASK & (1u << k)) && (P.mask & (1u << k))) {
                     const int b = tid - k * LARS_HIST_BINS;
                     const unsigned int *rowh = s_hist + (k * V2_HIST_ROWS + b) * V2_HIST_COPIES;
                     unsigned int v = 0;
@@ -688,12 +723,6 @@ namespace lars {
 template <unsigned MASK, bool WB, int STATS>
 static void v2_launch_out(bool out, bool nt, dim3 grid, hipStream_t s, const FusedParams &P)
 {
-    // A/B of the coverage counters in one process (lars_set_tuning("count_mode", 3)): float counters, only instantiated
-    // for the two statistics-only configurations the bench reports
-    if (!out && tuning().count_mode == 3 && WB && STATS == 1 && (MASK == 7u || MASK == 1u)) {
-        hipLaunchKernelGGL((k_fused_v2<(MASK == 7u ? 7u : 1u), true, 1, false, false, 0, 3>), grid, dim3(V2Block<false>::threads), 0, s, P);
-        return;
-    }
     if (!out) hipLaunchKernelGGL((k_fused_v2<MASK, WB, STATS, false, false>), grid, dim3(V2Block<false>::threads), 0, s, P);
     else if (nt) hipLaunchKernelGGL((k_fused_v2<MASK, WB, STATS, true, true>), grid, dim3(512), 0, s, P);
     else hipLaunchKernelGGL((k_fused_v2<MASK, WB, STATS, true, false>), grid, dim3(512), 0, s, P);
@@ -756,9 +785,10 @@ void fused_v2_launch(unsigned mask, bool wb, int stats, bool nt, dim3 grid, hipS
     }
 }
 
-void chan_hist_v2_launch(const uint8_t *tiles, long long npix, unsigned int *hist, dim3 grid, hipStream_t s)
+void chan_hist_v2_launch(const uint8_t *tiles, long long npix, unsigned int *hist, dim3 grid, hipStream_t s, int channels)
 {
-    hipLaunchKernelGGL(k_chan_hist_u8c3_v2, grid, dim3(1024), 0, s, tiles, npix, hist);
+    if (channels == 4) hipLaunchKernelGGL(k_chan_hist_u8c3_v2<4>, grid, dim3(1024), 0, s, tiles, npix, hist);
+    else hipLaunchKernelGGL(k_chan_hist_u8c3_v2<3>, grid, dim3(1024), 0, s, tiles, npix, hist);
 }
 
 int quot_check_launch(unsigned int max_den, unsigned long long *mismatches_dev, unsigned int *first_bad_dev, hipStream_t s)

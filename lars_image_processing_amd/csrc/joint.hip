@@ -23,6 +23,8 @@
 // samples), dword D = S >> 1, half h = S & 1.
 #include <string.h>
 
+#include <type_traits>
+
 #include "v2_device.h"
 
 namespace lars {
@@ -51,7 +53,8 @@ __device__ inline void jh_add(unsigned int addr, unsigned int val, char *tab)
     __hip_atomic_fetch_add(reinterpret_cast<unsigned int *>(tab + addr), val, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
 }
 
-template <int DEPTH>
+// CH = 4: RGBA tiles, one 16-byte load per lane and step, repacked into the three dwords of an RGB quad.
+template <int DEPTH, int CH = 3>
 __global__ __launch_bounds__(JH_THREADS, 4) void k_joint_count(JointCountParams P)
 {
     static_assert(JH_PERIOD_STEPS % DEPTH == 0, "a period is a whole number of ring turns");
@@ -87,7 +90,7 @@ __global__ __launch_bounds__(JH_THREADS, 4) void k_joint_count(JointCountParams 
     long long q_end = chunk == P.K - 1 ? nquads_tile : q_begin + P.chunk_quads;
     if (q_end > nquads_tile) q_end = nquads_tile;
     const long long nq = q_end > q_begin ? q_end - q_begin : 0;
-    const uint8_t *tile_base = P.tiles + tile * P.npix * 3;
+    const uint8_t *tile_base = P.tiles + tile * P.npix * CH;
 
     // byte selectors (wave-uniform): bytes of a quad r0 g0 n0 r1 | g1 n1 r2 g2 | n2 r3 g3 n3
     // pixels 0, 1 from (w0, w1): perm(src0 = w1, src1 = w0) -> selector = byte offset 0..7
@@ -114,7 +117,7 @@ __global__ __launch_bounds__(JH_THREADS, 4) void k_joint_count(JointCountParams 
 
     // tail pixels of the tile (npix % 4): its last chunk, before the first period (which starts from zero counts)
     if (chunk == P.K - 1 && tid < (int)(P.npix & 3)) {
-        const uint8_t *p = tile_base + (nquads_tile * 4 + tid) * 3;
+        const uint8_t *p = tile_base + (nquads_tile * 4 + tid) * CH;
         const unsigned int n = p[2], x = green ? p[1] : p[0];
         const unsigned int s = ((x << 8) | n) ^ x;
         jh_add((s << 1) & 0x1FFFCu, ((s & 1u) << 16) | 1u, tab);
@@ -148,21 +151,32 @@ __global__ __launch_bounds__(JH_THREADS, 4) void k_joint_count(JointCountParams 
     const int rem = (int)(nq & 1023);
     if (nq > 0) {
         const __amdgpu_buffer_rsrc_t rsrc =
-            __builtin_amdgcn_make_buffer_rsrc(const_cast<uint8_t *>(tile_base + q_begin * 12), 0, (int)(nq * 12), 0x00020000);
-        const unsigned int voff = (unsigned int)tid * 12u;
-        constexpr unsigned int STEP_B = JH_THREADS * 12u;
-        u32x3 w[DEPTH];
+            __builtin_amdgcn_make_buffer_rsrc(const_cast<uint8_t *>(tile_base + q_begin * (CH * 4)), 0, (int)(nq * (CH * 4)), 0x00020000);
+        const unsigned int voff = (unsigned int)tid * (CH * 4u);
+        constexpr unsigned int STEP_B = JH_THREADS * CH * 4u;
+        typedef unsigned int u32x4j __attribute__((ext_vector_type(4)));
+        typename std::conditional<CH == 4, u32x4j, u32x3>::type w[DEPTH];
+        auto load = [&](unsigned int soff_b) {
+            if constexpr (CH == 4) return __builtin_amdgcn_raw_buffer_load_b128(rsrc, voff, soff_b, 0);
+            else return __builtin_amdgcn_raw_buffer_load_b96(rsrc, voff, soff_b, 0);
+        };
+        auto count = [&](const auto &v) {
+            if constexpr (CH == 4)
+                do_quad(__builtin_amdgcn_perm(v.y, v.x, 0x04020100u), __builtin_amdgcn_perm(v.z, v.y, 0x05040201u),
+                        __builtin_amdgcn_perm(v.w, v.z, 0x06050402u));
+            else do_quad(v.x, v.y, v.z);
+        };
 #pragma unroll
-        for (int k = 0; k < DEPTH; ++k) w[k] = __builtin_amdgcn_raw_buffer_load_b96(rsrc, voff, (unsigned)k * STEP_B, 0);
+        for (int k = 0; k < DEPTH; ++k) w[k] = load((unsigned)k * STEP_B);
         long long it = 0;
         unsigned int soff = DEPTH * STEP_B;
         int since = 0;
         for (; it + DEPTH <= nfull; it += DEPTH) {
 #pragma unroll
             for (int k = 0; k < DEPTH; ++k) {
-                do_quad(w[k].x, w[k].y, w[k].z);
+                count(w[k]);
                 __builtin_amdgcn_sched_barrier(0);
-                w[k] = __builtin_amdgcn_raw_buffer_load_b96(rsrc, voff, soff + (unsigned)k * STEP_B, 0);   // past the end: zeros, never counted
+                w[k] = load(soff + (unsigned)k * STEP_B);                 // past the end: zeros, never counted
                 __builtin_amdgcn_sched_barrier(0);
             }
             soff += DEPTH * STEP_B;
@@ -176,7 +190,7 @@ __global__ __launch_bounds__(JH_THREADS, 4) void k_joint_count(JointCountParams 
 #pragma unroll
         for (int k = 0; k < DEPTH; ++k) {
             const long long step = it + k;
-            if (step < nfull || (step == nfull && tid < rem)) do_quad(w[k].x, w[k].y, w[k].z);
+            if (step < nfull || (step == nfull && tid < rem)) count(w[k]);
         }
     }
     __syncthreads();
@@ -609,8 +623,10 @@ extern "C" int lars_d_stats_joint(const lars_fused_args *a, int white_balance, i
     LARS_TRY(ensure_ctx(&c));
     if (!a || !a->tiles || !a->stats || !scratch || a->ntiles <= 0 || a->npix <= 0)
         return fail(LARS_ERR_INVALID, "lars_d_stats_joint: bad arguments");
-    if (a->dtype != LARS_U8 || a->channels != 3 || (reinterpret_cast<uintptr_t>(a->tiles) & 3) || (a->ntiles > 1 && (a->npix & 3)))
-        return fail(LARS_ERR_INVALID, "lars_d_stats_joint: uint8 [ntiles][npix][3] tiles on 4-byte boundaries are required");
+    const bool c3 = a->channels == 3 && !(reinterpret_cast<uintptr_t>(a->tiles) & 3);
+    const bool c4 = a->channels == 4 && !(reinterpret_cast<uintptr_t>(a->tiles) & 15);
+    if (a->dtype != LARS_U8 || !(c3 || c4) || (a->ntiles > 1 && (a->npix & 3)))
+        return fail(LARS_ERR_INVALID, "lars_d_stats_joint: uint8 tiles [ntiles][npix][3] on 4-byte or [ntiles][npix][4] on 16-byte boundaries are required");
     const unsigned mask = a->index_mask & LARS_MASK_ALL;
     if (!mask || (a->index_mask & ~LARS_MASK_ALL)) return fail(LARS_ERR_INVALID, "lars_d_stats_joint: index_mask");
     if (a->out_wb || a->out_index[0] || a->out_index[1] || a->out_index[2] || a->out_rgba[0] || a->out_rgba[1] || a->out_rgba[2])
@@ -632,7 +648,8 @@ extern "C" int lars_d_stats_joint(const lars_fused_args *a, int white_balance, i
     const long long units = (long long)a->ntiles * K;
     const long long nwg = S == 2 ? ((units + 7) / 8) * 16 : units;
     if (nwg > 0x7FFFFFFFll) return fail(LARS_ERR_INVALID, "lars_d_stats_joint: too many workgroups");
-    if (tuning().joint_depth == 4) hipLaunchKernelGGL((k_joint_count<4>), dim3((unsigned)nwg), dim3(JH_THREADS), 0, s, C);
+    if (c4) hipLaunchKernelGGL((k_joint_count<6, 4>), dim3((unsigned)nwg), dim3(JH_THREADS), 0, s, C);
+    else if (tuning().joint_depth == 4) hipLaunchKernelGGL((k_joint_count<4>), dim3((unsigned)nwg), dim3(JH_THREADS), 0, s, C);
     else hipLaunchKernelGGL((k_joint_count<6>), dim3((unsigned)nwg), dim3(JH_THREADS), 0, s, C);
     LARS_TRY(launch_check("lars_d_stats_joint (count)"));
 

@@ -27,9 +27,9 @@
 // the statistics records (count = 0, sums NaN) so that no caller mistakes it for a result.
 #include <string.h>
 
-#include "common.h"
-#include "device_common.h"
-#include "fused_device.h"
+#include "lab.h"
+#include "../device_common.h"
+#include "../fused_device.h"
 
 namespace lars {
 
@@ -500,7 +500,7 @@ extern "C" size_t lars_pipeline_scratch_bytes(int64_t ntiles, int64_t npix)
 {
     if (ntiles <= 0 || npix <= 0) return 0;
     const long long nsteps = ((npix >> 2) + 255) >> 8;
-    long long spi = tuning().pipe_steps > 0 ? tuning().pipe_steps : 64;
+    long long spi = lab_tuning().pipe_steps > 0 ? lab_tuning().pipe_steps : 64;
     const long long items = (nsteps + spi - 1) / spi;
     return (size_t)ntiles * (size_t)items * 768 * 4 + (size_t)(2 + 2 * ntiles) * 4 + 512 + (size_t)4096 * PIPE_TRACE_ITEMS * 6 * 8;
 }
@@ -529,9 +529,9 @@ extern "C" int lars_d_pipeline(const lars_fused_args *a, double *percentiles, ui
     P.npix = a->npix;
     P.ntiles = (int)a->ntiles;
     const long long nsteps = ((a->npix >> 2) + 255) >> 8;
-    P.steps_per_item = tuning().pipe_steps > 0 ? tuning().pipe_steps : 64;
+    P.steps_per_item = lab_tuning().pipe_steps > 0 ? lab_tuning().pipe_steps : 64;
     P.items = (int)((nsteps + P.steps_per_item - 1) / P.steps_per_item);
-    P.head = tuning().pipe_head > 0 ? tuning().pipe_head : 2;
+    P.head = lab_tuning().pipe_head > 0 ? lab_tuning().pipe_head : 2;
     if (P.head > P.items) P.head = P.items;
     for (int k = 0; k < 3; ++k) P.out_index[k] = a->out_index[k];
     P.stats = a->stats;
@@ -541,9 +541,9 @@ extern "C" int lars_d_pipeline(const lars_fused_args *a, double *percentiles, ui
     P.partial = static_cast<unsigned int *>(scratch);
     P.sync = P.partial + (size_t)a->ntiles * P.items * 768;
     P.rgn_variant = rgn_variant;
-    P.flags = (tuning().nt_stores ? 0x20000000u : 0u) | (tuning().pipe_cold ? 1u : 0u);
+    P.flags = (tuning().nt_stores ? 0x20000000u : 0u) | (lab_tuning().pipe_cold ? 1u : 0u);
     // item timestamps for tools/pipebench.py: behind the sync words, 8-byte aligned, room for 4096 workgroups
-    P.trace = tuning().pipe_trace ? reinterpret_cast<unsigned long long *>((reinterpret_cast<uintptr_t>(P.sync + 2 + 2 * a->ntiles) + 255) & ~(uintptr_t)255) : nullptr;
+    P.trace = lab_tuning().pipe_trace ? reinterpret_cast<unsigned long long *>((reinterpret_cast<uintptr_t>(P.sync + 2 + 2 * a->ntiles) + 255) & ~(uintptr_t)255) : nullptr;
     if (P.trace) LARS_HIP_TRY(hipMemsetAsync(P.trace, 0, (size_t)4096 * PIPE_TRACE_ITEMS * 6 * 8, s));
 
     LARS_HIP_TRY(hipMemsetAsync(P.sync, 0, (size_t)(2 + 2 * a->ntiles) * 4, s));

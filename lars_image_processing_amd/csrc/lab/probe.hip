@@ -1,7 +1,7 @@
 // Roofline probes: what this device sustains for plain streaming reads / copies
 // with the access shapes the hot path uses.  Reported by bench.py next to the
 // kernel numbers ("verify the peak with a STREAM-like kernel").
-#include "common.h"
+#include "lab.h"
 
 namespace lars {
 

@@ -3,13 +3,7 @@
 #include <stdarg.h>
 #include <stdlib.h>
 #include <string.h>
-#include <map>
-#include <mutex>
-#include <utility>
-#include <vector>
-
 #include <cmath>
-#include <mutex>
 
 #include "common.h"
 
@@ -136,107 +130,12 @@ int lars_device_name(char *buf, size_t buflen)
     return LARS_OK;
 }
 
-// LARS_MALLOC_KIND=3 (experiments, tools/allocbench.py): virtual-memory-management allocations -- one address range, physical
-// memory created in chunks of LARS_VMM_CHUNK_MB (0 / unset = the whole allocation in ONE handle) and mapped back to back.
-namespace {
-struct VmmBlock { size_t bytes, chunk; std::vector<hipMemGenericAllocationHandle_t> handles; };
-std::mutex g_vmm_lock;
-std::map<void *, VmmBlock> g_vmm;
-
-int vmm_alloc(int device, void **dptr, size_t bytes)
-{
-    hipMemAllocationProp prop;
-    memset(&prop, 0, sizeof prop);
-    prop.type = hipMemAllocationTypePinned;
-    prop.location.type = hipMemLocationTypeDevice;
-    prop.location.id = device;
-    size_t gran = 0;
-    if (hipMemGetAllocationGranularity(&gran, &prop, hipMemAllocationGranularityRecommended) != hipSuccess || !gran)
-        return fail(LARS_ERR_HIP, "hipMemGetAllocationGranularity failed");
-    const char *chunk_env = getenv("LARS_VMM_CHUNK_MB");
-    size_t chunk = chunk_env ? (size_t)atoll(chunk_env) << 20 : 0;
-    const size_t total = (bytes + gran - 1) / gran * gran;
-    if (!chunk || chunk > total) chunk = total;
-    chunk = (chunk + gran - 1) / gran * gran;
-    void *base = nullptr;
-    const char *align_env = getenv("LARS_VMM_ALIGN_MB");          // alignment of the address range (0 / unset = the driver's default)
-    const size_t align = align_env ? (size_t)atoll(align_env) << 20 : 0;
-    if (hipMemAddressReserve(&base, total, align, nullptr, 0) != hipSuccess) return fail(LARS_ERR_OOM, "hipMemAddressReserve(%zu) failed", total);
-    VmmBlock blk;
-    blk.bytes = total;
-    blk.chunk = chunk;
-    // LARS_VMM_SHUFFLE=1: all chunks are created first and then mapped in a pseudo-random order, so that neighbouring
-    // addresses are backed by physical memory from unrelated places
-    const bool shuffle = getenv("LARS_VMM_SHUFFLE") && getenv("LARS_VMM_SHUFFLE")[0] == '1';
-    const size_t nchunks = (total + chunk - 1) / chunk;
-    auto undo = [&](size_t mapped) {
-        for (size_t i = 0; i < mapped; ++i) hipMemUnmap(static_cast<char *>(base) + i * chunk, (i + 1) * chunk <= total ? chunk : total - i * chunk);
-        for (auto &hh : blk.handles) hipMemRelease(hh);
-        hipMemAddressFree(base, total);
-    };
-    for (size_t i = 0; i < nchunks; ++i) {
-        const size_t n = (i + 1) * chunk <= total ? chunk : total - i * chunk;
-        hipMemGenericAllocationHandle_t h;
-        const hipError_t e = hipMemCreate(&h, n, &prop, 0);
-        if (e != hipSuccess) { undo(0); return fail(LARS_ERR_OOM, "hipMemCreate(%zu): %s", n, hipGetErrorString(e)); }
-        blk.handles.push_back(h);
-    }
-    if (shuffle && total % chunk == 0) {
-        unsigned long long x = 0x9E3779B97F4A7C15ull;
-        for (size_t i = nchunks - 1; i > 0; --i) {
-            x ^= x << 13; x ^= x >> 7; x ^= x << 17;
-            std::swap(blk.handles[i], blk.handles[(size_t)(x % (i + 1))]);
-        }
-    }
-    for (size_t i = 0; i < nchunks; ++i) {
-        const size_t n = (i + 1) * chunk <= total ? chunk : total - i * chunk;
-        const hipError_t e = hipMemMap(static_cast<char *>(base) + i * chunk, n, 0, blk.handles[i], 0);
-        if (e != hipSuccess) { undo(i); return fail(LARS_ERR_OOM, "hipMemMap(%zu): %s", n, hipGetErrorString(e)); }
-    }
-    hipMemAccessDesc acc;
-    memset(&acc, 0, sizeof acc);
-    acc.location = prop.location;
-    acc.flags = hipMemAccessFlagsProtReadWrite;
-    if (hipMemSetAccess(base, total, &acc, 1) != hipSuccess) { undo(nchunks); return fail(LARS_ERR_HIP, "hipMemSetAccess failed"); }
-    {
-        std::lock_guard<std::mutex> g(g_vmm_lock);
-        g_vmm[base] = blk;
-    }
-    *dptr = base;
-    return LARS_OK;
-}
-// true if dptr was a VMM block (and is gone now)
-bool vmm_free(void *dptr)
-{
-    VmmBlock blk;
-    {
-        std::lock_guard<std::mutex> g(g_vmm_lock);
-        auto it = g_vmm.find(dptr);
-        if (it == g_vmm.end()) return false;
-        blk = it->second;
-        g_vmm.erase(it);
-    }
-    hipMemUnmap(dptr, blk.bytes);
-    for (auto &h : blk.handles) hipMemRelease(h);
-    hipMemAddressFree(dptr, blk.bytes);
-    return true;
-}
-}  // namespace
-
 int lars_malloc(void **dptr, size_t bytes)
 {
     ThreadCtx *c;
     LARS_TRY(ensure_ctx(&c));
     if (!dptr) return fail(LARS_ERR_INVALID, "lars_malloc: NULL");
-    // LARS_MALLOC_KIND (experiments, tools/allocbench.py): 1 uncached, 2 fine-grained device memory, 3 virtual-memory-management
-    // blocks, 4 physically contiguous memory (hipDeviceMallocContiguous) instead of plain hipMalloc
-    const char *kind = getenv("LARS_MALLOC_KIND");
-    hipError_t e;
-    if (kind && kind[0] == '3' && bytes >= (64u << 20)) return vmm_alloc(c->device, dptr, bytes);
-    if (kind && kind[0] == '1') e = hipExtMallocWithFlags(dptr, bytes ? bytes : 1, hipDeviceMallocUncached);
-    else if (kind && kind[0] == '2') e = hipExtMallocWithFlags(dptr, bytes ? bytes : 1, hipDeviceMallocFinegrained);
-    else if (kind && kind[0] == '4' && bytes >= (64u << 20)) e = hipExtMallocWithFlags(dptr, bytes, hipDeviceMallocContiguous);
-    else e = hipMalloc(dptr, bytes ? bytes : 1);
+    const hipError_t e = hipMalloc(dptr, bytes ? bytes : 1);
     if (e != hipSuccess) { *dptr = nullptr; return fail(LARS_ERR_OOM, "hipMalloc(%zu): %s", bytes, hipGetErrorString(e)); }
     return LARS_OK;
 }
@@ -245,7 +144,6 @@ int lars_free(void *dptr)
     if (!dptr) return LARS_OK;
     ThreadCtx *c;
     LARS_TRY(ensure_ctx(&c));
-    if (vmm_free(dptr)) return LARS_OK;
     LARS_HIP_TRY(hipFree(dptr));
     return LARS_OK;
 }
@@ -353,15 +251,8 @@ int lars_set_tuning(const char *key, int value)
     else if (!strcmp(key, "hist_impl")) t.hist_impl = value;
     else if (!strcmp(key, "nt_stores")) t.nt_stores = value;
     else if (!strcmp(key, "blocks_per_tile")) t.blocks_per_tile = value;
-    else if (!strcmp(key, "traverse")) t.traverse = value;
-    else if (!strcmp(key, "grid_swap")) t.grid_swap = value;
-    else if (!strcmp(key, "count_mode")) t.count_mode = value;
-    else if (!strcmp(key, "pipe_steps")) t.pipe_steps = value;
     else if (!strcmp(key, "selq_window")) t.selq_window = value;
     else if (!strcmp(key, "selq_list_wgs")) t.selq_list_wgs = value;
-    else if (!strcmp(key, "pipe_head")) t.pipe_head = value;
-    else if (!strcmp(key, "pipe_trace")) t.pipe_trace = value;
-    else if (!strcmp(key, "pipe_cold")) t.pipe_cold = value;
     else if (!strcmp(key, "joint_depth")) t.joint_depth = value;
     else return fail(LARS_ERR_INVALID, "lars_set_tuning: unknown key %s", key);
     return LARS_OK;
@@ -374,16 +265,10 @@ int lars_get_tuning(const char *key, int *value)
     else if (!strcmp(key, "hist_impl")) *value = t.hist_impl;
     else if (!strcmp(key, "nt_stores")) *value = t.nt_stores;
     else if (!strcmp(key, "blocks_per_tile")) *value = t.blocks_per_tile;
-    else if (!strcmp(key, "traverse")) *value = t.traverse;
-    else if (!strcmp(key, "grid_swap")) *value = t.grid_swap;
-    else if (!strcmp(key, "count_mode")) *value = t.count_mode;
-    else if (!strcmp(key, "pipe_steps")) *value = t.pipe_steps;
     else if (!strcmp(key, "selq_window")) *value = t.selq_window;
     else if (!strcmp(key, "selq_list_wgs")) *value = t.selq_list_wgs;
-    else if (!strcmp(key, "pipe_head")) *value = t.pipe_head;
-    else if (!strcmp(key, "pipe_trace")) *value = t.pipe_trace;
-    else if (!strcmp(key, "pipe_cold")) *value = t.pipe_cold;
     else if (!strcmp(key, "joint_depth")) *value = t.joint_depth;
+    else if (!strcmp(key, "last_fused_kernel")) *value = t.last_fused_kernel;
     else return fail(LARS_ERR_INVALID, "lars_get_tuning: unknown key %s", key);
     return LARS_OK;
 }

@@ -18,6 +18,12 @@ def header_symbols():
     return sorted(set(re.findall(r"\b(lars_[a-z0-9_]+)\s*\(", text)))
 
 
+def exported_symbols(path):
+    import subprocess
+    out = subprocess.run(["nm", "-D", "--defined-only", path], capture_output=True, text=True, check=True).stdout
+    return sorted({ln.split()[-1] for ln in out.splitlines() if ln.split() and ln.split()[-1].startswith("lars_")})
+
+
 def test_library_exports_every_declared_symbol():
     lib = _ffi.load()
     names = header_symbols()
@@ -27,6 +33,25 @@ def test_library_exports_every_declared_symbol():
     # and the binding declares a prototype for each of them
     assert set(names) == set(_ffi.SIGNATURES), set(names) ^ set(_ffi.SIGNATURES)
     assert lib.lars_abi_version() == 1
+
+
+def test_product_exports_are_exactly_the_documented_set():
+    """The product library exports the entry points include/lars_hip.h documents and nothing else: no probes, no
+    pipeline, no allocation experiments (those live in liblars_lab.so, include/lars_lab.h), and it reads no environment
+    variable that changes how it allocates."""
+    got = exported_symbols(_ffi.LIB_PATH)
+    assert got == header_symbols(), set(got) ^ set(header_symbols())
+    for name in ("lars_d_probe", "lars_d_pipeline", "lars_pipeline_scratch_bytes", "lars_d_output_arena", "lars_lab_malloc"):
+        assert name not in got
+    blob = open(_ffi.LIB_PATH, "rb").read()
+    for env in (b"LARS_MALLOC_KIND", b"LARS_VMM_CHUNK_MB", b"LARS_VMM_SHUFFLE", b"LARS_VMM_ALIGN_MB"):
+        assert env not in blob, env
+    lab = os.path.join(os.path.dirname(_ffi.LIB_PATH), "liblars_lab.so")
+    if os.path.exists(lab):
+        text = open(os.path.join(ROOT, "include", "lars_lab.h")).read()
+        text = re.sub(r"/\*.*?\*/", "", text, flags=re.S)
+        declared = sorted(set(re.findall(r"\b(lars_[a-z0-9_]+)\s*\(", text)))
+        assert exported_symbols(lab) == declared, set(exported_symbols(lab)) ^ set(declared)
 
 
 def test_struct_layouts_match_header():

@@ -258,16 +258,6 @@ def test_tuning_does_not_change_results(lars):
                 assert got == ref, (impl, nt, bpt)
                 np.testing.assert_allclose(sumsq, ref_sumsq, rtol=1e-12)
     _ffi.set_tuning(fused_impl=keep[0], hist_impl=keep[1], nt_stores=0, blocks_per_tile=0)
-    # the plane-writing kernel's A/B mappings (statistics without histograms: the configuration they exist for)
-    ref = None
-    for knobs in ({}, {"traverse": 0}, {"traverse": 2}, {"grid_swap": 1}, {"grid_swap": 1, "blocks_per_tile": 3}):
-        _ffi.set_tuning(**knobs)
-        rec = b.process(outputs=outs)
-        got = (rec.tobytes(), outs.host_index("NDVI", 0, 4).tobytes(), outs.host_index("GNDVI", 0, 4).tobytes())
-        _ffi.set_tuning(traverse=-1, grid_swap=0, blocks_per_tile=0)
-        if ref is None:
-            ref = got
-        assert got == ref, knobs
     outs.free()
     b.free()
 
@@ -422,6 +412,90 @@ def test_output_ring_placement_trials(lars):
     np.testing.assert_array_equal(bits(tuned.host_index("NDVI", 1, 1)), bits(ndvi_a))
     assert rec_a.tobytes() == rec_b.tobytes()
     plain.free(); tuned.free(); b.free()
+
+
+def test_planes_stay_aligned_inside_the_arena(lars):
+    """Odd plane sizes (slots * npix not a multiple of 4): planes start on 256-byte boundaries inside the arena, so the
+    quad-per-lane kernel keeps running; multi-GiB arenas are chosen among timed plain allocations by default."""
+    from lars_image_processing_amd import _ffi
+    odd = lars.TileBatch.synthetic(1, 33, 35, seed=2)
+    o = odd.make_outputs(index=True)
+    assert o.plane_bytes % 256 == 0 and all(o.index[k].ptr % 256 == 0 for k in range(3))
+    assert o.arena_report["kind"] == "plain hipMalloc"
+    rec = odd.process(outputs=o)
+    assert _ffi.get_tuning("last_fused_kernel") in (1, 2)
+    with warnings.catch_warnings():
+        warnings.simplefilter("ignore")
+        want = orc.index_app(orc.wb_app(odd.host_tiles()[0]), "GNDVI")
+    np.testing.assert_array_equal(bits(o.host_index("GNDVI", 0, 1)[0]), bits(want))
+    assert float(rec[0, 1]["sum"]) == orc.tile_partials(want, "GNDVI")["sum"]
+    with pytest.raises(ValueError):
+        odd.make_outputs(index=True, arena="assembled")
+    o.free(); odd.free()
+
+
+def test_rgba_tiles_and_two_index_masks_take_the_fast_kernels(lars):
+    """RGBA uint8 uploads (alpha ignored, zero in the white-balanced image: process-images.py:432-435) and the two-index
+    masks the multiselect can hand over (process-images.py:1501-1505) run on the quad-per-lane kernels, not on the
+    one-pixel-per-lane fallback -- with the same results as the RGB tiles / the three-index launch."""
+    from lars_image_processing_amd import _ffi
+    rng = np.random.default_rng(11)
+    rgb = np.stack([orc.synth_tile_u8(3, t, 64, 96, profile="vegetation") for t in range(5)])
+    rgba = np.concatenate([rgb, rng.integers(0, 256, rgb.shape[:3] + (1,), dtype=np.uint8)], axis=-1)
+    b3, b4 = lars.TileBatch.from_host(rgb), lars.TileBatch.from_host(rgba)
+    o3, o4 = b3.make_outputs(index=True, wb=True, rgba=True), b4.make_outputs(index=True, wb=True, rgba=True)
+    rec3 = b3.process(hist=True, sumsq=True, outputs=o3)
+    rec4 = b4.process(hist=True, sumsq=True, outputs=o4)
+    assert _ffi.get_tuning("last_fused_kernel") == 5
+    np.testing.assert_allclose(rec3["sumsq"], rec4["sumsq"], rtol=1e-12)
+    rec3["sumsq"] = rec4["sumsq"] = 0
+    assert rec3.tobytes() == rec4.tobytes()
+    np.testing.assert_array_equal(b4.host_hist(), b3.host_hist())
+    np.testing.assert_array_equal(b4.host_tables(), b3.host_tables())
+    wb4 = o4.host_wb(0, 5)
+    np.testing.assert_array_equal(wb4[..., :3], o3.host_wb(0, 5))
+    assert not wb4[..., 3].any()
+    for t in TYPES:
+        np.testing.assert_array_equal(bits(o4.host_index(t, 0, 5)), bits(o3.host_index(t, 0, 5)))
+        np.testing.assert_array_equal(o4.host_rgba(t, 0, 5), o3.host_rgba(t, 0, 5))
+    # statistics only: the one-read route and the per-pixel kernels, medians included
+    for route in ("joint", "classic"):
+        r3, m3 = b3.process(medians=True, route="classic")
+        r4, m4 = b4.process(medians=True, route=route)
+        assert r3.tobytes() == r4.tobytes(), route
+        np.testing.assert_array_equal(m3, m4)
+    # a single RGBA tile whose pixel count is not a multiple of 4, without white balance
+    odd = lars.TileBatch.from_host(rgba[:1, :33, :35])
+    oo = odd.make_outputs(index=True)
+    ro = odd.process(white_balance=False, outputs=oo)
+    assert _ffi.get_tuning("last_fused_kernel") == 5
+    want = orc.index_app(rgba[0, :33, :35], "GNDVI")
+    np.testing.assert_array_equal(bits(oo.host_index("GNDVI", 0, 1)[0]), bits(want))
+    assert float(ro[0, 1]["sum"]) == orc.tile_partials(want, "GNDVI")["sum"]
+    assert odd.process(white_balance=False, route="joint").tobytes() == ro.tobytes()
+    oo.free(); odd.free()
+    # two-index masks: three-index kernel, third plane and record untouched
+    full = b3.process(hist=True)
+    for pair in (("NDVI", "NDWI"), ("NDVI", "GNDVI"), ("GNDVI", "NDWI")):
+        op = b3.make_outputs(indices=pair, index=True)
+        for route in ("classic", "joint"):
+            rp = b3.process(indices=pair, hist=True, outputs=op if route == "classic" else None, route=route)
+            if route == "classic":
+                assert _ffi.get_tuning("last_fused_kernel") in (1, 2)
+            for k, t in enumerate(TYPES):
+                if t in pair:
+                    assert rp[:, k].tobytes() == full[:, k].tobytes(), (pair, t, route)
+                else:
+                    assert not rp[:, k].tobytes().strip(b"\0"), (pair, t, route)
+        for t in pair:
+            np.testing.assert_array_equal(bits(op.host_index(t, 0, 5)), bits(o3.host_index(t, 0, 5)))
+        rs = b3.process(indices=pair, route="classic")                 # statistics only through the per-pixel kernel
+        assert _ffi.get_tuning("last_fused_kernel") in (1, 2)
+        for k, t in enumerate(TYPES):
+            if t in pair:
+                assert rs[:, k]["sum"].tolist() == full[:, k]["sum"].tolist() and rs[:, k]["above"].tolist() == full[:, k]["above"].tolist()
+        op.free()
+    o3.free(); o4.free(); b3.free(); b4.free()
 
 
 def test_batch_medians_are_numpy_medians(lars):
@@ -612,60 +686,6 @@ def test_every_quotient_of_bytes_is_found_back_on_the_device():
             assert np.array_equal(med2[:, k], want), t
             assert not np.signbit(med[want == 0, k]).any() or t == "NDWI"
         b.free()
-
-
-@pytest.mark.parametrize("shape,ntiles,steps,head", [((256, 256), 5, 8, 2), ((64, 96), 3, 0, 0), ((130, 62), 4, 1, 1), ((512, 512), 9, 16, 4),
-                                                       ((256, 256), 1, 8, 3)])
-def test_pipelined_launch_equals_the_two_pass_path(lars, shape, ntiles, steps, head):
-    """csrc/pipeline.hip: histograms -> tables -> fused pass in one persistent launch.  Histograms, percentiles, tables,
-    planes and statistics records must be the bytes the separate launches produce (and hence the oracle's)."""
-    from lars_image_processing_amd import _ffi
-    b = lars.TileBatch.synthetic(ntiles, shape[0], shape[1], seed=31, profile="vegetation")
-    want_outs = b.make_outputs(index=True)
-    b.compute_wb_tables()
-    want_hist, want_tab, want_pct = b.host_hist().copy(), b.host_tables().copy(), b.host_percentiles().copy()
-    stats = b.new_stats()
-    b.run_fused(b.fused_args(("NDVI", "GNDVI", "NDWI"), True, stats, False, want_outs))
-    _ffi.call("lars_synchronize", None)
-    want_rec = stats.download(_ffi.STATS_DTYPE, (ntiles, 3)).tobytes()
-    want_planes = [want_outs.host_index(t, 0, ntiles).tobytes() for t in ("NDVI", "GNDVI", "NDWI")]
-    # forget everything, run the pipeline
-    for buf in (b.hist, b.table, b.percentiles, stats):
-        buf.zero()
-    outs = b.make_outputs(index=True)
-    assert b.can_pipeline(("NDVI", "GNDVI", "NDWI"), outs)
-    _ffi.set_tuning(pipe_steps=steps, pipe_head=head)
-    try:
-        b.run_pipeline(stats, outs)
-        _ffi.call("lars_synchronize", None)
-    finally:
-        _ffi.set_tuning(pipe_steps=0, pipe_head=0)
-    np.testing.assert_array_equal(b.host_hist(), want_hist)
-    np.testing.assert_array_equal(b.host_percentiles(), want_pct)
-    np.testing.assert_array_equal(b.host_tables(), want_tab)
-    got = stats.download(_ffi.STATS_DTYPE, (ntiles, 3))
-    assert (got["count"] == shape[0] * shape[1]).all()
-    assert got.tobytes() == want_rec
-    for t, want in zip(("NDVI", "GNDVI", "NDWI"), want_planes):
-        assert outs.host_index(t, 0, ntiles).tobytes() == want, t
-    # a tile of the result against the oracle as well
-    tile = b.host_tiles(ntiles - 1, 1)[0]
-    with warnings.catch_warnings():
-        warnings.simplefilter("ignore")
-        wb = orc.wb_app(tile)
-    np.testing.assert_array_equal(bits(outs.host_index("GNDVI", ntiles - 1, 1)[0]), bits(orc.index_app(wb, "GNDVI")))
-    # a sub-range of the batch into a ring
-    ring = b.make_outputs(index=True, ring=2)
-    if ntiles >= 4:
-        stats.zero()
-        b.run_pipeline(stats, ring, tile_start=2, tile_count=2)
-        _ffi.call("lars_synchronize", None)
-        part = stats.download(_ffi.STATS_DTYPE, (ntiles, 3))
-        assert part[2:4].tobytes() == got[2:4].tobytes() and not part[:2]["count"].any()
-        assert ring.host_index("NDVI", 0, 2).tobytes() == outs.host_index("NDVI", 2, 2).tobytes()
-    for o in (want_outs, outs, ring):
-        o.free()
-    stats.free(); b.free()
 
 
 def test_caller_stream_is_ordered_against_the_zeroing(lars):

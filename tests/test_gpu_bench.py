@@ -103,16 +103,6 @@ def test_bench_statistics_fold_transports_agree(transport):
     assert line["global_stats"] == base["global_stats"]
 
 
-def test_bench_moves_to_torch_when_the_library_communicator_does_not_come_up():
-    """auto: the vote picks the library's RCCL communicator, its bootstrap fails (test hook) on every rank, the second vote
-    moves the group to torch.distributed -- same statistics, no dead run."""
-    base = run_bench({}, "--no-cpu-baseline")
-    line = run_bench({"LARS_FORCE_RCCL": "1", "LARS_BENCH_FAIL_RCCL": "1"}, "--no-cpu-baseline")
-    check_line(line)
-    assert "torch.distributed" in line["config"]["collective"]
-    assert line["global_stats"] == base["global_stats"]
-
-
 @pytest.mark.parametrize("ranks", [2, 3, 4])
 def test_ranks_on_one_gpu_equal_one_process_over_all_tiles(tmp_path, ranks):
     """The N > 1 flow end to end on real kernels: `ranks` ranks (all on GPU 0, statistics exchanged over gloo) with

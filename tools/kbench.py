@@ -134,21 +134,6 @@ def main():
                 ts.append((time.perf_counter() - t0) * 1e3)
             results[name] = {"ms": float(np.median(ts[1:])), "min_ms": float(min(ts[1:])), "Gpix_s": npix / float(np.median(ts[1:])) / 1e6}
         outs.free()
-    if "probe" in args.what:
-        nbytes = args.tiles * b.tile_bytes
-        nbytes -= nbytes % 960
-        dst = _ffi.DeviceBuffer(nbytes)
-        kinds = [(1, "probe read12", 1), (5, "probe mix12r48w", 1), (6, "probe mix12r48w nt", 1), (7, "probe mix12r16w", 1),
-                 (3, "probe write16", 1)]
-        variants = [(k, n, m, blocks) for k, n, m in kinds for blocks in (16384, 65536, 262144)]
-        times = {v: [] for v in variants}
-        for _ in range(args.rounds + 1):
-            for v in variants:
-                times[v].append(timer.time(lambda: _ffi.call("lars_d_probe", v[0], 1, v[3], C.c_void_p(b.tiles.ptr),
-                                                             C.c_void_p(dst.ptr), nbytes, None)))
-        for v, t in times.items():
-            med = float(np.median(t[1:]))
-            results[f"{v[1]} blocks={v[3]}"] = {"ms": med, "min_ms": float(min(t[1:])), "GBs": nbytes * v[2] / med / 1e6}
     for k, v in results.items():
         print(f"{k:58s} " + "  ".join(f"{kk}={vv:9.3f}" for kk, vv in v.items()))
     print(json.dumps(results))

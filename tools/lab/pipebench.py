@@ -1,12 +1,14 @@
 #!/usr/bin/env python3
 """The whole step (histograms -> tables -> three planes + statistics) as separate launches vs the persistent pipeline
-(csrc/pipeline.hip), interleaved in one process, same output arena; sweeps the pipeline's item size and H-item lead.
+(csrc/lab/pipeline.hip, liblars_lab.so), interleaved in one process, same output arena; sweeps the pipeline's item size and
+H-item lead.
 
-    python tools/pipebench.py [tiles=256] [rounds=4] [arenas=3]
+    python tools/lab/pipebench.py [tiles=256] [rounds=4] [arenas=3]
 """
 import ctypes as C, json, os, sys
 import numpy as np
-sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+import lablib
 from lars_image_processing_amd import _ffi
 import lars_image_processing_amd as lars
 
@@ -37,7 +39,7 @@ def main():
     variants = [("two-pass", None)] + [(f"pipeline spi={spi} head={head}", (spi, head))
                                        for spi, head in ((16, 8), (32, 4), (32, 8), (32, 16), (64, 4), (64, 8), (64, 16), (128, 8), (256, 8))]
     for a in range(narena):
-        outs = b.make_outputs(index=True, ring=slots)
+        outs = b.make_outputs(index=True, ring=slots, arena="plain")
         times = {name: [] for name, _ in variants}
         recs = {}
         for r in range(rounds + 1):
@@ -48,10 +50,10 @@ def main():
                         for start in range(0, b.ntiles, slots):
                             b.run_fused(b.fused_args(IDX, True, stats, False, outs, None, start, slots))
                 else:
-                    _ffi.set_tuning(pipe_steps=cfg[0], pipe_head=cfg[1])
+                    lablib.set_tuning(pipe_steps=cfg[0], pipe_head=cfg[1])
                     def go():
                         for start in range(0, b.ntiles, slots):
-                            b.run_pipeline(stats, outs, None, start, slots)
+                            lablib.run_pipeline(b, stats, outs, None, start, slots)
                 times[name].append(timed(go))
                 if r == 0 and a == 0:
                     recs[name] = (stats.download(_ffi.STATS_DTYPE, (b.ntiles, 3)).tobytes(), outs.host_index("NDWI", 5, 1).tobytes(),
@@ -67,7 +69,7 @@ def main():
             res[f"arena{a} {name}"] = med
             print(f"arena {a}  {name:26s} {med:8.3f} ms per {tiles} tiles  {tiles * b.npix / med / 1e6:8.1f} Gpix/s  whole step {gbs:7.1f} GB/s algorithmic = {gbs / 8000:.3f} of 8 TB/s   x{base / med:.3f}")
         outs.free()
-    _ffi.set_tuning(pipe_steps=0, pipe_head=0)
+    lablib.set_tuning(pipe_steps=0, pipe_head=0)
     print(json.dumps(res))
 
 

@@ -1,8 +1,9 @@
 #!/usr/bin/env python3
-"""What the device sustains for plain streaming with the hot path's access shapes."""
+"""What the device sustains for plain streaming with the hot path's access shapes (lars_d_probe, liblars_lab.so)."""
 import ctypes as C, json, os, sys
 import numpy as np
-sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+import lablib
 from lars_image_processing_amd import _ffi
 
 def main():
@@ -10,7 +11,7 @@ def main():
     nbytes = gib << 30
     nbytes -= nbytes % (48 * 1024)
     src, dst = _ffi.DeviceBuffer(nbytes), _ffi.DeviceBuffer(nbytes)
-    _ffi.call("lars_d_probe", 3, 1, 8192, None, C.c_void_p(src.ptr), nbytes, None)
+    lablib.probe(3, 1, 8192, None, src.ptr, nbytes)
     a, b = C.c_void_p(), C.c_void_p()
     _ffi.call("lars_event_create", C.byref(a)); _ffi.call("lars_event_create", C.byref(b))
     res = {}
@@ -21,7 +22,7 @@ def main():
                 ts = []
                 for _ in range(4):
                     _ffi.call("lars_event_record", a, None)
-                    _ffi.call("lars_d_probe", kind, unroll, blocks, C.c_void_p(src.ptr), C.c_void_p(dst.ptr), nbytes, None)
+                    lablib.probe(kind, unroll, blocks, src.ptr, dst.ptr, nbytes)
                     _ffi.call("lars_event_record", b, None)
                     ms = C.c_float(0); _ffi.call("lars_event_elapsed_ms", a, b, C.byref(ms)); ts.append(ms.value)
                 t = float(np.median(ts[1:]))

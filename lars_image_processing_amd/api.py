@@ -54,6 +54,7 @@ __all__ = [
     "timeseries_row", "colormap_lut", "preprocess_large_image", "align_images", "change_detection",
     "colorize_difference", "calculate_index_statistics_by_timeframe", "time_series_points",
     "calculate_ndvi_array", "generate_ndvi_report", "download_processed_images",
+    "create_index_visualization", "create_comparison_view", "create_time_series_plot", "create_change_detection_visualization",
 ]
 
 _CMAPS = None
@@ -596,3 +597,23 @@ def generate_ndvi_report(image_path, output_dir):
         for key, value in stats.items():
             f.write(f"{key}: {value:.4f}\n")
     return ndvi_array, stats
+
+
+# ---------------------------------------------------------------------------
+# the reference's figure functions: out of scope here, and saying so loudly
+# ---------------------------------------------------------------------------
+def _figure_function(name, lines, instead):
+    def stub(*_args, **_kwargs):
+        raise NotImplementedError(
+            f"{name} (process-images.py:{lines}) draws a matplotlib figure and stays in the reference: this package replaces the "
+            f"hot-path functions it calls, not the drawing.  Keep the reference's {name} and swap its imports as INTEGRATION.md "
+            f"section 1 shows; the numbers it draws come from {instead}.")
+    stub.__name__ = name
+    stub.__doc__ = f"Not provided: {name} (process-images.py:{lines}) is figure rendering; see INTEGRATION.md (differs from the reference)."
+    return stub
+
+
+create_index_visualization = _figure_function("create_index_visualization", "669-716", "calculate_index / colorize_index")
+create_comparison_view = _figure_function("create_comparison_view", "718-799", "process_image / colorize_index")
+create_time_series_plot = _figure_function("create_time_series_plot", "801-883", "time_series_points")
+create_change_detection_visualization = _figure_function("create_change_detection_visualization", "885-989", "change_detection")

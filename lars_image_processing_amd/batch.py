@@ -22,14 +22,16 @@ from ._ffi import FusedArgs, INDEX_IDS, INDEX_NAMES, STATS_DTYPE, DeviceBuffer, 
 
 MAX_TILES_PER_LAUNCH = 65535      # grid.y limit
 ARENA_MIN_BYTES = 2 << 30         # smaller arenas run alike wherever they land
-ARENA_TRIALS = 16                 # candidate allocations of the default search (it stops early once one is clearly faster)
+ARENA_TRIALS = 16                 # candidate allocations of the default search at most
+ARENA_MIN_TRIALS = 8              # ... and at least (then it stops once the best has not improved over the last three)
 
 
 # How statistics-only passes over uint8 RGNir batches run (no output planes):
 #   "joint"   one read of the tiles: joint byte-pair histograms in LDS, everything else -- the white balance's percentiles
 #             included -- derived from the counts (lars_d_stats_joint, csrc/joint.hip)
 #   "classic" channel-histogram pass, then the per-pixel statistics kernel (and its median passes)
-#   "auto"    joint wherever it applies
+#   "auto"    with medians: joint; without: whichever of the two measures faster on the first tiles of the batch
+#             (TileBatch.pick_stats_route; small batches: joint)
 # Results are identical bit for bit; LARS_STATS_ROUTE presets it.
 _STATS_ROUTE = os.environ.get("LARS_STATS_ROUTE", "auto")
 
@@ -170,16 +172,13 @@ class TileBatch:
             return outs
         t_search = time.perf_counter()
         # Candidates are allocated one by one and ALL kept until the choice is made (a freed arena would be handed out
-        # again).  The classes are ~15 % apart, so the search ends two candidates after one is clearly faster than the
-        # slowest seen (>= 7 %, at least four tried), and otherwise goes on to `placement_trials` or the memory limit.
+        # again).  The classes are ~15 % apart and the fast class has levels of its own 1-3 % apart (0.79 / 0.78 / 0.765 of
+        # 8 TB/s on one box), so the search looks at ARENA_MIN_TRIALS candidates at least and ends when the best time has not
+        # improved by 1 % over the last three, at `placement_trials`, or at the memory limit.
         arenas, timings = [outs.arena], [self._time_outputs(outs, indices)]
         free_b, total_b = C.c_size_t(), C.c_size_t()
-        gap_at = None                                               # number of candidates when the 7 % gap first showed
         while len(arenas) < int(placement_trials):
-            if gap_at is None and len(arenas) >= 4 and min(timings) * 1.07 <= max(timings):
-                gap_at = len(arenas)
-            # the fast class itself has levels 2-3 % apart (profiles/r02_placement_vmm.txt): two more candidates, then the best
-            if gap_at is not None and len(arenas) >= gap_at + 2:
+            if len(arenas) >= min(ARENA_MIN_TRIALS, int(placement_trials)) and min(timings[:-3]) <= min(timings[-3:]) * 1.01:
                 break
             _ffi.call("lars_mem_info", C.byref(free_b), C.byref(total_b))
             if free_b.value < outs.arena.nbytes + (8 << 30):       # keep 8 GiB of headroom for the caller
@@ -307,7 +306,8 @@ class TileBatch:
         """What ``lars_d_stats_joint`` serves: uint8 tiles with 3 (RGNir) or 4 (RGBA: alpha ignored) channels."""
         return self.code == _ffi.U8 and self.channels in (3, 4) and (self.ntiles == 1 or self.npix % 4 == 0)
 
-    def run_joint(self, indices, white_balance, stats, hist=False, sumsq=False, pairs=None, stream=None, rgn_variant=0):
+    def run_joint(self, indices, white_balance, stats, hist=False, sumsq=False, pairs=None, stream=None, rgn_variant=0,
+                  tile_count=None):
         """Enqueue ``lars_d_stats_joint``: final records into ``stats`` and, with ``pairs`` (a DeviceBuffer of
         ntiles * 4 floats), the two middle order statistics of every tile's NDVI / GNDVI values.  With white balance the
         call also leaves ``self.hist`` / ``self.percentiles`` / ``self.table`` filled for the channels the indices read
@@ -333,7 +333,7 @@ class TileBatch:
             self._table_channels |= channels_of(indices)
         a = FusedArgs()
         a.tiles = self.tiles.ptr
-        a.ntiles, a.npix, a.channels, a.dtype = self.ntiles, self.npix, self.channels, self.code
+        a.ntiles, a.npix, a.channels, a.dtype = (self.ntiles if tile_count is None else int(tile_count)), self.npix, self.channels, self.code
         a.wb_table = self.table.ptr if white_balance else None
         a.index_mask = mask
         a.flags = _ffi.F_STATS | (_ffi.F_HIST if hist else 0) | (_ffi.F_SUMSQ if sumsq else 0)
@@ -343,6 +343,47 @@ class TileBatch:
                   C.c_void_p(self.percentiles.ptr) if white_balance else None,
                   C.c_void_p(self.hist.ptr) if white_balance else None,
                   C.c_void_p(pairs.ptr) if pairs is not None else None, C.c_void_p(self._joint_scratch.ptr))
+
+    def pick_stats_route(self, indices, white_balance=True, sample=32):
+        """"joint" or "classic" for statistics WITHOUT medians over this batch, by measurement: both routes over the first
+        ``sample`` tiles, once per (indices, white balance), remembered.  The one-read route counts byte pairs with LDS
+        atomics, which queue up where the neighbouring pixels of a wave share cells (smooth imagery: profiles/
+        r03_joint_hist_content.txt), while the per-pixel kernels do not care; with medians the one-read route wins on every
+        content measured, so nothing is timed for those.  Small batches take the one-read route unmeasured."""
+        key = (tuple(sorted(INDEX_IDS[t] for t in indices)), bool(white_balance))
+        cache = self.__dict__.setdefault("_route_cache", {})
+        if key in cache:
+            return cache[key]
+        if self.ntiles < sample or self.npix < (1 << 20) or self.channels != 3:
+            cache[key] = "joint"
+            return "joint"
+        ev = [C.c_void_p() for _ in range(3)]
+        for e in ev:
+            _ffi.call("lars_event_create", C.byref(e))
+        stats = self.new_stats()
+        ms = {}
+        for _ in range(2):                                  # the first round warms both routes up
+            _ffi.call("lars_event_record", ev[0], None)
+            self.run_joint(indices, white_balance, stats, tile_count=sample)
+            _ffi.call("lars_event_record", ev[1], None)
+            if white_balance:
+                if self.hist is None:
+                    self.hist = DeviceBuffer(self.ntiles * 3 * 256 * 4)
+                _ffi.call("lars_d_channel_hist", C.c_void_p(self.tiles.ptr), sample, self.npix, self.channels, self.code,
+                          C.c_void_p(self.hist.ptr), None)
+                _ffi.call("lars_d_wb_table", C.c_void_p(self.hist.ptr), sample, self.npix, self.code, C.c_void_p(self.table.ptr),
+                          C.c_void_p(self.percentiles.ptr), 0, None)
+            self.run_fused(self.fused_args(indices, white_balance, stats, False, None, None, 0, sample))
+            _ffi.call("lars_event_record", ev[2], None)
+            t = C.c_float(0)
+            _ffi.call("lars_event_elapsed_ms", ev[0], ev[1], C.byref(t)); ms["joint"] = t.value
+            _ffi.call("lars_event_elapsed_ms", ev[1], ev[2], C.byref(t)); ms["classic"] = t.value
+        for e in ev:
+            _ffi.call("lars_event_destroy", e)
+        stats.free()
+        cache[key] = "joint" if ms["joint"] <= ms["classic"] else "classic"
+        self._route_ms = dict(ms)
+        return cache[key]
 
     def process(self, indices=INDEX_NAMES, white_balance=True, hist=False, outputs=None, stream=None,
                 recompute_tables=True, medians=False, sumsq=False, route=None):
@@ -355,6 +396,8 @@ class TileBatch:
         select on the float32 planes, which must then be written -- a small ring is
         allocated when ``outputs`` has none.  ``route``: see ``set_stats_route`` (None = the module's setting)."""
         route = _STATS_ROUTE if route is None else route
+        if route == "auto" and outputs is None and not medians and self.can_joint() and indices:
+            route = self.pick_stats_route(indices, white_balance)
         if outputs is None and route != "classic" and self.can_joint() and indices:
             # nothing to write: one read of the tiles serves the percentiles, the statistics and the medians
             stats = self.new_stats()

@@ -108,11 +108,39 @@ __global__ __launch_bounds__(JH_THREADS, 4) void k_joint_count(JointCountParams 
         jh_add(a0, v0, tab);
         jh_add(a1, v1, tab);
     };
+    // Flat areas (nodata borders, saturated sky: every lane of the wave holds the same four pixels) would queue all 64 lanes on
+    // one LDS word per atomic.  Two v_readfirstlane + a compare per quad find them; one lane then adds the wave's whole count.
+    auto count_pair_n = [&](unsigned int s2, unsigned int n) {
+        const unsigned int a0 = (s2 << 1) & 0x1FFFCu, v0 = (((s2 & 1u) << 16) | 1u) * n;
+        const unsigned int a1 = (s2 >> 15) & 0x1FFFCu, v1 = ((s2 & 0x10000u) | 1u) * n;
+        jh_add(a0, v0, tab);
+        jh_add(a1, v1, tab);
+    };
     auto do_quad = [&](unsigned int w0, unsigned int w1, unsigned int w2) {
-        const unsigned int c01 = __builtin_amdgcn_perm(w1, w0, selc01) ^ __builtin_amdgcn_perm(w1, w0, selx01);
-        const unsigned int c23 = __builtin_amdgcn_perm(w2, w1, selc23) ^ __builtin_amdgcn_perm(w2, w1, selx23);
-        count_pair(c01);
-        count_pair(c23);
+        // the cheap test first: one v_readfirstlane + one compare on the quad's first dword settle it for any textured content
+        const unsigned int f0 = __builtin_amdgcn_readfirstlane(w0);
+        bool flat = __builtin_amdgcn_ballot_w64(w0 != f0) == 0ull;
+        if (flat) {
+            const unsigned int f1 = __builtin_amdgcn_readfirstlane(w1), f2 = __builtin_amdgcn_readfirstlane(w2);
+            flat = __builtin_amdgcn_ballot_w64(((w1 ^ f1) | (w2 ^ f2)) != 0u) == 0ull;
+            if (flat) {
+                const unsigned long long active = __builtin_amdgcn_ballot_w64(true);
+                if ((active & (0ull - active)) == (1ull << (tid & 63))) {             // the first active lane
+                    const unsigned int n = (unsigned int)__builtin_popcountll(active);
+                    const unsigned int c01 = __builtin_amdgcn_perm(f1, f0, selc01) ^ __builtin_amdgcn_perm(f1, f0, selx01);
+                    const unsigned int c23 = __builtin_amdgcn_perm(f2, f1, selc23) ^ __builtin_amdgcn_perm(f2, f1, selx23);
+                    if (c01 == c23 && (c01 >> 16) == (c01 & 0xFFFFu)) {               // one colour: one add for the whole 256 pixels
+                        jh_add((c01 << 1) & 0x1FFFCu, (((c01 & 1u) << 16) | 1u) * (4u * n), tab);
+                    } else {
+                        count_pair_n(c01, n);
+                        count_pair_n(c23, n);
+                    }
+                }
+                return;
+            }
+        }
+        count_pair(__builtin_amdgcn_perm(w1, w0, selc01) ^ __builtin_amdgcn_perm(w1, w0, selx01));
+        count_pair(__builtin_amdgcn_perm(w2, w1, selc23) ^ __builtin_amdgcn_perm(w2, w1, selx23));
     };
 
     // tail pixels of the tile (npix % 4): its last chunk, before the first period (which starts from zero counts)

@@ -195,9 +195,12 @@ def test_no_figure_plumbing_in_the_package(lars):
         if name.endswith(".py"):
             text = open(os.path.join(pkg, name)).read()
             assert not re.search(r"^\s*(import|from)\s+matplotlib", text, re.M), name
+    # the reference's figure functions exist as names that say where to go instead (no silent breakage for a caller that
+    # expected a drop-in for them)
     for gone in ("create_time_series_plot", "create_change_detection_visualization", "create_index_visualization",
                  "create_comparison_view"):
-        assert not hasattr(lars, gone), gone
+        with pytest.raises(NotImplementedError, match="INTEGRATION.md"):
+            getattr(lars.api, gone)(None, "NDVI")
     series = _series(2, shape=(64, 80))
     idx = lars.calculate_index(orc.wb_app(series[0]["array"]), "NDWI")
     rgba = lars.colorize_index(idx, "NDWI")

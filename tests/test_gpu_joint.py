@@ -151,6 +151,30 @@ def test_joint_full_size_tiles(lars):
     b.free()
 
 
+def test_measured_route_choice(lars):
+    """route="auto" without medians: both routes are timed once on the first tiles of a large batch and the faster one is
+    remembered (flat or smooth imagery makes the LDS atomics of the one-read route queue up); whatever is chosen, the
+    records are the same bytes."""
+    from lars_image_processing_amd import batch as lb
+    yy, xx = np.mgrid[0:1024, 0:1024]
+    smooth = np.stack([np.clip(60 + 50 * c + 40 * np.sin(xx / 300.0 + c) + 30 * np.cos(yy / 200.0) + ((xx * 7 + yy * 3 + c) % 3), 0, 255)
+                       for c in range(3)], axis=-1).astype(np.uint8)
+    tiles = np.stack([np.roll(smooth, 17 * t, axis=1) for t in range(32)])
+    for content in (tiles, None):
+        b = lars.TileBatch.from_host(content) if content is not None else lars.TileBatch.synthetic(32, 1024, 1024, seed=3, profile="uniform")
+        assert lb.get_stats_route() == "auto"
+        chosen = b.pick_stats_route(TYPES)
+        assert chosen in ("joint", "classic") and b.pick_stats_route(TYPES) == chosen and set(b._route_ms) == {"joint", "classic"}
+        rec = b.process()
+        assert rec.tobytes() == b.process(route="joint").tobytes() == b.process(route="classic").tobytes()
+        rec_m, med = b.process(medians=True)                        # medians: always the one-read route
+        assert rec_m.tobytes() == rec.tobytes()
+        b.free()
+    small = lars.TileBatch.synthetic(3, 64, 64, seed=1)
+    assert small.pick_stats_route(("NDVI",)) == "joint" and not hasattr(small, "_route_ms")
+    small.free()
+
+
 def test_joint_bad_arguments(lars):
     import ctypes as C
     from lars_image_processing_amd import _ffi

@@ -24,6 +24,35 @@ def read(rnd, counter):
     return out
 
 
+def headline_launches(rnd, src):
+    """The headline kernel's launches of the profiled bench run, split by what they were: the arena search (four launches
+    per candidate allocation, before anything else) and the steps (warm-up, timed and self-check steps: the same launch
+    over a ring of tile slots).  Written to profiles/<round>_bench_headline_launches.csv so that bytes / mean duration /
+    8 TB/s of the 'step' row can be held against roofline.frac of <round>_bench_under_rocprof.json."""
+    import csv
+    line = json.loads(open(f"{src}/bench_under_rocprof.json").read().strip().splitlines()[-1])
+    ncand = len((line["config"].get("arena") or {}).get("candidate_ms") or [])
+    trace = max(glob.glob(f"{src}/trace/**/*kernel_trace.csv", recursive=True), key=os.path.getmtime)
+    rows = [r for r in csv.DictReader(open(trace)) if r["Kernel_Name"].startswith("void lars::k_fused_u8c3<unsigned char, 7u, true, 1, 3>")]
+    rows.sort(key=lambda r: int(r["Start_Timestamp"]))
+    ring_grid = max(set((r["Grid_Size_X"] if "Grid_Size_X" in r else r.get("Grid_Size"), r.get("Grid_Size_Y", "")) for r in rows),
+                    key=lambda g: sum(1 for r in rows if (r.get("Grid_Size_X", r.get("Grid_Size")), r.get("Grid_Size_Y", "")) == g))
+    ring = [r for r in rows if (r.get("Grid_Size_X", r.get("Grid_Size")), r.get("Grid_Size_Y", "")) == ring_grid]
+    dur = [int(r["End_Timestamp"]) - int(r["Start_Timestamp"]) for r in ring]
+    search, steps = dur[:4 * ncand], dur[4 * ncand:]
+    nbytes = line["roofline"]["bytes_per_launch"]
+    out = f"{ROOT}/profiles/{rnd}_bench_headline_launches.csv"
+    with open(out, "w") as fh:
+        fh.write("class,launches,mean_ns,GBs_algorithmic,frac_of_8TBs\n")
+        for name, d in (("arena_search", search), ("step", steps)):
+            if d:
+                mean = sum(d) / len(d)
+                fh.write(f"{name},{len(d)},{mean:.1f},{nbytes / mean:.1f},{nbytes / mean / 8000:.4f}\n")
+        fh.write(f"# bench line of the same run: roofline.frac {line['roofline']['frac']:.4f}, avg_launch_ms {line['roofline']['avg_launch_ms']:.4f}, "
+                 f"{ncand} candidate arenas; other launches of this kernel (single tiles of the self-check): {len(rows) - len(ring)}\n")
+    print(open(out).read())
+
+
 def main():
     rnd = sys.argv[1] if len(sys.argv) > 1 else "r01"
     src = f"{ROOT}/gpurun_out/prof_{rnd}"
@@ -34,21 +63,29 @@ def main():
     stats = max(glob.glob(f"{src}/trace/**/*kernel_stats.csv", recursive=True), key=os.path.getmtime)
     shutil.copy(stats, f"{ROOT}/profiles/{rnd}_bench_kernel_stats.csv")
     shutil.copy(f"{src}/bench_under_rocprof.json", f"{ROOT}/profiles/{rnd}_bench_under_rocprof.json")
+    headline_launches(rnd, src)
     f, w = read(rnd, "FETCH_SIZE"), read(rnd, "WRITE_SIZE")
     px64, px256 = 64 * 4096 * 4096, 256 * 4096 * 4096
     # kernel names as rocprofv3 prints them, up to the template arguments that only tuning knobs change (matched by prefix)
     rows = {
-        "wb3idx_out_stats": ("k_fused_u8c3<unsigned char, 7u, true, 1, 1>", px64),
-        "wb3idx_out_stats_hist": ("k_fused_u8c3<unsigned char, 7u, true, 2, 1>", px64),
-        "wb_ndvi_out_stats": ("k_fused_u8c3<unsigned char, 1u, true, 1, 1>", px64),
-        "wb3idx_stats_only": ("k_fused_v2<7u, true, 1, false, false, 0,", px256),
-        "wb_ndvi_stats_only": ("k_fused_v2<1u, true, 1, false, false, 0,", px256),
-        "channel_hist": ("k_chan_hist_u8c3_v2", px256),
+        "wb3idx_out_stats": ("k_fused_u8c3<unsigned char, 7u, true, 1, 3>", px64),
+        "wb3idx_out_stats_hist": ("k_fused_u8c3<unsigned char, 7u, true, 2, 3>", px64),
+        "wb_ndvi_out_stats": ("k_fused_u8c3<unsigned char, 1u, true, 1, 3>", px64),
+        "wb3idx_out_stats_medians": ("k_fused_u8c3<unsigned char, 7u, true, 0, 3>", px64),      # planes only; its statistics pass is k_joint_count
+        # the one-read statistics route: one counting launch per step over the whole batch, whatever the indices (the second
+        # stream's reads are served by the XCD's L2); the per-tile finish kernel reads the counts back
+        "wb3idx_stats_only": ("k_joint_count<6, 3>", px256),
+        "wb_ndvi_stats_only": ("k_joint_count<6, 3>", px256),
+        "wb3idx_stats_medians": ("k_joint_count<6, 3>", px256),
+        "joint_finish": ("k_joint_finish", px256),
+        "wb3idx_stats_only_classic": ("k_fused_v2<7u, true, 1, false, false, 0,", px256),
+        "wb_ndvi_stats_only_classic": ("k_fused_v2<1u, true, 1, false, false, 0,", px256),
+        "channel_hist": ("k_chan_hist_u8c3_v2<3>", px256),
     }
 
     def find(table, prefix):
         hits = [k for k in table if k.startswith(prefix)]
-        return hits[0] if len(hits) == 1 else None
+        return hits[0] if len(hits) >= 1 else None
     t = {"_comment": "HBM bytes per pixel from rocprofv3 PMC (separate --pmc FETCH_SIZE / --pmc WRITE_SIZE passes): "
                      "(2*FETCH_SIZE + WRITE_SIZE)*1024 / pixels per launch; FETCH_SIZE doubled as MI355X_MICROARCH.md "
                      "(HBM) prescribes for wide coalesced streaming reads on gfx950.  _kernel_sources_sha identifies "

@@ -1,7 +1,7 @@
 #!/usr/bin/env bash
 # Collects the rocprofv3 evidence of round $1 (default r01) on a GPU box into gpurun_out/prof_<round>/ (the only
 # directory that travels back); tools/collect_profiles.py then writes the summaries into profiles/:
-#   rm -rf gpurun_out/prof_r02; gpurun --timeout 1200 -- 'bash tools/profile_round.sh r02' && python tools/collect_profiles.py r02
+#   rm -rf gpurun_out/prof_r03; gpurun --timeout 1200 -- 'bash tools/profile_round.sh r03' && python tools/collect_profiles.py r03
 # 1. kernel-trace --stats of bench.py (per-kernel average durations)
 # 2. --pmc FETCH_SIZE and --pmc WRITE_SIZE in separate passes (HBM traffic per launch)
 # 3. profiles/traffic.json (bytes per pixel, FETCH_SIZE doubled as MI355X_MICROARCH.md prescribes)
@@ -15,6 +15,6 @@ rocprofv3 --kernel-trace --stats --output-format csv -d "$OUT/trace" -- python3 
     --no-cpu-baseline --no-probe > "$OUT/bench_under_rocprof.json" 2> "$OUT/trace.err"
 for c in FETCH_SIZE WRITE_SIZE; do
     rocprofv3 --pmc $c --output-format csv -d "$OUT/pmc_$c" -- python3 "$R/bench.py" --steps 2 --warmup 1 --tiles 256 \
-        --no-cpu-baseline --no-probe > /dev/null 2> "$OUT/pmc_$c.err"
+        --no-cpu-baseline --no-probe --no-verify --no-u16-leg --arena plain --placement-trials 0 > /dev/null 2> "$OUT/pmc_$c.err"
 done
 echo "collected under gpurun_out/prof_$ROUND; back in the container: python tools/collect_profiles.py $ROUND"

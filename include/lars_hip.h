@@ -262,10 +262,12 @@ int lars_d_quotient_median_pairs(const void *tiles, int64_t ntiles, int64_t npix
  *   percentiles   [ntiles][3][2] double or NULL, hist [ntiles][3][256] or NULL: outputs, same channels as the tables
  *   out_pairs     float[ntiles][2 streams: NDVI, GNDVI][2] or NULL: the two middle order statistics (median = their
  *                 float32 mean; NDWI's is -GNDVI's); a stream the mask does not need comes back as NaN
- *   scratch       lars_joint_scratch_bytes(ntiles, npix, index_mask) bytes */
+ *   scratch       scratch_bytes >= lars_joint_scratch_bytes(ntiles, npix, index_mask) bytes of device memory; its first word
+ *                 is an error flag the launch leaves at 0 (1 = a workgroup's hand-over list overflowed: cannot happen while a
+ *                 workgroup counts at most 2^24 pixels, which the chunking guarantees) */
 size_t lars_joint_scratch_bytes(int64_t ntiles, int64_t npix, uint32_t index_mask);
 int lars_d_stats_joint(const lars_fused_args *a, int white_balance, int rgn_variant, double *percentiles, uint32_t *hist,
-                       float *out_pairs, void *scratch);
+                       float *out_pairs, void *scratch, size_t scratch_bytes);
 
 /* classification mask (see lars_h_threshold_mask_f32); x 16-byte, out_mask 4-byte aligned */
 int lars_d_threshold_mask_f32(const float *x, int64_t n, float threshold, uint8_t *out_mask, void *stream);

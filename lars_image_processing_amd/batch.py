@@ -342,7 +342,7 @@ class TileBatch:
         _ffi.call("lars_d_stats_joint", C.byref(a), 1 if white_balance else 0, int(rgn_variant),
                   C.c_void_p(self.percentiles.ptr) if white_balance else None,
                   C.c_void_p(self.hist.ptr) if white_balance else None,
-                  C.c_void_p(pairs.ptr) if pairs is not None else None, C.c_void_p(self._joint_scratch.ptr))
+                  C.c_void_p(pairs.ptr) if pairs is not None else None, C.c_void_p(self._joint_scratch.ptr), self._joint_scratch.nbytes)
 
     def pick_stats_route(self, indices, white_balance=True, sample=32):
         """"joint" or "classic" for statistics WITHOUT medians over this batch, by measurement: both routes over the first
@@ -405,6 +405,8 @@ class TileBatch:
             pairs_dev = DeviceBuffer(self.ntiles * 4 * 4) if medians else None
             self.run_joint(indices, white_balance, stats, hist, sumsq, pairs_dev, stream)
             _ffi.call("lars_synchronize", stream)
+            if int(self._joint_scratch.download(np.uint32, (1,))[0]):
+                raise RuntimeError("lars_d_stats_joint: a workgroup's hand-over list overflowed (a chunk of more than 2^24 pixels?)")
             rec = stats.download(STATS_DTYPE, (self.ntiles, 3))
             stats.free()
             if not medians:

@@ -645,7 +645,7 @@ extern "C" size_t lars_joint_scratch_bytes(int64_t ntiles, int64_t npix, uint32_
 }
 
 extern "C" int lars_d_stats_joint(const lars_fused_args *a, int white_balance, int rgn_variant, double *percentiles,
-                                  uint32_t *hist, float *out_pairs, void *scratch)
+                                  uint32_t *hist, float *out_pairs, void *scratch, size_t scratch_bytes)
 {
     ThreadCtx *c;
     LARS_TRY(ensure_ctx(&c));
@@ -665,6 +665,10 @@ extern "C" int lars_d_stats_joint(const lars_fused_args *a, int white_balance, i
     const unsigned streams = ((mask & 1u) ? 1u : 0u) | ((mask & 6u) ? 2u : 0u);
     const int S = streams == 3u ? 2 : 1;
     const int K = joint_chunks(a->ntiles, a->npix, S);
+    const size_t need = (size_t)a->ntiles * S * K * (2 * JH_DWORDS) * sizeof(unsigned int) + 256;
+    if (scratch_bytes < need)
+        return fail(LARS_ERR_INVALID, "lars_d_stats_joint: scratch holds %zu bytes, %zu are needed (lars_joint_scratch_bytes, with the "
+                                      "tuning in force at the launch)", scratch_bytes, need);
 
     unsigned int *error = reinterpret_cast<unsigned int *>(scratch);
     LARS_HIP_TRY(hipMemsetAsync(error, 0, 256, s));

@@ -401,6 +401,51 @@ static void issue_launch(int iters, int blocks, unsigned int *sink, hipStream_t 
     hipLaunchKernelGGL((k_probe_issue<OP>), dim3(blocks), dim3(256), 0, s, iters, sink);
 }
 
+// Shared readers (kind 30 + R, 40 + R): R workgroups of 1024 threads read the SAME chunk at the same moment -- block b = 8 R a + 8 r + x
+// is reader r of chunk 8 a + x, so the readers of a chunk sit 8 apart in dispatch order (one XCD) -- with 128 KiB of LDS
+// reserved so that one workgroup fills a CU, as the counting kernel of csrc/joint.hip does.  W dwords per lane and load (3 | 4),
+// six loads in flight.  What a CU can take in from the XCD's L2 when the HBM side delivers each byte once.
+template <int W>
+__global__ __launch_bounds__(1024, 4) void k_probe_shared(const unsigned int *__restrict__ src, long long chunk_vecs, long long nchunks,
+                                                          int readers, unsigned int *sink)
+{
+    __shared__ unsigned int s_pad[32768];
+    const unsigned int b = blockIdx.x;
+    const long long chunk = (long long)(b / (8u * readers)) * 8 + (b & 7u);
+    if (chunk >= nchunks) return;
+    if (threadIdx.x == 0) s_pad[b & 32767u] = b;
+    // the chunk as a raw buffer: loads past its end return zeros (no access outside the allocation)
+    const __amdgpu_buffer_rsrc_t rsrc = __builtin_amdgcn_make_buffer_rsrc(
+        const_cast<unsigned int *>(src) + chunk * chunk_vecs * W, 0, (int)(chunk_vecs * W * 4), 0x00020000);
+    typedef unsigned int v3 __attribute__((ext_vector_type(3)));
+    typedef unsigned int v4 __attribute__((ext_vector_type(4)));
+    const unsigned int voff = threadIdx.x * (W * 4u);
+    constexpr unsigned int STEP_B = 1024u * W * 4u;
+    auto load = [&](unsigned int soff) {
+        v4 r;
+        if constexpr (W == 3) { const v3 t = __builtin_amdgcn_raw_buffer_load_b96(rsrc, voff, soff, 0); r = v4{t.x, t.y, t.z, 0u}; }
+        else r = __builtin_amdgcn_raw_buffer_load_b128(rsrc, voff, soff, 0);
+        return r;
+    };
+    const long long nsteps = (chunk_vecs + 1023) / 1024;
+    unsigned int acc = 0;
+    v4 w[6];
+#pragma unroll
+    for (int k = 0; k < 6; ++k) w[k] = load((unsigned)k * STEP_B);
+    unsigned int soff = 6u * STEP_B;
+    for (long long it = 0; it < nsteps; it += 6) {
+#pragma unroll
+        for (int k = 0; k < 6; ++k) {
+            acc ^= w[k].x ^ w[k].y ^ w[k].z ^ w[k].w;
+            __builtin_amdgcn_sched_barrier(0);
+            w[k] = load(soff + (unsigned)k * STEP_B);
+            __builtin_amdgcn_sched_barrier(0);
+        }
+        soff += 6u * STEP_B;
+    }
+    if (acc == 0x12345677u) sink[0] = acc + s_pad[1];
+}
+
 // kind: 0 read 16 B/lane, 1 read 12 B/lane, 2 copy 16 B/lane (bytes read + bytes written = 2*bytes), 3 write 16 B/lane,
 // 4 non-temporal write, 5 / 6 the fused kernel's mix (12 B read + 48 B written per lane; plain / non-temporal stores),
 // 7 the NDVI-plane mix (12 B read + 16 B written per lane); 8..19 round-2 shapes of the 12 B / 48 B mix (see the
@@ -414,6 +459,17 @@ extern "C" int lars_d_probe(int kind, int unroll, int blocks, const void *src, v
     LARS_TRY(scratch_reserve(c, 64));
     unsigned int *sink = static_cast<unsigned int *>(c->scratch);
     const unsigned int *p = static_cast<const unsigned int *>(src);
+    if (kind > 30 && kind < 50) {
+        // 31..34: R = kind - 30 readers, 12 B per lane; 41..44: 16 B per lane; `blocks` = chunks
+        const int wide = kind > 40, readers = kind - (wide ? 40 : 30);
+        if (readers < 1 || readers > 4) return fail(LARS_ERR_INVALID, "lars_d_probe: 1..4 readers");
+        const long long per = wide ? 16 : 12, chunk_vecs = bytes / per / blocks;
+        const long long groups = (blocks + 7) / 8;
+        const dim3 grid((unsigned)(groups * 8 * readers));
+        if (wide) hipLaunchKernelGGL((k_probe_shared<4>), grid, dim3(1024), 0, s, p, chunk_vecs, (long long)blocks, readers, sink);
+        else hipLaunchKernelGGL((k_probe_shared<3>), grid, dim3(1024), 0, s, p, chunk_vecs, (long long)blocks, readers, sink);
+        return launch_check("lars_d_probe (shared readers)");
+    }
     if (kind == 0) {
         const long long n = bytes / 16;
         if (unroll >= 8) hipLaunchKernelGGL((k_probe_read<4, 8>), dim3(blocks), dim3(256), 0, s, p, n, sink);

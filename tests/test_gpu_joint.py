@@ -183,15 +183,20 @@ def test_joint_bad_arguments(lars):
     stats = b.new_stats()
     scratch = _ffi.DeviceBuffer(int(lib.lars_joint_scratch_bytes(2, 256, 7)))
     a = b.fused_args(("NDVI",), False, stats)
-    assert lib.lars_d_stats_joint(C.byref(a), 0, 0, None, None, None, None) == -1          # no scratch
+    assert lib.lars_d_stats_joint(C.byref(a), 0, 0, None, None, None, None, 0) == -1       # no scratch
     a.index_mask = 0
-    assert lib.lars_d_stats_joint(C.byref(a), 0, 0, None, None, None, C.c_void_p(scratch.ptr)) == -1
+    assert lib.lars_d_stats_joint(C.byref(a), 0, 0, None, None, None, C.c_void_p(scratch.ptr), scratch.nbytes) == -1
     a.index_mask = 1
     a.dtype = _ffi.U16
-    assert lib.lars_d_stats_joint(C.byref(a), 0, 0, None, None, None, C.c_void_p(scratch.ptr)) == -1
+    assert lib.lars_d_stats_joint(C.byref(a), 0, 0, None, None, None, C.c_void_p(scratch.ptr), scratch.nbytes) == -1
     a.dtype = _ffi.U8
     a.out_index[0] = scratch.ptr
-    assert lib.lars_d_stats_joint(C.byref(a), 0, 0, None, None, None, C.c_void_p(scratch.ptr)) == -1
+    assert lib.lars_d_stats_joint(C.byref(a), 0, 0, None, None, None, C.c_void_p(scratch.ptr), scratch.nbytes) == -1
+    a.out_index[0] = None
+    assert lib.lars_d_stats_joint(C.byref(a), 0, 0, None, None, None, C.c_void_p(scratch.ptr), 1024) == -1         # scratch too small
+    assert b"scratch holds 1024 bytes" in lib.lars_last_error()
+    assert lib.lars_d_stats_joint(C.byref(a), 0, 0, None, None, None, C.c_void_p(scratch.ptr), scratch.nbytes) == 0
+    _ffi.call("lars_synchronize", None)
     assert lib.lars_joint_scratch_bytes(0, 256, 7) == 0 and lib.lars_joint_scratch_bytes(2, 256, 0) == 0
     with pytest.raises(ValueError):
         wide = lars.TileBatch.from_host(np.zeros((1, 8, 8, 3), np.uint16))

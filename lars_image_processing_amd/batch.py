@@ -23,7 +23,7 @@ from ._ffi import FusedArgs, INDEX_IDS, INDEX_NAMES, STATS_DTYPE, DeviceBuffer, 
 MAX_TILES_PER_LAUNCH = 65535      # grid.y limit
 ARENA_MIN_BYTES = 2 << 30         # smaller arenas run alike wherever they land
 ARENA_TRIALS = 16                 # candidate allocations of the default search at most
-ARENA_MIN_TRIALS = 8              # ... and at least (then it stops once the best has not improved over the last three)
+ARENA_MIN_TRIALS = 12             # ... and at least (then it stops once the best has not improved over the last three)
 
 
 # How statistics-only passes over uint8 RGNir batches run (no output planes):
@@ -173,7 +173,7 @@ class TileBatch:
         t_search = time.perf_counter()
         # Candidates are allocated one by one and ALL kept until the choice is made (a freed arena would be handed out
         # again).  The classes are ~15 % apart and the fast class has levels of its own 1-3 % apart (0.79 / 0.78 / 0.765 of
-        # 8 TB/s on one box), so the search looks at ARENA_MIN_TRIALS candidates at least and ends when the best time has not
+        # 8 TB/s on one box), so the search looks at ARENA_MIN_TRIALS (12) candidates at least and ends when the best time has not
         # improved by 1 % over the last three, at `placement_trials`, or at the memory limit.
         arenas, timings = [outs.arena], [self._time_outputs(outs, indices)]
         free_b, total_b = C.c_size_t(), C.c_size_t()

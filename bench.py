@@ -393,7 +393,7 @@ def traffic_from_profiles(mode, pixels_per_launch):
 
 def config4_leg(tiles=64, edge=8192, ring=16):
     """BASELINE configs[4] shape on this GPU (not the headline): uint16 8192 x 8192 tiles, percentile white balance,
-    float32 NDVI + RdYlGn RGBA written (ring of 16 tile slots, assembled arena) + statistics.  14 algorithmic bytes per
+    float32 NDVI + RdYlGn RGBA written (ring of 16 tile slots, arena chosen like the headline's) + statistics.  14 algorithmic bytes per
     pixel (6 read, 8 written)."""
     import lars_image_processing_amd as lars
     from lars_image_processing_amd import _ffi

@@ -153,8 +153,8 @@ class TileBatch:
                       made one by one, the batch's own fused launch is timed into each, the fastest is kept and the rest
                       freed; smaller arenas (they run alike wherever they land) are one plain allocation
           "plain"     one plain allocation as it comes, unless ``placement_trials`` asks for a search
-        (Arenas put together from timed groups of physical chunks were built and measured in round 3 -- tools/lab/arenalab.py,
-        profiles/r03_arena_assembled.txt: a group's probe time does not predict the arena's speed; not in the product.)
+        (Arenas put together from timed groups of physical chunks were built and measured in round 3 --
+        profiles/r03_arena_assembled.txt: a group's probe time does not predict the arena's speed; removed again.)
         ``outs.arena_report`` = {kind, search_ms, chosen_ms, rejected, ...} says what was done."""
         outs = BatchOutputs(self, indices, index, wb, rgba, ring, allocate=False)
         nplanes = len(outs._index_ids) + len(outs._rgba_ids)

@@ -1,5 +1,5 @@
 // Laboratory library (liblars_lab.so, `make lab`): experiments that are NOT part of the product -- streaming probes, the
-// persistent one-launch pipeline, output arenas assembled from timed groups of physical memory, allocation kinds.  It links
+// persistent one-launch pipeline, allocation kinds.  It links
 // against liblars_hip.so and is only loaded by tools/lab/ and tests/test_gpu_lab.py; the product never reads its knobs.
 #pragma once
 #include "../common.h"
@@ -11,11 +11,7 @@ struct LabTuning {
     int pipe_cold = 0;         // pipeline.hip timing experiment: fused items read a far-away tile (results are wrong)
     int pipe_trace = 0;        // pipeline.hip: record item timestamps behind the scratch's sync words
     int pipe_head = 0;         // pipeline.hip: histogram items handed out before each fused item (0 = 2)
-    int arena_chunk_mb = 64;   // arena.cpp: size of the physical pieces of an assembled arena
-    int arena_align_mb = 0;    // arena.cpp: alignment of the arena's address range (0 = the driver's default)
-    int arena_shuffle = 0;     // arena.cpp: pieces of a group mapped in a pseudo-random order
 };
 LabTuning &lab_tuning();
-bool arena_free(void *dptr);   // arena.cpp: true if dptr was an assembled output arena (freed)
 bool vmm_free(void *dptr);     // lab_alloc.cpp
 }  // namespace lars

@@ -120,7 +120,7 @@ extern "C" int lars_lab_free(void *dptr)
     if (!dptr) return LARS_OK;
     ThreadCtx *c;
     LARS_TRY(ensure_ctx(&c));
-    if (arena_free(dptr) || vmm_free(dptr)) return LARS_OK;
+    if (vmm_free(dptr)) return LARS_OK;
     LARS_HIP_TRY(hipFree(dptr));
     return LARS_OK;
 }
@@ -133,9 +133,6 @@ extern "C" int lars_lab_set_tuning(const char *key, int value)
     else if (!strcmp(key, "pipe_head")) t.pipe_head = value;
     else if (!strcmp(key, "pipe_trace")) t.pipe_trace = value;
     else if (!strcmp(key, "pipe_cold")) t.pipe_cold = value;
-    else if (!strcmp(key, "arena_chunk_mb")) t.arena_chunk_mb = value;
-    else if (!strcmp(key, "arena_align_mb")) t.arena_align_mb = value;
-    else if (!strcmp(key, "arena_shuffle")) t.arena_shuffle = value;
     else return fail(LARS_ERR_INVALID, "lars_lab_set_tuning: unknown key %s", key);
     return LARS_OK;
 }

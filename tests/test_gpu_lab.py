@@ -1,6 +1,5 @@
 """The laboratory library (liblars_lab.so, include/lars_lab.h): experiments that are not part of the product stay
-buildable and correct -- the persistent one-launch pipeline, output arenas assembled from timed groups of physical memory,
-the streaming probes (needs a MI355X)."""
+buildable and correct -- the persistent one-launch pipeline and the streaming probes (needs a MI355X)."""
 import os
 import sys
 import warnings
@@ -91,50 +90,15 @@ def test_pipelined_launch_equals_the_two_pass_path(lars, lablib, shape, ntiles, 
 
 
 
-def test_assembled_output_arena(lars, lablib):
-    """lars_d_output_arena: the planes' memory is put together from candidate groups of physical memory that were timed with
-    the batch's own launch; the arena behaves like any other (same records; planes compared on the device), reports what
-    the search did and goes back to the driver when freed."""
-    import ctypes as C
-    from lars_image_processing_amd import _ffi
-    b = lars.TileBatch.synthetic(70, 1024, 1024, seed=9, profile="vegetation")
-    assert lablib.arena_group_slots(3, b.npix) == 64 and lablib.arena_group_slots(3, 4096 * 4096) == 16
-    assert lablib.arena_group_slots(2, 8192 * 8192) == 8
-    free0, total = C.c_size_t(), C.c_size_t()
-    _ffi.call("lars_mem_info", C.byref(free0), C.byref(total))
-    plain = b.make_outputs(index=True, ring=64, arena="plain")
-    built = lablib.assembled_outputs(b, ring=64, max_groups=3)
-    rep = built.arena_report
-    assert rep["kind"].startswith("assembled from 1 of ") and 1 <= len(rep["group_ms"]) <= 3
-    assert rep["rejected"] == len(rep["group_ms"]) - 1 and rep["chosen_ms"] == pytest.approx(min(rep["group_ms"])) and rep["search_ms"] > 0
-    assert [built.index[k].ptr - built.arena.ptr for k in range(3)] == [0, built.plane_bytes, 2 * built.plane_bytes]
-    assert built.plane_bytes == 64 * b.npix * 4
-    rec_a = b.process(outputs=plain)
-    rec_b = b.process(outputs=built)
-    assert rec_a.tobytes() == rec_b.tobytes()
-    # the planes, compared by a kernel (late - early over the whole ring): all zeros
-    diff = _ffi.DeviceBuffer(64 * b.npix * 4)
-    for k in range(3):
-        _ffi.call("lars_d_diff_f32", C.c_void_p(plain.index[k].ptr), C.c_void_p(built.index[k].ptr), 64 * b.npix, C.c_void_p(diff.ptr), None)
-        _ffi.call("lars_synchronize", None)
-        assert not diff.download(np.float32, (64 * b.npix,)).any(), k
-    diff.free(); plain.free(); built.free()
-    free1 = C.c_size_t()
-    _ffi.call("lars_mem_info", C.byref(free1), C.byref(total))
-    assert free1.value >= free0.value - (64 << 20)                   # every candidate group went back to the driver
-    with pytest.raises(_ffi.LarsError):
-        lablib.assembled_outputs(b, ring=32)                         # not whole groups of 64 slots
-    b.free()
-
-
 def test_streaming_probe_and_allocation_kinds(lablib):
     from lars_image_processing_amd import _ffi
     nbytes = 96 << 20
     src = _ffi.DeviceBuffer(nbytes)
     src.zero()
-    for kind, chunk in ((0, 0), (3, 32), (3, 0)):
-        dst = lablib.LabBuffer(nbytes, kind=kind, chunk_mb=chunk)
-        lablib.probe(2, 1, 4096, src.ptr, dst.ptr, nbytes - nbytes % 960)     # copy, 16 bytes per lane
-        _ffi.call("lars_synchronize", None)
-        dst.free()
-    src.free()
+    dst = lablib.LabBuffer(nbytes, kind=0)
+    lablib.probe(2, 1, 4096, src.ptr, dst.ptr, nbytes - nbytes % 960)         # copy, 16 bytes per lane
+    lablib.probe(32, 1, 64, src.ptr, None, nbytes)                            # two readers per chunk, 12-byte loads
+    lablib.probe(43, 1, 64, src.ptr, None, nbytes)                            # three readers, 16-byte loads
+    _ffi.call("lars_synchronize", None)
+    assert not dst.download(np.uint8, (1 << 20,)).any()                        # the copy of a zeroed buffer
+    dst.free(); src.free()

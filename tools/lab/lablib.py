@@ -1,5 +1,5 @@
 """ctypes binding of liblars_lab.so (include/lars_lab.h): the LABORATORY library -- streaming probes, the persistent
-one-launch pipeline, output arenas assembled from timed groups of physical memory, allocation kinds.  Not part of the
+one-launch pipeline, allocation kinds.  Not part of the
 product; build it with ``make -C lars_image_processing_amd/csrc lab`` (``__graft_entry__.build()`` does)."""
 from __future__ import annotations
 
@@ -17,22 +17,12 @@ LIB_PATH = os.path.join(ROOT, "lars_image_processing_amd", "liblars_lab.so")
 _P, _I, _I64, _SZ = C.c_void_p, C.c_int, C.c_int64, C.c_size_t
 
 
-class ArenaReport(C.Structure):
-    """``lars_arena_report`` (include/lars_lab.h)."""
-    _fields_ = [
-        ("kind", C.c_int32), ("groups_tried", C.c_int32), ("groups_kept", C.c_int32), ("rejected", C.c_int32),
-        ("group_bytes", C.c_uint64), ("search_ms", C.c_float), ("chosen_ms", C.c_float), ("slowest_kept_ms", C.c_float),
-        ("group_ms", C.c_float * 32),
-    ]
-
-
 SIGNATURES = {
     "lars_lab_malloc": (_I, [C.POINTER(_P), _SZ, _I, _I, _I, _I]),
     "lars_lab_free": (_I, [_P]),
     "lars_lab_set_tuning": (_I, [C.c_char_p, _I]),
     "lars_pipeline_scratch_bytes": (_SZ, [_I64, _I64]),
     "lars_d_pipeline": (_I, [C.POINTER(FusedArgs), _P, _P, _I, _P]),
-    "lars_d_output_arena": (_I, [C.POINTER(FusedArgs), _I64, _I64, _I, C.POINTER(_P), C.POINTER(ArenaReport)]),
     "lars_d_probe": (_I, [_I, _I, _I, _P, _P, _I64, _P]),
 }
 _lib = None
@@ -122,51 +112,3 @@ def run_pipeline(batch, stats, outputs, stream=None, tile_start=0, tile_count=No
     a = batch.fused_args(_ffi.INDEX_NAMES, True, stats, False, outputs, stream, tile_start, tile_count)
     call("lars_d_pipeline", C.byref(a), C.c_void_p(batch.percentiles.ptr + tile_start * 48),
          C.c_void_p(batch.hist.ptr + tile_start * 3072), int(rgn_variant), C.c_void_p(batch._pipe_scratch.ptr))
-
-
-# ---- output arenas assembled from timed groups of physical memory (csrc/lab/arena.cpp) -----------------------------------
-ARENA_GROUP_BYTES = 3 << 30
-
-
-def arena_group_slots(nplanes, npix):
-    """Tile slots per candidate group: the power of two that brings a group to ARENA_GROUP_BYTES (1 .. 64)."""
-    per_slot = max(1, nplanes * npix * 4)
-    g = 1
-    while g < 64 and g * per_slot < ARENA_GROUP_BYTES:
-        g *= 2
-    return g
-
-
-def assembled_outputs(batch, indices=_ffi.INDEX_NAMES, ring=None, rgba=False, max_groups=None):
-    """``TileBatch.make_outputs`` with the planes' arena put together by ``lars_d_output_arena``; ``outs.arena_report`` says
-    what the search did."""
-    from lars_image_processing_amd.batch import BatchOutputs, channels_of
-    outs = BatchOutputs(batch, indices, True, False, rgba, ring, allocate=False)
-    nplanes = len(outs._index_ids) + len(outs._rgba_ids)
-    group = arena_group_slots(nplanes, batch.npix)
-    a = batch.fused_args(indices, batch.table is not None and channels_of(indices) <= batch._table_channels, None, False, None, None, 0,
-                         min(group, batch.ntiles))
-    scratch_stats = DeviceBuffer(group * 3 * STATS_DTYPE.itemsize)
-    a.stats = scratch_stats.ptr
-    a.flags = _ffi.F_STATS
-    a.ntiles = batch.ntiles
-    for k in outs._index_ids:
-        a.out_index[k] = 1                                      # markers: which planes exist
-    for k in outs._rgba_ids:
-        a.out_rgba[k] = 1
-        a.cmap_lut[k] = outs.luts[k].ptr
-    need = outs.slots // group if group else 0
-    limit = int(max_groups) if max_groups else min(32, max(need + 4, 3 * need))
-    base, rep = C.c_void_p(), ArenaReport()
-    try:
-        call("lars_d_output_arena", C.byref(a), outs.slots, group, limit, C.byref(base), C.byref(rep))
-    finally:
-        _ffi.call("lars_synchronize", None)
-        scratch_stats.free()
-    outs.plane_bytes = outs.slots * batch.npix * 4               # assembled arenas are packed: [plane][slot][npix]
-    outs.adopt_arena(LabBuffer(nplanes * outs.plane_bytes, adopt=base.value))
-    outs.arena_report = {"kind": f"assembled from {rep.groups_kept} of {rep.groups_tried} timed groups of {group} tile slots "
-                                 f"({rep.group_bytes >> 20} MiB of physical memory each)",
-                         "search_ms": float(rep.search_ms), "chosen_ms": float(rep.chosen_ms), "slowest_kept_ms": float(rep.slowest_kept_ms),
-                         "rejected": int(rep.rejected), "group_ms": [float(rep.group_ms[i]) for i in range(min(rep.groups_tried, 32))]}
-    return outs

@@ -153,9 +153,11 @@ int lars_d_wb_table(const uint32_t *hist, int64_t ntiles, int64_t npix, int dtyp
 size_t lars_wb_table_bytes(int dtype);
 
 /* The whole white-balance pre-pass of a batch in one call (histogram pass(es) + tables), both
- * sample types.  For LARS_U16 the percentiles come from a two-level radix pass (high-byte
- * histograms, then low-byte histograms of the bins that hold the order statistics) instead of a
- * 65536-bin histogram per channel.  Scratch comes from the calling thread's library workspace. */
+ * sample types.  For LARS_U16 the percentiles come from two radix levels (high-byte histograms,
+ * then low-byte histograms of the bins that hold the order statistics) instead of a 65536-bin
+ * histogram per channel -- usually in ONE full pass: a subsample predicts candidate bins, the pass
+ * counts high bytes and the candidates' low bytes together, and only tiles whose exact bins were
+ * not among their candidates are recounted.  Scratch comes from the calling thread's library workspace. */
 int lars_d_wb_prepare(const void *tiles, int64_t ntiles, int64_t npix, int channels, int dtype,
                       uint8_t *table, double *percentiles, int rgn_variant, void *stream);
 
@@ -306,6 +308,8 @@ int lars_d_synth_u8(uint8_t *tiles, int64_t ntiles, int64_t first_tile, int64_t 
 
 /* Tuning knobs (per process): "fused_impl" 0 (auto)|1|2, "hist_impl" 1|2, "nt_stores" 0|1, "blocks_per_tile" 0 = automatic
  * (also the chunks per tile of lars_d_stats_joint), "joint_depth" 4|6 loads in flight per lane of the counting kernel,
+ * "u16_hist_impl" 2 (uint16 percentiles usually from one full pass: candidate bins predicted from a subsample)|1 (always the two
+ * radix passes)|3 (wrong candidates on purpose: exercises the recount),
  * "selq_window" 1 (one-pass medians)|0 (always two select passes)|2 (wrong windows: exercises the fallback), "selq_list_wgs"
  * workgroups per select pass over the tiles a window missed (0 = 2048).  Results never depend on them.  Read-only:
  * "last_fused_kernel" = the kernel family the last lars_d_fused launched (1 k_fused_u8c3, 2 k_fused_v2, 3 its uint16 form,

@@ -13,6 +13,12 @@
 //
 // Both data passes stream the tile once at HBM rate; a 3 x 65536-bin histogram would need one
 // global atomic per sample instead.
+//
+// Round 3: usually ONE full pass.  A 1/16 subsample of the high-byte histograms predicts, per channel, the bins that will
+// hold the order statistics (each predicted bin and its two neighbours: up to six candidates); the full pass then counts the
+// high bytes of every sample AND the low bytes of the samples in candidate bins (k_hist_u16_both).  The exact high-byte
+// histogram settles which bins were needed; a tile whose bins were not all among its candidates (a percentile within a sample
+// error of a bin boundary, or a 16-bit image that is not smooth at the 2 % / 98 % marks) is recounted by the classic second pass.
 #include "common.h"
 #include "device_common.h"
 
@@ -30,8 +36,9 @@ struct U16Pick {
 
 // ---- pass 1: high-byte histograms --------------------------------------------------------
 // lane owns 4 pixels = 24 bytes (6 dwords: r0g0 n0r1 g1n1 r2g2 n2r3 g3n3, two samples per dword)
+// every > 1: only every `every`-th grid stride is counted (the subsample that predicts the candidate bins)
 __global__ __launch_bounds__(1024) void k_hist_u16_hi(const uint16_t *__restrict__ tiles, long long npix,
-                                                      unsigned int *__restrict__ hist)
+                                                      unsigned int *__restrict__ hist, int every)
 {
     __shared__ unsigned int s_h[3 * 256 * 32];             // [channel][bin][copy = lane % 32]
     const int tid = threadIdx.x;
@@ -44,7 +51,7 @@ __global__ __launch_bounds__(1024) void k_hist_u16_hi(const uint16_t *__restrict
     char *hb = reinterpret_cast<char *>(s_h);
 #define HADD16(word, half, ch)                                                                         \
     atomicAdd(reinterpret_cast<unsigned int *>(hb + (ch) * 32768 + ((((word) >> ((half) * 16 + 8)) & 0xFFu) << 7) + lane_off), 1u)
-    const long long step = (long long)gridDim.x * 1024;
+    const long long step = (long long)gridDim.x * 1024 * every;
     if (nquads > 0) {
         const __amdgpu_buffer_rsrc_t rsrc =
             __builtin_amdgcn_make_buffer_rsrc(const_cast<uint16_t *>(base), 0, (int)(nquads * 24), 0x00020000);
@@ -57,7 +64,7 @@ __global__ __launch_bounds__(1024) void k_hist_u16_hi(const uint16_t *__restrict
             HADD16(b.x, 0, 2); HADD16(b.x, 1, 0); HADD16(b.y, 0, 1); HADD16(b.y, 1, 2);
         }
     }
-    if (blockIdx.x == 0 && tid < (int)(npix & 3)) {
+    if (every == 1 && blockIdx.x == 0 && tid < (int)(npix & 3)) {
         const uint16_t *p = base + (nquads * 4 + tid) * 3;
         HADD16((unsigned)p[0], 0, 0); HADD16((unsigned)p[1], 0, 1); HADD16((unsigned)p[2], 0, 2);
     }
@@ -195,9 +202,182 @@ __global__ __launch_bounds__(1024) void k_hist_u16_lo(const uint16_t *__restrict
         if (s_h[i]) atomicAdd(&g[i], s_h[i]);
 }
 
+// ---- one full pass: candidate bins from a subsample, high bytes + low bytes of the candidates together --------------------
+#define U16_CAND 6                 /* candidate high-byte bins per channel: each predicted bin and its two neighbours */
+struct U16Cand { unsigned char bin[U16_CAND]; unsigned char n; unsigned char pad; };
+
+// from the subsample's high-byte histogram: the bins holding the 2 % and the 98 % mark of the sample, +- 1
+__global__ __launch_bounds__(256) void k_u16_predict(const unsigned int *__restrict__ sample_hist, U16Cand *__restrict__ cand)
+{
+    __shared__ unsigned long long s_scan[256];
+    __shared__ int s_t[2];
+    const int tid = threadIdx.x;
+    const long long slot = (long long)blockIdx.y * 3 + blockIdx.x;
+    const unsigned long long c = sample_hist[slot * 256 + tid];
+    s_scan[tid] = c;
+    __syncthreads();
+    for (int off = 1; off < 256; off <<= 1) {
+        unsigned long long v = (tid >= off) ? s_scan[tid - off] : 0;
+        __syncthreads();
+        s_scan[tid] += v;
+        __syncthreads();
+    }
+    const unsigned long long total = s_scan[255], before = s_scan[tid] - c;
+    if (tid < 2) s_t[tid] = tid == 0 ? 0 : 255;
+    __syncthreads();
+    if (total > 0) {
+        for (int k = 0; k < 2; ++k) {
+            const unsigned long long r = (unsigned long long)((double)(total - 1) * (k == 0 ? 0.02 : 0.98));
+            if (c && r >= before && r < before + c) s_t[k] = tid;
+        }
+    }
+    __syncthreads();
+    if (tid == 0) {
+        U16Cand out;
+        out.n = 0; out.pad = 0;
+        for (int j = 0; j < U16_CAND; ++j) out.bin[j] = 0;
+        for (int k = 0; k < 2; ++k)
+            for (int d = -1; d <= 1; ++d) {
+                const int b = s_t[k] + d;
+                if (b < 0 || b > 255) continue;
+                bool have = false;
+                for (int j = 0; j < out.n; ++j) have |= out.bin[j] == (unsigned char)b;
+                if (!have) out.bin[out.n++] = (unsigned char)b;
+            }
+        cand[slot] = out;
+    }
+}
+
+// test hook (lars_set_tuning("u16_hist_impl", 3)): every channel's candidates = {bin 0}, so that (almost) every tile misses and
+// takes the recount
+__global__ void k_u16_spoil(U16Cand *cand, long long n)
+{
+    const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    U16Cand c;
+    c.n = 1; c.pad = 0;
+    for (int j = 0; j < U16_CAND; ++j) c.bin[j] = 0;
+    cand[i] = c;
+}
+
+// ONLY_FLAGGED: the recount of the tiles whose candidates missed (low bytes only, candidates = the exact bins by then)
+template <bool ONLY_FLAGGED>
+__global__ __launch_bounds__(1024) void k_hist_u16_both(const uint16_t *__restrict__ tiles, long long npix, const U16Cand *__restrict__ cand,
+                                                        const unsigned int *__restrict__ flags, unsigned int *__restrict__ hist,
+                                                        unsigned int *__restrict__ lohist)
+{
+    __shared__ unsigned int s_h[ONLY_FLAGGED ? 32 : 3 * 256 * 32];       // high bytes: [channel][bin][copy = lane % 32]
+    __shared__ unsigned int s_lo[3 * U16_CAND * 256];
+    __shared__ unsigned char s_slot[3 * 256];
+    const int tid = threadIdx.x;
+    const long long tile = blockIdx.y;
+    if (ONLY_FLAGGED && !flags[tile]) return;
+    if (!ONLY_FLAGGED)
+        for (int i = tid; i < 3 * 256 * 32; i += 1024) s_h[i] = 0;
+    for (int i = tid; i < 3 * U16_CAND * 256; i += 1024) s_lo[i] = 0;
+    if (tid < 768) s_slot[tid] = 0xFF;
+    __syncthreads();
+    if (tid < 3 * U16_CAND) {
+        const int c = tid / U16_CAND, j = tid % U16_CAND;
+        const U16Cand cd = cand[tile * 3 + c];
+        if (j < cd.n) s_slot[c * 256 + cd.bin[j]] = (unsigned char)j;
+    }
+    __syncthreads();
+    const uint16_t *base = tiles + tile * npix * 3;
+    const long long nquads = npix >> 2;
+    const unsigned int lane_off = (tid & 31) << 2;
+    char *hb = reinterpret_cast<char *>(s_h);
+#define BADD(sample, ch)                                                                               \
+    {                                                                                                  \
+        const unsigned int s_ = (sample);                                                              \
+        if (!ONLY_FLAGGED)                                                                             \
+            atomicAdd(reinterpret_cast<unsigned int *>(hb + (ch) * 32768 + ((s_ >> 8) << 7) + lane_off), 1u); \
+        const unsigned int sl_ = s_slot[(ch) * 256 + (s_ >> 8)];                                       \
+        if (sl_ != 0xFFu) atomicAdd(&s_lo[((ch) * U16_CAND + sl_) * 256 + (s_ & 0xFFu)], 1u);         \
+    }
+    const long long step = (long long)gridDim.x * 1024;
+    if (nquads > 0) {
+        const __amdgpu_buffer_rsrc_t rsrc =
+            __builtin_amdgcn_make_buffer_rsrc(const_cast<uint16_t *>(base), 0, (int)(nquads * 24), 0x00020000);
+        for (long long q = (long long)blockIdx.x * 1024 + tid; q < nquads; q += step) {
+            const unsigned int off = (unsigned int)q * 24u;
+            const u32x4v a = __builtin_amdgcn_raw_buffer_load_b128(rsrc, off, 0, 0);
+            const u32x2v b = __builtin_amdgcn_raw_buffer_load_b64(rsrc, off + 16u, 0, 0);
+            BADD(a.x & 0xFFFFu, 0) BADD(a.x >> 16, 1) BADD(a.y & 0xFFFFu, 2) BADD(a.y >> 16, 0)
+            BADD(a.z & 0xFFFFu, 1) BADD(a.z >> 16, 2) BADD(a.w & 0xFFFFu, 0) BADD(a.w >> 16, 1)
+            BADD(b.x & 0xFFFFu, 2) BADD(b.x >> 16, 0) BADD(b.y & 0xFFFFu, 1) BADD(b.y >> 16, 2)
+        }
+    }
+    if (blockIdx.x == 0 && tid < (int)(npix & 3)) {
+        const uint16_t *p = base + (nquads * 4 + tid) * 3;
+        BADD((unsigned)p[0], 0) BADD((unsigned)p[1], 1) BADD((unsigned)p[2], 2)
+    }
+#undef BADD
+    __syncthreads();
+    if (!ONLY_FLAGGED && tid < 768) {
+        const unsigned int *row = s_h + tid * 32;
+        unsigned int v = 0;
+        for (int j = 0; j < 32; ++j) v += row[(j + tid) & 31];
+        if (v) atomicAdd(&hist[tile * 768 + tid], v);
+    }
+    unsigned int *g = lohist + tile * (3 * U16_CAND * 256);
+    for (int i = tid; i < 3 * U16_CAND * 256; i += 1024)
+        if (s_lo[i]) atomicAdd(&g[i], s_lo[i]);
+}
+
+// After the exact pick: point each rank at its candidate's low-byte histogram; a tile with a rank outside its candidates is
+// flagged, gets the exact bins as its candidates and its low-byte histograms zeroed (the recount follows).  One block per tile.
+__global__ __launch_bounds__(256) void k_u16_resolve(U16Pick *__restrict__ picks, U16Cand *__restrict__ cand, unsigned int *__restrict__ lohist,
+                                                     unsigned int *__restrict__ flags)
+{
+    __shared__ int s_miss;
+    const int tid = threadIdx.x;
+    const long long tile = blockIdx.x;
+    if (tid == 0) s_miss = 0;
+    __syncthreads();
+    if (tid < 3) {
+        U16Pick p = picks[tile * 3 + tid];
+        const U16Cand cd = cand[tile * 3 + tid];
+        bool miss = false;
+        for (int r = 0; r < 4; ++r) {
+            int j = 0;
+            for (; j < cd.n; ++j)
+                if (cd.bin[j] == p.target[r]) break;
+            if (j == cd.n) miss = true;
+            p.slot[r] = (unsigned)j;
+        }
+        if (miss) atomicExch(&s_miss, 1);
+        else picks[tile * 3 + tid] = p;
+    }
+    __syncthreads();
+    if (!s_miss) {
+        if (tid == 0) flags[tile] = 0;
+        return;
+    }
+    if (tid < 3) {
+        U16Pick p = picks[tile * 3 + tid];
+        U16Cand cd;
+        cd.n = 0; cd.pad = 0;
+        for (int j = 0; j < U16_CAND; ++j) cd.bin[j] = 0;
+        for (int r = 0; r < 4; ++r) {
+            int j = 0;
+            for (; j < cd.n; ++j)
+                if (cd.bin[j] == p.target[r]) break;
+            if (j == cd.n) cd.bin[cd.n++] = (unsigned char)p.target[r];
+            p.slot[r] = (unsigned)j;
+        }
+        cand[tile * 3 + tid] = cd;
+        picks[tile * 3 + tid] = p;
+    }
+    unsigned int *g = lohist + tile * (3 * U16_CAND * 256);
+    for (int i = tid; i < 3 * U16_CAND * 256; i += 256) g[i] = 0;
+    if (tid == 0) flags[tile] = 1;
+}
+
 // ---- table: order statistics -> percentiles -> 65536-entry table + thresholds ----------------
+// nslots: low-byte histograms per channel in lohist (4: the classic second pass, U16_CAND: the candidate layout)
 __global__ __launch_bounds__(256) void k_wb_table_u16(const unsigned int *__restrict__ lohist, const U16Pick *__restrict__ picks,
-                                                      uint8_t *__restrict__ blobs, double *__restrict__ pcts, int rgn_variant)
+                                                      uint8_t *__restrict__ blobs, double *__restrict__ pcts, int rgn_variant, int nslots)
 {
     __shared__ unsigned long long s_scan[256];
     __shared__ double s_val[4];
@@ -211,7 +391,7 @@ __global__ __launch_bounds__(256) void k_wb_table_u16(const unsigned int *__rest
 
     for (int r = 0; r < 4; ++r) {
         // scan the slot of rank r (ranks sharing a high byte rescan the same slot)
-        const unsigned int *h = lohist + ((tile * 3 + c) * 4 + pk.slot[r]) * 256;
+        const unsigned int *h = lohist + ((tile * 3 + c) * nslots + pk.slot[r]) * 256;
         const unsigned long long cnt = h[tid];
         __syncthreads();
         s_scan[tid] = cnt;
@@ -264,14 +444,18 @@ extern "C" int lars_d_wb_prepare(const void *tiles, int64_t ntiles, int64_t npix
     }
     if (dtype != LARS_U16) return fail(LARS_ERR_INVALID, "lars_d_wb_prepare: dtype");
     const size_t hi_bytes = (size_t)ntiles * 768 * 4, pick_bytes = (size_t)ntiles * 3 * sizeof(U16Pick),
-                 lo_bytes = (size_t)ntiles * 3 * 4 * 256 * 4;
-    LARS_TRY(scratch_reserve(c, hi_bytes + pick_bytes + lo_bytes + 512));
+                 lo_bytes = (size_t)ntiles * 3 * U16_CAND * 256 * 4, cand_bytes = (size_t)ntiles * 3 * sizeof(U16Cand),
+                 flag_bytes = (size_t)ntiles * 4;
+    auto up = [](size_t b) { return (b + 255) & ~(size_t)255; };
+    LARS_TRY(scratch_reserve(c, 2 * up(hi_bytes) + up(pick_bytes) + up(lo_bytes) + up(cand_bytes) + up(flag_bytes) + 512));
     char *p = static_cast<char *>(c->scratch);
-    unsigned int *hi = reinterpret_cast<unsigned int *>(p);
-    U16Pick *picks = reinterpret_cast<U16Pick *>(p + ((hi_bytes + 255) & ~(size_t)255));
-    unsigned int *lo = reinterpret_cast<unsigned int *>(reinterpret_cast<char *>(picks) + ((pick_bytes + 255) & ~(size_t)255));
-    LARS_HIP_TRY(hipMemsetAsync(hi, 0, hi_bytes, s));
-    LARS_HIP_TRY(hipMemsetAsync(lo, 0, lo_bytes, s));
+    unsigned int *hi = reinterpret_cast<unsigned int *>(p);                  p += up(hi_bytes);
+    unsigned int *hi_sample = reinterpret_cast<unsigned int *>(p);           p += up(hi_bytes);
+    unsigned int *lo = reinterpret_cast<unsigned int *>(p);                  p += up(lo_bytes);
+    unsigned int *flags = reinterpret_cast<unsigned int *>(p);               p += up(flag_bytes);
+    U16Pick *picks = reinterpret_cast<U16Pick *>(p);                         p += up(pick_bytes);
+    U16Cand *cand = reinterpret_cast<U16Cand *>(p);
+    LARS_HIP_TRY(hipMemsetAsync(hi, 0, 2 * up(hi_bytes) + up(lo_bytes) + up(flag_bytes), s));     // hi, hi_sample, lo, flags are contiguous
     const uint16_t *t16 = static_cast<const uint16_t *>(tiles);
     const bool fast = channels == 3 && (ntiles == 1 || (npix & 3) == 0) && ((reinterpret_cast<uintptr_t>(tiles) & 3) == 0) &&
                       (long long)npix * 6 < (1ll << 30);
@@ -280,11 +464,26 @@ extern "C" int lars_d_wb_prepare(const void *tiles, int64_t ntiles, int64_t npix
     if (want > cap) want = cap;
     if (want < 1) want = 1;
     dim3 grid((unsigned)want, (unsigned)ntiles);
-    if (fast) hipLaunchKernelGGL(k_hist_u16_hi, grid, dim3(1024), 0, s, t16, (long long)npix, hi);
+    const dim3 per_channel(3, (unsigned)ntiles);
+    if (fast && tuning().u16_hist_impl != 1 && cap >= 64) {
+        // ONE full pass: candidates from a 1/16 subsample, then high bytes + low bytes of the candidate bins together; the exact
+        // pick decides which tiles (if any) need the classic recount
+        hipLaunchKernelGGL(k_hist_u16_hi, grid, dim3(1024), 0, s, t16, (long long)npix, hi_sample, 16);
+        hipLaunchKernelGGL(k_u16_predict, per_channel, dim3(256), 0, s, hi_sample, cand);
+        if (tuning().u16_hist_impl == 3)
+            hipLaunchKernelGGL(k_u16_spoil, dim3((unsigned)((ntiles * 3 + 255) / 256)), dim3(256), 0, s, cand, (long long)ntiles * 3);
+        hipLaunchKernelGGL((k_hist_u16_both<false>), grid, dim3(1024), 0, s, t16, (long long)npix, cand, flags, hi, lo);
+        hipLaunchKernelGGL(k_u16_pick, per_channel, dim3(256), 0, s, hi, (long long)npix, picks);
+        hipLaunchKernelGGL(k_u16_resolve, dim3((unsigned)ntiles), dim3(256), 0, s, picks, cand, lo, flags);
+        hipLaunchKernelGGL((k_hist_u16_both<true>), grid, dim3(1024), 0, s, t16, (long long)npix, cand, flags, hi, lo);
+        hipLaunchKernelGGL(k_wb_table_u16, per_channel, dim3(256), 0, s, lo, picks, table, percentiles, rgn_variant, U16_CAND);
+        return launch_check("lars_d_wb_prepare (one pass)");
+    }
+    if (fast) hipLaunchKernelGGL(k_hist_u16_hi, grid, dim3(1024), 0, s, t16, (long long)npix, hi, 1);
     else hipLaunchKernelGGL(k_hist_u16_hi_generic, dim3((unsigned)want * 4, (unsigned)ntiles), dim3(256), 0, s, t16, (long long)npix, channels, hi);
-    hipLaunchKernelGGL(k_u16_pick, dim3(3, (unsigned)ntiles), dim3(256), 0, s, hi, (long long)npix, picks);
+    hipLaunchKernelGGL(k_u16_pick, per_channel, dim3(256), 0, s, hi, (long long)npix, picks);
     if (fast) hipLaunchKernelGGL((k_hist_u16_lo<true>), grid, dim3(1024), 0, s, t16, (long long)npix, channels, picks, lo);
     else hipLaunchKernelGGL((k_hist_u16_lo<false>), grid, dim3(1024), 0, s, t16, (long long)npix, channels, picks, lo);
-    hipLaunchKernelGGL(k_wb_table_u16, dim3(3, (unsigned)ntiles), dim3(256), 0, s, lo, picks, table, percentiles, rgn_variant);
+    hipLaunchKernelGGL(k_wb_table_u16, per_channel, dim3(256), 0, s, lo, picks, table, percentiles, rgn_variant, 4);
     return launch_check("lars_d_wb_prepare");
 }

@@ -346,6 +346,47 @@ def test_uint16_batch_against_oracle(lars, kind):
     hist.free(); outs.free(); b.free()
 
 
+def test_uint16_percentiles_one_pass_and_its_recount(lars):
+    """lars_d_wb_prepare for uint16 tiles: candidate high-byte bins predicted from a subsample, one full pass counting high bytes
+    and the candidates' low bytes, exact pick, recount only where a candidate set missed -- against the two radix passes and
+    np.percentile; with wrong candidates on purpose every tile takes the recount.  Heavy-tailed, constant and few-level
+    channels included."""
+    from lars_image_processing_amd import _ffi
+    rng = np.random.default_rng(21)
+    h, w = 512, 768
+    ramp = (np.arange(h * w * 3, dtype=np.int64).reshape(h, w, 3) * 7919 % 65536).astype(np.uint16)
+    tiles = np.stack([
+        rng.integers(0, 65536, (h, w, 3), dtype=np.uint16),
+        np.clip(rng.normal(30000, 900, (h, w, 3)), 0, 65535).astype(np.uint16),
+        np.full((h, w, 3), 4242, np.uint16),
+        np.where(rng.random((h, w, 3)) < 0.03, 65535, 7).astype(np.uint16),
+        (rng.integers(0, 4, (h, w, 3)) * 21845).astype(np.uint16),
+        np.clip(rng.normal(255.6 * 50, 40, (h, w, 3)), 0, 65535).astype(np.uint16),      # the marks sit next to a bin boundary
+        ramp,
+    ])
+    b = lars.TileBatch.from_host(tiles)
+    b.compute_wb_tables()                                            # allocates the blobs (their padding is never written)
+    got = {}
+    try:
+        for impl in (2, 1, 3):
+            _ffi.set_tuning(u16_hist_impl=impl)
+            b.table.zero(); b.percentiles.zero()
+            b.compute_wb_tables()
+            _ffi.call("lars_synchronize", None)
+            got[impl] = (b.host_percentiles().tobytes(), b.table.download(np.uint8, (b.ntiles, b.table_bytes)).tobytes())
+    finally:
+        _ffi.set_tuning(u16_hist_impl=2)
+    assert got[1] == got[2] == got[3]
+    pcts = b.host_percentiles()
+    for i in range(len(tiles)):
+        for c in range(3):
+            with warnings.catch_warnings():
+                warnings.simplefilter("ignore")
+                want = [float(v) for v in np.percentile(tiles[i][:, :, c].astype(np.float32), (2, 98))]
+            assert pcts[i, c].tolist() == want, (i, c)
+    b.free()
+
+
 def test_uint16_full_size_tile(lars):
     """BASELINE configs[4] at its full size: one 8192 x 8192 uint16 tile (384 MiB), float32 NDVI + RdYlGn RGBA written.
     Percentiles against np.percentile on the whole channel; planes bit-exact on strips (first, middle, last rows) with the

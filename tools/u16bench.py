@@ -23,8 +23,12 @@ def main():
         return float(np.median(ts[1:]))
     npix = tiles * edge * edge
     res = {}
-    t = timed(lambda: b.compute_wb_tables())
-    res["wb_prepare (2 radix passes + tables)"] = {"ms": t, "GBs_input_once": npix * 6 / t / 1e6}
+    for impl, name in ((2, "wb_prepare (one full pass: candidate bins from a subsample)"), (1, "wb_prepare (2 radix passes + tables)"),
+                       (3, "wb_prepare (wrong candidates on purpose: full pass + recount)")):
+        _ffi.set_tuning(u16_hist_impl=impl)
+        t = timed(lambda: b.compute_wb_tables())
+        res[name] = {"ms": t, "GBs_input_once": npix * 6 / t / 1e6, "frac_8TBs": npix * 6 / t / 1e6 / 8000}
+    _ffi.set_tuning(u16_hist_impl=2)
     stats = b.new_stats()
     outs = b.make_outputs(indices=("NDVI",), index=True, rgba=True)
     for name, kw, bpp in (("ndvi_f32+rgba+stats (configs[4])", dict(indices=("NDVI",), outputs=outs), 14),
@@ -33,7 +37,7 @@ def main():
         t = timed(lambda: b.run_fused(b.fused_args(kw["indices"], True, stats, False, kw["outputs"])))
         res[name] = {"ms": t, "GBs": npix * bpp / t / 1e6, "frac_8TBs": npix * bpp / t / 1e6 / 8000, "Gpix_s": npix / t / 1e6}
     for k, v in res.items():
-        print(f"{k:42s} " + "  ".join(f"{kk}={vv:9.3f}" for kk, vv in v.items()))
+        print(f"{k:66s} " + "  ".join(f"{kk}={vv:9.3f}" for kk, vv in v.items()))
     print(json.dumps(res))
 
 if __name__ == "__main__":

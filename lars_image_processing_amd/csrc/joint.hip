@@ -19,8 +19,8 @@
 // (16383 + 49152 = 65535); a workgroup counts at most 2^24 pixels, so at most 1024 moves.  With two streams the two
 // workgroups of a tile chunk sit 8 apart in dispatch order (the same XCD, at the same time): the second reader of a
 // line finds it in that XCD's L2 or in the Infinity Cache.
-// Cell of a pixel: S = (x << 8 | n) ^ x  (x = r or g: the low byte becomes n ^ x so that the LDS bank is a mix of both
-// samples), dword D = S >> 1, half h = S & 1.
+// Cell of a pixel: S = (x << 8 | n) ^ JH_MIX(x)  (x = r or g: the low byte becomes n ^ 2x so that the LDS bank is a mix of both
+// samples, under common and under independent changes), dword D = S >> 1, half h = S & 1.
 #include <string.h>
 
 #include <type_traits>
@@ -29,6 +29,10 @@
 
 namespace lars {
 
+// The low byte of a cell is n ^ JH_MIX(x): the LDS bank (bits 1..5 of the cell) must spread for neighbouring pixels, whose
+// samples move TOGETHER under shading (n ^ x alone would stay put) as well as apart under noise.
+#define JH_MIX(x) (((x) << 1) & 0xFEu)
+#define JH_MIX2(px) (((px) << 1) & 0x00FE00FEu)         /* two cells per dword: x0 0 x1 0 */
 #define JH_DWORDS 32768
 #define JH_THREADS 1024
 #define JH_PERIOD_STEPS 12                    /* steps of 4096 pixels between two scans */
@@ -127,8 +131,8 @@ __global__ __launch_bounds__(JH_THREADS, 4) void k_joint_count(JointCountParams 
                 const unsigned long long active = __builtin_amdgcn_ballot_w64(true);
                 if ((active & (0ull - active)) == (1ull << (tid & 63))) {             // the first active lane
                     const unsigned int n = (unsigned int)__builtin_popcountll(active);
-                    const unsigned int c01 = __builtin_amdgcn_perm(f1, f0, selc01) ^ __builtin_amdgcn_perm(f1, f0, selx01);
-                    const unsigned int c23 = __builtin_amdgcn_perm(f2, f1, selc23) ^ __builtin_amdgcn_perm(f2, f1, selx23);
+                    const unsigned int c01 = __builtin_amdgcn_perm(f1, f0, selc01) ^ JH_MIX2(__builtin_amdgcn_perm(f1, f0, selx01));
+                    const unsigned int c23 = __builtin_amdgcn_perm(f2, f1, selc23) ^ JH_MIX2(__builtin_amdgcn_perm(f2, f1, selx23));
                     if (c01 == c23 && (c01 >> 16) == (c01 & 0xFFFFu)) {               // one colour: one add for the whole 256 pixels
                         jh_add((c01 << 1) & 0x1FFFCu, (((c01 & 1u) << 16) | 1u) * (4u * n), tab);
                     } else {
@@ -139,15 +143,15 @@ __global__ __launch_bounds__(JH_THREADS, 4) void k_joint_count(JointCountParams 
                 return;
             }
         }
-        count_pair(__builtin_amdgcn_perm(w1, w0, selc01) ^ __builtin_amdgcn_perm(w1, w0, selx01));
-        count_pair(__builtin_amdgcn_perm(w2, w1, selc23) ^ __builtin_amdgcn_perm(w2, w1, selx23));
+        count_pair(__builtin_amdgcn_perm(w1, w0, selc01) ^ JH_MIX2(__builtin_amdgcn_perm(w1, w0, selx01)));
+        count_pair(__builtin_amdgcn_perm(w2, w1, selc23) ^ JH_MIX2(__builtin_amdgcn_perm(w2, w1, selx23)));
     };
 
     // tail pixels of the tile (npix % 4): its last chunk, before the first period (which starts from zero counts)
     if (chunk == P.K - 1 && tid < (int)(P.npix & 3)) {
         const uint8_t *p = tile_base + (nquads_tile * 4 + tid) * CH;
         const unsigned int n = p[2], x = green ? p[1] : p[0];
-        const unsigned int s = ((x << 8) | n) ^ x;
+        const unsigned int s = ((x << 8) | n) ^ JH_MIX(x);
         jh_add((s << 1) & 0x1FFFCu, ((s & 1u) << 16) | 1u, tab);
     }
 
@@ -350,7 +354,7 @@ __global__ __launch_bounds__(JH_THREADS) void k_joint_finish(JointFinishParams P
     if (tid < 2) s_med[tid] = __builtin_nanf("");
 
     // This thread's 64 cells: dwords D = j * 1024 + tid (j < 32), cells S = 2D, 2D + 1; x = S >> 8 = D >> 7 (the same for
-    // the 64 lanes of a wave), n = (S & 255) ^ x.  Every pass below walks them in four groups of eight dwords, the next
+    // the 64 lanes of a wave), n = (S & 255) ^ JH_MIX(x).  Every pass below walks them in four groups of eight dwords, the next
     // group's loads (L2 hits: the counting kernel has just written them) in flight while the current one is worked on.
     constexpr int NJ = JH_DWORDS / JH_THREADS;                       // 32
     constexpr int GRP = 8;
@@ -390,7 +394,7 @@ __global__ __launch_bounds__(JH_THREADS) void k_joint_finish(JointFinishParams P
     // ---- marginals: the channel histograms np.percentile needs
     for_cells([&](unsigned int D, unsigned int c0, unsigned int c1) {
         const unsigned int x = D >> 7;
-        const unsigned int n0 = ((2u * D) & 255u) ^ x, n1 = ((2u * D + 1u) & 255u) ^ x;
+        const unsigned int n0 = ((2u * D) & 255u) ^ JH_MIX(x), n1 = ((2u * D + 1u) & 255u) ^ JH_MIX(x);
         if (c0) atomicAdd(&s_hn[n0], c0);
         if (c1) atomicAdd(&s_hn[n1], c1);
         unsigned int t = c0 + c1;
@@ -480,7 +484,7 @@ __global__ __launch_bounds__(JH_THREADS) void k_joint_finish(JointFinishParams P
             for (int h = 0; h < 2; ++h) {
                 const unsigned int cv = cc[h];
                 if (!cv) continue;
-                const unsigned int n = ((2u * D + (unsigned)h) & 255u) ^ x;
+                const unsigned int n = ((2u * D + (unsigned)h) & 255u) ^ JH_MIX(x);
                 const float q = norm_diff(s_fn[n], fx);
                 const long long cnt = (long long)cv;
                 sum_fx += cnt * (long long)((double)q * LARS_FX_SCALE);          // q is a multiple of 2^-32: exact
@@ -535,7 +539,7 @@ __global__ __launch_bounds__(JH_THREADS) void k_joint_finish(JointFinishParams P
             for (int h = 0; h < 2; ++h) {
                 const unsigned int cv = cc[h];
                 if (!cv) continue;
-                const unsigned int n = ((2u * D + (unsigned)h) & 255u) ^ x;
+                const unsigned int n = ((2u * D + (unsigned)h) & 255u) ^ JH_MIX(x);
                 const float t = selq_t(norm_diff(s_fn[n], fx));
                 const unsigned int b = selq_bucket_of(t), sl = (__builtin_bit_cast(unsigned int, t) & 0xFFFu) >> 2;
                 if (b == bk0) atomicAdd(&s_slot[0][sl], cv);
@@ -557,7 +561,7 @@ __global__ __launch_bounds__(JH_THREADS) void k_joint_finish(JointFinishParams P
 #pragma unroll
             for (int h = 0; h < 2; ++h) {
                 if (!cc[h]) continue;
-                const unsigned int n = ((2u * D + (unsigned)h) & 255u) ^ x;
+                const unsigned int n = ((2u * D + (unsigned)h) & 255u) ^ JH_MIX(x);
                 const float q = norm_diff(s_fn[n], fx);
                 const float t = selq_t(q);
                 const unsigned int b = selq_bucket_of(t), sl = (__builtin_bit_cast(unsigned int, t) & 0xFFFu) >> 2;

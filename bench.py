@@ -81,7 +81,7 @@ def parse():
     ap.add_argument("--stats-route", default="joint", choices=["joint", "classic"],
                     help="statistics-only modes: one read through joint byte-pair histograms, or histogram pass + per-pixel kernel")
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--cpu-tiles", type=int, default=4, help="tiles per run of the single-core CPU baseline (best of --cpu-runs)")
+    ap.add_argument("--cpu-tiles", type=int, default=8, help="tiles per run of the single-core CPU baseline (best of --cpu-runs; SURVEY.md 8(d): at least 8)")
     ap.add_argument("--cpu-runs", type=int, default=3)
     ap.add_argument("--cpu-workers", type=int, default=16,
                     help="process pool of the multi-core CPU baseline leg (16 = one GPU's share of the box's host cores; every "

@@ -203,7 +203,8 @@ __global__ __launch_bounds__(1024) void k_hist_u16_lo(const uint16_t *__restrict
 }
 
 // ---- one full pass: candidate bins from a subsample, high bytes + low bytes of the candidates together --------------------
-#define U16_CAND 6                 /* candidate high-byte bins per channel: each predicted bin and its two neighbours */
+#define U16_CAND 6                  /* candidate high-byte bins per channel: each predicted bin and its two neighbours */
+#define U16_DEPTH 3                 /* quads per lane in flight in the one-pass count */
 struct U16Cand { unsigned char bin[U16_CAND]; unsigned char n; unsigned char pad; };
 
 // from the subsample's high-byte histogram: the bins holding the 2 % and the 98 % mark of the sample, +- 1
@@ -299,13 +300,32 @@ __global__ __launch_bounds__(1024) void k_hist_u16_both(const uint16_t *__restri
     if (nquads > 0) {
         const __amdgpu_buffer_rsrc_t rsrc =
             __builtin_amdgcn_make_buffer_rsrc(const_cast<uint16_t *>(base), 0, (int)(nquads * 24), 0x00020000);
-        for (long long q = (long long)blockIdx.x * 1024 + tid; q < nquads; q += step) {
-            const unsigned int off = (unsigned int)q * 24u;
-            const u32x4v a = __builtin_amdgcn_raw_buffer_load_b128(rsrc, off, 0, 0);
-            const u32x2v b = __builtin_amdgcn_raw_buffer_load_b64(rsrc, off + 16u, 0, 0);
-            BADD(a.x & 0xFFFFu, 0) BADD(a.x >> 16, 1) BADD(a.y & 0xFFFFu, 2) BADD(a.y >> 16, 0)
-            BADD(a.z & 0xFFFFu, 1) BADD(a.z >> 16, 2) BADD(a.w & 0xFFFFu, 0) BADD(a.w >> 16, 1)
-            BADD(b.x & 0xFFFFu, 2) BADD(b.x >> 16, 0) BADD(b.y & 0xFFFFu, 1) BADD(b.y >> 16, 2)
+        // U16_DEPTH quads of every lane in flight: with one, a CU's 16 waves keep 24 KB on the way, which bounds the pass
+        // at about half of what HBM delivers.  Offsets past the tile (the ring's last turns) read as zero and are not counted.
+        u32x4v ra[U16_DEPTH];
+        u32x2v rb[U16_DEPTH];
+        long long q = (long long)blockIdx.x * 1024 + tid;
+#pragma unroll
+        for (int d = 0; d < U16_DEPTH; ++d) {
+            const unsigned int off = (unsigned int)(q + d * step) * 24u;
+            ra[d] = __builtin_amdgcn_raw_buffer_load_b128(rsrc, off, 0, 0);
+            rb[d] = __builtin_amdgcn_raw_buffer_load_b64(rsrc, off + 16u, 0, 0);
+        }
+        for (; q < nquads; q += U16_DEPTH * step) {
+#pragma unroll
+            for (int d = 0; d < U16_DEPTH; ++d) {
+                const long long qq = q + d * step;
+                const u32x4v a = ra[d];
+                const u32x2v b = rb[d];
+                const unsigned int off = (unsigned int)(qq + U16_DEPTH * step) * 24u;
+                ra[d] = __builtin_amdgcn_raw_buffer_load_b128(rsrc, off, 0, 0);
+                rb[d] = __builtin_amdgcn_raw_buffer_load_b64(rsrc, off + 16u, 0, 0);
+                if (qq < nquads) {
+                    BADD(a.x & 0xFFFFu, 0) BADD(a.x >> 16, 1) BADD(a.y & 0xFFFFu, 2) BADD(a.y >> 16, 0)
+                    BADD(a.z & 0xFFFFu, 1) BADD(a.z >> 16, 2) BADD(a.w & 0xFFFFu, 0) BADD(a.w >> 16, 1)
+                    BADD(b.x & 0xFFFFu, 2) BADD(b.x >> 16, 0) BADD(b.y & 0xFFFFu, 1) BADD(b.y >> 16, 2)
+                }
+            }
         }
     }
     if (blockIdx.x == 0 && tid < (int)(npix & 3)) {

@@ -63,12 +63,28 @@ def process_image(image_path, output_dir, process_wb=False, indices=None, full_d
     return stats
 
 
+def files_of_rank(files, rank=0, world=1):
+    """The files one rank of a multi-GPU run owns: a contiguous block of the sorted list (``batch.shard_range``, the split the
+    tile batches use).  Files are independent (backend-process.py:92-95 loops over them one by one), so there is no exchange."""
+    from .batch import shard_range
+    rank, world = int(rank), int(world)
+    if world < 1 or not 0 <= rank < world:
+        raise ValueError(f"rank {rank} of {world}")
+    files = list(files)
+    start, stop = shard_range(len(files), rank, world)
+    return files[start:stop]
+
+
 def batch_process(input_dir, output_dir, process_wb=False, process_ndvi=False, process_gndvi=False,
-                  process_ndwi=True, workers=4, verbose=True, full_depth=False, lut_format="png"):
-    """backend-process.py:75-97 with its module constants as arguments.  Returns ``{file name: stats | error}``."""
+                  process_ndwi=True, workers=4, verbose=True, full_depth=False, lut_format="png", rank=0, world=1,
+                  device=None):
+    """backend-process.py:75-97 with its module constants as arguments.  Returns ``{file name: stats | error}``.
+    ``rank`` / ``world``: one process per GPU, each takes its block of the sorted file list (``files_of_rank``); the output
+    directories are shared, the file names distinct.  ``device``: the GPU ordinal every worker thread binds (the library's
+    context is per thread and defaults to device 0); None leaves the threads' binding alone."""
     input_path, output_path = Path(input_dir), Path(output_dir)
     indices = [t for t, on in (("NDVI", process_ndvi), ("GNDVI", process_gndvi), ("NDWI", process_ndwi)) if on]
-    files = sorted(f for f in input_path.glob("*") if f.suffix.lower() in EXTENSIONS)
+    files = files_of_rank(sorted(f for f in input_path.glob("*") if f.suffix.lower() in EXTENSIONS), rank, world)
     total = len(files)
     results = {}
 
@@ -83,12 +99,18 @@ def batch_process(input_dir, output_dir, process_wb=False, process_ndvi=False, p
                 print(f"Error processing {f.name}: {str(e)}")
             return f.name, e
 
+    def bind():
+        if device is not None:
+            from . import _ffi
+            _ffi.call("lars_set_device", int(device))
+
     if workers <= 1:
+        bind()
         for job in enumerate(files, 1):
             k, v = one(job)
             results[k] = v
     else:
-        with ThreadPoolExecutor(max_workers=min(workers, os.cpu_count() or 1)) as pool:
+        with ThreadPoolExecutor(max_workers=min(workers, os.cpu_count() or 1), initializer=bind) as pool:
             for k, v in pool.map(one, enumerate(files, 1)):
                 results[k] = v
     return results
@@ -121,3 +143,35 @@ def export_zip(image_array, selected_indices, corrected_array=None):
             Image.fromarray(res["indices"][t]["rgba"], "RGBA").save(png, format="PNG", compress_level=LUT_PNG_LEVEL)
             zf.writestr(f"{t}_visualization.png", png.getvalue())
     return buf.getvalue()
+
+
+def main(argv=None):
+    """``python -m lars_image_processing_amd.driver IN OUT [--wb] [--ndvi] [--gndvi] [--no-ndwi] ...``: backend-process.py's
+    ``__main__`` with its constants as flags.  Under a launcher (``python -m torch.distributed.run --nproc-per-node N -m
+    lars_image_processing_amd.driver ...``) every rank binds GPU ``LOCAL_RANK`` and processes its block of the files."""
+    import argparse
+    import json
+    ap = argparse.ArgumentParser(prog="lars_image_processing_amd.driver")
+    ap.add_argument("input_dir")
+    ap.add_argument("output_dir")
+    ap.add_argument("--wb", action="store_true", help="also write white_balanced/<name>_wb.tif (PROCESS_WB)")
+    ap.add_argument("--ndvi", action="store_true")
+    ap.add_argument("--gndvi", action="store_true")
+    ap.add_argument("--no-ndwi", dest="ndwi", action="store_false", help="backend-process.py:12-15 has only NDWI on")
+    ap.add_argument("--workers", type=int, default=4)
+    ap.add_argument("--full-depth", action="store_true")
+    ap.add_argument("--lut-format", default="png", choices=["png", "tiff"])
+    ap.add_argument("--quiet", action="store_true")
+    args = ap.parse_args(argv)
+    from .dist import env_rank_world
+    rank, local_rank, world = env_rank_world()
+    res = batch_process(args.input_dir, args.output_dir, args.wb, args.ndvi, args.gndvi, args.ndwi, args.workers,
+                        not args.quiet, args.full_depth, args.lut_format, rank, world,
+                        device=local_rank if world > 1 else None)
+    failed = {k: str(v) for k, v in res.items() if isinstance(v, Exception)}
+    print(json.dumps({"rank": rank, "world": world, "files": len(res), "failed": failed}))
+    return 1 if failed else 0
+
+
+if __name__ == "__main__":
+    raise SystemExit(main())

@@ -142,3 +142,37 @@ def test_ndvi_report_and_zip_keep_the_reference_file_layout(tmp_path):
     with zipfile.ZipFile(io.BytesIO(blob)) as zf:
         assert zf.namelist() == ["white_balanced.png", "NDVI_visualization.png", "NDWI_visualization.png"]
         np.testing.assert_array_equal(np.array(Image.open(io.BytesIO(zf.read("white_balanced.png")))), corrected)
+
+
+def test_ranks_share_a_directory(tmp_path):
+    """One process per GPU over one directory (the driver's __main__ under a launcher; two ranks on this box's one GPU):
+    every file is processed by exactly one rank, and the union of the outputs equals a single-process run."""
+    import json
+    import os
+    import subprocess
+    import sys
+    from PIL import Image
+    from lars_image_processing_amd import driver
+    src = tmp_path / "in"
+    src.mkdir()
+    rng = np.random.default_rng(33)
+    names = [f"img_{i}.png" for i in range(5)]
+    for n in names:
+        Image.fromarray(rng.integers(0, 256, (40, 56, 3), dtype=np.uint8)).save(src / n)
+    one = driver.batch_process(src, tmp_path / "one", process_wb=True, process_ndvi=True, workers=2, verbose=False)
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    seen = []
+    for rank in range(2):
+        env = dict(os.environ, RANK=str(rank), LOCAL_RANK="0", WORLD_SIZE="2", PYTHONPATH=root)
+        out = subprocess.run([sys.executable, "-m", "lars_image_processing_amd.driver", str(src), str(tmp_path / "two"),
+                              "--wb", "--ndvi", "--workers", "2", "--quiet"], env=env, capture_output=True, text=True,
+                             timeout=600, cwd=root)
+        assert out.returncode == 0, out.stderr[-2000:]
+        line = json.loads(out.stdout.strip().splitlines()[-1])
+        assert line["rank"] == rank and line["world"] == 2 and not line["failed"]
+        seen.append(line["files"])
+    assert seen == [3, 2] and set(one) == set(names)
+    for n in names:
+        stem = n[:-4]
+        for rel in (f"white_balanced/{stem}_wb.tif", f"NDVI/{stem}_ndvi.png", f"NDWI/{stem}_ndwi.png"):
+            np.testing.assert_array_equal(np.array(Image.open(tmp_path / "two" / rel)), np.array(Image.open(tmp_path / "one" / rel)))

@@ -321,9 +321,22 @@ __global__ __launch_bounds__(1024) void k_hist_u16_both(const uint16_t *__restri
                 ra[d] = __builtin_amdgcn_raw_buffer_load_b128(rsrc, off, 0, 0);
                 rb[d] = __builtin_amdgcn_raw_buffer_load_b64(rsrc, off + 16u, 0, 0);
                 if (qq < nquads) {
-                    BADD(a.x & 0xFFFFu, 0) BADD(a.x >> 16, 1) BADD(a.y & 0xFFFFu, 2) BADD(a.y >> 16, 0)
-                    BADD(a.z & 0xFFFFu, 1) BADD(a.z >> 16, 2) BADD(a.w & 0xFFFFu, 0) BADD(a.w >> 16, 1)
-                    BADD(b.x & 0xFFFFu, 2) BADD(b.x >> 16, 0) BADD(b.y & 0xFFFFu, 1) BADD(b.y >> 16, 2)
+                    // all twelve slot look-ups first, then the twelve counts, then the (rare) candidates: one LDS round trip
+                    // per quad instead of one per sample
+                    const unsigned int w[6] = {a.x, a.y, a.z, a.w, b.x, b.y};
+                    unsigned int sl[12];
+#pragma unroll
+                    for (int i = 0; i < 12; ++i)
+                        sl[i] = s_slot[(i % 3) * 256 + ((w[i >> 1] >> ((i & 1) * 16 + 8)) & 0xFFu)];
+                    if (!ONLY_FLAGGED) {
+#pragma unroll
+                        for (int i = 0; i < 12; ++i)
+                            atomicAdd(reinterpret_cast<unsigned int *>(hb + (i % 3) * 32768 + (((w[i >> 1] >> ((i & 1) * 16 + 8)) & 0xFFu) << 7) + lane_off), 1u);
+                    }
+#pragma unroll
+                    for (int i = 0; i < 12; ++i)
+                        if (sl[i] != 0xFFu)
+                            atomicAdd(&s_lo[((i % 3) * U16_CAND + sl[i]) * 256 + ((w[i >> 1] >> ((i & 1) * 16)) & 0xFFu)], 1u);
                 }
             }
         }

@@ -268,3 +268,55 @@ def test_inputs_are_not_modified_and_outputs_are_fresh(lars):
     with warnings.catch_warnings():
         warnings.simplefilter("ignore")
         np.testing.assert_array_equal(lars.fix_white_balance(view), orc.wb_app(view))
+
+
+# ------------------------------------------------- special values, odd arrays ---
+def _same(a, b):
+    return a == b or (np.isnan(a) and np.isnan(b))
+
+
+def test_special_values_and_odd_arrays_follow_numpy(lars):
+    """NaN, +-inf, huge, denormal and zero samples, float16 / float64 / int64 / uint32 / bool bands, Fortran order, negative
+    strides, 4 and 5 channels: ``calculate_index`` is bit-identical to the reference's expression (oracle) on all of them, and
+    ``analyze_index`` reports what NumPy reports (NaN statistics for a NaN sample, infinite mean / extremum for an infinite
+    one).  White balance of NaN samples is the documented exception (parity unpinned: ``test_other_sample_types``)."""
+    rng = np.random.default_rng(1)
+
+    def bands(dtype, special):
+        a = rng.uniform(-300, 300, (19, 23, 3)).astype(dtype)
+        if not special:
+            return a
+        with np.errstate(over="ignore"):                            # float16 takes 1e38 as inf: one more special value
+            a[0, 0, :] = np.nan; a[1, 1, 0] = np.inf; a[2, 2, 2] = -np.inf; a[3, 3] = 0; a[4, 4] = 1e38
+            a[5, 5] = [-1e-10, 0, 0]; a[6, 6] = [3e38, 0, 3e38]; a[7, 7] = [1e-45, 0, 1e-45]
+        return a
+
+    u8 = rng.integers(0, 256, (9, 11, 3), dtype=np.uint8)
+    images = {"f32": bands(np.float32, True), "f64": bands(np.float64, True), "f16": bands(np.float16, True),
+              "i8": bands(np.int8, False), "i64": (bands(np.float64, False) * 1e15).astype(np.int64),
+              "u32": rng.integers(0, 2 ** 32, (9, 11, 3), dtype=np.uint32), "bool": u8 > 127,
+              "u8x4": rng.integers(0, 256, (9, 11, 4), dtype=np.uint8), "u8x5": rng.integers(0, 256, (9, 11, 5), dtype=np.uint8),
+              "fortran": np.asfortranarray(u8), "reversed": u8[::-1, ::-1], "1x1": u8[:1, :1]}
+    with warnings.catch_warnings():
+        warnings.simplefilter("ignore")
+        for name, img in images.items():
+            for t in TYPES:
+                want, got = orc.index_app(img, t), lars.calculate_index(img, t)
+                assert got.dtype == want.dtype and got.shape == want.shape and got.tobytes() == want.tobytes(), (name, t)
+        x = rng.uniform(-1, 1, (37, 53)).astype(np.float32)
+        arrays = {"plain": x, "f64": x.astype(np.float64), "i16": (x * 100).astype(np.int16), "bool": x > 0, "1-D": x.reshape(-1),
+                  "strided": x[::2, ::3], "zeros": np.array([[-0.0, 0.0, -0.0, 0.0]], dtype=np.float32), "one": x[:1, :1]}
+        for key, (i, j, v) in {"nan": (3, 4, np.nan), "+inf": (0, 0, np.inf), "-inf": (1, 1, -np.inf)}.items():
+            arrays[key] = x.copy()
+            arrays[key][i, j] = v
+        arrays["all nan"] = np.full((5, 7), np.nan, dtype=np.float32)
+        for name, arr in arrays.items():
+            for t in ("NDVI", "NDWI"):
+                want, got = orc.stats_app(arr, t), lars.analyze_index(arr, t)
+                assert list(got) == list(want), (name, t)
+                scale = float(np.mean(np.abs(np.nan_to_num(np.asarray(arr, dtype=np.float64), posinf=0, neginf=0)))) or 1.0
+                for k, v in want.items():
+                    if k.startswith("Mean") and np.isfinite(v):
+                        assert abs(got[k] - v) <= MEAN_RTOL * max(abs(v), scale), (name, t, k)
+                    else:
+                        assert _same(got[k], v), (name, t, k, got[k], v)

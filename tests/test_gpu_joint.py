@@ -22,9 +22,10 @@ def lars():
 
 
 def same_records(a, b):
-    """Records of two routes: everything but the (float64-accumulated, order-dependent) sum of squares bit for bit."""
+    """Records of two routes: everything but the sum of squares bit for bit.  That one is a float64 sum (order-dependent) that
+    the per-pixel kernels round to 2^-32 once per workgroup and the one-read route once per tile: a few units of 2^-32 apart."""
     a, b = a.copy(), b.copy()
-    np.testing.assert_allclose(a["sumsq"], b["sumsq"], rtol=1e-12)
+    np.testing.assert_allclose(a["sumsq"], b["sumsq"], rtol=1e-12, atol=2.0 ** -26)
     a["sumsq"] = b["sumsq"] = 0
     assert a.tobytes() == b.tobytes()
 

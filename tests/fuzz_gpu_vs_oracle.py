@@ -5,7 +5,7 @@ there and oracle == GPU here): fix_white_balance, calculate_index on the origina
 and process_image (one upload: white balance + indices + statistics).  Arrays bit for bit, statistics exact except the mean
 (1e-6 of max(|mean|, mean|x|)).
 
-    python tools/fuzz_gpu_vs_oracle.py [--cases 400] [--seed 0] [--max-edge 48]
+    python tests/fuzz_gpu_vs_oracle.py [--cases 400] [--seed 0] [--max-edge 48]
 """
 import argparse
 import os

@@ -3,7 +3,7 @@
 iid noise to constant channels, saturated and two-valued tiles), random index subsets and flags -- the one-read route
 (csrc/joint.hip) must give the records, medians, tables, percentiles and channel histograms of the per-pixel route, bit for bit.
 
-    python tools/fuzz_routes.py [--cases 300] [--seed 0] [--max-edge 200]
+    python tests/fuzz_routes.py [--cases 300] [--seed 0] [--max-edge 200]
 """
 import argparse
 import itertools

@@ -27,14 +27,25 @@ EXTENSIONS = {".tif", ".tiff", ".png", ".jpg", ".jpeg"}      # backend-process.p
 LUT_PNG_LEVEL = 1
 
 
+def colormap_entry(index_array):
+    """The colormap entry (0..255) of every pixel of a float32 index plane: ``Normalize(-1, 1)`` + ``Colormap.__call__`` of
+    matplotlib in the closed form the kernels use (``min(int((x + 1f) * 128f), 255)``, float32 arithmetic) --
+    ``colormap_lut(name)[colormap_entry(x)]`` is the RGBA image ``want_rgba`` returns."""
+    x = np.asarray(index_array, dtype=np.float32)
+    e = ((x + np.float32(1)) * np.float32(128)).astype(np.int32)
+    return np.clip(e, 0, 255).astype(np.uint8)
+
+
 def process_image(image_path, output_dir, process_wb=False, indices=None, full_depth=False, lut_format="png"):
     """One file: same outputs as backend-process.py:49-73.  Returns the statistics dicts.
     ``full_depth=True`` reads three-sample 16-bit TIFFs at their full depth (``tiffio.read_image``; Pillow, hence the
     reference, keeps their high bytes only).  ``lut_format="tiff"`` writes the colormap images as
     uncompressed RGBA TIFFs ``<name>_<index>.tif`` instead of PNGs: PNG compression of a 4096 x 4096 map takes seconds,
-    the GPU work milliseconds."""
-    if lut_format not in ("png", "tiff"):
-        raise ValueError(f"lut_format must be 'png' or 'tiff', got {lut_format!r}")
+    the GPU work milliseconds.  ``lut_format="png8"`` writes palette PNGs (one byte per pixel = the colormap entry, the
+    colormap as the palette): ``Image.open(p).convert("RGBA")`` gives the pixels of the RGBA file, from a quarter of the
+    bytes to compress."""
+    if lut_format not in ("png", "png8", "tiff"):
+        raise ValueError(f"lut_format must be 'png', 'png8' or 'tiff', got {lut_format!r}")
     from PIL import Image
     from .tiffio import read_image
     image_path, output_dir = Path(image_path), Path(output_dir)
@@ -43,7 +54,8 @@ def process_image(image_path, output_dir, process_wb=False, indices=None, full_d
     if arr.ndim != 3 or arr.shape[2] < 3:
         raise ValueError(f"{image_path.name}: expected an image with at least 3 channels, got shape {arr.shape}")
     indices = list(indices or [])
-    res = api.process_image(arr, indices=indices, white_balance=True, want_arrays=False, want_rgba=True) if indices else None
+    palette = lut_format == "png8"
+    res = api.process_image(arr, indices=indices, white_balance=True, want_arrays=palette, want_rgba=not palette) if indices else None
     corrected = res["corrected"] if res else api.fix_white_balance(arr)
     if process_wb:
         (output_dir / "white_balanced").mkdir(parents=True, exist_ok=True)
@@ -57,6 +69,10 @@ def process_image(image_path, output_dir, process_wb=False, indices=None, full_d
         if lut_format == "tiff":
             from .tiffio import write_tiff
             write_tiff(out.with_suffix(".tif"), entry["rgba"])
+        elif palette:
+            im = Image.fromarray(colormap_entry(entry["index"]), "P")
+            im.putpalette(api.colormap_lut(api._colormap_for(t)).tobytes(), rawmode="RGBA")
+            im.save(out, compress_level=LUT_PNG_LEVEL)
         else:
             Image.fromarray(entry["rgba"], "RGBA").save(out, compress_level=LUT_PNG_LEVEL)
         stats[t] = entry["stats"]
@@ -160,7 +176,7 @@ def main(argv=None):
     ap.add_argument("--no-ndwi", dest="ndwi", action="store_false", help="backend-process.py:12-15 has only NDWI on")
     ap.add_argument("--workers", type=int, default=4)
     ap.add_argument("--full-depth", action="store_true")
-    ap.add_argument("--lut-format", default="png", choices=["png", "tiff"])
+    ap.add_argument("--lut-format", default="png", choices=["png", "png8", "tiff"])
     ap.add_argument("--quiet", action="store_true")
     args = ap.parse_args(argv)
     from .dist import env_rank_world

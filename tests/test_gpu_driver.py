@@ -50,6 +50,14 @@ def test_batch_process_directory(tmp_path):
         stem = name.rsplit(".", 1)[0]
         np.testing.assert_array_equal(lars.read_tiff(tmp_path / "tif" / "NDVI" / f"{stem}_ndvi.tif"),
                                       np.array(Image.open(dst / "NDVI" / f"{stem}_ndvi.png")))
+    # palette PNGs (one byte per pixel + the colormap as palette): the same pixels once converted
+    driver.batch_process(src, tmp_path / "p8", process_ndvi=True, process_ndwi=True, lut_format="png8", workers=2, verbose=False)
+    for name in imgs:
+        stem = name.rsplit(".", 1)[0]
+        for t in ("NDVI", "NDWI"):
+            im = Image.open(tmp_path / "p8" / t / f"{stem}_{t.lower()}.png")
+            assert im.mode == "P"
+            np.testing.assert_array_equal(np.array(im.convert("RGBA")), np.array(Image.open(dst / t / f"{stem}_{t.lower()}.png")))
     # the reference's defaults (backend-process.py:12-15: NDWI only, no white-balanced copies), serial path
     res2 = driver.batch_process(src, tmp_path / "ser", workers=1, verbose=False)
     np.testing.assert_array_equal(np.array(Image.open(tmp_path / "ser" / "NDWI" / "a_ndwi.png")),

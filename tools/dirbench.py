@@ -3,7 +3,7 @@
 
     python tools/dirbench.py [--files 16] [--edge 4096] [--workers 8]
 Writes synthetic uncompressed 8-bit TIFFs to a temporary directory, then times driver.batch_process for the output
-flavours (PNG colormaps at zlib level 1, uncompressed TIFF colormaps) and worker counts.
+flavours (RGBA PNG colormaps at zlib level 1, palette PNGs, uncompressed TIFF colormaps) and worker counts.
 """
 import argparse
 import json
@@ -35,9 +35,9 @@ def main():
             tiffio.write_tiff(os.path.join(src, f"scene_{i:03d}.tif"), np.roll(base, i * 17, axis=1), rows_per_strip=64)
         npix = args.files * args.edge * args.edge
         results = {}
-        for fmt in ("tiff", "png"):
+        for fmt in ("tiff", "png8", "png"):
             for w in map(int, args.workers.split(",")):
-                if fmt == "png" and w == 1:
+                if fmt != "tiff" and w == 1:
                     continue                                  # minutes of zlib on one thread: nothing to learn
                 dst = os.path.join(root, f"out_{fmt}_{w}")
                 t0 = time.perf_counter()

@@ -1,4 +1,4 @@
-"""N>1 path on CPU: world_size 2 and 3 under torch.distributed.run with the gloo backend."""
+"""N>1 path on CPU: world_size 2, 3 and 8 (the driver's node; one rank then owns no tile) under torch.distributed.run with the gloo backend."""
 import json
 import os
 import socket
@@ -16,7 +16,7 @@ def free_port():
         return s.getsockname()[1]
 
 
-@pytest.mark.parametrize("world", [2, 3])
+@pytest.mark.parametrize("world", [2, 3, 8])
 def test_sharded_fold_matches_single_process(tmp_path, world):
     out = tmp_path / "result.json"
     env = dict(os.environ, LARS_RDZV_DIR=str(tmp_path), OMP_NUM_THREADS="1")

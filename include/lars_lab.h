@@ -33,7 +33,10 @@ int lars_d_pipeline(const lars_fused_args *args, double *percentiles, uint32_t *
 
 /* Roofline probes (bench.py reports them beside the kernel numbers when the laboratory library is built): kind 0 reads
  * 16 B/lane, 1 reads 12 B/lane (the fused kernel's load shape), 2 copies 16 B/lane
- * (traffic = 2 x bytes), 3 writes 16 B/lane.  src/dst are device buffers of `bytes`. */
+ * (traffic = 2 x bytes), 3 writes 16 B/lane.  src/dst are device buffers of `bytes`.  Further kinds (csrc/lab/probe.hip):
+ * 5-19 shapes of the 12 B read / 48 B written mix, 31-34 / 41-44 shared readers of one chunk, 60-63 the two passes of a
+ * tile interleaved tile by tile in one launch (unroll = read-only blocks per tile, blocks = plane-writing blocks per tile,
+ * bytes = ntiles x 48 MiB of source, dst = 64 tile slots x 3 planes x 64 MiB; tools/lab/twopass.py). */
 int lars_d_probe(int kind, int unroll, int blocks, const void *src, void *dst, int64_t bytes, void *stream);
 
 

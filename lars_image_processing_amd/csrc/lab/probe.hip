@@ -107,6 +107,49 @@ __global__ __launch_bounds__(256) void k_probe_mix1(const unsigned int *__restri
     }
 }
 
+// Two passes over the tiles in ONE launch, interleaved tile by tile in dispatch order: per tile t, `nh` read-only blocks that
+// sweep tile t + 1 (the histogram pass's traffic) and then `nf` blocks that read tile t and write three planes (the fused pass's
+// traffic).  Does the second read of a tile come out of the Infinity Cache when its first read was one tile period earlier?
+// mode 0: as described; 1: the read-only blocks sweep a tile half a batch away (same traffic, the second read is cold);
+// 2: no read-only blocks; 3: only the read-only blocks.  4096 x 4096 tiles, output ring of 64 tile slots.
+__global__ __launch_bounds__(256) void k_probe_two_pass(const unsigned int *__restrict__ src, pu32x4 *__restrict__ dst, int ntiles, int nh,
+                                                        int nf, int mode, unsigned int *__restrict__ sink)
+{
+    const long long QT = 4194304;                                // quads per tile
+    const int per = nh + nf;
+    const int t = (int)(blockIdx.x / (unsigned)per), j = (int)(blockIdx.x % (unsigned)per);
+    const int tid = threadIdx.x;
+    if (j < nh) {
+        if (mode == 2) return;
+        long long u = t + 1 < ntiles ? t + 1 : 0;
+        if (mode == 1) u = (u + ntiles / 2) % ntiles;
+        const unsigned int *p = src + u * QT * 3;
+        const long long lo = QT * j / nh, hi = QT * (j + 1) / nh;
+        unsigned int acc = 0;
+        long long i = lo + tid;
+        for (; i + 768 < hi; i += 1024) {
+            unsigned int w[4][3];
+#pragma unroll
+            for (int k = 0; k < 4; ++k) { w[k][0] = p[(i + 256 * k) * 3]; w[k][1] = p[(i + 256 * k) * 3 + 1]; w[k][2] = p[(i + 256 * k) * 3 + 2]; }
+#pragma unroll
+            for (int k = 0; k < 4; ++k) acc ^= w[k][0] ^ w[k][1] ^ w[k][2];
+        }
+        for (; i < hi; i += 256) acc ^= p[i * 3] ^ p[i * 3 + 1] ^ p[i * 3 + 2];
+        if (acc == 0x12345677u) sink[0] = acc;
+    } else {
+        if (mode == 3) return;
+        const int jj = j - nh;
+        const unsigned int *p = src + (long long)t * QT * 3;
+        pu32x4 *d0 = dst + (long long)(t & 63) * 3 * QT, *d1 = d0 + QT, *d2 = d1 + QT;
+        const long long lo = QT * jj / nf, hi = QT * (jj + 1) / nf;
+        for (long long i = lo + tid; i < hi; i += 256) {
+            const unsigned int a = p[i * 3], b = p[i * 3 + 1], c = p[i * 3 + 2];
+            const pu32x4 v0 = {a, b, c, a ^ b}, v1 = {b, c, a, b ^ c}, v2 = {c, a, b, c ^ a};
+            d0[i] = v0; d1[i] = v1; d2[i] = v2;
+        }
+    }
+}
+
 // ---------------------------------------------------------------------------
 // Round 2: more shapes of the plane-writing kernel's 1 : 4 mix (per 4 pixels 12 B read, 3 x 16 B written).
 // All move the same bytes as k_probe_mix; they differ in which lane touches which address when.
@@ -459,6 +502,17 @@ extern "C" int lars_d_probe(int kind, int unroll, int blocks, const void *src, v
     LARS_TRY(scratch_reserve(c, 64));
     unsigned int *sink = static_cast<unsigned int *>(c->scratch);
     const unsigned int *p = static_cast<const unsigned int *>(src);
+    if (kind >= 60 && kind <= 63) {
+        // two passes interleaved tile by tile in one launch: unroll = read-only blocks per tile, blocks = plane-writing blocks per tile,
+        // bytes = ntiles * 48 MiB of source; dst holds 64 tiles x 3 planes x 64 MiB
+        const int ntiles = (int)(bytes / 50331648ll);
+        if (ntiles < 2 || unroll < 1 || blocks < 1) return fail(LARS_ERR_INVALID, "lars_d_probe (two passes): arguments");
+        const long long grid = (long long)ntiles * (unroll + blocks);
+        if (grid > 0x7FFFFFFFll) return fail(LARS_ERR_INVALID, "lars_d_probe (two passes): grid");
+        hipLaunchKernelGGL(k_probe_two_pass, dim3((unsigned)grid), dim3(256), 0, s, p, static_cast<pu32x4 *>(dst), ntiles, unroll, blocks,
+                           kind - 60, sink);
+        return launch_check("lars_d_probe (two passes)");
+    }
     if (kind > 30 && kind < 50) {
         // 31..34: R = kind - 30 readers, 12 B per lane; 41..44: 16 B per lane; `blocks` = chunks
         const int wide = kind > 40, readers = kind - (wide ? 40 : 30);

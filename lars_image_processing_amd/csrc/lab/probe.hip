@@ -111,7 +111,7 @@ __global__ __launch_bounds__(256) void k_probe_mix1(const unsigned int *__restri
 // sweep tile t + 1 (the histogram pass's traffic) and then `nf` blocks that read tile t and write three planes (the fused pass's
 // traffic).  Does the second read of a tile come out of the Infinity Cache when its first read was one tile period earlier?
 // mode 0: as described; 1: the read-only blocks sweep a tile half a batch away (same traffic, the second read is cold);
-// 2: no read-only blocks; 3: only the read-only blocks.  4096 x 4096 tiles, output ring of 64 tile slots.
+// 2: no read-only blocks; 3: only the read-only blocks; 4: the read-only blocks sweep tile t itself (first read right before the second).  4096 x 4096 tiles, output ring of 64 tile slots.
 __global__ __launch_bounds__(256) void k_probe_two_pass(const unsigned int *__restrict__ src, pu32x4 *__restrict__ dst, int ntiles, int nh,
                                                         int nf, int mode, unsigned int *__restrict__ sink)
 {
@@ -123,6 +123,7 @@ __global__ __launch_bounds__(256) void k_probe_two_pass(const unsigned int *__re
         if (mode == 2) return;
         long long u = t + 1 < ntiles ? t + 1 : 0;
         if (mode == 1) u = (u + ntiles / 2) % ntiles;
+        if (mode == 4) u = t;                                       // the sweep of a tile right before its own plane-writing blocks
         const unsigned int *p = src + u * QT * 3;
         const long long lo = QT * j / nh, hi = QT * (j + 1) / nh;
         unsigned int acc = 0;
@@ -502,7 +503,7 @@ extern "C" int lars_d_probe(int kind, int unroll, int blocks, const void *src, v
     LARS_TRY(scratch_reserve(c, 64));
     unsigned int *sink = static_cast<unsigned int *>(c->scratch);
     const unsigned int *p = static_cast<const unsigned int *>(src);
-    if (kind >= 60 && kind <= 63) {
+    if (kind >= 60 && kind <= 64) {
         // two passes interleaved tile by tile in one launch: unroll = read-only blocks per tile, blocks = plane-writing blocks per tile,
         // bytes = ntiles * 48 MiB of source; dst holds 64 tiles x 3 planes x 64 MiB
         const int ntiles = (int)(bytes / 50331648ll);

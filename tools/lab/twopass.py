@@ -17,9 +17,10 @@ def main():
     a, b = C.c_void_p(), C.c_void_p()
     _ffi.call("lars_event_create", C.byref(a)); _ffi.call("lars_event_create", C.byref(b))
     names = {60: "interleaved, same tiles (second read one period later)", 61: "interleaved, first read elsewhere (second read cold)",
-             62: "plane-writing blocks only", 63: "read-only blocks only"}
+             62: "plane-writing blocks only", 63: "read-only blocks only",
+             64: "interleaved, the sweep of tile t right before its own writing blocks"}
     for nh, nf in ((64, 1024), (256, 1024), (256, 4096), (1024, 4096), (64, 512)):
-        for kind in (62, 63, 60, 61, 60, 61):
+        for kind in (62, 63, 60, 61, 64, 60, 61, 64):
             ts = []
             for _ in range(4):
                 _ffi.call("lars_event_record", a, None)
@@ -27,7 +28,7 @@ def main():
                 _ffi.call("lars_event_record", b, None)
                 ms = C.c_float(0); _ffi.call("lars_event_elapsed_ms", a, b, C.byref(ms)); ts.append(ms.value)
             t = float(np.median(ts[1:]))
-            print(f"read-only blocks {nh:5d}  writing blocks {nf:5d}  {names[kind]:58s} {t:8.3f} ms  {t / ntiles * 1e3:6.2f} us per tile", flush=True)
+            print(f"read-only blocks {nh:5d}  writing blocks {nf:5d}  {names[kind]:68s} {t:8.3f} ms  {t / ntiles * 1e3:6.2f} us per tile", flush=True)
 
 
 if __name__ == "__main__":

@@ -174,11 +174,13 @@ class TileBatch:
         # Candidates are allocated one by one and ALL kept until the choice is made (a freed arena would be handed out
         # again).  The classes are ~15 % apart and the fast class has levels of its own 1-3 % apart (0.79 / 0.78 / 0.765 of
         # 8 TB/s on one box), so the search looks at ARENA_MIN_TRIALS (12) candidates at least and ends when the best time has not
-        # improved by 1 % over the last three, at `placement_trials`, or at the memory limit.
+        # improved by 1 % over the last three AND a fast arena is among them (the best 7 % under the worst: with twelve of one kind
+        # -- 1 process in 70 at three fast ones in ten -- it goes on), at `placement_trials`, or at the memory limit.
         arenas, timings = [outs.arena], [self._time_outputs(outs, indices)]
         free_b, total_b = C.c_size_t(), C.c_size_t()
         while len(arenas) < int(placement_trials):
-            if len(arenas) >= min(ARENA_MIN_TRIALS, int(placement_trials)) and min(timings[:-3]) <= min(timings[-3:]) * 1.01:
+            if (len(arenas) >= min(ARENA_MIN_TRIALS, int(placement_trials)) and min(timings[:-3]) <= min(timings[-3:]) * 1.01
+                    and min(timings) <= 0.93 * max(timings)):
                 break
             _ffi.call("lars_mem_info", C.byref(free_b), C.byref(total_b))
             if free_b.value < outs.arena.nbytes + (8 << 30):       # keep 8 GiB of headroom for the caller

@@ -452,7 +452,11 @@ def test_output_ring_placement_trials(lars):
     rec_b = b.process(outputs=tuned)
     np.testing.assert_array_equal(bits(tuned.host_index("NDVI", 1, 1)), bits(ndvi_a))
     assert rec_a.tobytes() == rec_b.tobytes()
-    plain.free(); tuned.free(); b.free()
+    # the search's own rules: at least ARENA_MIN_TRIALS candidates, more while they are all of one kind, never more than asked
+    wide = b.make_outputs(index=True, ring=2, placement_trials=14)
+    assert 12 <= len(wide.arena_report["candidate_ms"]) <= 14 and wide.arena_report["rejected"] == len(wide.arena_report["candidate_ms"]) - 1
+    assert wide.arena_report["chosen_ms"] == min(wide.arena_report["candidate_ms"])
+    plain.free(); tuned.free(); wide.free(); b.free()
 
 
 def test_planes_stay_aligned_inside_the_arena(lars):

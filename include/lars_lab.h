@@ -18,23 +18,10 @@ extern "C" {
  * timed groups of such chunks -- lars_d_output_arena, removed again: NOTES.md, profiles/r03_arena_assembled.txt.) */
 int lars_lab_malloc(void **dptr, size_t bytes, int kind, int chunk_mb, int align_mb, int shuffle);
 int lars_lab_free(void *dptr);
-/* "pipe_steps", "pipe_head", "pipe_trace", "pipe_cold" (a timing experiment that reads the wrong tile on purpose) */
-int lars_lab_set_tuning(const char *key, int value);
-
-/* The whole step in one persistent launch (csrc/lab/pipeline.hip; 0.87x the speed of the separate launches, NOTES.md): channel histograms -> np.percentile(ch, (2, 98)) ->
- * white-balance tables -> the fused pass, ordered tile by tile so that a tile's second read comes out of the 256 MiB
- * Infinity Cache.  Same results as lars_d_channel_hist + lars_d_wb_table + lars_d_fused, bit for bit.  Serves what the
- * headline configuration needs: uint8 tiles with 3 channels, all three float32 planes written, LARS_F_STATS.
- * args->wb_table is the OUTPUT table buffer here ([ntiles][768]); percentiles is [ntiles][3][2]; hist [ntiles][768] or
- * NULL; scratch holds lars_pipeline_scratch_bytes(ntiles, npix) bytes.  If a wait inside the launch times out the
- * statistics records come back poisoned (count 0, NaN sums). */
-size_t lars_pipeline_scratch_bytes(int64_t ntiles, int64_t npix);
-int lars_d_pipeline(const lars_fused_args *args, double *percentiles, uint32_t *hist, int rgn_variant, void *scratch);
-
 /* Roofline probes (bench.py reports them beside the kernel numbers when the laboratory library is built): kind 0 reads
  * 16 B/lane, 1 reads 12 B/lane (the fused kernel's load shape), 2 copies 16 B/lane
  * (traffic = 2 x bytes), 3 writes 16 B/lane.  src/dst are device buffers of `bytes`.  Further kinds (csrc/lab/probe.hip):
- * 5-19 shapes of the 12 B read / 48 B written mix, 31-34 / 41-44 shared readers of one chunk, 60-63 the two passes of a
+ * 5-19 shapes of the 12 B read / 48 B written mix, 31-34 / 41-44 shared readers of one chunk, 60-64 the two passes of a
  * tile interleaved tile by tile in one launch (unroll = read-only blocks per tile, blocks = plane-writing blocks per tile,
  * bytes = ntiles x 48 MiB of source, dst = 64 tile slots x 3 planes x 64 MiB; tools/lab/twopass.py). */
 int lars_d_probe(int kind, int unroll, int blocks, const void *src, void *dst, int64_t bytes, void *stream);

@@ -485,8 +485,7 @@ class TileBatch:
         return rec, med
 
     def free(self):
-        for b in (self.tiles, self.hist, self.table, self.percentiles, getattr(self, "_pipe_scratch", None),
-                  getattr(self, "_joint_scratch", None)):
+        for b in (self.tiles, self.hist, self.table, self.percentiles, getattr(self, "_joint_scratch", None)):
             if b is not None:
                 b.free()
 

@@ -1,5 +1,4 @@
-// Per-pixel arithmetic of the plane-writing kernels, shared by fused.hip (one launch per pass) and pipeline.hip (the
-// persistent histogram -> tables -> fused pipeline).  Reference semantics: see fused.hip.
+// Per-pixel arithmetic of the plane-writing kernels (fused.hip).  Reference semantics: see fused.hip.
 #pragma once
 #include "common.h"
 #include "device_common.h"

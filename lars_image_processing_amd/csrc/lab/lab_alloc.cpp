@@ -12,8 +12,6 @@
 
 namespace lars {
 
-static LabTuning g_lab_tuning;
-LabTuning &lab_tuning() { return g_lab_tuning; }
 
 namespace {
 struct VmmBlock { size_t bytes, chunk; std::vector<hipMemGenericAllocationHandle_t> handles; };
@@ -122,17 +120,5 @@ extern "C" int lars_lab_free(void *dptr)
     LARS_TRY(ensure_ctx(&c));
     if (vmm_free(dptr)) return LARS_OK;
     LARS_HIP_TRY(hipFree(dptr));
-    return LARS_OK;
-}
-
-extern "C" int lars_lab_set_tuning(const char *key, int value)
-{
-    if (!key) return fail(LARS_ERR_INVALID, "lars_lab_set_tuning: NULL key");
-    LabTuning &t = lab_tuning();
-    if (!strcmp(key, "pipe_steps")) t.pipe_steps = value;
-    else if (!strcmp(key, "pipe_head")) t.pipe_head = value;
-    else if (!strcmp(key, "pipe_trace")) t.pipe_trace = value;
-    else if (!strcmp(key, "pipe_cold")) t.pipe_cold = value;
-    else return fail(LARS_ERR_INVALID, "lars_lab_set_tuning: unknown key %s", key);
     return LARS_OK;
 }

@@ -335,8 +335,13 @@ __device__ inline void acc_flush(Acc a, StatsAccView *rec, double (*s_red)[4], i
 // (np.zeros_like + range(3), process-images.py:432-435).
 // Two-index masks (3, 5, 6) run the MASK = 7 instantiation with the unrequested plane's pointers null and P.mask deciding
 // which records are flushed: a launch that is bound by its stores does not notice the spare quotient.
+// Resident waves per SIMD: the plane-writing uint8 kernels stream best with THREE (measured in one process against one arena,
+// bench.py modes: planes only 0.774 -> 0.808 of 8 TB/s where its 58 registers would allow eight; one plane + statistics 0.682 ->
+// 0.689; three planes + statistics, four by its registers, unchanged).  The variants with histograms (124 registers) lose 4 %
+// below four and keep what their registers give.
 template <typename PIX, unsigned MASK, bool WB, int STATS, int CH = 3>
-__global__ __launch_bounds__(256) void k_fused_u8c3(FusedParams P)
+__global__ __launch_bounds__(256)
+__attribute__((amdgpu_waves_per_eu(1, (sizeof(PIX) == 1 && CH == 3 && MASK != 0u && STATS <= 1) ? 3 : 8))) void k_fused_u8c3(FusedParams P)
 {
     constexpr bool U16 = sizeof(PIX) == 2;
     static_assert(CH == 3 || (CH == 4 && !U16), "4-channel fast path: uint8 tiles");

@@ -483,23 +483,28 @@ __attribute__((amdgpu_waves_per_eu(1, (sizeof(PIX) == 1 && CH == 3 && MASK != 0u
     // plane four wave-contiguous 1 KiB stores = 4 KiB of consecutive addresses.  Measured against the former mapping
     // (one 256-pixel slab per wave and step, slabs of a wave a grid stride apart) with the bare traffic mix:
     // 6.07-6.38 vs 5.63-5.95 TB/s in three sets of allocations (profiles/r02_stream_probe.txt, kinds 9-13 vs 5).
-    const long long nsteps = (nquads + 255) >> 8;
+    // Quads per lane and step (a wave owns 256 * RUN consecutive pixels: RUN loads of 768 bytes in flight, then per plane RUN
+    // back-to-back 1 KiB stores).  Three planes + basic statistics stream better the longer the run, as long as two waves per SIMD
+    // stay resident: 4 / 8 / 12 / 16 quads = 0.784 / 0.788 / 0.792 / 0.795 of 8 TB/s into one arena, 20 (one wave left) 0.66
+    // (profiles/r03_waves_ab.txt).  The other instantiations gain nothing from more than four or lose (one plane: 0.686 -> 0.672).
+    constexpr int RUN = (!U16 && CH == 3 && MASK == 7u && STATS == 1) ? 16 : 4;
+    const long long nsteps = (nquads + 64 * RUN - 1) / (64 * RUN);
     const long long wstride = (long long)gx * 4;
     const unsigned int lane = (unsigned int)tid & 63u;
     for (long long st = (long long)bx * 4 + (tid >> 6); st < nsteps; st += wstride) {
-        const long long q0 = st * 256 + lane;
-        unsigned int w[4][NW];
-        if (st * 256 + 256 <= nquads) {
+        const long long q0 = st * (64 * RUN) + lane;
+        unsigned int w[RUN][NW];
+        if (st * (64 * RUN) + 64 * RUN <= nquads) {
 #pragma unroll
-            for (int j = 0; j < 4; ++j) load_quad(q0 + 64 * j, w[j]);
+            for (int j = 0; j < RUN; ++j) load_quad(q0 + 64 * j, w[j]);
             __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
-            for (int j = 0; j < 4; ++j) {
+            for (int j = 0; j < RUN; ++j) {
                 do_quad(q0 + 64 * j, w[j]);
                 __builtin_amdgcn_sched_barrier(0);
             }
         } else {
-            for (int j = 0; j < 4; ++j) {
+            for (int j = 0; j < RUN; ++j) {
                 const long long q = q0 + 64 * j;
                 if (q < nquads) { load_quad(q, w[0]); do_quad(q, w[0]); }
             }

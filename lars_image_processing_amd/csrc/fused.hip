@@ -487,7 +487,9 @@ __attribute__((amdgpu_waves_per_eu(1, (sizeof(PIX) == 1 && CH == 3 && MASK != 0u
     // back-to-back 1 KiB stores).  Three planes + basic statistics stream better the longer the run, as long as two waves per SIMD
     // stay resident: 4 / 8 / 12 / 16 quads = 0.784 / 0.788 / 0.792 / 0.795 of 8 TB/s into one arena, 20 (one wave left) 0.66
     // (profiles/r03_waves_ab.txt).  The other instantiations gain nothing from more than four or lose (one plane: 0.686 -> 0.672).
-    constexpr int RUN = (!U16 && CH == 3 && MASK == 7u && STATS == 1) ? 16 : 4;
+    // uint16 tiles, one index (+ its RGBA picture) + basic statistics -- BASELINE configs[4]: 2 / 4 / 8 quads = 0.636 / 0.669 / 0.681;
+    // RGBA uint8 tiles: 4 is best (0.787 against 0.770 with 8).
+    constexpr int RUN = (!U16 && CH == 3 && MASK == 7u && STATS == 1) ? 16 : (U16 && MASK == 1u && STATS <= 1) ? 8 : 4;
     const long long nsteps = (nquads + 64 * RUN - 1) / (64 * RUN);
     const long long wstride = (long long)gx * 4;
     const unsigned int lane = (unsigned int)tid & 63u;

@@ -36,14 +36,15 @@ def main():
     ap.add_argument("libs", nargs="*")
     ap.add_argument("--case", default="u8")
     ap.add_argument("--rounds", type=int, default=5)
+    ap.add_argument("--arena", default="auto", choices=["auto", "plain"], help="plain: the first allocation as it comes (often of the slow kind)")
     args = ap.parse_args()
     dtype, ch, edge, tiles, ring, indices, planes, rgba, wbimg, want_stats, hist, bpp = CASES[args.case]
     b = lars.TileBatch(tiles, edge, edge, ch, dtype)
     _ffi.call("lars_d_synth_u8", C.c_void_p(b.tiles.ptr), tiles, 0, b.npix * np.dtype(dtype).itemsize, ch, 1234, 1 if dtype == np.uint8 else 0, None)   # uint16: random bytes
     b.compute_wb_tables()
-    outs = b.make_outputs(indices=indices or ("NDVI",), index=planes, rgba=rgba, wb=wbimg, ring=ring)
+    outs = b.make_outputs(indices=indices or ("NDVI",), index=planes, rgba=rgba, wb=wbimg, ring=ring, arena=args.arena)
     stats = b.new_stats() if want_stats else None
-    print("arena:", outs.arena_report.get("chosen_ms"), [round(x, 2) for x in outs.arena_report.get("candidate_ms", [])], flush=True)
+    print("arena:", outs.arena_report.get("kind"), outs.arena_report.get("chosen_ms"), [round(x, 2) for x in outs.arena_report.get("candidate_ms", [])], flush=True)
     libs = [("product", _ffi.load())]
     for path in args.libs:
         lib = C.CDLL(os.path.abspath(path), mode=os.RTLD_LOCAL | os.RTLD_DEEPBIND)     # its own copies of every symbol, not the product's

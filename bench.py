@@ -68,14 +68,18 @@ def parse():
     ap.add_argument("--tile", type=int, default=4096, help="tile edge in pixels")
     ap.add_argument("--ring", type=int, default=64, help="output ring, in tiles (same traffic, bounded footprint)")
     ap.add_argument("--mode", default="wb3idx_out_stats", choices=sorted(MODES))
+    ap.add_argument("--all-modes", dest="all_modes", action="store_true", default=None,
+                    help="time the other modes too (extra JSON field 'modes'): the default with one GPU; with --gpus N > 1 only "
+                         "the headline mode is timed unless this flag is given")
     ap.add_argument("--no-all-modes", dest="all_modes", action="store_false",
-                    help="skip timing the other modes (extra JSON field 'modes')")
+                    help="skip timing the other modes")
     ap.add_argument("--no-probe", dest="probe", action="store_false", help="skip the streaming-roofline probes")
     ap.add_argument("--profile", default="vegetation", choices=["uniform", "vegetation"])
-    ap.add_argument("--arena", default="auto", choices=["auto", "plain"],
+    ap.add_argument("--arena", default="auto", choices=["auto", "plain", "slowest"],
                     help="output arena of the plane-writing modes.  auto: the library's default (TileBatch.make_outputs) -- for "
-                         "multi-GiB arenas candidate allocations are timed with the batch's own launch and the fastest is kept; "
-                         "plain: one allocation as it comes")
+                         "multi-GiB arenas candidate allocations are timed with the batch's own launches until both speed classes "
+                         "have been seen and the fastest is kept; plain: one allocation as it comes; slowest: the same search but "
+                         "the SLOWEST candidate is kept (a diagnostic: the line of a process that finds no fast arena)")
     ap.add_argument("--placement-trials", type=int, default=-1,
                     help="candidate arenas of the search (-1: the library's default, 0/1: take the first)")
     ap.add_argument("--stats-route", default="joint", choices=["joint", "classic"],
@@ -113,6 +117,8 @@ class Runner:
             _ffi.call("lars_event_create", C.byref(e))
             self.ev.append(e)
         self.outputs = {}
+        self.launch_ev = []                 # per-launch events of ONE step (the first timed one of the headline mode)
+        self.first_step_launch_ms = None
 
     def outputs_for(self, indices, write):
         if not write:
@@ -121,11 +127,13 @@ class Runner:
         if key not in self.outputs:
             if self.batch.table is None:
                 self.batch.compute_wb_tables()
-            self.outputs[key] = self.batch.make_outputs(indices=indices, index=True, ring=self.args.ring, arena=self.args.arena,
+            self.outputs[key] = self.batch.make_outputs(indices=indices, index=True, ring=self.args.ring,
+                                                        arena="plain" if self.args.arena == "plain" else "auto",
+                                                        pick="slowest" if self.args.arena == "slowest" else "fastest",
                                                         placement_trials=None if self.args.placement_trials < 0 else self.args.placement_trials)
         return self.outputs[key]
 
-    def step(self, mode, timed=None):
+    def step(self, mode, timed=None, launch_events=None):
         """One pass over the batch.  ``timed`` collects (pre_ms, main_ms, launches of the main kernel): pre = the channel-
         histogram pass + tables (or, in the like-for-like mode, the one-read statistics pass), main = the fused kernel(s)
         (or the whole one-read pass of a statistics-only mode)."""
@@ -145,7 +153,7 @@ class Runner:
         elif base_mode == "wb3idx_out_stats_medians":
             b.run_joint(indices, True, self.stats, hist, False, self.pairs)        # statistics, medians and all three tables
             ffi.call("lars_event_record", self.ev[1], None)
-            launches = b.run_fused_chunks(indices, True, None, False, outs)      # planes only
+            launches = b.run_fused_chunks(indices, True, None, False, outs, launch_events=launch_events)      # planes only
         else:
             b.compute_wb_tables()
             ffi.call("lars_event_record", self.ev[1], None)
@@ -158,7 +166,7 @@ class Runner:
             else:
                 # one launch without output planes, one per ring of `outs.slots` tiles with them; the statistics records are
                 # opened and closed once around the launches (lars_d_stats_begin / _end), not by two small kernels per launch
-                launches = b.run_fused_chunks(indices, True, self.stats, hist, outs)
+                launches = b.run_fused_chunks(indices, True, self.stats, hist, outs, launch_events=launch_events)
         ffi.call("lars_event_record", self.ev[2], None)
         # per-index fold of the per-tile records on the device, then the exchange of 3 x 472 bytes (RCCL all-gather + fold in
         # rank order inside the library, or nothing at all with one rank): no per-tile record leaves the device in a step
@@ -172,19 +180,36 @@ class Runner:
             timed.append((pre_ms, ms.value, launches))
         return glob
 
-    def run(self, mode, steps, warmup):
+    def run(self, mode, steps, warmup, per_launch=False):
+        """``per_launch``: the fused launches of the FIRST timed step are bracketed by events of their own (17 records on the
+        stream, no synchronisation: the step is timed like the others) -> ``self.first_step_launch_ms``."""
         for _ in range(warmup):
             self.step(mode)
+        per_launch = per_launch and MODES[mode][1] and mode != "wb3idx_stats_medians"     # plane-writing modes only
+        if per_launch and not self.launch_ev:
+            outs = self.outputs_for(MODES[mode][0], MODES[mode][1])
+            n = 1 + (-(-self.batch.ntiles // outs.slots) if outs is not None else 1)
+            for _ in range(min(n, 65)):
+                e = C.c_void_p()
+                self.ffi.call("lars_event_create", C.byref(e))
+                self.launch_ev.append(e)
         timed = []
         self.ffi.call("lars_synchronize", None)
         self.comm.barrier()
         t0 = time.perf_counter()
         glob = None
-        for _ in range(steps):
-            glob = self.step(mode, timed)
+        for i in range(steps):
+            glob = self.step(mode, timed, self.launch_ev if (per_launch and i == 0) else None)
         self.ffi.call("lars_synchronize", None)
         self.comm.barrier()
         dt_local = time.perf_counter() - t0
+        if per_launch and self.launch_ev and steps:
+            ms = C.c_float(0)
+            out = []
+            for i in range(min(len(self.launch_ev) - 1, timed[0][2])):
+                self.ffi.call("lars_event_elapsed_ms", self.launch_ev[i], self.launch_ev[i + 1], C.byref(ms))
+                out.append(float(ms.value))
+            self.first_step_launch_ms = out
         dt = float(self.comm.allreduce_f64([dt_local], "max")[0])
         self.last_local_dt = dt_local
         return dt, timed, glob
@@ -198,7 +223,7 @@ class Runner:
         ffi, b = self.ffi, self.batch
         indices, write, hist, _ = MODES[mode]
         self.step(mode)
-        ffi.call("lars_synchronize", None)
+        b.check_joint()                     # synchronises; raises if a one-read pass of this step reported an overflow
         rec = self.stats.download(ffi.STATS_DTYPE, (b.ntiles, 3))
         outs = self.outputs_for(indices, write)
         ring = outs.slots if outs is not None else b.ntiles
@@ -571,7 +596,9 @@ def main():
 
     runner = Runner(args, comm, rank, world)
     npix_rank = args.tiles * args.tile * args.tile
-    dt, timed, glob = runner.run(args.mode, args.steps, args.warmup)
+    if args.all_modes is None:
+        args.all_modes = world == 1          # N > 1: only the headline mode is timed unless --all-modes (the line stays cheap)
+    dt, timed, glob = runner.run(args.mode, args.steps, args.warmup, per_launch=True)
     total_pix = npix_rank * world * args.steps
     value = total_pix / dt / 1e6
     local_step_ms = runner.last_local_dt / args.steps * 1e3
@@ -637,8 +664,10 @@ def main():
     outs_main = runner.outputs.get(tuple(indices))
     placement = getattr(outs_main, "placement_ms", None) or {}
     arena_report = getattr(outs_main, "arena_report", None) or {}
+    first_ms = runner.first_step_launch_ms or [0.0]
     mine = [rank, local_step_ms, fused_ms, hist_ms, fused_ms / launches, float(arena_report.get("chosen_ms") or 0.0),
-            float(arena_report.get("search_ms") or 0.0), float(arena_report.get("rejected") or 0)]
+            float(arena_report.get("search_ms") or 0.0), float(arena_report.get("rejected") or 0),
+            float(arena_report.get("post_free_ms") or 0.0), float(min(first_ms)), float(max(first_ms))]
     per_rank = comm.allgather_f64(mine)
 
     probe = device_probe(runner) if (args.probe and rank == 0) else None
@@ -680,10 +709,16 @@ def main():
                 "whole_step_frac": npix_rank * bpp / (step_ms * 1e-3) / 1e9 / HBM_PEAK_GBS,
                 "algorithmic_bytes_per_pixel": bpp, "bytes_per_launch": bytes_per_launch,
                 "launches_per_step": launches, "avg_launch_ms": fused_ms / launches,
+                # the fused launches of the first timed step, one by one (rank 0): what the arena probe's post_free_ms predicts
+                "first_step_launch_ms": runner.first_step_launch_ms,
+                "arena_probe_vs_steps": (None if not arena_report.get("post_free_ms") else
+                                         {"post_free_ms": arena_report["post_free_ms"], "avg_launch_ms": fused_ms / launches,
+                                          "rel_diff": arena_report["post_free_ms"] / (fused_ms / launches) - 1.0}),
             },
             "passes_ms": {"histogram+tables": hist_ms, "fused": fused_ms, "rest_of_step": step_ms - hist_ms - fused_ms},
             "ranks": [{"rank": int(r[0]), "ms_per_step": r[1], "fused_ms": r[2], "hist_ms": r[3], "avg_launch_ms": r[4],
-                       "arena_ms": r[5], "arena_search_ms": r[6], "arena_rejected": int(r[7])} for r in per_rank],
+                       "arena_ms": r[5], "arena_search_ms": r[6], "arena_rejected": int(r[7]), "arena_post_free_ms": r[8],
+                       "first_step_launch_ms_min_max": [r[9], r[10]]} for r in per_rank],
             "cpu_baseline": cpu,
             "verified": verified,
             "global_stats": {t: {k: v for k, v in s.items() if k != "hist"} for t, s in g.items()},

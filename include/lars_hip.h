@@ -255,8 +255,10 @@ int lars_d_quotient_median_pairs(const void *tiles, int64_t ntiles, int64_t npix
  * np.percentile(ch, (2, 98)) of fix_white_balance (process-images.py:437) is a function of how often each pair of raw
  * bytes (nir, red) resp. (nir, green) occurs.  A counting kernel builds those 2 x 65536 counts per tile in LDS (no table
  * look-up, no quotient per pixel), a second kernel derives channel histograms -> percentiles -> tables -> records ->
- * medians from them.  The records are bit-identical to lars_d_fused's, the medians to np.median.
- *   a             uint8 tiles with 3 channels; index_mask any non-empty subset; LARS_F_HIST / LARS_F_SUMSQ honoured; no
+ * medians from them.  The records are bit-identical to lars_d_fused's -- except the optional sum of squares (LARS_F_SUMSQ:
+ * count x value^2 per cell here, value^2 per pixel there; they agree to a few units of 2^-32) -- the medians to np.median.
+ *   a             uint8 tiles with 3 channels (RGNir; 4-byte aligned) or 4 (RGBA, alpha ignored; 16-byte aligned), npix < 2^32
+ *                 (the per-cell counts are uint32); index_mask any non-empty subset; LARS_F_HIST / LARS_F_SUMSQ honoured; no
  *                 output planes; a->stats [ntiles][3] receives final records (unrequested indices untouched);
  *                 a->wb_table, if not NULL, is an OUTPUT here: [ntiles][3][256] tables of the channels the mask needs
  *                 (NIR and red for NDVI, NIR and green for GNDVI / NDWI)

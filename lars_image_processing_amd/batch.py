@@ -22,8 +22,9 @@ from ._ffi import FusedArgs, INDEX_IDS, INDEX_NAMES, STATS_DTYPE, DeviceBuffer, 
 
 MAX_TILES_PER_LAUNCH = 65535      # grid.y limit
 ARENA_MIN_BYTES = 2 << 30         # smaller arenas run alike wherever they land
-ARENA_TRIALS = 16                 # candidate allocations of the default search at most
-ARENA_MIN_TRIALS = 12             # ... and at least (then it stops once the best has not improved over the last three)
+ARENA_TRIALS = 16                 # candidate allocations of the default search at most (0.7^16: no fast one among them in 0.3 % of processes)
+ARENA_CLASS_GAP = 0.93            # the search ends once its best candidate is 7 % under its worst: both classes seen (they are ~18 % apart)
+ARENA_WARM_MS = 30.0              # untimed launches before a candidate is timed: after an idle gap a fast arena needs ~22 ms to reach its level
 
 
 # How statistics-only passes over uint8 RGNir batches run (no output planes):
@@ -32,7 +33,10 @@ ARENA_MIN_TRIALS = 12             # ... and at least (then it stops once the bes
 #   "classic" channel-histogram pass, then the per-pixel statistics kernel (and its median passes)
 #   "auto"    with medians: joint; without: whichever of the two measures faster on the first tiles of the batch
 #             (TileBatch.pick_stats_route; small batches: joint)
-# Results are identical bit for bit; LARS_STATS_ROUTE presets it.
+# Records are identical bit for bit, with ONE exception: the optional sum of squares (``sumsq=True`` / LARS_F_SUMSQ) is
+# accumulated per pixel on the classic route and per cell (count x value^2) on the one-read route and may differ by a few
+# units of 2^-32, so "auto" never decides by measurement when sumsq is requested (it takes the one-read route whenever that
+# route can serve the batch): a given batch always gets the same bytes.  LARS_STATS_ROUTE presets the route.
 _STATS_ROUTE = os.environ.get("LARS_STATS_ROUTE", "auto")
 
 
@@ -85,6 +89,7 @@ class TileBatch:
         self.table = None
         self.percentiles = None
         self._table_channels = set()       # channels whose tables are valid (a one-read pass fills only those its indices read)
+        self._rgn_variant = 0              # flavour of the tables in force (process-rgn.py's extra inner clip = 1)
 
     # -- construction -----------------------------------------------------
     @classmethod
@@ -127,106 +132,162 @@ class TileBatch:
             _ffi.call("lars_d_wb_prepare", C.c_void_p(self.tiles.ptr), self.ntiles, self.npix, self.channels,
                       self.code, C.c_void_p(self.table.ptr), C.c_void_p(self.percentiles.ptr), int(rgn_variant), stream)
         self._table_channels = {0, 1, 2}
+        self._rgn_variant = int(rgn_variant)
         return self
 
-    def host_tables(self):
+    def _need_channels(self, partial):
+        """The host_* getters hand out all three channels: after a one-read pass that served NDVI only (or GNDVI / NDWI
+        only) the third channel's rows were never computed -- refuse unless the caller asks for them as they are."""
+        if self.table is None:
+            raise RuntimeError("compute_wb_tables() first")
+        if not partial and self._table_channels != {0, 1, 2}:
+            missing = sorted({0, 1, 2} - self._table_channels)
+            raise RuntimeError(f"white-balance tables of channel(s) {missing} are not valid: the last pass computed only the "
+                               f"channels its indices read (compute_wb_tables() for all three, or partial=True)")
+
+    def host_tables(self, partial=False):
+        self._need_channels(partial)
         blob = self.table.download(np.uint8, (self.ntiles, self.table_bytes))
         return np.ascontiguousarray(blob[:, :3 * self.nvalues]).reshape(self.ntiles, 3, self.nvalues)
 
-    def host_percentiles(self):
+    def host_percentiles(self, partial=False):
+        self._need_channels(partial)
         return self.percentiles.download(np.float64, (self.ntiles, 3, 2))
 
-    def host_hist(self):
+    def host_hist(self, partial=False):
         """uint8 batches only (uint16 percentiles come from two radix levels, no full histogram)."""
+        self._need_channels(partial)
         return self.hist.download(np.uint32, (self.ntiles, 3, 256))
 
     # -- pass 2: the fused kernel ------------------------------------------
-    def make_outputs(self, indices=INDEX_NAMES, index=False, wb=False, rgba=False, ring=None, placement_trials=None, arena="auto"):
+    def make_outputs(self, indices=INDEX_NAMES, index=False, wb=False, rgba=False, ring=None, placement_trials=None, arena="auto",
+                     pick="fastest"):
         """Allocate output planes.  ``ring`` < ntiles reuses a ring of that many
         tile slots (same HBM traffic, bounded footprint) -- see BatchOutputs.
 
         The float32 index planes (and RGBA8 planes) live in ONE allocation (an arena).  How fast the write-bound fused
-        kernel runs into an arena is a stable property of that allocation: 5.2 - 6.3 TB/s on the same box, independent of
-        the offsets between the planes, of the input batch and of time (profiles/r02_placement_*.txt,
-        r03_arena_*.txt).  ``arena``:
-          "auto"      multi-GiB arenas are CHOSEN: up to ``placement_trials`` (default ARENA_TRIALS) plain allocations are
-                      made one by one, the batch's own fused launch is timed into each, the fastest is kept and the rest
-                      freed; smaller arenas (they run alike wherever they land) are one plain allocation
+        kernel runs into a multi-GiB arena is a stable property of that allocation: two classes about 18 % apart (2.50-2.56
+        against 3.00-3.11 ms per 64-tile launch of the headline kernel; three of ten allocations fast), the same in every
+        round of bursts, with the other candidates alive or freed (profiles/r04_arena_probe_phases.txt).  ``arena``:
+          "auto"      multi-GiB arenas are CHOSEN: plain allocations are made one by one, each is timed with the batch's
+                      own launches (``_probe_arena``), and the search ends as soon as both classes have been seen (the best
+                      7 % under the worst) -- 3.3 candidates on average at three fast ones in ten -- or at
+                      ``placement_trials`` (default ARENA_TRIALS = 16) candidates or when less than arena + 8 GiB of
+                      device memory is free; the fastest is kept, the rest freed.  Candidates stay allocated until the
+                      choice is made (a freed arena would be handed out again), so the search transiently holds
+                      (candidates seen) x the arena's size.  Smaller arenas (they run alike wherever they land) are one
+                      plain allocation
           "plain"     one plain allocation as it comes, unless ``placement_trials`` asks for a search
+        ``pick="slowest"`` keeps the slowest candidate instead (a diagnostic: what a process without a fast arena sees).
         (Arenas put together from timed groups of physical chunks were built and measured in round 3 --
         profiles/r03_arena_assembled.txt: a group's probe time does not predict the arena's speed; removed again.)
-        ``outs.arena_report`` = {kind, search_ms, chosen_ms, rejected, ...} says what was done."""
+        ``outs.arena_report`` = {kind, search_ms, chosen_ms, post_free_ms, rejected, candidate_ms, malloc_ms, ...}."""
         outs = BatchOutputs(self, indices, index, wb, rgba, ring, allocate=False)
         nplanes = len(outs._index_ids) + len(outs._rgba_ids)
         report = {"kind": "none"} if not nplanes else None
         if nplanes and arena not in ("auto", "plain"):
             raise ValueError("arena must be auto or plain")
+        if pick not in ("fastest", "slowest"):
+            raise ValueError("pick must be fastest or slowest")
         big = bool(nplanes) and nplanes * outs.slots * self.npix * 4 >= ARENA_MIN_BYTES
         if placement_trials is None:
             placement_trials = ARENA_TRIALS if (arena == "auto" and big) else 0
         if nplanes and report is None:
+            t0 = time.perf_counter()
             outs.adopt_arena(DeviceBuffer(nplanes * outs.plane_bytes))
-            report = {"kind": "plain hipMalloc", "search_ms": 0.0, "chosen_ms": None, "rejected": 0}
+            first_malloc_ms = (time.perf_counter() - t0) * 1e3
+            report = {"kind": "plain hipMalloc", "search_ms": 0.0, "chosen_ms": None, "post_free_ms": None, "rejected": 0}
         outs.arena_report = report
         if placement_trials <= 1 or outs.arena is None or report.get("kind") != "plain hipMalloc":
             return outs
         t_search = time.perf_counter()
-        # Candidates are allocated one by one and ALL kept until the choice is made (a freed arena would be handed out
-        # again).  The classes are ~15 % apart and the fast class has levels of its own 1-3 % apart (0.79 / 0.78 / 0.765 of
-        # 8 TB/s on one box), so the search looks at ARENA_MIN_TRIALS (12) candidates at least and ends when the best time has not
-        # improved by 1 % over the last three AND a fast arena is among them (the best 7 % under the worst: with twelve of one kind
-        # -- 1 process in 70 at three fast ones in ten -- it goes on), at `placement_trials`, or at the memory limit.
-        arenas, timings = [outs.arena], [self._time_outputs(outs, indices)]
+        stats = self.new_stats()
+        arenas, timings, malloc_ms = [outs.arena], [self._probe_arena(outs, indices, stats)], [first_malloc_ms]
         free_b, total_b = C.c_size_t(), C.c_size_t()
+        stopped = "placement_trials"
         while len(arenas) < int(placement_trials):
-            if (len(arenas) >= min(ARENA_MIN_TRIALS, int(placement_trials)) and min(timings[:-3]) <= min(timings[-3:]) * 1.01
-                    and min(timings) <= 0.93 * max(timings)):
+            if len(arenas) >= 2 and min(timings) <= ARENA_CLASS_GAP * max(timings):
+                stopped = "both classes seen"
                 break
             _ffi.call("lars_mem_info", C.byref(free_b), C.byref(total_b))
             if free_b.value < outs.arena.nbytes + (8 << 30):       # keep 8 GiB of headroom for the caller
+                stopped = "device memory"
                 break
+            t0 = time.perf_counter()
             try:
                 cand = DeviceBuffer(outs.arena.nbytes)
             except _ffi.LarsError:
+                stopped = "device memory"
                 break                                               # out of memory: choose among what fits
+            malloc_ms.append((time.perf_counter() - t0) * 1e3)
             arenas.append(cand)
             outs.adopt_arena(cand)
-            timings.append(self._time_outputs(outs, indices))
-        best = int(np.argmin(timings))
+            timings.append(self._probe_arena(outs, indices, stats))
+        best = int(np.argmin(timings) if pick == "fastest" else np.argmax(timings))
         outs.adopt_arena(arenas[best])
         for j, cand in enumerate(arenas):
             if j != best:
                 cand.free()
         _ffi.call("lars_synchronize", None)
+        # the survivor once more, now that the rejected candidates are gone: the figure the steps should reproduce
+        post_free = self._probe_arena(outs, indices, stats) if len(arenas) > 1 else float(timings[best])
+        stats.free()
         outs.placement_ms = {"arenas": [float(x) for x in timings], "chosen": float(timings[best])}
-        outs.arena_report = {"kind": f"plain hipMalloc, the fastest of {len(arenas)} candidates timed with the batch's own launch",
+        outs.arena_report = {"kind": f"plain hipMalloc, the {pick} of {len(arenas)} candidates timed with the batch's own launches "
+                                     f"(search ended by: {stopped})",
                              "search_ms": (time.perf_counter() - t_search) * 1e3, "chosen_ms": float(timings[best]),
-                             "rejected": len(arenas) - 1, "candidate_ms": [float(x) for x in timings]}
+                             "post_free_ms": float(post_free), "rejected": len(arenas) - 1,
+                             "candidate_ms": [float(x) for x in timings], "malloc_ms": [float(x) for x in malloc_ms],
+                             "transient_bytes": int(len(arenas) * outs.arena.nbytes),
+                             "probe": f">= {ARENA_WARM_MS:.0f} ms of untimed launches, then one timed pass of launches over the batch's chunks"}
         return outs
 
-    def _time_outputs(self, outs, indices):
-        """Milliseconds of fused launches that fill ``outs`` from up to three chunks of the batch (first, middle, last:
-        the pairing with the input's placement matters too); the warm-up launch is not timed."""
+    def _probe_arena(self, outs, indices, stats):
+        """Milliseconds per fused launch into ``outs`` at the level a step sees: the step's own launch sequence (one launch
+        per ring of tile slots over the batch, LARS_F_RAW records; sixteen evenly spaced chunks of a longer sequence).
+
+        After an idle gap -- a 12 GiB hipMalloc takes 0.25-0.36 s once the first ~150 GiB are handed out -- launches into a
+        FAST arena run at the slow class's level and come down over about eight launches / 22 ms (2.6, 3.1-3.2, 3.0, 2.83,
+        2.7, 2.67, 2.63, 2.57, 2.53 -> 2.50 ms; slow arenas show no such ramp): profiles/r04_arena_probe_phases.txt, phases
+        B and C.  Round 3's probe (one warm-up + three launches right after the allocation) therefore read 2.94-3.04 ms for
+        every candidate whenever the allocations were slow, whatever their class.  Hence: untimed launches until
+        ARENA_WARM_MS of device time have passed, then one timed pass; and the pass covers every chunk of the batch because
+        the level also moves by 2-4 % with the input region a launch reads (launches 11-16 of a step against 1-10)."""
+        count = min(outs.slots, self.ntiles)
+        starts = list(range(0, self.ntiles, count))
+        if len(starts) > 16:
+            starts = [starts[int(round(i * (len(starts) - 1) / 15.0))] for i in range(16)]
+        mask = 0
+        for t in indices:
+            mask |= 1 << INDEX_IDS[t]
+        wb_on = self.table is not None
+        launches = [self.fused_args(indices, wb_on, stats, False, outs, None, st, min(count, self.ntiles - st), raw=True) for st in starts]
+        while len(launches) < 4:
+            launches = launches + launches
         ev = [C.c_void_p(), C.c_void_p()]
         for e in ev:
             _ffi.call("lars_event_create", C.byref(e))
-        stats = self.new_stats()
-        count = min(outs.slots, self.ntiles)
-        nchunks = max(1, self.ntiles // count)
-        starts = sorted({0, (nchunks // 2) * count, (nchunks - 1) * count})
-        launches = [self.fused_args(indices, self.table is not None, stats, False, outs, None, st, count) for st in starts]
-        self.run_fused(launches[0])
-        _ffi.call("lars_event_record", ev[0], None)
-        for a in launches:
-            self.run_fused(a)
-        _ffi.call("lars_event_record", ev[1], None)
-        _ffi.call("lars_synchronize", None)
+        _ffi.call("lars_d_stats_begin", C.c_void_p(stats.ptr), self.ntiles, mask, None)
         ms = C.c_float(0)
-        _ffi.call("lars_event_elapsed_ms", ev[0], ev[1], C.byref(ms))
+
+        def one_pass():
+            _ffi.call("lars_event_record", ev[0], None)
+            for a in launches:
+                self.run_fused(a)
+            _ffi.call("lars_event_record", ev[1], None)
+            _ffi.call("lars_event_elapsed_ms", ev[0], ev[1], C.byref(ms))     # synchronises on ev[1]
+            return float(ms.value)
+
+        warmed, passes = 0.0, 0
+        while warmed < ARENA_WARM_MS and passes < 8:
+            warmed += one_pass()
+            passes += 1
+        timed = one_pass()
+        _ffi.call("lars_d_stats_end", C.c_void_p(stats.ptr), self.ntiles, mask, self.npix, None)
+        _ffi.call("lars_synchronize", None)
         for e in ev:
             _ffi.call("lars_event_destroy", e)
-        stats.free()
-        return float(ms.value) / len(launches)
+        return timed / len(launches)
 
     def fused_args(self, indices=INDEX_NAMES, white_balance=True, stats=None, hist=False, outputs=None,
                    stream=None, tile_start=0, tile_count=None, sumsq=False, raw=False):
@@ -277,13 +338,18 @@ class TileBatch:
         _ffi.call("lars_d_stats_fold", C.c_void_p(stats.ptr), self.ntiles, mask, C.c_void_p(out.ptr), stream)
         return out
 
-    def run_fused_chunks(self, indices, white_balance, stats, hist, outputs, stream=None, sumsq=False):
+    def run_fused_chunks(self, indices, white_balance, stats, hist, outputs, stream=None, sumsq=False, launch_events=None):
         """``lars_d_fused`` over the whole batch in launches of ``outputs.slots`` tiles (one launch without a ring); the
         statistics records are opened and closed ONCE around the launches (LARS_F_RAW) instead of by two small kernels per
-        launch.  Returns the number of fused launches."""
+        launch.  Returns the number of fused launches.  ``launch_events``: event handles, [0] recorded before the first
+        launch and [i + 1] after launch i (as many launches as there are handles for): per-launch times for diagnostics."""
         chunk = self.ntiles if outputs is None else outputs.slots
         if chunk >= self.ntiles:
+            if launch_events:
+                _ffi.call("lars_event_record", launch_events[0], stream)
             self.run_fused(self.fused_args(indices, white_balance, stats, hist, outputs, stream, sumsq=sumsq))
+            if launch_events and len(launch_events) > 1:
+                _ffi.call("lars_event_record", launch_events[1], stream)
             return 1
         mask = 0
         for t in indices:
@@ -291,11 +357,15 @@ class TileBatch:
         if stats is not None:
             _ffi.call("lars_d_stats_begin", C.c_void_p(stats.ptr), self.ntiles, mask, stream)
         launches = 0
+        if launch_events:
+            _ffi.call("lars_event_record", launch_events[0], stream)
         for start in range(0, self.ntiles, chunk):
             count = min(chunk, self.ntiles - start)
             self.run_fused(self.fused_args(indices, white_balance, stats, hist, outputs, stream, start, count, sumsq=sumsq,
                                            raw=stats is not None))
             launches += 1
+            if launch_events and launches < len(launch_events):
+                _ffi.call("lars_event_record", launch_events[launches], stream)
         if stats is not None:
             _ffi.call("lars_d_stats_end", C.c_void_p(stats.ptr), self.ntiles, mask, self.npix, stream)
         return launches
@@ -332,7 +402,13 @@ class TileBatch:
             if self.hist is None:
                 self.hist = DeviceBuffer(self.ntiles * 3 * 256 * 4)
                 self.hist.zero(stream)
-            self._table_channels |= channels_of(indices)
+            if tile_count is None or int(tile_count) == self.ntiles:
+                # valid rows: those this pass writes, plus what an earlier pass of the same flavour left for the other channels
+                keep = self._table_channels if int(rgn_variant) == self._rgn_variant else set()
+                self._table_channels = keep | channels_of(indices)
+                self._rgn_variant = int(rgn_variant)
+            else:
+                self._table_channels = set()                # a partial pass leaves the batch's tables in no usable state
         a = FusedArgs()
         a.tiles = self.tiles.ptr
         a.ntiles, a.npix, a.channels, a.dtype = (self.ntiles if tile_count is None else int(tile_count)), self.npix, self.channels, self.code
@@ -346,12 +422,21 @@ class TileBatch:
                   C.c_void_p(self.hist.ptr) if white_balance else None,
                   C.c_void_p(pairs.ptr) if pairs is not None else None, C.c_void_p(self._joint_scratch.ptr), self._joint_scratch.nbytes)
 
+    def check_joint(self, stream=None):
+        """After a ``run_joint``: wait for ``stream`` and raise if the counting kernel reported a hand-over list overflow
+        (its published counts would be truncated).  Every consumer of ``run_joint`` calls this before it trusts the records."""
+        _ffi.call("lars_synchronize", stream)
+        if getattr(self, "_joint_scratch", None) is not None and int(self._joint_scratch.download(np.uint32, (1,))[0]):
+            raise RuntimeError("lars_d_stats_joint: a workgroup's hand-over list overflowed (a chunk of more than 2^24 pixels?)")
+
     def pick_stats_route(self, indices, white_balance=True, sample=32):
         """"joint" or "classic" for statistics WITHOUT medians over this batch, by measurement: both routes over the first
         ``sample`` tiles, once per (indices, white balance), remembered.  The one-read route counts byte pairs with LDS
         atomics, which queue up where the neighbouring pixels of a wave share cells (smooth imagery: profiles/
         r03_joint_hist_content.txt), while the per-pixel kernels do not care; with medians the one-read route wins on every
-        content measured, so nothing is timed for those.  Small batches take the one-read route unmeasured."""
+        content measured, so nothing is timed for those.  Small batches take the one-read route unmeasured.  The timing
+        runs on tables, percentiles and histograms of its own: the batch's (and which of their channels are valid) are
+        left exactly as they were."""
         key = (tuple(sorted(INDEX_IDS[t] for t in indices)), bool(white_balance))
         cache = self.__dict__.setdefault("_route_cache", {})
         if key in cache:
@@ -359,36 +444,45 @@ class TileBatch:
         if self.ntiles < sample or self.npix < (1 << 20) or self.channels != 3:
             cache[key] = "joint"
             return "joint"
+        saved = (self.table, self.percentiles, self.hist, set(self._table_channels), self._rgn_variant)
+        self.table = self.percentiles = self.hist = None
+        self._table_channels = set()
         ev = [C.c_void_p() for _ in range(3)]
         for e in ev:
             _ffi.call("lars_event_create", C.byref(e))
         stats = self.new_stats()
         ms = {}
-        for _ in range(2):                                  # the first round warms both routes up
-            _ffi.call("lars_event_record", ev[0], None)
-            self.run_joint(indices, white_balance, stats, tile_count=sample)
-            _ffi.call("lars_event_record", ev[1], None)
-            if white_balance:
-                if self.hist is None:
-                    self.hist = DeviceBuffer(self.ntiles * 3 * 256 * 4)
-                _ffi.call("lars_d_channel_hist", C.c_void_p(self.tiles.ptr), sample, self.npix, self.channels, self.code,
-                          C.c_void_p(self.hist.ptr), None)
-                _ffi.call("lars_d_wb_table", C.c_void_p(self.hist.ptr), sample, self.npix, self.code, C.c_void_p(self.table.ptr),
-                          C.c_void_p(self.percentiles.ptr), 0, None)
-            self.run_fused(self.fused_args(indices, white_balance, stats, False, None, None, 0, sample))
-            _ffi.call("lars_event_record", ev[2], None)
-            t = C.c_float(0)
-            _ffi.call("lars_event_elapsed_ms", ev[0], ev[1], C.byref(t)); ms["joint"] = t.value
-            _ffi.call("lars_event_elapsed_ms", ev[1], ev[2], C.byref(t)); ms["classic"] = t.value
-        for e in ev:
-            _ffi.call("lars_event_destroy", e)
-        stats.free()
+        try:
+            for _ in range(2):                                  # the first round warms both routes up
+                _ffi.call("lars_event_record", ev[0], None)
+                self.run_joint(indices, white_balance, stats, tile_count=sample)
+                _ffi.call("lars_event_record", ev[1], None)
+                if white_balance:
+                    _ffi.call("lars_d_channel_hist", C.c_void_p(self.tiles.ptr), sample, self.npix, self.channels, self.code,
+                              C.c_void_p(self.hist.ptr), None)
+                    _ffi.call("lars_d_wb_table", C.c_void_p(self.hist.ptr), sample, self.npix, self.code, C.c_void_p(self.table.ptr),
+                              C.c_void_p(self.percentiles.ptr), 0, None)
+                self.run_fused(self.fused_args(indices, white_balance, stats, False, None, None, 0, sample))
+                _ffi.call("lars_event_record", ev[2], None)
+                t = C.c_float(0)
+                _ffi.call("lars_event_elapsed_ms", ev[0], ev[1], C.byref(t)); ms["joint"] = t.value
+                _ffi.call("lars_event_elapsed_ms", ev[1], ev[2], C.byref(t)); ms["classic"] = t.value
+            self.check_joint()
+        finally:
+            _ffi.call("lars_synchronize", None)
+            for e in ev:
+                _ffi.call("lars_event_destroy", e)
+            stats.free()
+            for buf in (self.table, self.percentiles, self.hist):
+                if buf is not None:
+                    buf.free()
+            self.table, self.percentiles, self.hist, self._table_channels, self._rgn_variant = saved
         cache[key] = "joint" if ms["joint"] <= ms["classic"] else "classic"
         self._route_ms = dict(ms)
         return cache[key]
 
     def process(self, indices=INDEX_NAMES, white_balance=True, hist=False, outputs=None, stream=None,
-                recompute_tables=True, medians=False, sumsq=False, route=None):
+                recompute_tables=True, medians=False, sumsq=False, route=None, rgn_variant=None):
         """Both passes over the whole batch; returns per-tile records
         (structured ndarray ``[ntiles, 3]`` of STATS_DTYPE; rows of indices not
         requested are zero).  ``hist`` adds the 50-bin histograms, ``sumsq`` the sums of squares
@@ -396,19 +490,30 @@ class TileBatch:
         with np.median of each tile's index plane, exact: uint8 RGNir tiles take the
         two-level select on recomputed values (planes or not); other tiles a batched radix
         select on the float32 planes, which must then be written -- a small ring is
-        allocated when ``outputs`` has none.  ``route``: see ``set_stats_route`` (None = the module's setting)."""
+        allocated when ``outputs`` has none.  ``route``: see ``set_stats_route`` (None = the module's setting).
+
+        Tables: ``recompute_tables=False`` uses the white-balance tables the batch already holds (``compute_wb_tables``,
+        any ``rgn_variant``) when they cover the channels this pass reads -- such a pass runs on the per-pixel route, the
+        one-read route derives its tables from its own counts -- and computes them otherwise.  ``rgn_variant`` (None: 0
+        for tables computed here, whatever the reused tables are) selects the flavour of tables computed here."""
         route = _STATS_ROUTE if route is None else route
-        if route == "auto" and outputs is None and not medians and self.can_joint() and indices:
+        variant = 0 if rgn_variant is None else int(rgn_variant)
+        need = channels_of(indices, outputs is not None and outputs.wb is not None)
+        reuse = (white_balance and not recompute_tables and self.table is not None and need <= self._table_channels
+                 and (rgn_variant is None or variant == self._rgn_variant))
+        if reuse and outputs is None and route == "joint":
+            raise ValueError("route='joint' derives the tables from its own counts: it cannot honour recompute_tables=False")
+        may_joint = outputs is None and route != "classic" and not reuse and self.can_joint() and bool(indices)
+        if route == "auto" and may_joint and not medians and not sumsq:
             route = self.pick_stats_route(indices, white_balance)
-        if outputs is None and route != "classic" and self.can_joint() and indices:
+            may_joint = route != "classic"
+        if may_joint:
             # nothing to write: one read of the tiles serves the percentiles, the statistics and the medians
             stats = self.new_stats()
             stats.zero(stream)
             pairs_dev = DeviceBuffer(self.ntiles * 4 * 4) if medians else None
-            self.run_joint(indices, white_balance, stats, hist, sumsq, pairs_dev, stream)
-            _ffi.call("lars_synchronize", stream)
-            if int(self._joint_scratch.download(np.uint32, (1,))[0]):
-                raise RuntimeError("lars_d_stats_joint: a workgroup's hand-over list overflowed (a chunk of more than 2^24 pixels?)")
+            self.run_joint(indices, white_balance, stats, hist, sumsq, pairs_dev, stream, rgn_variant=variant)
+            self.check_joint(stream)
             rec = stats.download(STATS_DTYPE, (self.ntiles, 3))
             stats.free()
             if not medians:
@@ -418,9 +523,8 @@ class TileBatch:
             return rec, med
         if route == "joint" and outputs is None:
             raise ValueError("route='joint' serves uint8 tiles with 3 channels (4-byte aligned) only")
-        need = channels_of(indices, outputs is not None and outputs.wb is not None)
-        if white_balance and (recompute_tables or self.table is None or not need <= self._table_channels):
-            self.compute_wb_tables(stream)
+        if white_balance and not reuse:
+            self.compute_wb_tables(stream, rgn_variant=variant)
         stats = self.new_stats()
         stats.zero(stream)                                  # same stream as the kernels that accumulate into it
         # uint8 RGNir tiles: medians come from the two-level select on recomputed values (two passes over the 3-byte
@@ -450,7 +554,8 @@ class TileBatch:
             return rec, med
         own_outputs = None
         if medians and (outputs is None or any(outputs.index[INDEX_IDS[t]] is None for t in indices)):
-            own_outputs = outputs = self.make_outputs(indices=indices, index=True, ring=min(self.ntiles, 16))
+            # a temporary ring: one plain allocation, never the arena search (seconds and several arenas' worth of memory per call)
+            own_outputs = outputs = self.make_outputs(indices=indices, index=True, ring=min(self.ntiles, 16), arena="plain")
         med_dev = sel = None
         if medians:
             med_dev = DeviceBuffer(self.ntiles * 3 * 2 * 4)

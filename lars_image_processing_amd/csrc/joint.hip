@@ -61,7 +61,9 @@ __device__ inline void jh_add(unsigned int addr, unsigned int val, char *tab)
 template <int DEPTH, int CH = 3>
 __global__ __launch_bounds__(JH_THREADS, 4) void k_joint_count(JointCountParams P)
 {
-    static_assert(JH_PERIOD_STEPS % DEPTH == 0, "a period is a whole number of ring turns");
+    // a period is a whole number of ring turns and adds at most 65535 - 16383 = 49152 pixels (12 steps) to any one dword
+    constexpr int PERIOD = (JH_PERIOD_STEPS % DEPTH == 0) ? JH_PERIOD_STEPS : DEPTH;
+    static_assert(PERIOD % DEPTH == 0 && PERIOD <= JH_PERIOD_STEPS, "a period is a whole number of ring turns, at most 12 steps");
     __shared__ __attribute__((aligned(16))) unsigned int s_tab[JH_DWORDS];          // 128 KiB
     __shared__ uint2 s_list[JH_LIST_CAP];                                          // moved dwords: (D, value)
     __shared__ unsigned int s_nlist;
@@ -213,12 +215,12 @@ __global__ __launch_bounds__(JH_THREADS, 4) void k_joint_count(JointCountParams 
             }
             soff += DEPTH * STEP_B;
             since += DEPTH;
-            if (since == JH_PERIOD_STEPS) {
+            if (since == PERIOD) {
                 scan();
                 since = 0;
             }
         }
-        // the last (fewer than DEPTH) full steps and the ragged one: since + DEPTH <= JH_PERIOD_STEPS, no scan needed
+        // the last (fewer than DEPTH) full steps and the ragged one: since + DEPTH <= PERIOD, no scan needed
 #pragma unroll
         for (int k = 0; k < DEPTH; ++k) {
             const long long step = it + k;
@@ -663,8 +665,8 @@ extern "C" int lars_d_stats_joint(const lars_fused_args *a, int white_balance, i
     if (!mask || (a->index_mask & ~LARS_MASK_ALL)) return fail(LARS_ERR_INVALID, "lars_d_stats_joint: index_mask");
     if (a->out_wb || a->out_index[0] || a->out_index[1] || a->out_index[2] || a->out_rgba[0] || a->out_rgba[1] || a->out_rgba[2])
         return fail(LARS_ERR_INVALID, "lars_d_stats_joint: no output planes (lars_d_fused writes those)");
-    if (a->ntiles > 65535 || (long long)a->npix * 3 >= (1ll << 40))
-        return fail(LARS_ERR_INVALID, "lars_d_stats_joint: at most 65535 tiles per call");
+    if (a->ntiles > 65535 || (long long)a->npix >= (1ll << 32))
+        return fail(LARS_ERR_INVALID, "lars_d_stats_joint: at most 65535 tiles per call, fewer than 2^32 pixels per tile (the per-cell counts are uint32)");
     hipStream_t s = pick_stream(c, a->stream);
     const unsigned streams = ((mask & 1u) ? 1u : 0u) | ((mask & 6u) ? 2u : 0u);
     const int S = streams == 3u ? 2 : 1;
@@ -686,6 +688,8 @@ extern "C" int lars_d_stats_joint(const lars_fused_args *a, int white_balance, i
     if (nwg > 0x7FFFFFFFll) return fail(LARS_ERR_INVALID, "lars_d_stats_joint: too many workgroups");
     if (c4) hipLaunchKernelGGL((k_joint_count<6, 4>), dim3((unsigned)nwg), dim3(JH_THREADS), 0, s, C);
     else if (tuning().joint_depth == 4) hipLaunchKernelGGL((k_joint_count<4>), dim3((unsigned)nwg), dim3(JH_THREADS), 0, s, C);
+    else if (tuning().joint_depth == 8) hipLaunchKernelGGL((k_joint_count<8>), dim3((unsigned)nwg), dim3(JH_THREADS), 0, s, C);
+    else if (tuning().joint_depth == 12) hipLaunchKernelGGL((k_joint_count<12>), dim3((unsigned)nwg), dim3(JH_THREADS), 0, s, C);
     else hipLaunchKernelGGL((k_joint_count<6>), dim3((unsigned)nwg), dim3(JH_THREADS), 0, s, C);
     LARS_TRY(launch_check("lars_d_stats_joint (count)"));
 

@@ -449,7 +449,7 @@ static void issue_launch(int iters, int blocks, unsigned int *sink, hipStream_t 
 // is reader r of chunk 8 a + x, so the readers of a chunk sit 8 apart in dispatch order (one XCD) -- with 128 KiB of LDS
 // reserved so that one workgroup fills a CU, as the counting kernel of csrc/joint.hip does.  W dwords per lane and load (3 | 4),
 // six loads in flight.  What a CU can take in from the XCD's L2 when the HBM side delivers each byte once.
-template <int W>
+template <int W, int D = 6>
 __global__ __launch_bounds__(1024, 4) void k_probe_shared(const unsigned int *__restrict__ src, long long chunk_vecs, long long nchunks,
                                                           int readers, unsigned int *sink)
 {
@@ -473,19 +473,19 @@ __global__ __launch_bounds__(1024, 4) void k_probe_shared(const unsigned int *__
     };
     const long long nsteps = (chunk_vecs + 1023) / 1024;
     unsigned int acc = 0;
-    v4 w[6];
+    v4 w[D];
 #pragma unroll
-    for (int k = 0; k < 6; ++k) w[k] = load((unsigned)k * STEP_B);
-    unsigned int soff = 6u * STEP_B;
-    for (long long it = 0; it < nsteps; it += 6) {
+    for (int k = 0; k < D; ++k) w[k] = load((unsigned)k * STEP_B);
+    unsigned int soff = (unsigned)D * STEP_B;
+    for (long long it = 0; it < nsteps; it += D) {
 #pragma unroll
-        for (int k = 0; k < 6; ++k) {
+        for (int k = 0; k < D; ++k) {
             acc ^= w[k].x ^ w[k].y ^ w[k].z ^ w[k].w;
             __builtin_amdgcn_sched_barrier(0);
             w[k] = load(soff + (unsigned)k * STEP_B);
             __builtin_amdgcn_sched_barrier(0);
         }
-        soff += 6u * STEP_B;
+        soff += (unsigned)D * STEP_B;
     }
     if (acc == 0x12345677u) sink[0] = acc + s_pad[1];
 }
@@ -521,8 +521,12 @@ extern "C" int lars_d_probe(int kind, int unroll, int blocks, const void *src, v
         const long long per = wide ? 16 : 12, chunk_vecs = bytes / per / blocks;
         const long long groups = (blocks + 7) / 8;
         const dim3 grid((unsigned)(groups * 8 * readers));
-        if (wide) hipLaunchKernelGGL((k_probe_shared<4>), grid, dim3(1024), 0, s, p, chunk_vecs, (long long)blocks, readers, sink);
-        else hipLaunchKernelGGL((k_probe_shared<3>), grid, dim3(1024), 0, s, p, chunk_vecs, (long long)blocks, readers, sink);
+        // unroll = loads in flight per lane: 6 (default; 0 and 1 mean 6 too), 8, 12, 16
+        const int depth = unroll <= 1 ? 6 : unroll;
+#define LARS_SHARED(WW, DD) hipLaunchKernelGGL((k_probe_shared<WW, DD>), grid, dim3(1024), 0, s, p, chunk_vecs, (long long)blocks, readers, sink)
+        if (wide) { if (depth == 6) LARS_SHARED(4, 6); else if (depth == 8) LARS_SHARED(4, 8); else if (depth == 12) LARS_SHARED(4, 12); else return fail(LARS_ERR_INVALID, "lars_d_probe: depth 6, 8 or 12 (16-byte loads)"); }
+        else { if (depth == 6) LARS_SHARED(3, 6); else if (depth == 8) LARS_SHARED(3, 8); else if (depth == 12) LARS_SHARED(3, 12); else if (depth == 16) LARS_SHARED(3, 16); else return fail(LARS_ERR_INVALID, "lars_d_probe: depth 6, 8, 12 or 16"); }
+#undef LARS_SHARED
         return launch_check("lars_d_probe (shared readers)");
     }
     if (kind == 0) {

@@ -54,10 +54,17 @@ def check_line(line, tiles=6, tile=512):
     # one entry per rank, gathered over the communicator; the slowest rank is the line's step time
     assert [r["rank"] for r in line["ranks"]] == list(range(line["n_gpus"]))
     for r in line["ranks"]:
-        for key in ("ms_per_step", "fused_ms", "hist_ms", "avg_launch_ms", "arena_ms", "arena_search_ms"):
+        for key in ("ms_per_step", "fused_ms", "hist_ms", "avg_launch_ms", "arena_ms", "arena_search_ms", "arena_post_free_ms",
+                    "first_step_launch_ms_min_max"):
             assert key in r, key
+        assert 0 < r["first_step_launch_ms_min_max"][0] <= r["first_step_launch_ms_min_max"][1]
         assert 0 < r["ms_per_step"] <= line["ms_per_step"] * (1 + 1e-9) and r["fused_ms"] > 0
     assert abs(max(r["ms_per_step"] for r in line["ranks"]) - line["ms_per_step"]) <= 1e-6 * line["ms_per_step"]
+    # the fused launches of the first timed step one by one, next to what the arena probe predicted for them
+    assert len(roof["first_step_launch_ms"]) == roof["launches_per_step"] and min(roof["first_step_launch_ms"]) > 0
+    assert abs(sum(roof["first_step_launch_ms"]) / roof["launches_per_step"] - roof["avg_launch_ms"]) < 0.5 * roof["avg_launch_ms"]
+    if line["config"]["arena"] and line["config"]["arena"].get("rejected"):
+        assert roof["arena_probe_vs_steps"]["post_free_ms"] == line["config"]["arena"]["post_free_ms"] > 0
     assert "lars_d_stats_fold" in line["config"]["statistics_fold"] and line["config"]["stats_route"] in ("joint", "classic")
     assert abs(line["passes_ms"]["rest_of_step"] - (line["ms_per_step"] - line["passes_ms"]["histogram+tables"] - line["passes_ms"]["fused"])) < 1e-9
 
@@ -103,17 +110,19 @@ def test_bench_statistics_fold_transports_agree(transport):
     assert line["global_stats"] == base["global_stats"]
 
 
-@pytest.mark.parametrize("ranks", [2, 3, 4])
-def test_ranks_on_one_gpu_equal_one_process_over_all_tiles(tmp_path, ranks):
+@pytest.mark.parametrize("ranks,all_modes", [(2, False), (3, True), (4, False)])
+def test_ranks_on_one_gpu_equal_one_process_over_all_tiles(tmp_path, ranks, all_modes):
     """The N > 1 flow end to end on real kernels: `ranks` ranks (all on GPU 0, statistics exchanged over gloo) with
     12 / ranks tiles each must report the global statistics and medians of one process over the same 12 tiles (rank r
-    owns a contiguous block of the same counter-hash sequence; sums are exact, so even the means are identical)."""
+    owns a contiguous block of the same counter-hash sequence; sums are exact, so even the means are identical).
+    With N > 1 the line times the headline mode only (no `modes`, no global medians) unless --all-modes is given."""
     per_rank = 12 // ranks
     port = 29000 + os.getpid() % 2000
     env = dict(os.environ, LARS_COMM="gloo", LARS_DEVICE="0")
     for k in ("RANK", "LOCAL_RANK", "WORLD_SIZE"):
         env.pop(k, None)
-    common = ["--tile", "512", "--ring", "4", "--steps", "2", "--warmup", "1", "--no-probe", "--placement-trials", "0", "--no-cpu-baseline"]
+    common = ["--tile", "512", "--ring", "4", "--steps", "2", "--warmup", "1", "--no-probe", "--placement-trials", "2", "--no-cpu-baseline",
+              *(["--all-modes", "--no-u16-leg"] if all_modes else [])]
     cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(ranks), "--master-addr", "127.0.0.1",
            "--master-port", str(port + ranks), os.path.join(ROOT, "bench.py"), "--gpus", str(ranks), "--tiles", str(per_rank), *common]
     out = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=900, cwd=ROOT)
@@ -121,7 +130,7 @@ def test_ranks_on_one_gpu_equal_one_process_over_all_tiles(tmp_path, ranks):
     lines = [ln for ln in out.stdout.splitlines() if ln.startswith("{")]
     assert len(lines) == 1, out.stdout                                      # rank 0 alone prints
     two = json.loads(lines[0])
-    cmd1 = [sys.executable, os.path.join(ROOT, "bench.py"), "--tiles", "12", *common]
+    cmd1 = [sys.executable, os.path.join(ROOT, "bench.py"), "--tiles", "12", *common, *([] if all_modes else ["--no-all-modes"])]
     out1 = subprocess.run(cmd1, env={k: v for k, v in os.environ.items() if k not in ("RANK", "LOCAL_RANK", "WORLD_SIZE")},
                           capture_output=True, text=True, timeout=600, cwd=ROOT)
     assert out1.returncode == 0, out1.stderr[-2000:]
@@ -131,9 +140,15 @@ def test_ranks_on_one_gpu_equal_one_process_over_all_tiles(tmp_path, ranks):
     assert abs(max(r["ms_per_step"] for r in two["ranks"]) - two["ms_per_step"]) <= 1e-6 * two["ms_per_step"]
     assert two["config"]["tiles_per_gpu"] == per_rank and one["config"]["tiles_per_gpu"] == 12
     assert two["global_stats"] == one["global_stats"]
+    assert ("modes" in two) == all_modes
     for name in ("NDVI", "GNDVI", "NDWI"):
         assert two["global_stats"][name]["count"] == 12 * 512 * 512
-        assert two["global_stats"][name]["median"] == one["global_stats"][name]["median"]
+        assert ("median" in two["global_stats"][name]) == all_modes
+        if all_modes:
+            assert two["global_stats"][name]["median"] == one["global_stats"][name]["median"]
+    # every rank reports its arena: the probe's figure after the rejected candidates were freed, and its first step's launches
+    for r in two["ranks"]:
+        assert r["arena_post_free_ms"] > 0 and r["arena_rejected"] == 1 and 0 < r["first_step_launch_ms_min_max"][0]
     assert abs(two["value"] - 12 * 512 * 512 / (two["ms_per_step"] * 1e-3) / 1e6) <= 1e-6 * two["value"]
 
 

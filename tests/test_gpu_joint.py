@@ -57,7 +57,7 @@ def test_joint_route_equals_classic_route(lars, profile, shape, ntiles):
             if wb:
                 # the by-products: channel histograms, percentiles and tables of the channels the indices read
                 chans = sorted({2} | ({0} if "NDVI" in indices else set()) | ({1} if set(indices) & {"GNDVI", "NDWI"} else set()))
-                got_tab, got_pct, got_hist = b.host_tables(), b.host_percentiles(), b.host_hist()
+                got_tab, got_pct, got_hist = b.host_tables(partial=True), b.host_percentiles(partial=True), b.host_hist(partial=True)
                 for c in chans:
                     np.testing.assert_array_equal(got_hist[:, c], want_hist[:, c])
                     np.testing.assert_array_equal(got_pct[:, c], want_pct[:, c])
@@ -203,3 +203,57 @@ def test_joint_bad_arguments(lars):
         wide = lars.TileBatch.from_host(np.zeros((1, 8, 8, 3), np.uint16))
         wide.process(route="joint")
     scratch.free(); stats.free(); b.free()
+
+
+def test_route_timing_leaves_the_tables_alone_and_supplied_tables_are_used(lars):
+    """(i) pick_stats_route() times both routes over the first tiles only -- on tables of its own; the batch's
+    tables and their validity stay as they were, so a classic pass with recompute_tables=False afterwards is a normal pass;
+    (ii) process(recompute_tables=False) uses the tables the caller computed (here process-rgn.py's flavour, rgn_variant=1)
+    instead of silently taking the one-read route with flavour 0; (iii) the host getters refuse half-filled tables."""
+    b = lars.TileBatch.synthetic(40, 1024, 1024, seed=31, profile="vegetation")
+    want = b.process(route="classic")
+    want_tab = b.host_tables()
+    # (i) fresh batch state, route timing first
+    b2 = lars.TileBatch.synthetic(40, 1024, 1024, seed=31, profile="vegetation")
+    assert b2.pick_stats_route(("NDVI", "GNDVI", "NDWI")) in ("joint", "classic")
+    assert b2.table is None and b2._table_channels == set()
+    got = b2.process(recompute_tables=False, route="classic")          # no tables yet: they are computed, over ALL tiles
+    assert got.tobytes() == want.tobytes()
+    np.testing.assert_array_equal(b2.host_tables(), want_tab)
+    b2.compute_wb_tables()
+    b2._route_cache.clear()
+    b2.pick_stats_route(("NDVI",))
+    assert b2._table_channels == {0, 1, 2}
+    np.testing.assert_array_equal(b2.host_tables(), want_tab)          # untouched by the timing
+    # (ii) supplied tables of the other flavour are used, on every route setting that may honour them
+    b2.compute_wb_tables(rgn_variant=1)
+    tab1 = b2.host_tables()
+    rec1 = b2.process(recompute_tables=False)                            # route from the module's setting ("auto")
+    assert b2._rgn_variant == 1
+    np.testing.assert_array_equal(b2.host_tables(), tab1)
+    ref1 = b2.process(recompute_tables=False, route="classic")
+    assert rec1.tobytes() == ref1.tobytes()
+    rec1j = b2.process(rgn_variant=1, route="joint")                    # the one-read route computes the same flavour itself
+    assert rec1j.tobytes() == ref1.tobytes()
+    np.testing.assert_array_equal(b2.host_tables(), tab1)
+    with pytest.raises(ValueError):
+        b2.process(recompute_tables=False, route="joint")
+    # (iii) a one-read pass over NDVI alone with another flavour leaves green invalid
+    b2.process(indices=("NDVI",), route="joint")                         # flavour 0 again: red and NIR rows only
+    assert b2._table_channels == {0, 2}
+    with pytest.raises(RuntimeError):
+        b2.host_tables()
+    assert b2.host_tables(partial=True)[:, (0, 2)].tobytes() == want_tab[:, (0, 2)].tobytes()
+    rec_g = b2.process(indices=("GNDVI",), recompute_tables=False)     # green is missing: tables are recomputed, not reused
+    assert rec_g[:, 1].tobytes() == want[:, 1].tobytes()
+    b.free(); b2.free()
+
+
+def test_joint_rejects_tiles_beyond_its_counters(lars):
+    from lars_image_processing_amd import _ffi
+    import ctypes as C
+    a = _ffi.FusedArgs()
+    a.tiles, a.ntiles, a.npix, a.channels, a.dtype = 256, 1, 1 << 32, 3, _ffi.U8
+    a.index_mask, a.flags, a.stats = 1, _ffi.F_STATS, 256
+    with pytest.raises(_ffi.LarsError):
+        _ffi.call("lars_d_stats_joint", C.byref(a), 1, 0, None, None, None, C.c_void_p(256), 1 << 40)

@@ -19,7 +19,7 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--runs", type=int, default=10)
-    ap.add_argument("--arena", default="auto")
+    ap.add_argument("--arena", default="auto", help="auto, plain or slowest (bench.py --arena)")
     ap.add_argument("--trials", type=int, default=-1)
     ap.add_argument("rest", nargs="*")
     args = ap.parse_args()
@@ -34,10 +34,15 @@ def main():
         line = json.loads([ln for ln in out.stdout.splitlines() if ln.startswith("{")][-1])
         a = line["config"]["arena"] or {}
         fracs.append(line["roofline"]["frac"])
-        groups = " ".join(f"{x:.3f}" for x in a.get("group_ms", a.get("candidate_ms", [])))
-        print(f"run {i:2d}: frac {line['roofline']['frac']:.4f}  whole step {line['roofline']['whole_step_frac']:.4f}  "
-              f"{line['roofline']['avg_launch_ms']:.3f} ms per launch  search {a.get('search_ms') or 0:7.1f} ms  rejected {a.get('rejected')}  "
-              f"[{groups}]  {a.get('kind')}", flush=True)
+        cands = " ".join(f"{x:.3f}" for x in a.get("candidate_ms", []))
+        mallocs = " ".join(f"{x:.0f}" for x in a.get("malloc_ms", []))
+        avg = line["roofline"]["avg_launch_ms"]
+        post = a.get("post_free_ms") or 0.0
+        first = line["roofline"].get("first_step_launch_ms") or [0.0]
+        print(f"run {i:2d}: frac {line['roofline']['frac']:.4f}  whole step {line['roofline']['whole_step_frac']:.4f}  steps {avg:.3f} ms per launch  "
+              f"probe chosen {a.get('chosen_ms') or 0:.3f}  after freeing {post:.3f} ({100 * (post / avg - 1) if post else 0:+.1f} % vs steps)  "
+              f"first step {min(first):.3f}-{max(first):.3f}  search {a.get('search_ms') or 0:7.1f} ms  candidates [{cands}]  hipMalloc ms [{mallocs}]  {a.get('kind')}",
+              flush=True)
     if fracs:
         print(f"# {len(fracs)} processes: min {min(fracs):.4f}  median {sorted(fracs)[len(fracs) // 2]:.4f}  max {max(fracs):.4f}")
 

@@ -422,12 +422,35 @@ class TileBatch:
                   C.c_void_p(self.hist.ptr) if white_balance else None,
                   C.c_void_p(pairs.ptr) if pairs is not None else None, C.c_void_p(self._joint_scratch.ptr), self._joint_scratch.nbytes)
 
-    def check_joint(self, stream=None):
-        """After a ``run_joint``: wait for ``stream`` and raise if the counting kernel reported a hand-over list overflow
-        (its published counts would be truncated).  Every consumer of ``run_joint`` calls this before it trusts the records."""
+    def joint_flag(self, stream=None):
+        """Wait for ``stream`` and return the error word of the last ``run_joint`` (0 = its counts are good)."""
         _ffi.call("lars_synchronize", stream)
-        if getattr(self, "_joint_scratch", None) is not None and int(self._joint_scratch.download(np.uint32, (1,))[0]):
-            raise RuntimeError("lars_d_stats_joint: a workgroup's hand-over list overflowed (a chunk of more than 2^24 pixels?)")
+        if getattr(self, "_joint_scratch", None) is None:
+            return 0
+        return int(self._joint_scratch.download(np.uint32, (1,))[0])
+
+    def check_joint(self, stream=None, rerun=None):
+        """After a ``run_joint``: wait for ``stream`` and see whether the counting kernel raised its error flag -- a 16-bit
+        counter pair came within 16384 of wrapping before the lane that has to move it onto the hand-over list got there
+        (csrc/joint.hip; never observed), or the list overflowed (cannot happen: a workgroup counts at most 2^24 pixels).
+        Such a launch's counts are void.  With ``rerun`` (a callable that enqueues the same ``run_joint`` again) the pass is
+        repeated ONCE with the barrier form of the kernel (``joint_impl = 1``: plain adds, the table swept every 12 steps),
+        which cannot wrap by construction; without it, or if that fails too, RuntimeError.  Every consumer of ``run_joint``
+        calls this before it trusts the records."""
+        if not self.joint_flag(stream):
+            return
+        if rerun is not None:
+            before = _ffi.get_tuning("joint_impl")
+            self._joint_fallbacks = getattr(self, "_joint_fallbacks", 0) + 1
+            try:
+                _ffi.set_tuning(joint_impl=1)
+                rerun()
+                if not self.joint_flag(stream):
+                    return
+            finally:
+                _ffi.set_tuning(joint_impl=before)
+        raise RuntimeError("lars_d_stats_joint: the counting kernel raised its error flag (a counter pair close to wrapping, or a "
+                           "hand-over list overflow: a chunk of more than 2^24 pixels?)")
 
     def pick_stats_route(self, indices, white_balance=True, sample=32):
         """"joint" or "classic" for statistics WITHOUT medians over this batch, by measurement: both routes over the first
@@ -510,10 +533,13 @@ class TileBatch:
         if may_joint:
             # nothing to write: one read of the tiles serves the percentiles, the statistics and the medians
             stats = self.new_stats()
-            stats.zero(stream)
             pairs_dev = DeviceBuffer(self.ntiles * 4 * 4) if medians else None
-            self.run_joint(indices, white_balance, stats, hist, sumsq, pairs_dev, stream, rgn_variant=variant)
-            self.check_joint(stream)
+
+            def enqueue():
+                stats.zero(stream)
+                self.run_joint(indices, white_balance, stats, hist, sumsq, pairs_dev, stream, rgn_variant=variant)
+            enqueue()
+            self.check_joint(stream, rerun=enqueue)
             rec = stats.download(STATS_DTYPE, (self.ntiles, 3))
             stats.free()
             if not medians:

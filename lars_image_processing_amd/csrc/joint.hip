@@ -12,15 +12,27 @@
 // kernels produce, because every ingredient is a function of the counts.
 //
 // k_joint_count: one 1024-thread workgroup per (tile chunk, stream) with the stream's 65536 counters in LDS as 16-bit
-// pairs: dword D holds in its low half the pixels of BOTH cells 2D and 2D + 1 and in its high half those of cell 2D + 1,
-// so one ds_add_u32 of 1 | (h << 16) per pixel counts it and the high half can never pass the low one.  128 KiB of the
-// 160 KiB: one workgroup per CU.  16-bit sums cannot overflow between two scans: a workgroup adds 12 x 4096 = 49152
-// pixels per period, and at every period's end it moves each dword whose sum has reached 16384 onto a list in LDS
-// (16383 + 49152 = 65535); a workgroup counts at most 2^24 pixels, so at most 1024 moves.  With two streams the two
-// workgroups of a tile chunk sit 8 apart in dispatch order (the same XCD, at the same time): the second reader of a
-// line finds it in that XCD's L2 or in the Infinity Cache.
-// Cell of a pixel: S = (x << 8 | n) ^ JH_MIX(x)  (x = r or g: the low byte becomes n ^ 2x so that the LDS bank is a mix of both
-// samples, under common and under independent changes), dword D = S >> 1, half h = S & 1.
+// pairs: dword D holds in its low half the pixels of BOTH its cells (D, h = 0) and (D, 1) and in its high half those of (D, 1),
+// so one ds_add of 1 | (h << 16) per pixel counts it and the high half can never pass the low one.  128 KiB of the
+// 160 KiB: one workgroup per CU.  With two streams the two workgroups of a tile chunk sit 8 apart in dispatch order (the same
+// XCD, at the same time): the second reader of a line finds it in that XCD's L2 or in the Infinity Cache.
+//
+// 16-bit sums and how they are kept from wrapping.  SCAN = false (the default since round 4): every add RETURNS the dword's
+// previous value (ds_add_rtn_u32); one step later the lane looks at its four returns: the add that took a low half from below
+// 16384 to 16384 or more (exactly one add does: the adds of a dword are serialised) moves what the dword held right after it onto
+// a list in LDS and subtracts exactly that (ds_sub_u32) -- adds that arrived in between stay.  A workgroup counts at most 2^24
+// pixels, so at most 1024 moves.  Nothing stops the other waves meanwhile: no barrier, no sweep of the table.  The mover is a few
+// hundred cycles behind its add; the low half would need 49152 more pixels in that time to wrap.  That cannot be PROVEN impossible,
+// so it is CHECKED: an add whose result reaches 49152 raises the launch's error flag (no wrap can happen without one: increments
+// are at most 256), and the host then repeats the launch with SCAN = true.  SCAN = true (round 3's form): plain adds; every 12
+// steps (12 x 4096 = 49152 pixels, 16383 + 49152 = 65535) two barriers around a sweep of the table that moves every dword at
+// 16384 or more onto the list.  Measured in isolation (tools/lab/ldsatomics.py, profiles/r04_lds_atomics.txt): 6.7 cycles per
+// wave-add plain, 7.8 returning + checked, 10.5 plain + sweeps -- the barriers cost three times the sweep's own LDS reads.
+// Cell of a pixel (x = r or g, n = NIR): m = (n + 5 x) & 255, dword D = x << 7 | (m & 127), half h = m >> 7.  The LDS bank of a
+// dword is D & 31 = (n + 5 x) & 31: the 5 x 5 neighbourhood of cells that a wave's 64 pixels of a smooth image fall into lands in
+// 25 DIFFERENT banks (and dwords), as do common shifts of both samples (shading: +6 per level) and shifts of one sample alone.
+// Round 3's n ^ 2x put such a neighbourhood into about six banks (tools/lab/banksim.py: 10-12 lanes on the fullest bank against
+// 5.4 for independent samples; the linear form: 5.5-5.7).
 #include <string.h>
 
 #include <type_traits>
@@ -29,10 +41,7 @@
 
 namespace lars {
 
-// The low byte of a cell is n ^ JH_MIX(x): the LDS bank (bits 1..5 of the cell) must spread for neighbouring pixels, whose
-// samples move TOGETHER under shading (n ^ x alone would stay put) as well as apart under noise.
-#define JH_MIX(x) (((x) << 1) & 0xFEu)
-#define JH_MIX2(px) (((px) << 1) & 0x00FE00FEu)         /* two cells per dword: x0 0 x1 0 */
+#define JH_K 5u                                          /* m = n + JH_K * x: odd, and 5 x 5 neighbourhoods tile 25 consecutive values */
 #define JH_DWORDS 32768
 #define JH_THREADS 1024
 #define JH_PERIOD_STEPS 12                    /* steps of 4096 pixels between two scans */
@@ -45,20 +54,44 @@ struct JointCountParams {
     long long npix;
     long long ntiles;
     long long chunk_quads;                    // quads per chunk: a multiple of 1024 (the last chunk of a tile takes the rest)
-    unsigned int *part;                       // [ntiles][S][K][32768][2] uint32: counts of cell 2D, cell 2D + 1
+    unsigned int *part;                       // [ntiles][S][K][32768][2] uint32: counts of the cells (D, 0), (D, 1)
     unsigned int *error;                      // set to 1 if a list overflows (cannot happen: see JH_MAX_WG_PIXELS)
     int K;                                    // chunks per tile
     int S;                                    // streams counted: 1 or 2
     unsigned int streams;                     // bit 0: (n, r) pairs, bit 1: (n, g) pairs
+    unsigned int danger_at;                   // SCAN = false: an add whose low half reaches this raises *error (JH_DANGER_AT)
 };
 
 __device__ inline void jh_add(unsigned int addr, unsigned int val, char *tab)
 {
     __hip_atomic_fetch_add(reinterpret_cast<unsigned int *>(tab + addr), val, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
 }
+__device__ inline unsigned int jh_add_rtn(unsigned int addr, unsigned int val, char *tab)
+{
+    return __hip_atomic_fetch_add(reinterpret_cast<unsigned int *>(tab + addr), val, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+}
+#define JH_MOVE_AT 0x4000u                    /* the add that takes a low half to 16384 or beyond moves the dword onto the list */
+#define JH_DANGER_AT 0xC000u                  /* an add whose result reaches 49152: the launch is void (error flag); tests lower it */
+
+// nn + 5 px in one full-rate instruction (px < 2^24; the compiler's own choice for * 5 + is the quarter-rate v_mad_u64_u32)
+__device__ inline unsigned int jh_mad5(unsigned int px, unsigned int nn)
+{
+    unsigned int r;
+    asm("v_mad_u32_u24 %0, %1, 5, %2" : "=v"(r) : "v"(px), "v"(nn));
+    return r;
+}
+static_assert(JH_K == 5u, "jh_mad5 spells the factor out");
+
+// (D, h) of a pair of samples, and back
+__device__ inline unsigned int jh_m(unsigned int n, unsigned int x) { return (n + JH_K * x) & 255u; }
+__device__ inline unsigned int jh_n_of(unsigned int D, unsigned int h)
+{
+    const unsigned int x = D >> 7, m = (D & 127u) | (h << 7);
+    return (m - JH_K * x) & 255u;
+}
 
 // CH = 4: RGBA tiles, one 16-byte load per lane and step, repacked into the three dwords of an RGB quad.
-template <int DEPTH, int CH = 3>
+template <int DEPTH, int CH = 3, bool SCAN = false>
 __global__ __launch_bounds__(JH_THREADS, 4) void k_joint_count(JointCountParams P)
 {
     // a period is a whole number of ring turns and adds at most 65535 - 16383 = 49152 pixels (12 steps) to any one dword
@@ -102,27 +135,67 @@ __global__ __launch_bounds__(JH_THREADS, 4) void k_joint_count(JointCountParams 
     // pixels 0, 1 from (w0, w1): perm(src0 = w1, src1 = w0) -> selector = byte offset 0..7
     // pixels 2, 3 from (w1, w2): perm(src0 = w2, src1 = w1) -> selector = byte offset - 4
     const unsigned int xo = green ? 1u : 0u;
-    const unsigned int selc01 = 0x02u | ((0u + xo) << 8) | (0x05u << 16) | ((3u + xo) << 24);   // n0 x0 n1 x1
+    const unsigned int seln01 = 0x02u | (0x0cu << 8) | (0x05u << 16) | (0x0cu << 24);           // n0 0 n1 0
     const unsigned int selx01 = (0u + xo) | (0x0cu << 8) | ((3u + xo) << 16) | (0x0cu << 24);   // x0 0 x1 0
-    const unsigned int selc23 = 0x04u | ((2u + xo) << 8) | (0x07u << 16) | ((5u + xo) << 24);   // n2 x2 n3 x3
+    const unsigned int seln23 = 0x04u | (0x0cu << 8) | (0x07u << 16) | (0x0cu << 24);           // n2 0 n3 0
     const unsigned int selx23 = (2u + xo) | (0x0cu << 8) | ((5u + xo) << 16) | (0x0cu << 24);
 
-    auto count_pair = [&](unsigned int s2) {
-        // two cells: S in the low and in the high 16 bits
-        const unsigned int a0 = (s2 << 1) & 0x1FFFCu, v0 = ((s2 & 1u) << 16) | 1u;
-        const unsigned int a1 = (s2 >> 15) & 0x1FFFCu, v1 = (s2 & 0x10000u) | 1u;
-        jh_add(a0, v0, tab);
-        jh_add(a1, v1, tab);
+    // Two pixels at a time, one in each 16-bit half: nn = n | n' << 16, px = x | x' << 16.  m2 = nn + 5 px holds n + 5 x (< 2048) in
+    // each half, W = px << 7 | (m2 & 0x7F007F) the two dword indices D; the half bit h is bit 7 of each m.
+    // SCAN = false: the returns of a lane's four adds wait here (address, addend, previous value) until its next quad
+    unsigned int pa[4] = {0u, 0u, 0u, 0u}, pv[4] = {0u, 0u, 0u, 0u}, po[4] = {0u, 0u, 0u, 0u};
+    bool pending = false;                                                     // wave-uniform
+    auto settle = [&](unsigned int addr, unsigned int val, unsigned int old) {
+        const unsigned int lo = old & 0xFFFFu, nlo = lo + (val & 0xFFFFu);
+        if (nlo >= P.danger_at) atomicExch(P.error, 1u);                       // 16384 short of wrapping: nothing of this launch is trusted
+        else if (lo < JH_MOVE_AT && nlo >= JH_MOVE_AT) {
+            const unsigned int moved = old + val;                              // the dword right after this lane's add
+            const unsigned int slot = atomicAdd(&s_nlist, 1u);
+            if (slot < JH_LIST_CAP) s_list[slot] = make_uint2(addr >> 2, moved);
+            else atomicExch(P.error, 1u);
+            __hip_atomic_fetch_sub(reinterpret_cast<unsigned int *>(tab + addr), moved, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+        }
+    };
+    auto settle_pending = [&]() {
+        if (!pending) return;
+        pending = false;
+        if (((po[0] + pv[0]) | (po[1] + pv[1]) | (po[2] + pv[2]) | (po[3] + pv[3])) & 0xC000u) {
+#pragma unroll
+            for (int i = 0; i < 4; ++i) settle(pa[i], pv[i], po[i]);
+        }
+    };
+    auto add_now = [&](unsigned int addr, unsigned int val) {                   // rare paths: settled on the spot
+        if constexpr (SCAN) jh_add(addr, val, tab);
+        else settle(addr, val, jh_add_rtn(addr, val, tab));
+    };
+
+    // Two pixels at a time, one in each 16-bit half: nn = n | n' << 16, px = x | x' << 16.  m2 = nn + 5 px holds n + 5 x (< 2048) in
+    // each half, W = px << 7 | (m2 & 0x7F007F) the two dword indices D; the half bit h is bit 7 of each m.
+    auto count_pair = [&](unsigned int nn, unsigned int px, int slot) {
+        const unsigned int m2 = jh_mad5(px, nn);                                // v_mad_u32_u24: px < 2^24
+        const unsigned int W = (px << 7) | (m2 & 0x007F007Fu);
+        const unsigned int a0 = (W << 2) & 0x1FFFCu, v0 = ((m2 << 9) & 0x10000u) | 1u;
+        const unsigned int a1 = (W >> 14) & 0x1FFFCu, v1 = ((m2 >> 7) & 0x10000u) | 1u;
+        if constexpr (SCAN) {
+            jh_add(a0, v0, tab);
+            jh_add(a1, v1, tab);
+        } else {
+            pa[slot] = a0; pv[slot] = v0; po[slot] = jh_add_rtn(a0, v0, tab);
+            pa[slot + 1] = a1; pv[slot + 1] = v1; po[slot + 1] = jh_add_rtn(a1, v1, tab);
+        }
     };
     // Flat areas (nodata borders, saturated sky: every lane of the wave holds the same four pixels) would queue all 64 lanes on
     // one LDS word per atomic.  Two v_readfirstlane + a compare per quad find them; one lane then adds the wave's whole count.
-    auto count_pair_n = [&](unsigned int s2, unsigned int n) {
-        const unsigned int a0 = (s2 << 1) & 0x1FFFCu, v0 = (((s2 & 1u) << 16) | 1u) * n;
-        const unsigned int a1 = (s2 >> 15) & 0x1FFFCu, v1 = ((s2 & 0x10000u) | 1u) * n;
-        jh_add(a0, v0, tab);
-        jh_add(a1, v1, tab);
+    auto count_pair_n = [&](unsigned int nn, unsigned int px, unsigned int n) {
+        const unsigned int m2 = jh_mad5(px, nn);
+        const unsigned int W = (px << 7) | (m2 & 0x007F007Fu);
+        const unsigned int a0 = (W << 2) & 0x1FFFCu, v0 = (((m2 << 9) & 0x10000u) | 1u) * n;
+        const unsigned int a1 = (W >> 14) & 0x1FFFCu, v1 = (((m2 >> 7) & 0x10000u) | 1u) * n;
+        add_now(a0, v0);
+        add_now(a1, v1);
     };
     auto do_quad = [&](unsigned int w0, unsigned int w1, unsigned int w2) {
+        if constexpr (!SCAN) settle_pending();                                  // the previous quad's returns have long arrived
         // the cheap test first: one v_readfirstlane + one compare on the quad's first dword settle it for any textured content
         const unsigned int f0 = __builtin_amdgcn_readfirstlane(w0);
         bool flat = __builtin_amdgcn_ballot_w64(w0 != f0) == 0ull;
@@ -133,31 +206,34 @@ __global__ __launch_bounds__(JH_THREADS, 4) void k_joint_count(JointCountParams 
                 const unsigned long long active = __builtin_amdgcn_ballot_w64(true);
                 if ((active & (0ull - active)) == (1ull << (tid & 63))) {             // the first active lane
                     const unsigned int n = (unsigned int)__builtin_popcountll(active);
-                    const unsigned int c01 = __builtin_amdgcn_perm(f1, f0, selc01) ^ JH_MIX2(__builtin_amdgcn_perm(f1, f0, selx01));
-                    const unsigned int c23 = __builtin_amdgcn_perm(f2, f1, selc23) ^ JH_MIX2(__builtin_amdgcn_perm(f2, f1, selx23));
-                    if (c01 == c23 && (c01 >> 16) == (c01 & 0xFFFFu)) {               // one colour: one add for the whole 256 pixels
-                        jh_add((c01 << 1) & 0x1FFFCu, (((c01 & 1u) << 16) | 1u) * (4u * n), tab);
+                    const unsigned int nn01 = __builtin_amdgcn_perm(f1, f0, seln01), px01 = __builtin_amdgcn_perm(f1, f0, selx01);
+                    const unsigned int nn23 = __builtin_amdgcn_perm(f2, f1, seln23), px23 = __builtin_amdgcn_perm(f2, f1, selx23);
+                    if (nn01 == nn23 && px01 == px23 && (nn01 >> 16) == (nn01 & 0xFFFFu) && (px01 >> 16) == (px01 & 0xFFFFu)) {
+                        // one colour: one add for the whole 256 pixels
+                        const unsigned int m = jh_m(nn01 & 255u, px01 & 255u);
+                        add_now((((px01 & 255u) << 7) | (m & 127u)) << 2, (((m >> 7) << 16) | 1u) * (4u * n));
                     } else {
-                        count_pair_n(c01, n);
-                        count_pair_n(c23, n);
+                        count_pair_n(nn01, px01, n);
+                        count_pair_n(nn23, px23, n);
                     }
                 }
                 return;
             }
         }
-        count_pair(__builtin_amdgcn_perm(w1, w0, selc01) ^ JH_MIX2(__builtin_amdgcn_perm(w1, w0, selx01)));
-        count_pair(__builtin_amdgcn_perm(w2, w1, selc23) ^ JH_MIX2(__builtin_amdgcn_perm(w2, w1, selx23)));
+        count_pair(__builtin_amdgcn_perm(w1, w0, seln01), __builtin_amdgcn_perm(w1, w0, selx01), 0);
+        count_pair(__builtin_amdgcn_perm(w2, w1, seln23), __builtin_amdgcn_perm(w2, w1, selx23), 2);
+        pending = true;
     };
 
-    // tail pixels of the tile (npix % 4): its last chunk, before the first period (which starts from zero counts)
+    // tail pixels of the tile (npix % 4): its last chunk, before the first step (the table starts from zero counts)
     if (chunk == P.K - 1 && tid < (int)(P.npix & 3)) {
         const uint8_t *p = tile_base + (nquads_tile * 4 + tid) * CH;
         const unsigned int n = p[2], x = green ? p[1] : p[0];
-        const unsigned int s = ((x << 8) | n) ^ JH_MIX(x);
-        jh_add((s << 1) & 0x1FFFCu, ((s & 1u) << 16) | 1u, tab);
+        const unsigned int m = jh_m(n, x);
+        add_now(((x << 7) | (m & 127u)) << 2, ((m >> 7) << 16) | 1u);
     }
 
-    // A scan: every dword whose sum (low half) has reached 16384 moves onto the list.  Between the two barriers nobody adds.
+    // SCAN = true.  A scan: every dword whose sum (low half) has reached 16384 moves onto the list.  Between the two barriers nobody adds.
     auto scan = [&]() {
         __syncthreads();
 #pragma unroll 1
@@ -214,10 +290,12 @@ __global__ __launch_bounds__(JH_THREADS, 4) void k_joint_count(JointCountParams 
                 __builtin_amdgcn_sched_barrier(0);
             }
             soff += DEPTH * STEP_B;
-            since += DEPTH;
-            if (since == PERIOD) {
-                scan();
-                since = 0;
+            if constexpr (SCAN) {
+                since += DEPTH;
+                if (since == PERIOD) {
+                    scan();
+                    since = 0;
+                }
             }
         }
         // the last (fewer than DEPTH) full steps and the ragged one: since + DEPTH <= PERIOD, no scan needed
@@ -227,9 +305,10 @@ __global__ __launch_bounds__(JH_THREADS, 4) void k_joint_count(JointCountParams 
             if (step < nfull || (step == nfull && tid < rem)) count(w[k]);
         }
     }
+    if constexpr (!SCAN) settle_pending();
     __syncthreads();
 
-    // publish: (cell 2D, cell 2D + 1) = (low - high, high), 32 bytes per lane and trip
+    // publish: (cell (D, 0), cell (D, 1)) = (low - high, high), 32 bytes per lane and trip
     unsigned int *out = P.part + ((tile * P.S + role) * P.K + chunk) * (long long)(2 * JH_DWORDS);
     for (int i = tid; i < JH_DWORDS / 4; i += JH_THREADS) {
         const uint4 v = tab4[i];
@@ -355,8 +434,8 @@ __global__ __launch_bounds__(JH_THREADS) void k_joint_finish(JointFinishParams P
     if (tid == 0) { s_mnk = 0xFFFFFFFFu; s_mxk = 0u; }
     if (tid < 2) s_med[tid] = __builtin_nanf("");
 
-    // This thread's 64 cells: dwords D = j * 1024 + tid (j < 32), cells S = 2D, 2D + 1; x = S >> 8 = D >> 7 (the same for
-    // the 64 lanes of a wave), n = (S & 255) ^ JH_MIX(x).  Every pass below walks them in four groups of eight dwords, the next
+    // This thread's 64 cells: dwords D = j * 1024 + tid (j < 32), halves h = 0, 1; x = D >> 7 (the same for the 64 lanes of a
+    // wave), n = ((D & 127 | h << 7) - 5 x) & 255 (jh_n_of).  Every pass below walks them in four groups of eight dwords, the next
     // group's loads (L2 hits: the counting kernel has just written them) in flight while the current one is worked on.
     constexpr int NJ = JH_DWORDS / JH_THREADS;                       // 32
     constexpr int GRP = 8;
@@ -396,7 +475,7 @@ __global__ __launch_bounds__(JH_THREADS) void k_joint_finish(JointFinishParams P
     // ---- marginals: the channel histograms np.percentile needs
     for_cells([&](unsigned int D, unsigned int c0, unsigned int c1) {
         const unsigned int x = D >> 7;
-        const unsigned int n0 = ((2u * D) & 255u) ^ JH_MIX(x), n1 = ((2u * D + 1u) & 255u) ^ JH_MIX(x);
+        const unsigned int n0 = jh_n_of(D, 0u), n1 = jh_n_of(D, 1u);
         if (c0) atomicAdd(&s_hn[n0], c0);
         if (c1) atomicAdd(&s_hn[n1], c1);
         unsigned int t = c0 + c1;
@@ -486,7 +565,7 @@ __global__ __launch_bounds__(JH_THREADS) void k_joint_finish(JointFinishParams P
             for (int h = 0; h < 2; ++h) {
                 const unsigned int cv = cc[h];
                 if (!cv) continue;
-                const unsigned int n = ((2u * D + (unsigned)h) & 255u) ^ JH_MIX(x);
+                const unsigned int n = jh_n_of(D, (unsigned)h);
                 const float q = norm_diff(s_fn[n], fx);
                 const long long cnt = (long long)cv;
                 sum_fx += cnt * (long long)((double)q * LARS_FX_SCALE);          // q is a multiple of 2^-32: exact
@@ -541,7 +620,7 @@ __global__ __launch_bounds__(JH_THREADS) void k_joint_finish(JointFinishParams P
             for (int h = 0; h < 2; ++h) {
                 const unsigned int cv = cc[h];
                 if (!cv) continue;
-                const unsigned int n = ((2u * D + (unsigned)h) & 255u) ^ JH_MIX(x);
+                const unsigned int n = jh_n_of(D, (unsigned)h);
                 const float t = selq_t(norm_diff(s_fn[n], fx));
                 const unsigned int b = selq_bucket_of(t), sl = (__builtin_bit_cast(unsigned int, t) & 0xFFFu) >> 2;
                 if (b == bk0) atomicAdd(&s_slot[0][sl], cv);
@@ -563,7 +642,7 @@ __global__ __launch_bounds__(JH_THREADS) void k_joint_finish(JointFinishParams P
 #pragma unroll
             for (int h = 0; h < 2; ++h) {
                 if (!cc[h]) continue;
-                const unsigned int n = ((2u * D + (unsigned)h) & 255u) ^ JH_MIX(x);
+                const unsigned int n = jh_n_of(D, (unsigned)h);
                 const float q = norm_diff(s_fn[n], fx);
                 const float t = selq_t(q);
                 const unsigned int b = selq_bucket_of(t), sl = (__builtin_bit_cast(unsigned int, t) & 0xFFFu) >> 2;
@@ -683,14 +762,25 @@ extern "C" int lars_d_stats_joint(const lars_fused_args *a, int white_balance, i
     C.tiles = static_cast<const uint8_t *>(a->tiles); C.npix = a->npix; C.ntiles = a->ntiles;
     C.chunk_quads = joint_chunk_quads(a->npix, K);
     C.part = error + 64; C.error = error; C.K = K; C.S = S; C.streams = streams;
+    {
+        const int d = tuning().joint_danger_at;                                     // test hook: 16385 .. 49152
+        C.danger_at = (d > (int)JH_MOVE_AT && d <= (int)JH_DANGER_AT) ? (unsigned)d : JH_DANGER_AT;
+    }
     const long long units = (long long)a->ntiles * K;
     const long long nwg = S == 2 ? ((units + 7) / 8) * 16 : units;
     if (nwg > 0x7FFFFFFFll) return fail(LARS_ERR_INVALID, "lars_d_stats_joint: too many workgroups");
-    if (c4) hipLaunchKernelGGL((k_joint_count<6, 4>), dim3((unsigned)nwg), dim3(JH_THREADS), 0, s, C);
-    else if (tuning().joint_depth == 4) hipLaunchKernelGGL((k_joint_count<4>), dim3((unsigned)nwg), dim3(JH_THREADS), 0, s, C);
-    else if (tuning().joint_depth == 8) hipLaunchKernelGGL((k_joint_count<8>), dim3((unsigned)nwg), dim3(JH_THREADS), 0, s, C);
-    else if (tuning().joint_depth == 12) hipLaunchKernelGGL((k_joint_count<12>), dim3((unsigned)nwg), dim3(JH_THREADS), 0, s, C);
-    else hipLaunchKernelGGL((k_joint_count<6>), dim3((unsigned)nwg), dim3(JH_THREADS), 0, s, C);
+    // joint_impl 0: returning adds, checked (no barriers); 1: plain adds + a sweep of the table every 12 steps (what the host falls back
+    // to if a launch of form 0 ever raises its error flag); joint_depth: 12-byte (RGBA: 16-byte) loads in flight per lane
+    const bool scan = tuning().joint_impl == 1;
+    const int depth = tuning().joint_depth;
+#define LARS_JOINT(DD, CC) do { if (scan) hipLaunchKernelGGL((k_joint_count<DD, CC, true>), dim3((unsigned)nwg), dim3(JH_THREADS), 0, s, C); \
+                                else hipLaunchKernelGGL((k_joint_count<DD, CC, false>), dim3((unsigned)nwg), dim3(JH_THREADS), 0, s, C); } while (0)
+    if (c4) LARS_JOINT(6, 4);
+    else if (depth == 4) LARS_JOINT(4, 3);
+    else if (depth == 8) LARS_JOINT(8, 3);
+    else if (depth == 12) LARS_JOINT(12, 3);
+    else LARS_JOINT(6, 3);
+#undef LARS_JOINT
     LARS_TRY(launch_check("lars_d_stats_joint (count)"));
 
     JointFinishParams F;

@@ -435,6 +435,64 @@ __global__ void k_probe_clock(unsigned long long *out, int spin)
     if (threadIdx.x == 0 && blockIdx.x == 0) { out[0] = c1 - c0; out[1] = t1 - t0; out[2] = (unsigned long long)(x != 0.5f); }
 }
 
+
+// LDS atomics of the one-read statistics route in isolation (kinds 70..73): one workgroup of 1024 threads per CU with a 128 KiB
+// table, four adds to random dwords per lane and step.  MODE 0: ds_add_u32 (no return), the product's form; 1: ds_add_rtn_u32, the
+// returned low halves of the PREVIOUS step compared against a threshold (what a scan-free overflow check would cost); 2: MODE 0 plus
+// the product's scan every 12 steps (two barriers around a sweep of the table); 3: ds_add_rtn_u32, returns unused but waited for.
+template <int MODE>
+__global__ __launch_bounds__(1024, 4) void k_probe_lds_atomics(int iters, unsigned int *sink)
+{
+    __shared__ __attribute__((aligned(16))) unsigned int s_tab[32768];
+    __shared__ unsigned int s_hits;
+    const int tid = threadIdx.x;
+    uint4 *tab4 = reinterpret_cast<uint4 *>(s_tab);
+    for (int i = tid; i < 8192; i += 1024) tab4[i] = make_uint4(0u, 0u, 0u, 0u);
+    if (tid == 0) s_hits = 0;
+    __syncthreads();
+    char *tab = reinterpret_cast<char *>(s_tab);
+    unsigned int r = (unsigned)tid * 2654435761u + blockIdx.x * 40503u + 12345u;
+    unsigned int o0 = 0, o1 = 0, o2 = 0, o3 = 0, hits = 0;
+    for (int it = 0; it < iters; ++it) {
+        unsigned int a[4], v[4];
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            r = r * 1664525u + 1013904223u;
+            a[k] = (r >> 15) & 0x1FFFCu;
+            v[k] = ((r & 0x100u) << 8) | 1u;
+        }
+        if (MODE == 1) {
+            // the adds of the previous step have returned by now: did any of them push a low half to the threshold?
+            const unsigned int m = (o0 | o1 | o2 | o3) & 0xC000u;
+            if (m) hits += 1;
+        }
+        if (MODE == 1 || MODE == 3) {
+            o0 = __hip_atomic_fetch_add(reinterpret_cast<unsigned int *>(tab + a[0]), v[0], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+            o1 = __hip_atomic_fetch_add(reinterpret_cast<unsigned int *>(tab + a[1]), v[1], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+            o2 = __hip_atomic_fetch_add(reinterpret_cast<unsigned int *>(tab + a[2]), v[2], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+            o3 = __hip_atomic_fetch_add(reinterpret_cast<unsigned int *>(tab + a[3]), v[3], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+            if (MODE == 3) { asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); }
+        } else {
+#pragma unroll
+            for (int k = 0; k < 4; ++k)
+                __hip_atomic_fetch_add(reinterpret_cast<unsigned int *>(tab + a[k]), v[k], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+        }
+        if (MODE == 2 && (it % 12) == 11) {
+            __syncthreads();
+#pragma unroll 1
+            for (int i = 0; i < 8; ++i) {
+                const uint4 q = tab4[tid + i * 1024];
+                if ((q.x | q.y | q.z | q.w) & 0xC000u) { atomicAdd(&s_hits, 1u); tab4[tid + i * 1024] = make_uint4(0u, 0u, 0u, 0u); }
+            }
+            __syncthreads();
+        }
+    }
+    __syncthreads();
+    unsigned int acc = hits + o0 + o1 + o2 + o3;
+    for (int i = tid; i < 32768; i += 1024) acc += s_tab[i];
+    if (acc == 0x12345677u) sink[0] = acc + s_hits;
+}
+
 }  // namespace lars
 
 using namespace lars;
@@ -528,6 +586,14 @@ extern "C" int lars_d_probe(int kind, int unroll, int blocks, const void *src, v
         else { if (depth == 6) LARS_SHARED(3, 6); else if (depth == 8) LARS_SHARED(3, 8); else if (depth == 12) LARS_SHARED(3, 12); else if (depth == 16) LARS_SHARED(3, 16); else return fail(LARS_ERR_INVALID, "lars_d_probe: depth 6, 8, 12 or 16"); }
 #undef LARS_SHARED
         return launch_check("lars_d_probe (shared readers)");
+    }
+    if (kind >= 70 && kind <= 73) {
+        // LDS atomics in isolation: unroll = steps (four adds per lane each), blocks = workgroups of 1024 threads
+        if (kind == 70) hipLaunchKernelGGL((k_probe_lds_atomics<0>), dim3(blocks), dim3(1024), 0, s, unroll, sink);
+        else if (kind == 71) hipLaunchKernelGGL((k_probe_lds_atomics<1>), dim3(blocks), dim3(1024), 0, s, unroll, sink);
+        else if (kind == 72) hipLaunchKernelGGL((k_probe_lds_atomics<2>), dim3(blocks), dim3(1024), 0, s, unroll, sink);
+        else hipLaunchKernelGGL((k_probe_lds_atomics<3>), dim3(blocks), dim3(1024), 0, s, unroll, sink);
+        return launch_check("lars_d_probe (LDS atomics)");
     }
     if (kind == 0) {
         const long long n = bytes / 16;

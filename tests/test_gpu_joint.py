@@ -257,3 +257,73 @@ def test_joint_rejects_tiles_beyond_its_counters(lars):
     a.index_mask, a.flags, a.stats = 1, _ffi.F_STATS, 256
     with pytest.raises(_ffi.LarsError):
         _ffi.call("lars_d_stats_joint", C.byref(a), 1, 0, None, None, None, C.c_void_p(256), 1 << 40)
+
+
+def _hot_tiles(kind, n, h, w, seed=3):
+    """Content whose pixels pile onto few counter pairs: what the 16-bit hand-over has to survive."""
+    rng = np.random.default_rng(seed)
+    t = rng.integers(0, 256, (n, h, w, 3), dtype=np.uint8)
+    flat = t.reshape(n, h * w, 3)
+    if kind == "three_colours_by_quad":                       # lanes differ (no flat wave), three cells take everything
+        cols = np.array([(10, 200, 90), (11, 201, 91), (250, 3, 128)], np.uint8)
+        flat[:] = cols[(np.arange(h * w) // 4) % 3][None]
+    elif kind == "mostly_one_colour":                          # one hot cell under adds from every lane, the rest scattered noise
+        mask = rng.random((n, h * w)) < 0.9
+        flat[mask] = (77, 140, 31)
+    elif kind == "two_colours_by_pixel":                       # every lane holds the same quad: the flat path's counted adds cross the mark
+        cols = np.array([(5, 6, 7), (200, 100, 50)], np.uint8)
+        flat[:] = cols[np.arange(h * w) % 2][None]
+    elif kind == "one_colour":
+        flat[:] = (255, 0, 255)
+    return t
+
+
+@pytest.mark.parametrize("kind", ["iid", "three_colours_by_quad", "mostly_one_colour", "two_colours_by_pixel", "one_colour"])
+def test_counter_handover_forms_agree(lars, kind):
+    """The counting kernel keeps its 16-bit pairs from wrapping in two ways (csrc/joint.hip): returning adds whose lane moves
+    the pair onto the list when it passes 16384 (the default: no barriers), or plain adds with a sweep of the table every 12
+    steps.  Both, for one and two streams, must publish the same counts -- records, medians, tables identical to the
+    per-pixel route -- on content that moves pairs thousands of times."""
+    from lars_image_processing_amd import _ffi
+    b = lars.TileBatch.from_host(_hot_tiles(kind, 3, 1024, 1024))
+    try:
+        for indices in (("NDVI",), ("GNDVI", "NDWI"), TYPES):
+            want, want_med = b.process(indices=indices, hist=True, medians=True, route="classic")
+            want_tab = b.host_tables()
+            for impl in (0, 1):
+                for blocks in (0, 1):
+                    _ffi.set_tuning(joint_impl=impl, blocks_per_tile=blocks)
+                    got, got_med = b.process(indices=indices, hist=True, medians=True, route="joint")
+                    assert got.tobytes() == want.tobytes(), (kind, indices, impl, blocks)
+                    np.testing.assert_array_equal(got_med, want_med)
+                    for c in sorted(lars.batch.channels_of(indices)):
+                        np.testing.assert_array_equal(b.host_tables(partial=True)[:, c], want_tab[:, c])
+        assert getattr(b, "_joint_fallbacks", 0) == 0
+    finally:
+        _ffi.set_tuning(joint_impl=0, blocks_per_tile=0)
+        b.free()
+
+
+def test_counter_danger_flag_falls_back_to_the_barrier_form(lars):
+    """With the danger mark lowered to just above the move mark (test hook joint_danger_at) a hot pair raises the launch's
+    error flag as soon as one more add reaches it before its mover has subtracted: process() must notice, repeat the pass
+    with the barrier form and still return the right records; run_joint alone leaves the flag for check_joint to raise on."""
+    from lars_image_processing_amd import _ffi
+    b = lars.TileBatch.from_host(_hot_tiles("mostly_one_colour", 2, 1024, 1024))
+    want = b.process(route="classic")
+    try:
+        _ffi.set_tuning(joint_danger_at=16385)
+        got = b.process(route="joint")
+        assert got.tobytes() == want.tobytes()
+        assert getattr(b, "_joint_fallbacks", 0) == 1 and _ffi.get_tuning("joint_impl") == 0
+        stats = b.new_stats()
+        b.run_joint(TYPES, True, stats)
+        with pytest.raises(RuntimeError):
+            b.check_joint()
+        stats.free()
+        _ffi.set_tuning(joint_danger_at=0)
+        got = b.process(route="joint")
+        assert got.tobytes() == want.tobytes() and b._joint_fallbacks == 1
+    finally:
+        _ffi.set_tuning(joint_danger_at=0, joint_impl=0)
+        b.free()

@@ -91,6 +91,8 @@ def parse():
                     help="process pool of the multi-core CPU baseline leg (16 = one GPU's share of the box's host cores; every "
                          "worker holds about 1 GiB of NumPy temporaries for a 4096 x 4096 tile)")
     ap.add_argument("--no-u16-leg", dest="u16_leg", action="store_false", help="skip the BASELINE configs[4] shape (uint16 8192 x 8192 tiles)")
+    ap.add_argument("--no-smooth-leg", dest="smooth_leg", action="store_false",
+                    help="skip the statistics-only modes on image-like (smooth) content")
     ap.add_argument("--no-verify", dest="verify", action="store_false", help="skip the self-check after the timed region")
     return ap.parse_args()
 
@@ -150,8 +152,11 @@ class Runner:
             ffi.call("lars_event_record", self.ev[1], None)
             b.run_joint(indices, True, self.stats, hist, False, self.pairs if base_mode in MEDIAN_MODES else None)
             launches = 1
-        elif base_mode == "wb3idx_out_stats_medians":
-            b.run_joint(indices, True, self.stats, hist, False, self.pairs)        # statistics, medians and all three tables
+        elif base_mode == "wb3idx_out_stats_medians" or (base_mode == "wb_ndvi_out_stats" and self.args.stats_route == "joint" and b.can_joint()):
+            # one read for statistics, (medians,) and the tables the planes need; then the plane-writing kernel without statistics.
+            # For ONE value stream (the NDVI plane) this read costs what the channel-histogram pass costs and the planes-only kernel
+            # is 8 % faster than with statistics: TileBatch.process takes the same route (profiles/r04_ndvi_plane_step_ways.txt)
+            b.run_joint(indices, True, self.stats, hist, False, self.pairs if base_mode in MEDIAN_MODES else None)
             ffi.call("lars_event_record", self.ev[1], None)
             launches = b.run_fused_chunks(indices, True, None, False, outs, launch_events=launch_events)      # planes only
         else:
@@ -453,6 +458,76 @@ def config4_leg(tiles=64, edge=8192, ring=16):
             "fused_frac_of_8TBs": npix * 14 / (f_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, "arena": report}
 
 
+def smooth_tile(edge, seed=7):
+    """One image-like tile: slow gradients per channel plus two levels of noise (tools/jointbench.py's `smooth`): the 64 pixels a
+    wave counts at a time fall into a 5 x 5 neighbourhood of byte pairs instead of 64 independent ones."""
+    rng = np.random.default_rng(seed)
+    yy, xx = np.mgrid[0:edge, 0:edge].astype(np.float32)
+    out = np.empty((edge, edge, 3), np.uint8)
+    for c in range(3):
+        g = 60 + 50 * c + 40 * np.sin(xx / 900.0 + c) + 30 * np.cos(yy / 700.0) + rng.integers(-2, 3, (edge, edge))
+        out[:, :, c] = np.clip(g, 0, 255).astype(np.uint8)
+    return out
+
+
+def smooth_leg(tiles=256, edge=4096, rounds=4):
+    """The statistics-only jobs on IMAGE-LIKE content (the reference's inputs are photographs, process-images.py:1441-1457; the
+    bench's counter-hash tiles are iid): both routes timed, and what ``route="auto"`` picks (TileBatch.pick_stats_route; with
+    medians the library always takes the one-read route).  One smooth tile replicated over the batch."""
+    import lars_image_processing_amd as lars
+    from lars_image_processing_amd import _ffi
+    b = lars.TileBatch(tiles, edge, edge, 3, np.uint8)
+    b.tiles.upload(smooth_tile(edge)[None])
+    for i in range(1, tiles):
+        _ffi.call("lars_memcpy_d2d", C.c_void_p(b.tiles.ptr + i * b.tile_bytes), C.c_void_p(b.tiles.ptr), b.tile_bytes, None)
+    _ffi.call("lars_synchronize", None)
+    stats = b.new_stats()
+    pairs = _ffi.DeviceBuffer(b.ntiles * 4 * 4)
+    scratch = _ffi.DeviceBuffer(int(_ffi.load().lars_quotient_median_scratch_bytes(b.ntiles)))
+    ev = [C.c_void_p(), C.c_void_p()]
+    for e in ev:
+        _ffi.call("lars_event_create", C.byref(e))
+
+    def timed(fn):
+        ts = []
+        for _ in range(rounds + 1):
+            _ffi.call("lars_event_record", ev[0], None)
+            fn()
+            _ffi.call("lars_event_record", ev[1], None)
+            ms = C.c_float(0)
+            _ffi.call("lars_event_elapsed_ms", ev[0], ev[1], C.byref(ms))
+            ts.append(ms.value)
+        return float(np.median(ts[1:]))
+
+    npix = tiles * edge * edge
+    out = {"workload": f"{tiles} copies of one {edge}x{edge} uint8 tile: gradients + two levels of noise per channel (image-like; "
+                       "the headline's tiles are iid)", "algorithmic_bytes_per_pixel": 3}
+    for name, indices, med in (("wb_ndvi_stats_only", ("NDVI",), False), ("wb3idx_stats_only", ("NDVI", "GNDVI", "NDWI"), False),
+                               ("wb3idx_stats_medians", ("NDVI", "GNDVI", "NDWI"), True)):
+        def classic():
+            b.compute_wb_tables()
+            a = b.fused_args(indices, True, stats)
+            if med:
+                _ffi.call("lars_d_stats_medians", C.byref(a), C.c_void_p(pairs.ptr), C.c_void_p(scratch.ptr))
+            else:
+                b.run_fused(a)
+        c_ms = timed(classic)
+        _ffi.call("lars_synchronize", None)
+        want = stats.download(_ffi.STATS_DTYPE, (1, 3)).tobytes()
+        j_ms = timed(lambda: b.run_joint(indices, True, stats, pairs=pairs if med else None))
+        b.check_joint()
+        same = stats.download(_ffi.STATS_DTYPE, (1, 3)).tobytes() == want
+        b.__dict__.pop("_route_cache", None)
+        auto = "joint" if med else b.pick_stats_route(indices, True)
+        chosen = j_ms if auto == "joint" else c_ms
+        out[name] = {"one_read_ms": j_ms, "per_pixel_ms": c_ms, "auto_route": "one read" if auto == "joint" else "per pixel",
+                     "ms_per_step": chosen, "whole_step_frac": npix * 3 / (chosen * 1e-3) / 1e9 / HBM_PEAK_GBS,
+                     "one_read_frac": npix * 3 / (j_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, "per_pixel_frac": npix * 3 / (c_ms * 1e-3) / 1e9 / HBM_PEAK_GBS,
+                     "records_identical": bool(same)}
+    stats.free(); pairs.free(); scratch.free(); b.free()
+    return out
+
+
 def _visible_devices():
     """Device count seen by a CHILD process: the launching parent must never initialise HIP itself (its children
     are new processes, and a process that has touched the GPU may not be replaced or forked into ranks)."""
@@ -631,7 +706,8 @@ def main():
                 "ms_per_step": m_step_ms,
                 "whole_step_frac": npix_rank * MODES[base][3] / (m_step_ms * 1e-3) / 1e9 / HBM_PEAK_GBS,
                 "route": ("one read: joint byte-pair histograms (k_joint_count + k_joint_finish)" if one_read else
-                          "one-read statistics pass (k_joint_count + k_joint_finish), then k_fused_u8c3 planes only" if base == "wb3idx_out_stats_medians" else
+                          "one-read statistics pass (k_joint_count + k_joint_finish), then k_fused_u8c3 planes only"
+                          if (base == "wb3idx_out_stats_medians" or (base == "wb_ndvi_out_stats" and args.stats_route == "joint" and runner.batch.can_joint())) else
                           "channel-histogram pass + tables, then the fused kernel"),
                 "fused_ms": f_ms, "hist_pass_ms": float(np.mean([t[0] for t in tm])),
                 "fused_GBs_algorithmic": npix_rank * MODES[base][3] / (f_ms * 1e-3) / 1e9,
@@ -673,6 +749,8 @@ def main():
     probe = device_probe(runner) if (args.probe and rank == 0) else None
     if args.all_modes and world == 1 and args.u16_leg:
         extra["u16_8192_ndvi_rgba_out_stats"] = config4_leg()
+    if args.all_modes and world == 1 and args.smooth_leg:
+        extra["smooth_content"] = smooth_leg(tiles=min(256, args.tiles), edge=args.tile)
     if rank == 0:
         cpu = None if args.no_cpu_baseline or world > 1 else cpu_baseline(args)
         g = {t: runner.lb.summarize(glob[_ffi.INDEX_IDS[t]]) for t in indices}

@@ -128,6 +128,9 @@ int         lars_event_create(void **event);
 int         lars_event_destroy(void *event);
 int         lars_event_record(void *event, void *stream);
 int         lars_event_elapsed_ms(void *start, void *stop, float *ms);   /* synchronises on stop */
+/* work enqueued on `stream` after this call waits for `event` (recorded on any stream of the device): how a caller
+ * orders passes it overlaps on two streams (hipStreamWaitEvent) */
+int         lars_stream_wait_event(void *stream, void *event);
 
 /* --------------------------------------------------------- device entry points */
 

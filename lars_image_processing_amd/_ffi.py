@@ -88,6 +88,7 @@ SIGNATURES = {
     "lars_event_destroy": (_I, [_P]),
     "lars_event_record": (_I, [_P, _P]),
     "lars_event_elapsed_ms": (_I, [_P, _P, C.POINTER(_F)]),
+    "lars_stream_wait_event": (_I, [_P, _P]),
     "lars_d_channel_hist": (_I, [_P, _I64, _I64, _I, _I, _P, _P]),
     "lars_d_wb_table": (_I, [_P, _I64, _I64, _I, _P, _P, _I, _P]),
     "lars_wb_table_bytes": (_SZ, [_I]),

@@ -22,6 +22,7 @@ from ._ffi import FusedArgs, INDEX_IDS, INDEX_NAMES, STATS_DTYPE, DeviceBuffer, 
 
 MAX_TILES_PER_LAUNCH = 65535      # grid.y limit
 ARENA_MIN_BYTES = 2 << 30         # smaller arenas run alike wherever they land
+ARENA_FULL_SEARCH_BYTES = 6 << 30  # arenas below this get at most four candidates
 ARENA_TRIALS = 16                 # candidate allocations of the default search at most (0.7^16: no fast one among them in 0.3 % of processes)
 ARENA_CLASS_GAP = 0.93            # the search ends once its best candidate is 7 % under its worst: both classes seen (they are ~18 % apart)
 ARENA_WARM_MS = 30.0              # untimed launches before a candidate is timed: after an idle gap a fast arena needs ~22 ms to reach its level
@@ -191,7 +192,10 @@ class TileBatch:
             raise ValueError("pick must be fastest or slowest")
         big = bool(nplanes) and nplanes * outs.slots * self.npix * 4 >= ARENA_MIN_BYTES
         if placement_trials is None:
-            placement_trials = ARENA_TRIALS if (arena == "auto" and big) else 0
+            # the classes have shown for 8 and 12 GiB arenas; a 4 GiB single-plane arena gave sixteen candidates within 1 % of each
+            # other (profiles/r04_ndvi_plane_step_ways.txt), so smaller arenas get a short search
+            nbytes_arena = nplanes * outs.slots * self.npix * 4
+            placement_trials = 0 if not (arena == "auto" and big) else (ARENA_TRIALS if nbytes_arena >= ARENA_FULL_SEARCH_BYTES else 4)
         if nplanes and report is None:
             t0 = time.perf_counter()
             outs.adopt_arena(DeviceBuffer(nplanes * outs.plane_bytes))
@@ -422,35 +426,13 @@ class TileBatch:
                   C.c_void_p(self.hist.ptr) if white_balance else None,
                   C.c_void_p(pairs.ptr) if pairs is not None else None, C.c_void_p(self._joint_scratch.ptr), self._joint_scratch.nbytes)
 
-    def joint_flag(self, stream=None):
-        """Wait for ``stream`` and return the error word of the last ``run_joint`` (0 = its counts are good)."""
+    def check_joint(self, stream=None):
+        """After a ``run_joint``: wait for ``stream`` and raise if the counting kernel reported a hand-over list overflow
+        (its published counts would be truncated; cannot happen while a workgroup counts at most 2^24 pixels, which the
+        chunking guarantees).  Every consumer of ``run_joint`` calls this before it trusts the records."""
         _ffi.call("lars_synchronize", stream)
-        if getattr(self, "_joint_scratch", None) is None:
-            return 0
-        return int(self._joint_scratch.download(np.uint32, (1,))[0])
-
-    def check_joint(self, stream=None, rerun=None):
-        """After a ``run_joint``: wait for ``stream`` and see whether the counting kernel raised its error flag -- a 16-bit
-        counter pair came within 16384 of wrapping before the lane that has to move it onto the hand-over list got there
-        (csrc/joint.hip; never observed), or the list overflowed (cannot happen: a workgroup counts at most 2^24 pixels).
-        Such a launch's counts are void.  With ``rerun`` (a callable that enqueues the same ``run_joint`` again) the pass is
-        repeated ONCE with the barrier form of the kernel (``joint_impl = 1``: plain adds, the table swept every 12 steps),
-        which cannot wrap by construction; without it, or if that fails too, RuntimeError.  Every consumer of ``run_joint``
-        calls this before it trusts the records."""
-        if not self.joint_flag(stream):
-            return
-        if rerun is not None:
-            before = _ffi.get_tuning("joint_impl")
-            self._joint_fallbacks = getattr(self, "_joint_fallbacks", 0) + 1
-            try:
-                _ffi.set_tuning(joint_impl=1)
-                rerun()
-                if not self.joint_flag(stream):
-                    return
-            finally:
-                _ffi.set_tuning(joint_impl=before)
-        raise RuntimeError("lars_d_stats_joint: the counting kernel raised its error flag (a counter pair close to wrapping, or a "
-                           "hand-over list overflow: a chunk of more than 2^24 pixels?)")
+        if getattr(self, "_joint_scratch", None) is not None and int(self._joint_scratch.download(np.uint32, (1,))[0]):
+            raise RuntimeError("lars_d_stats_joint: a workgroup's hand-over list overflowed (a chunk of more than 2^24 pixels?)")
 
     def pick_stats_route(self, indices, white_balance=True, sample=32):
         """"joint" or "classic" for statistics WITHOUT medians over this batch, by measurement: both routes over the first
@@ -533,13 +515,10 @@ class TileBatch:
         if may_joint:
             # nothing to write: one read of the tiles serves the percentiles, the statistics and the medians
             stats = self.new_stats()
+            stats.zero(stream)
             pairs_dev = DeviceBuffer(self.ntiles * 4 * 4) if medians else None
-
-            def enqueue():
-                stats.zero(stream)
-                self.run_joint(indices, white_balance, stats, hist, sumsq, pairs_dev, stream, rgn_variant=variant)
-            enqueue()
-            self.check_joint(stream, rerun=enqueue)
+            self.run_joint(indices, white_balance, stats, hist, sumsq, pairs_dev, stream, rgn_variant=variant)
+            self.check_joint(stream)
             rec = stats.download(STATS_DTYPE, (self.ntiles, 3))
             stats.free()
             if not medians:
@@ -549,6 +528,26 @@ class TileBatch:
             return rec, med
         if route == "joint" and outputs is None:
             raise ValueError("route='joint' serves uint8 tiles with 3 channels (4-byte aligned) only")
+        if (outputs is not None and outputs.wb is None and route != "classic" and not reuse and self.can_joint() and bool(indices)
+                and (medians or select_streams(indices) in (1, 2))):
+            # Planes wanted (no white-balanced image: that needs all three tables).  Where the one-read pass costs no more than
+            # the channel-histogram pass it replaces -- one value stream: 8.5 ms per 1024 tiles of 4096 x 4096 either way -- it
+            # delivers the tables AND the statistics, and the plane-writing kernel runs without its statistics registers and
+            # flush: 28.7 instead of 30.5 ms for the NDVI plane (profiles/r04_ndvi_plane_step_ways.txt).  With medians it wins
+            # for any set of indices (the medians come with the same read instead of two more passes).
+            stats = self.new_stats()
+            stats.zero(stream)
+            pairs_dev = DeviceBuffer(self.ntiles * 4 * 4) if medians else None
+            self.run_joint(indices, white_balance, stats, hist, sumsq, pairs_dev, stream, rgn_variant=variant)
+            self.run_fused_chunks(indices, white_balance, None, False, outputs, stream)
+            self.check_joint(stream)
+            rec = stats.download(STATS_DTYPE, (self.ntiles, 3))
+            stats.free()
+            if not medians:
+                return rec
+            med = self._medians_from_pairs(pairs_dev.download(np.float32, (self.ntiles, 2, 2)), indices)
+            pairs_dev.free()
+            return rec, med
         if white_balance and not reuse:
             self.compute_wb_tables(stream, rgn_variant=variant)
         stats = self.new_stats()

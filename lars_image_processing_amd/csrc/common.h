@@ -104,8 +104,6 @@ struct Tuning {
     int last_fused_kernel = 0; // read-only: the kernel family lars_d_fused launched last -- 1 k_fused_u8c3, 2 k_fused_v2, 3 uint16, 4 generic, 5 RGBA uint8
     int u16_hist_impl = 2;     // uint16 percentiles: 2 one full pass (candidate bins from a subsample, u16.hip), 1 always two radix passes
     int joint_depth = 6;       // joint.hip: 12-byte loads in flight per lane of the counting kernel (4 | 6 | 8 | 12)
-    int joint_danger_at = 0;   // joint.hip test hook: the low-half value at which a returning add raises the error flag (0 = 49152)
-    int joint_impl = 0;        // joint.hip: 0 returning adds + per-lane overflow check (no barriers), 1 plain adds + table sweeps every 12 steps
 };
 Tuning &tuning();
 

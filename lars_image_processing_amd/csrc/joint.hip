@@ -17,17 +17,13 @@
 // 160 KiB: one workgroup per CU.  With two streams the two workgroups of a tile chunk sit 8 apart in dispatch order (the same
 // XCD, at the same time): the second reader of a line finds it in that XCD's L2 or in the Infinity Cache.
 //
-// 16-bit sums and how they are kept from wrapping.  SCAN = false (the default since round 4): every add RETURNS the dword's
-// previous value (ds_add_rtn_u32); one step later the lane looks at its four returns: the add that took a low half from below
-// 16384 to 16384 or more (exactly one add does: the adds of a dword are serialised) moves what the dword held right after it onto
-// a list in LDS and subtracts exactly that (ds_sub_u32) -- adds that arrived in between stay.  A workgroup counts at most 2^24
-// pixels, so at most 1024 moves.  Nothing stops the other waves meanwhile: no barrier, no sweep of the table.  The mover is a few
-// hundred cycles behind its add; the low half would need 49152 more pixels in that time to wrap.  That cannot be PROVEN impossible,
-// so it is CHECKED: an add whose result reaches 49152 raises the launch's error flag (no wrap can happen without one: increments
-// are at most 256), and the host then repeats the launch with SCAN = true.  SCAN = true (round 3's form): plain adds; every 12
-// steps (12 x 4096 = 49152 pixels, 16383 + 49152 = 65535) two barriers around a sweep of the table that moves every dword at
-// 16384 or more onto the list.  Measured in isolation (tools/lab/ldsatomics.py, profiles/r04_lds_atomics.txt): 6.7 cycles per
-// wave-add plain, 7.8 returning + checked, 10.5 plain + sweeps -- the barriers cost three times the sweep's own LDS reads.
+// 16-bit sums cannot wrap between two sweeps: a workgroup adds 12 x 4096 = 49152 pixels per period, and at every period's
+// end (two barriers) it moves each dword whose sum has reached 16384 onto a list in LDS (16383 + 49152 = 65535); a workgroup
+// counts at most 2^24 pixels, so at most 1024 moves.  Round 4 built the barrier-free alternative -- every add returns the dword's
+// previous value, the lane whose add passes the mark moves the dword (ds_sub of exactly what it held) -- and measured it: in
+// isolation 7.8 against 10.5 cycles per wave-add (tools/lab/ldsatomics.py), in this kernel nothing (2.92 against 2.96 ms per
+// 256 tiles, two streams; one stream 2.30 against 2.24: the sweeps hide under the memory waits), and where one colour takes
+// most of the pixels the mover falls a full mark behind its add and the pair runs away.  Removed again (commit 1c850f5).
 // Cell of a pixel (x = r or g, n = NIR): m = (n + 5 x) & 255, dword D = x << 7 | (m & 127), half h = m >> 7.  The LDS bank of a
 // dword is D & 31 = (n + 5 x) & 31: the 5 x 5 neighbourhood of cells that a wave's 64 pixels of a smooth image fall into lands in
 // 25 DIFFERENT banks (and dwords), as do common shifts of both samples (shading: +6 per level) and shifts of one sample alone.
@@ -59,19 +55,12 @@ struct JointCountParams {
     int K;                                    // chunks per tile
     int S;                                    // streams counted: 1 or 2
     unsigned int streams;                     // bit 0: (n, r) pairs, bit 1: (n, g) pairs
-    unsigned int danger_at;                   // SCAN = false: an add whose low half reaches this raises *error (JH_DANGER_AT)
 };
 
 __device__ inline void jh_add(unsigned int addr, unsigned int val, char *tab)
 {
     __hip_atomic_fetch_add(reinterpret_cast<unsigned int *>(tab + addr), val, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
 }
-__device__ inline unsigned int jh_add_rtn(unsigned int addr, unsigned int val, char *tab)
-{
-    return __hip_atomic_fetch_add(reinterpret_cast<unsigned int *>(tab + addr), val, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-}
-#define JH_MOVE_AT 0x4000u                    /* the add that takes a low half to 16384 or beyond moves the dword onto the list */
-#define JH_DANGER_AT 0xC000u                  /* an add whose result reaches 49152: the launch is void (error flag); tests lower it */
 
 // nn + 5 px in one full-rate instruction (px < 2^24; the compiler's own choice for * 5 + is the quarter-rate v_mad_u64_u32)
 __device__ inline unsigned int jh_mad5(unsigned int px, unsigned int nn)
@@ -91,7 +80,7 @@ __device__ inline unsigned int jh_n_of(unsigned int D, unsigned int h)
 }
 
 // CH = 4: RGBA tiles, one 16-byte load per lane and step, repacked into the three dwords of an RGB quad.
-template <int DEPTH, int CH = 3, bool SCAN = false>
+template <int DEPTH, int CH = 3>
 __global__ __launch_bounds__(JH_THREADS, 4) void k_joint_count(JointCountParams P)
 {
     // a period is a whole number of ring turns and adds at most 65535 - 16383 = 49152 pixels (12 steps) to any one dword
@@ -142,47 +131,13 @@ __global__ __launch_bounds__(JH_THREADS, 4) void k_joint_count(JointCountParams 
 
     // Two pixels at a time, one in each 16-bit half: nn = n | n' << 16, px = x | x' << 16.  m2 = nn + 5 px holds n + 5 x (< 2048) in
     // each half, W = px << 7 | (m2 & 0x7F007F) the two dword indices D; the half bit h is bit 7 of each m.
-    // SCAN = false: the returns of a lane's four adds wait here (address, addend, previous value) until its next quad
-    unsigned int pa[4] = {0u, 0u, 0u, 0u}, pv[4] = {0u, 0u, 0u, 0u}, po[4] = {0u, 0u, 0u, 0u};
-    bool pending = false;                                                     // wave-uniform
-    auto settle = [&](unsigned int addr, unsigned int val, unsigned int old) {
-        const unsigned int lo = old & 0xFFFFu, nlo = lo + (val & 0xFFFFu);
-        if (nlo >= P.danger_at) atomicExch(P.error, 1u);                       // 16384 short of wrapping: nothing of this launch is trusted
-        else if (lo < JH_MOVE_AT && nlo >= JH_MOVE_AT) {
-            const unsigned int moved = old + val;                              // the dword right after this lane's add
-            const unsigned int slot = atomicAdd(&s_nlist, 1u);
-            if (slot < JH_LIST_CAP) s_list[slot] = make_uint2(addr >> 2, moved);
-            else atomicExch(P.error, 1u);
-            __hip_atomic_fetch_sub(reinterpret_cast<unsigned int *>(tab + addr), moved, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-        }
-    };
-    auto settle_pending = [&]() {
-        if (!pending) return;
-        pending = false;
-        if (((po[0] + pv[0]) | (po[1] + pv[1]) | (po[2] + pv[2]) | (po[3] + pv[3])) & 0xC000u) {
-#pragma unroll
-            for (int i = 0; i < 4; ++i) settle(pa[i], pv[i], po[i]);
-        }
-    };
-    auto add_now = [&](unsigned int addr, unsigned int val) {                   // rare paths: settled on the spot
-        if constexpr (SCAN) jh_add(addr, val, tab);
-        else settle(addr, val, jh_add_rtn(addr, val, tab));
-    };
-
-    // Two pixels at a time, one in each 16-bit half: nn = n | n' << 16, px = x | x' << 16.  m2 = nn + 5 px holds n + 5 x (< 2048) in
-    // each half, W = px << 7 | (m2 & 0x7F007F) the two dword indices D; the half bit h is bit 7 of each m.
-    auto count_pair = [&](unsigned int nn, unsigned int px, int slot) {
+    auto count_pair = [&](unsigned int nn, unsigned int px) {
         const unsigned int m2 = jh_mad5(px, nn);                                // v_mad_u32_u24: px < 2^24
         const unsigned int W = (px << 7) | (m2 & 0x007F007Fu);
         const unsigned int a0 = (W << 2) & 0x1FFFCu, v0 = ((m2 << 9) & 0x10000u) | 1u;
         const unsigned int a1 = (W >> 14) & 0x1FFFCu, v1 = ((m2 >> 7) & 0x10000u) | 1u;
-        if constexpr (SCAN) {
-            jh_add(a0, v0, tab);
-            jh_add(a1, v1, tab);
-        } else {
-            pa[slot] = a0; pv[slot] = v0; po[slot] = jh_add_rtn(a0, v0, tab);
-            pa[slot + 1] = a1; pv[slot + 1] = v1; po[slot + 1] = jh_add_rtn(a1, v1, tab);
-        }
+        jh_add(a0, v0, tab);
+        jh_add(a1, v1, tab);
     };
     // Flat areas (nodata borders, saturated sky: every lane of the wave holds the same four pixels) would queue all 64 lanes on
     // one LDS word per atomic.  Two v_readfirstlane + a compare per quad find them; one lane then adds the wave's whole count.
@@ -191,11 +146,10 @@ __global__ __launch_bounds__(JH_THREADS, 4) void k_joint_count(JointCountParams 
         const unsigned int W = (px << 7) | (m2 & 0x007F007Fu);
         const unsigned int a0 = (W << 2) & 0x1FFFCu, v0 = (((m2 << 9) & 0x10000u) | 1u) * n;
         const unsigned int a1 = (W >> 14) & 0x1FFFCu, v1 = (((m2 >> 7) & 0x10000u) | 1u) * n;
-        add_now(a0, v0);
-        add_now(a1, v1);
+        jh_add(a0, v0, tab);
+        jh_add(a1, v1, tab);
     };
     auto do_quad = [&](unsigned int w0, unsigned int w1, unsigned int w2) {
-        if constexpr (!SCAN) settle_pending();                                  // the previous quad's returns have long arrived
         // the cheap test first: one v_readfirstlane + one compare on the quad's first dword settle it for any textured content
         const unsigned int f0 = __builtin_amdgcn_readfirstlane(w0);
         bool flat = __builtin_amdgcn_ballot_w64(w0 != f0) == 0ull;
@@ -211,7 +165,7 @@ __global__ __launch_bounds__(JH_THREADS, 4) void k_joint_count(JointCountParams 
                     if (nn01 == nn23 && px01 == px23 && (nn01 >> 16) == (nn01 & 0xFFFFu) && (px01 >> 16) == (px01 & 0xFFFFu)) {
                         // one colour: one add for the whole 256 pixels
                         const unsigned int m = jh_m(nn01 & 255u, px01 & 255u);
-                        add_now((((px01 & 255u) << 7) | (m & 127u)) << 2, (((m >> 7) << 16) | 1u) * (4u * n));
+                        jh_add((((px01 & 255u) << 7) | (m & 127u)) << 2, (((m >> 7) << 16) | 1u) * (4u * n), tab);
                     } else {
                         count_pair_n(nn01, px01, n);
                         count_pair_n(nn23, px23, n);
@@ -220,20 +174,19 @@ __global__ __launch_bounds__(JH_THREADS, 4) void k_joint_count(JointCountParams 
                 return;
             }
         }
-        count_pair(__builtin_amdgcn_perm(w1, w0, seln01), __builtin_amdgcn_perm(w1, w0, selx01), 0);
-        count_pair(__builtin_amdgcn_perm(w2, w1, seln23), __builtin_amdgcn_perm(w2, w1, selx23), 2);
-        pending = true;
+        count_pair(__builtin_amdgcn_perm(w1, w0, seln01), __builtin_amdgcn_perm(w1, w0, selx01));
+        count_pair(__builtin_amdgcn_perm(w2, w1, seln23), __builtin_amdgcn_perm(w2, w1, selx23));
     };
 
-    // tail pixels of the tile (npix % 4): its last chunk, before the first step (the table starts from zero counts)
+    // tail pixels of the tile (npix % 4): its last chunk, before the first period (which starts from zero counts)
     if (chunk == P.K - 1 && tid < (int)(P.npix & 3)) {
         const uint8_t *p = tile_base + (nquads_tile * 4 + tid) * CH;
         const unsigned int n = p[2], x = green ? p[1] : p[0];
         const unsigned int m = jh_m(n, x);
-        add_now(((x << 7) | (m & 127u)) << 2, ((m >> 7) << 16) | 1u);
+        jh_add(((x << 7) | (m & 127u)) << 2, ((m >> 7) << 16) | 1u, tab);
     }
 
-    // SCAN = true.  A scan: every dword whose sum (low half) has reached 16384 moves onto the list.  Between the two barriers nobody adds.
+    // A scan: every dword whose sum (low half) has reached 16384 moves onto the list.  Between the two barriers nobody adds.
     auto scan = [&]() {
         __syncthreads();
 #pragma unroll 1
@@ -290,12 +243,10 @@ __global__ __launch_bounds__(JH_THREADS, 4) void k_joint_count(JointCountParams 
                 __builtin_amdgcn_sched_barrier(0);
             }
             soff += DEPTH * STEP_B;
-            if constexpr (SCAN) {
-                since += DEPTH;
-                if (since == PERIOD) {
-                    scan();
-                    since = 0;
-                }
+            since += DEPTH;
+            if (since == PERIOD) {
+                scan();
+                since = 0;
             }
         }
         // the last (fewer than DEPTH) full steps and the ragged one: since + DEPTH <= PERIOD, no scan needed
@@ -305,7 +256,6 @@ __global__ __launch_bounds__(JH_THREADS, 4) void k_joint_count(JointCountParams 
             if (step < nfull || (step == nfull && tid < rem)) count(w[k]);
         }
     }
-    if constexpr (!SCAN) settle_pending();
     __syncthreads();
 
     // publish: (cell (D, 0), cell (D, 1)) = (low - high, high), 32 bytes per lane and trip
@@ -762,19 +712,13 @@ extern "C" int lars_d_stats_joint(const lars_fused_args *a, int white_balance, i
     C.tiles = static_cast<const uint8_t *>(a->tiles); C.npix = a->npix; C.ntiles = a->ntiles;
     C.chunk_quads = joint_chunk_quads(a->npix, K);
     C.part = error + 64; C.error = error; C.K = K; C.S = S; C.streams = streams;
-    {
-        const int d = tuning().joint_danger_at;                                     // test hook: 16385 .. 49152
-        C.danger_at = (d > (int)JH_MOVE_AT && d <= (int)JH_DANGER_AT) ? (unsigned)d : JH_DANGER_AT;
-    }
     const long long units = (long long)a->ntiles * K;
     const long long nwg = S == 2 ? ((units + 7) / 8) * 16 : units;
     if (nwg > 0x7FFFFFFFll) return fail(LARS_ERR_INVALID, "lars_d_stats_joint: too many workgroups");
-    // joint_impl 0: returning adds, checked (no barriers); 1: plain adds + a sweep of the table every 12 steps (what the host falls back
-    // to if a launch of form 0 ever raises its error flag); joint_depth: 12-byte (RGBA: 16-byte) loads in flight per lane
-    const bool scan = tuning().joint_impl == 1;
+    // joint_depth: 12-byte (RGBA: 16-byte) loads in flight per lane; 6 by default -- 4, 8 and 12 measure the same within noise
+    // (profiles/r04_joint_depths.txt), although the bare two-reader pattern gains 5 % from 6 to 12 (profiles/r04_shared_readers_depths.txt)
     const int depth = tuning().joint_depth;
-#define LARS_JOINT(DD, CC) do { if (scan) hipLaunchKernelGGL((k_joint_count<DD, CC, true>), dim3((unsigned)nwg), dim3(JH_THREADS), 0, s, C); \
-                                else hipLaunchKernelGGL((k_joint_count<DD, CC, false>), dim3((unsigned)nwg), dim3(JH_THREADS), 0, s, C); } while (0)
+#define LARS_JOINT(DD, CC) hipLaunchKernelGGL((k_joint_count<DD, CC>), dim3((unsigned)nwg), dim3(JH_THREADS), 0, s, C)
     if (c4) LARS_JOINT(6, 4);
     else if (depth == 4) LARS_JOINT(4, 3);
     else if (depth == 8) LARS_JOINT(8, 3);

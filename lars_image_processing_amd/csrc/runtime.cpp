@@ -236,6 +236,14 @@ int lars_event_record(void *event, void *stream)
     LARS_HIP_TRY(hipEventRecord(reinterpret_cast<hipEvent_t>(event), pick_stream(c, stream)));
     return LARS_OK;
 }
+int lars_stream_wait_event(void *stream, void *event)
+{
+    ThreadCtx *c;
+    LARS_TRY(ensure_ctx(&c));
+    if (!event) return fail(LARS_ERR_INVALID, "lars_stream_wait_event: NULL event");
+    LARS_HIP_TRY(hipStreamWaitEvent(pick_stream(c, stream), reinterpret_cast<hipEvent_t>(event), 0));
+    return LARS_OK;
+}
 int lars_event_elapsed_ms(void *start, void *stop, float *ms)
 {
     LARS_HIP_TRY(hipEventSynchronize(reinterpret_cast<hipEvent_t>(stop)));
@@ -254,8 +262,6 @@ int lars_set_tuning(const char *key, int value)
     else if (!strcmp(key, "selq_window")) t.selq_window = value;
     else if (!strcmp(key, "selq_list_wgs")) t.selq_list_wgs = value;
     else if (!strcmp(key, "joint_depth")) t.joint_depth = value;
-    else if (!strcmp(key, "joint_impl")) t.joint_impl = value;
-    else if (!strcmp(key, "joint_danger_at")) t.joint_danger_at = value;
     else if (!strcmp(key, "u16_hist_impl")) t.u16_hist_impl = value;
     else return fail(LARS_ERR_INVALID, "lars_set_tuning: unknown key %s", key);
     return LARS_OK;
@@ -271,8 +277,6 @@ int lars_get_tuning(const char *key, int *value)
     else if (!strcmp(key, "selq_window")) *value = t.selq_window;
     else if (!strcmp(key, "selq_list_wgs")) *value = t.selq_list_wgs;
     else if (!strcmp(key, "joint_depth")) *value = t.joint_depth;
-    else if (!strcmp(key, "joint_impl")) *value = t.joint_impl;
-    else if (!strcmp(key, "joint_danger_at")) *value = t.joint_danger_at;
     else if (!strcmp(key, "u16_hist_impl")) *value = t.u16_hist_impl;
     else if (!strcmp(key, "last_fused_kernel")) *value = t.last_fused_kernel;
     else return fail(LARS_ERR_INVALID, "lars_get_tuning: unknown key %s", key);

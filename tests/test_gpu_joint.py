@@ -279,51 +279,23 @@ def _hot_tiles(kind, n, h, w, seed=3):
 
 
 @pytest.mark.parametrize("kind", ["iid", "three_colours_by_quad", "mostly_one_colour", "two_colours_by_pixel", "one_colour"])
-def test_counter_handover_forms_agree(lars, kind):
-    """The counting kernel keeps its 16-bit pairs from wrapping in two ways (csrc/joint.hip): returning adds whose lane moves
-    the pair onto the list when it passes 16384 (the default: no barriers), or plain adds with a sweep of the table every 12
-    steps.  Both, for one and two streams, must publish the same counts -- records, medians, tables identical to the
-    per-pixel route -- on content that moves pairs thousands of times."""
+def test_hot_cells_survive_the_16_bit_counters(lars, kind):
+    """Content whose pixels pile onto a few counter pairs moves those pairs onto the hand-over list thousands of times (plain
+    adds, flat-wave adds of up to 256 at once, one and two streams, one workgroup per tile and several): records, medians
+    and tables stay identical to the per-pixel route."""
     from lars_image_processing_amd import _ffi
     b = lars.TileBatch.from_host(_hot_tiles(kind, 3, 1024, 1024))
     try:
         for indices in (("NDVI",), ("GNDVI", "NDWI"), TYPES):
             want, want_med = b.process(indices=indices, hist=True, medians=True, route="classic")
             want_tab = b.host_tables()
-            for impl in (0, 1):
-                for blocks in (0, 1):
-                    _ffi.set_tuning(joint_impl=impl, blocks_per_tile=blocks)
-                    got, got_med = b.process(indices=indices, hist=True, medians=True, route="joint")
-                    assert got.tobytes() == want.tobytes(), (kind, indices, impl, blocks)
-                    np.testing.assert_array_equal(got_med, want_med)
-                    for c in sorted(lars.batch.channels_of(indices)):
-                        np.testing.assert_array_equal(b.host_tables(partial=True)[:, c], want_tab[:, c])
-        assert getattr(b, "_joint_fallbacks", 0) == 0
+            for blocks, depth in ((0, 6), (1, 6), (0, 12), (3, 8)):
+                _ffi.set_tuning(blocks_per_tile=blocks, joint_depth=depth)
+                got, got_med = b.process(indices=indices, hist=True, medians=True, route="joint")
+                assert got.tobytes() == want.tobytes(), (kind, indices, blocks, depth)
+                np.testing.assert_array_equal(got_med, want_med)
+                for c in sorted(lars.batch.channels_of(indices)):
+                    np.testing.assert_array_equal(b.host_tables(partial=True)[:, c], want_tab[:, c])
     finally:
-        _ffi.set_tuning(joint_impl=0, blocks_per_tile=0)
-        b.free()
-
-
-def test_counter_danger_flag_falls_back_to_the_barrier_form(lars):
-    """With the danger mark lowered to just above the move mark (test hook joint_danger_at) a hot pair raises the launch's
-    error flag as soon as one more add reaches it before its mover has subtracted: process() must notice, repeat the pass
-    with the barrier form and still return the right records; run_joint alone leaves the flag for check_joint to raise on."""
-    from lars_image_processing_amd import _ffi
-    b = lars.TileBatch.from_host(_hot_tiles("mostly_one_colour", 2, 1024, 1024))
-    want = b.process(route="classic")
-    try:
-        _ffi.set_tuning(joint_danger_at=16385)
-        got = b.process(route="joint")
-        assert got.tobytes() == want.tobytes()
-        assert getattr(b, "_joint_fallbacks", 0) == 1 and _ffi.get_tuning("joint_impl") == 0
-        stats = b.new_stats()
-        b.run_joint(TYPES, True, stats)
-        with pytest.raises(RuntimeError):
-            b.check_joint()
-        stats.free()
-        _ffi.set_tuning(joint_danger_at=0)
-        got = b.process(route="joint")
-        assert got.tobytes() == want.tobytes() and b._joint_fallbacks == 1
-    finally:
-        _ffi.set_tuning(joint_danger_at=0, joint_impl=0)
+        _ffi.set_tuning(blocks_per_tile=0, joint_depth=6)
         b.free()

@@ -84,7 +84,6 @@ def main():
     ap.add_argument("--content", default="vegetation,uniform")
     ap.add_argument("--depths", default="6,4")
     ap.add_argument("--blocks", default="0", help="chunks per tile of the counting kernel (blocks_per_tile), 0 = automatic")
-    ap.add_argument("--impls", default="0", help="counter hand-over forms: 0 returning adds + per-lane check (no barriers), 1 plain adds + table sweeps")
     args = ap.parse_args()
     lib = _ffi.load()
     for content in args.content.split(","):
@@ -118,13 +117,13 @@ def main():
             report(f"classic {mname} statistics + medians", ms, mn)
             _ffi.call("lars_synchronize", None)
             ref[mname + "_med"] = pairs.download(np.float32, (b.ntiles, 2, 2)).copy()
-        for impl, depth in [(i, d) for i in map(int, args.impls.split(",")) for d in map(int, args.depths.split(","))]:
+        for depth in map(int, args.depths.split(",")):
             for blocks in map(int, args.blocks.split(",")):
-                _ffi.set_tuning(joint_depth=depth, blocks_per_tile=blocks, joint_impl=impl)
+                _ffi.set_tuning(joint_depth=depth, blocks_per_tile=blocks)
                 for mname, indices in MODES.items():
                     for med in (False, True):
                         ms, mn = timed(lambda: b.run_joint(indices, True, stats, pairs=pairs if med else None), args.rounds)
-                        report(f"joint   {mname} statistics{' + medians' if med else ''} impl {impl} depth {depth} blocks {blocks}", ms, mn)
+                        report(f"joint   {mname} statistics{' + medians' if med else ''} depth {depth} blocks {blocks}", ms, mn)
                         b.check_joint()
                         rec = stats.download(_ffi.STATS_DTYPE, (b.ntiles, 3))
                         ids = [_ffi.INDEX_IDS[t] for t in indices]
@@ -132,7 +131,7 @@ def main():
                         if med:
                             got = pairs.download(np.float32, (b.ntiles, 2, 2))
                             assert np.array_equal(got, ref[mname + "_med"], equal_nan=True), "medians differ between the routes"
-        _ffi.set_tuning(joint_depth=6, blocks_per_tile=0, joint_impl=0)
+        _ffi.set_tuning(joint_depth=6, blocks_per_tile=0)
         stats.free(); pairs.free(); med_scratch.free(); b.free()
 
 

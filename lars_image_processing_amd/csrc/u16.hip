@@ -265,11 +265,18 @@ __global__ void k_u16_spoil(U16Cand *cand, long long n)
 template <bool ONLY_FLAGGED>
 __global__ __launch_bounds__(1024) void k_hist_u16_both(const uint16_t *__restrict__ tiles, long long npix, const U16Cand *__restrict__ cand,
                                                         const unsigned int *__restrict__ flags, unsigned int *__restrict__ hist,
-                                                        unsigned int *__restrict__ lohist)
+                                                        unsigned int *__restrict__ lohist, int allow_windows)
 {
     __shared__ unsigned int s_h[ONLY_FLAGGED ? 32 : 3 * 256 * 32];       // high bytes: [channel][bin][copy = lane % 32]
     __shared__ unsigned int s_lo[3 * U16_CAND * 256];
     __shared__ unsigned char s_slot[3 * 256];
+    // The candidates of a channel as two windows of consecutive bins [A0, A0 + la) and [B0, B0 + lb), slots 0 .. la - 1 and la .. la + lb - 1:
+    // what k_u16_predict produces (each predicted bin and its neighbours).  A sample is then tested with two subtractions and two compares
+    // in registers instead of a byte look-up in LDS per sample (twelve random ds_read_u8 per quad were 70 % of this kernel's LDS time).
+    // s_win[c] = {A0, la, B0, lb}; s_windows = 0 if some channel's list is not of that form (the recount's exact bins need not be):
+    // then the look-up table decides, as before.
+    __shared__ unsigned int s_win[3][4];
+    __shared__ int s_windows;
     const int tid = threadIdx.x;
     const long long tile = blockIdx.y;
     if (ONLY_FLAGGED && !flags[tile]) return;
@@ -277,11 +284,21 @@ __global__ __launch_bounds__(1024) void k_hist_u16_both(const uint16_t *__restri
         for (int i = tid; i < 3 * 256 * 32; i += 1024) s_h[i] = 0;
     for (int i = tid; i < 3 * U16_CAND * 256; i += 1024) s_lo[i] = 0;
     if (tid < 768) s_slot[tid] = 0xFF;
+    if (tid == 0) s_windows = (ONLY_FLAGGED || !allow_windows) ? 0 : 1;
     __syncthreads();
     if (tid < 3 * U16_CAND) {
         const int c = tid / U16_CAND, j = tid % U16_CAND;
         const U16Cand cd = cand[tile * 3 + c];
         if (j < cd.n) s_slot[c * 256 + cd.bin[j]] = (unsigned char)j;
+        if (!ONLY_FLAGGED && j == 0) {
+            int la = 1;
+            while (la < cd.n && cd.bin[la] == cd.bin[0] + la) ++la;
+            int lb = 0;
+            while (la + lb < cd.n && (lb == 0 || cd.bin[la + lb] == cd.bin[la] + lb)) ++lb;
+            if (cd.n < 1 || la + lb != cd.n) atomicExch(&s_windows, 0);
+            s_win[c][0] = cd.n ? cd.bin[0] : 0u; s_win[c][1] = cd.n ? (unsigned)la : 0u;
+            s_win[c][2] = lb ? cd.bin[la] : 0u;  s_win[c][3] = (unsigned)lb;
+        }
     }
     __syncthreads();
     const uint16_t *base = tiles + tile * npix * 3;
@@ -304,6 +321,14 @@ __global__ __launch_bounds__(1024) void k_hist_u16_both(const uint16_t *__restri
         // at about half of what HBM delivers.  Offsets past the tile (the ring's last turns) read as zero and are not counted.
         u32x4v ra[U16_DEPTH];
         u32x2v rb[U16_DEPTH];
+        // the windows, wave-uniform (scalar registers)
+        const bool use_windows = !ONLY_FLAGGED && __builtin_amdgcn_readfirstlane(s_windows) != 0;
+        unsigned int wA0[3], wla[3], wB0[3], wlb[3];
+#pragma unroll
+        for (int c = 0; c < 3; ++c) {
+            wA0[c] = __builtin_amdgcn_readfirstlane(s_win[c][0]); wla[c] = __builtin_amdgcn_readfirstlane(s_win[c][1]);
+            wB0[c] = __builtin_amdgcn_readfirstlane(s_win[c][2]); wlb[c] = __builtin_amdgcn_readfirstlane(s_win[c][3]);
+        }
         long long q = (long long)blockIdx.x * 1024 + tid;
 #pragma unroll
         for (int d = 0; d < U16_DEPTH; ++d) {
@@ -320,7 +345,20 @@ __global__ __launch_bounds__(1024) void k_hist_u16_both(const uint16_t *__restri
                 const unsigned int off = (unsigned int)(qq + U16_DEPTH * step) * 24u;
                 ra[d] = __builtin_amdgcn_raw_buffer_load_b128(rsrc, off, 0, 0);
                 rb[d] = __builtin_amdgcn_raw_buffer_load_b64(rsrc, off + 16u, 0, 0);
-                if (qq < nquads) {
+                if (qq < nquads && use_windows) {
+                    const unsigned int w[6] = {a.x, a.y, a.z, a.w, b.x, b.y};
+#pragma unroll
+                    for (int i = 0; i < 12; ++i) {
+                        const int ch = i % 3;
+                        const unsigned int hi = (w[i >> 1] >> ((i & 1) * 16 + 8)) & 0xFFu;
+                        atomicAdd(reinterpret_cast<unsigned int *>(hb + ch * 32768 + (hi << 7) + lane_off), 1u);
+                        const unsigned int ra = hi - wA0[ch], rb = hi - wB0[ch];
+                        if ((ra < wla[ch]) | (rb < wlb[ch])) {
+                            const unsigned int slot = ra < wla[ch] ? ra : wla[ch] + rb;
+                            atomicAdd(&s_lo[(ch * U16_CAND + slot) * 256 + ((w[i >> 1] >> ((i & 1) * 16)) & 0xFFu)], 1u);
+                        }
+                    }
+                } else if (qq < nquads) {
                     // all twelve slot look-ups first, then the twelve counts, then the (rare) candidates: one LDS round trip
                     // per quad instead of one per sample
                     const unsigned int w[6] = {a.x, a.y, a.z, a.w, b.x, b.y};
@@ -505,10 +543,11 @@ extern "C" int lars_d_wb_prepare(const void *tiles, int64_t ntiles, int64_t npix
         hipLaunchKernelGGL(k_u16_predict, per_channel, dim3(256), 0, s, hi_sample, cand);
         if (tuning().u16_hist_impl == 3)
             hipLaunchKernelGGL(k_u16_spoil, dim3((unsigned)((ntiles * 3 + 255) / 256)), dim3(256), 0, s, cand, (long long)ntiles * 3);
-        hipLaunchKernelGGL((k_hist_u16_both<false>), grid, dim3(1024), 0, s, t16, (long long)npix, cand, flags, hi, lo);
+        // u16_hist_impl 4: the same pass with a slot look-up in LDS per sample instead of the window tests in registers (round 3's form)
+        hipLaunchKernelGGL((k_hist_u16_both<false>), grid, dim3(1024), 0, s, t16, (long long)npix, cand, flags, hi, lo, tuning().u16_hist_impl == 4 ? 0 : 1);
         hipLaunchKernelGGL(k_u16_pick, per_channel, dim3(256), 0, s, hi, (long long)npix, picks);
         hipLaunchKernelGGL(k_u16_resolve, dim3((unsigned)ntiles), dim3(256), 0, s, picks, cand, lo, flags);
-        hipLaunchKernelGGL((k_hist_u16_both<true>), grid, dim3(1024), 0, s, t16, (long long)npix, cand, flags, hi, lo);
+        hipLaunchKernelGGL((k_hist_u16_both<true>), grid, dim3(1024), 0, s, t16, (long long)npix, cand, flags, hi, lo, 0);
         hipLaunchKernelGGL(k_wb_table_u16, per_channel, dim3(256), 0, s, lo, picks, table, percentiles, rgn_variant, U16_CAND);
         return launch_check("lars_d_wb_prepare (one pass)");
     }

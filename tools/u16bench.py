@@ -23,7 +23,8 @@ def main():
         return float(np.median(ts[1:]))
     npix = tiles * edge * edge
     res = {}
-    for impl, name in ((2, "wb_prepare (one full pass: candidate bins from a subsample)"), (1, "wb_prepare (2 radix passes + tables)"),
+    for impl, name in ((2, "wb_prepare (one full pass: candidate bins from a subsample)"), (4, "wb_prepare (one full pass, slot look-ups in LDS: round 3)"),
+                       (1, "wb_prepare (2 radix passes + tables)"),
                        (3, "wb_prepare (wrong candidates on purpose: full pass + recount)")):
         _ffi.set_tuning(u16_hist_impl=impl)
         t = timed(lambda: b.compute_wb_tables())

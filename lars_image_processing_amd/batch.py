@@ -434,19 +434,23 @@ class TileBatch:
         if getattr(self, "_joint_scratch", None) is not None and int(self._joint_scratch.download(np.uint32, (1,))[0]):
             raise RuntimeError("lars_d_stats_joint: a workgroup's hand-over list overflowed (a chunk of more than 2^24 pixels?)")
 
-    def pick_stats_route(self, indices, white_balance=True, sample=32):
+    def pick_stats_route(self, indices, white_balance=True, sample=256, min_pixels=1 << 29):
         """"joint" or "classic" for statistics WITHOUT medians over this batch, by measurement: both routes over the first
         ``sample`` tiles, once per (indices, white balance), remembered.  The one-read route counts byte pairs with LDS
         atomics, which queue up where the neighbouring pixels of a wave share cells (smooth imagery: profiles/
         r03_joint_hist_content.txt), while the per-pixel kernels do not care; with medians the one-read route wins on every
-        content measured, so nothing is timed for those.  Small batches take the one-read route unmeasured.  The timing
-        runs on tables, percentiles and histograms of its own: the batch's (and which of their channels are valid) are
-        left exactly as they were."""
+        content measured, so nothing is timed for those.  Small batches (fewer than ``min_pixels`` = 2^29 pixels in the sample)
+        take the one-read route unmeasured.  The sample has to be large: the one-read route splits every tile into more chunks the fewer tiles a
+        launch has, and each chunk publishes 256 KiB of counts -- over 32 tiles of 4096 x 4096 that overhead is 17 % of the
+        input and made round 3's 32-tile sample pick the per-pixel route for content on which the one-read route is twice as
+        fast over the batch (profiles/r04_bench_full.json, smooth_content).  The timing runs on tables, percentiles and
+        histograms of its own: the batch's (and which of their channels are valid) are left exactly as they were."""
         key = (tuple(sorted(INDEX_IDS[t] for t in indices)), bool(white_balance))
         cache = self.__dict__.setdefault("_route_cache", {})
         if key in cache:
             return cache[key]
-        if self.ntiles < sample or self.npix < (1 << 20) or self.channels != 3:
+        sample = min(int(sample), self.ntiles)
+        if sample * self.npix < int(min_pixels) or self.channels != 3:
             cache[key] = "joint"
             return "joint"
         saved = (self.table, self.percentiles, self.hist, set(self._table_channels), self._rgn_variant)

@@ -326,10 +326,12 @@ __device__ inline void acc_flush(Acc a, StatsAccView *rec, double (*s_red)[4], i
 // LDS): g = trunc((v - p2) * 255/(p98 - p2)) in float64 is within one level of the reference's
 // trunc(float32(float64 expression)), and two threshold compares settle it exactly.
 
-// Pixel -> wave mapping: a wave owns runs of 1024 consecutive pixels, the four quads of a run unrolled: four loads, then per
-// plane four back-to-back 1 KiB stores = 4 KiB bursts.  Round 2 measured it against the same runs one quad per trip and
-// against 256-pixel slabs a grid stride apart (profiles/r02_traverse_ab.txt): 8 % faster wherever the planes' placement
-// allows more than 5.3 TB/s at all, and equal elsewhere; the other mappings are gone from the source.
+// Pixel -> wave mapping: a wave owns runs of 256 * RUN consecutive pixels, the RUN quads of a run unrolled: RUN loads, then per
+// plane RUN back-to-back 1 KiB stores.  RUN = 16 (runs of 4096 pixels, 16 KiB bursts per plane) in the headline instantiation (three
+// planes + basic statistics), 8 for uint16 NDVI + RGBA, 4 everywhere else -- measured per instantiation in round 3 (the table at
+// `constexpr int RUN` below, profiles/r03_waves_ab.txt).  Round 2 had measured runs of 1024 pixels against one quad per trip and
+// against 256-pixel slabs a grid stride apart (profiles/r02_traverse_ab.txt): 8 % faster wherever the planes' placement allows
+// more than 5.3 TB/s at all, and equal elsewhere; the other mappings are gone from the source.
 // CH = 4 (uint8 only): RGBA tiles -- 16 bytes per quad of pixels, one dwordx4 load per lane, repacked in three v_perm_b32 into
 // the three dwords the rest of the kernel works on; alpha is ignored and comes back as 0 in the white-balanced image
 // (np.zeros_like + range(3), process-images.py:432-435).
@@ -479,10 +481,10 @@ __attribute__((amdgpu_waves_per_eu(1, (sizeof(PIX) == 1 && CH == 3 && MASK != 0u
                                                                   lut2[cmap_index(v2[2])], lut2[cmap_index(v2[3])]);
     };
 
-    // A wave owns 1024 consecutive pixels per step: four wave-contiguous loads (4 x 768 bytes of uint8 samples), then per
-    // plane four wave-contiguous 1 KiB stores = 4 KiB of consecutive addresses.  Measured against the former mapping
-    // (one 256-pixel slab per wave and step, slabs of a wave a grid stride apart) with the bare traffic mix:
-    // 6.07-6.38 vs 5.63-5.95 TB/s in three sets of allocations (profiles/r02_stream_probe.txt, kinds 9-13 vs 5).
+    // A wave owns 256 * RUN consecutive pixels per step: RUN wave-contiguous loads (768 bytes of uint8 samples each), then per
+    // plane RUN wave-contiguous 1 KiB stores of consecutive addresses.  (Round 2, RUN = 4 against one 256-pixel slab per wave and
+    // step, slabs a grid stride apart, as bare traffic: 6.07-6.38 vs 5.63-5.95 TB/s in three sets of allocations,
+    // profiles/r02_stream_probe.txt, kinds 9-13 vs 5.)
     // Quads per lane and step (a wave owns 256 * RUN consecutive pixels: RUN loads of 768 bytes in flight, then per plane RUN
     // back-to-back 1 KiB stores).  Three planes + basic statistics stream better the longer the run, as long as two waves per SIMD
     // stay resident: 4 / 8 / 12 / 16 quads = 0.784 / 0.788 / 0.792 / 0.795 of 8 TB/s into one arena, 20 (one wave left) 0.66

@@ -1,4 +1,13 @@
-// Second-generation hot-path kernels, written for the CDNA4 issue budget.
+// The per-pixel statistics kernels ("classic" route), written for the CDNA4 issue budget.
+//
+// WHAT STILL DEPENDS ON THIS FILE (round 4).  Since round 3 the statistics of uint8 RGNir / RGBA batches come from the one-read
+// route (joint.hip) by default; these kernels serve
+//   * statistics-only passes the one-read route does not take: uint16 tiles, channel counts other than 3 / 4, unaligned tiles,
+//     passes over tables the caller supplied (process(recompute_tables=False)), and route="auto" on content where it measures faster;
+//   * lars_d_stats_medians / lars_d_quotient_select_hist (the first select pass lives inside k_fused_v2<..., SEL>) and with them
+//     TileBatch.global_medians, the exact median over all tiles of all ranks;
+//   * k_chan_hist_u8c3_v2: the channel-histogram pre-pass of every launch that writes planes from tables (the bench headline);
+//   * the other side of every route-equality test (tests/test_gpu_joint.py, tests/fuzz_routes.py) and of bench.py's self-check.
 //
 // The stats-only configurations move 3 bytes per pixel, so at HBM rate a CU has
 // only ~35 vector-instruction slots per pixel.  What this file does about it:

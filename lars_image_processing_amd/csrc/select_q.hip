@@ -1,5 +1,11 @@
 // Exact medians without index planes: radix select on values recomputed from the tiles.
 // The first (bucket) pass also exists inside the statistics kernel (fused_v2.hip, SEL).
+//
+// WHAT STILL DEPENDS ON THIS FILE (round 4).  Per-tile medians of uint8 RGNir / RGBA batches come out of the one-read route's
+// finish kernel (joint.hip) since round 3.  These passes remain for: TileBatch.global_medians (ONE median over all tiles of all
+// ranks: histograms are summed over the communicator between the passes, which a per-tile finish cannot do), tile_medians /
+// lars_d_quotient_median_pairs on tables the caller supplied or with planes that carry a white-balanced image, lars_d_stats_medians
+// on the per-pixel route, and the other side of the median checks in tests/test_gpu_joint.py and bench.py's self-check.
 #include <string.h>
 
 #include <type_traits>

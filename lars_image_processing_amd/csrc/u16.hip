@@ -207,11 +207,17 @@ __global__ __launch_bounds__(1024) void k_hist_u16_lo(const uint16_t *__restrict
 #define U16_DEPTH 3                 /* quads per lane in flight in the one-pass count */
 struct U16Cand { unsigned char bin[U16_CAND]; unsigned char n; unsigned char pad; };
 
-// from the subsample's high-byte histogram: the bins holding the 2 % and the 98 % mark of the sample, +- 1
+// From the subsample's high-byte histogram: the bin holding the 2 % resp. the 98 % mark of the sample, and a neighbour only where the
+// mark sits within six standard deviations of its sampling error from that side of its bin (sigma = sqrt(n q (1 - q)) ranks of the
+// subsample, as a fraction of the bin's count).  Round 3 took both neighbours always: six candidate bins per channel = 2.3 % of random
+// samples, and the one-pass count -- bound by instruction issue -- pays for every sample position at which ANY lane of a wave holds a
+// candidate (profiles/r04_u16_prepass_counters.txt).  A mark that lands outside its candidates costs that tile a recount, never a wrong
+// percentile: the exact high-byte histogram of the full pass decides (k_u16_resolve).
 __global__ __launch_bounds__(256) void k_u16_predict(const unsigned int *__restrict__ sample_hist, U16Cand *__restrict__ cand)
 {
     __shared__ unsigned long long s_scan[256];
     __shared__ int s_t[2];
+    __shared__ int s_side[2][2];                           // [mark][0: take the bin below, 1: the bin above]
     const int tid = threadIdx.x;
     const long long slot = (long long)blockIdx.y * 3 + blockIdx.x;
     const unsigned long long c = sample_hist[slot * 256 + tid];
@@ -224,12 +230,18 @@ __global__ __launch_bounds__(256) void k_u16_predict(const unsigned int *__restr
         __syncthreads();
     }
     const unsigned long long total = s_scan[255], before = s_scan[tid] - c;
-    if (tid < 2) s_t[tid] = tid == 0 ? 0 : 255;
+    if (tid < 2) { s_t[tid] = tid == 0 ? 0 : 255; s_side[tid][0] = 1; s_side[tid][1] = 1; }
     __syncthreads();
     if (total > 0) {
         for (int k = 0; k < 2; ++k) {
-            const unsigned long long r = (unsigned long long)((double)(total - 1) * (k == 0 ? 0.02 : 0.98));
-            if (c && r >= before && r < before + c) s_t[k] = tid;
+            const double q = k == 0 ? 0.02 : 0.98;
+            const unsigned long long r = (unsigned long long)((double)(total - 1) * q);
+            if (c && r >= before && r < before + c) {
+                s_t[k] = tid;
+                const double margin = 6.0 * sqrt((double)total * q * (1.0 - q)) + 2.0;        // ranks of the subsample
+                s_side[k][0] = (double)(r - before) < margin ? 1 : 0;
+                s_side[k][1] = (double)(before + c - 1 - r) < margin ? 1 : 0;
+            }
         }
     }
     __syncthreads();
@@ -239,12 +251,16 @@ __global__ __launch_bounds__(256) void k_u16_predict(const unsigned int *__restr
         for (int j = 0; j < U16_CAND; ++j) out.bin[j] = 0;
         for (int k = 0; k < 2; ++k)
             for (int d = -1; d <= 1; ++d) {
+                if ((d < 0 && !s_side[k][0]) || (d > 0 && !s_side[k][1])) continue;
                 const int b = s_t[k] + d;
                 if (b < 0 || b > 255) continue;
                 bool have = false;
                 for (int j = 0; j < out.n; ++j) have |= out.bin[j] == (unsigned char)b;
                 if (!have) out.bin[out.n++] = (unsigned char)b;
             }
+        // ascending order: the full pass reads the list as two windows of consecutive bins
+        for (int i = 1; i < out.n; ++i)
+            for (int j = i; j > 0 && out.bin[j] < out.bin[j - 1]; --j) { const unsigned char t = out.bin[j]; out.bin[j] = out.bin[j - 1]; out.bin[j - 1] = t; }
         cand[slot] = out;
     }
 }

@@ -164,7 +164,8 @@ def test_measured_route_choice(lars):
     for content in (tiles, None):
         b = lars.TileBatch.from_host(content) if content is not None else lars.TileBatch.synthetic(32, 1024, 1024, seed=3, profile="uniform")
         assert lb.get_stats_route() == "auto"
-        chosen = b.pick_stats_route(TYPES)
+        assert b.pick_stats_route(("NDVI",)) == "joint" and not hasattr(b, "_route_ms")        # 2^25 pixels: too small to measure
+        chosen = b.pick_stats_route(TYPES, min_pixels=0)
         assert chosen in ("joint", "classic") and b.pick_stats_route(TYPES) == chosen and set(b._route_ms) == {"joint", "classic"}
         rec = b.process()
         assert rec.tobytes() == b.process(route="joint").tobytes() == b.process(route="classic").tobytes()
@@ -215,14 +216,14 @@ def test_route_timing_leaves_the_tables_alone_and_supplied_tables_are_used(lars)
     want_tab = b.host_tables()
     # (i) fresh batch state, route timing first
     b2 = lars.TileBatch.synthetic(40, 1024, 1024, seed=31, profile="vegetation")
-    assert b2.pick_stats_route(("NDVI", "GNDVI", "NDWI")) in ("joint", "classic")
+    assert b2.pick_stats_route(("NDVI", "GNDVI", "NDWI"), min_pixels=0) in ("joint", "classic") and set(b2._route_ms) == {"joint", "classic"}
     assert b2.table is None and b2._table_channels == set()
     got = b2.process(recompute_tables=False, route="classic")          # no tables yet: they are computed, over ALL tiles
     assert got.tobytes() == want.tobytes()
     np.testing.assert_array_equal(b2.host_tables(), want_tab)
     b2.compute_wb_tables()
     b2._route_cache.clear()
-    b2.pick_stats_route(("NDVI",))
+    b2.pick_stats_route(("NDVI",), min_pixels=0)
     assert b2._table_channels == {0, 1, 2}
     np.testing.assert_array_equal(b2.host_tables(), want_tab)          # untouched by the timing
     # (ii) supplied tables of the other flavour are used, on every route setting that may honour them

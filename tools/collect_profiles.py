@@ -25,21 +25,36 @@ def read(rnd, counter):
 
 
 def headline_launches(rnd, src):
-    """The headline kernel's launches of the profiled bench run, split by what they were: the arena search (four launches
-    per candidate allocation, before anything else) and the steps (warm-up, timed and self-check steps: the same launch
-    over a ring of tile slots).  Written to profiles/<round>_bench_headline_launches.csv so that bytes / mean duration /
-    8 TB/s of the 'step' row can be held against roofline.frac of <round>_bench_under_rocprof.json."""
+    """The headline kernel's launches of the profiled bench run, split by what they were: the arena search (untimed and timed
+    passes of the probe into every candidate, and once more into the survivor) and the steps (warm-up, timed and self-check
+    steps).  A step is recognised by its channel-histogram pass: the `launches_per_step` ring launches of the headline kernel
+    that follow a full-batch k_chan_hist_u8c3_v2 launch.  Written to profiles/<round>_bench_headline_launches.csv so that
+    bytes / mean duration / 8 TB/s of the 'step' row can be held against roofline.frac of <round>_bench_under_rocprof.json."""
     import csv
     line = json.loads(open(f"{src}/bench_under_rocprof.json").read().strip().splitlines()[-1])
     ncand = len((line["config"].get("arena") or {}).get("candidate_ms") or [])
+    per_step = int(line["roofline"]["launches_per_step"])
     trace = max(glob.glob(f"{src}/trace/**/*kernel_trace.csv", recursive=True), key=os.path.getmtime)
-    rows = [r for r in csv.DictReader(open(trace)) if r["Kernel_Name"].startswith("void lars::k_fused_u8c3<unsigned char, 7u, true, 1, 3>")]
-    rows.sort(key=lambda r: int(r["Start_Timestamp"]))
-    ring_grid = max(set((r["Grid_Size_X"] if "Grid_Size_X" in r else r.get("Grid_Size"), r.get("Grid_Size_Y", "")) for r in rows),
-                    key=lambda g: sum(1 for r in rows if (r.get("Grid_Size_X", r.get("Grid_Size")), r.get("Grid_Size_Y", "")) == g))
-    ring = [r for r in rows if (r.get("Grid_Size_X", r.get("Grid_Size")), r.get("Grid_Size_Y", "")) == ring_grid]
-    dur = [int(r["End_Timestamp"]) - int(r["Start_Timestamp"]) for r in ring]
-    search, steps = dur[:4 * ncand], dur[4 * ncand:]
+    allrows = sorted(csv.DictReader(open(trace)), key=lambda r: int(r["Start_Timestamp"]))
+    head = "void lars::k_fused_u8c3<unsigned char, 7u, true, 1, 3>"
+
+    def grid(r):
+        return (r.get("Grid_Size_X", r.get("Grid_Size")), r.get("Grid_Size_Y", ""))
+    rows = [r for r in allrows if r["Kernel_Name"].startswith(head)]
+    ring_grid = max(set(grid(r) for r in rows), key=lambda g: sum(1 for r in rows if grid(r) == g))
+    hist = [r for r in allrows if "k_chan_hist_u8c3_v2<3>" in r["Kernel_Name"]]
+    hist_grid = max(set(grid(r) for r in hist), key=lambda g: int(g[0] or 0) * max(1, int(g[1] or 1)))
+    steps, search, left = [], [], 0
+    for r in allrows:
+        if "k_chan_hist_u8c3_v2<3>" in r["Kernel_Name"] and grid(r) == hist_grid:
+            left = per_step
+        elif r["Kernel_Name"].startswith(head) and grid(r) == ring_grid:
+            d = int(r["End_Timestamp"]) - int(r["Start_Timestamp"])
+            if left > 0:
+                steps.append(d)
+                left -= 1
+            else:
+                search.append(d)
     nbytes = line["roofline"]["bytes_per_launch"]
     out = f"{ROOT}/profiles/{rnd}_bench_headline_launches.csv"
     with open(out, "w") as fh:
@@ -49,7 +64,8 @@ def headline_launches(rnd, src):
                 mean = sum(d) / len(d)
                 fh.write(f"{name},{len(d)},{mean:.1f},{nbytes / mean:.1f},{nbytes / mean / 8000:.4f}\n")
         fh.write(f"# bench line of the same run: roofline.frac {line['roofline']['frac']:.4f}, avg_launch_ms {line['roofline']['avg_launch_ms']:.4f}, "
-                 f"{ncand} candidate arenas; other launches of this kernel (single tiles of the self-check): {len(rows) - len(ring)}\n")
+                 f"{ncand} candidate arenas (the search's launches include the untimed passes of its probe and every candidate's class); "
+                 f"other launches of this kernel (single tiles of the self-check): {len(rows) - len(steps) - len(search)}\n")
     print(open(out).read())
 
 

@@ -43,7 +43,7 @@ def headline_launches(rnd, src):
     rows = [r for r in allrows if r["Kernel_Name"].startswith(head)]
     ring_grid = max(set(grid(r) for r in rows), key=lambda g: sum(1 for r in rows if grid(r) == g))
     hist = [r for r in allrows if "k_chan_hist_u8c3_v2<3>" in r["Kernel_Name"]]
-    hist_grid = max(set(grid(r) for r in hist), key=lambda g: int(g[0] or 0) * max(1, int(g[1] or 1)))
+    hist_grid = max(set(grid(r) for r in hist), key=lambda g: int(g[1] or 1))        # grid.y = tiles: the pass over the whole batch
     steps, search, left = [], [], 0
     for r in allrows:
         if "k_chan_hist_u8c3_v2<3>" in r["Kernel_Name"] and grid(r) == hist_grid:

@@ -10,13 +10,13 @@ TILES=${TILES:-256}
 rm -rf "$OUT"; mkdir -p "$OUT"
 cd /tmp && export TMPDIR=/tmp
 rocprofv3 --kernel-trace --stats --output-format csv -d "$OUT/trace" -- python3 "$R/tools/jointbench.py" --tiles $TILES --rounds 3 \
-    --content vegetation --depths 6 > "$OUT/trace.log" 2> "$OUT/trace.err"
+    --content vegetation --depths ${DEPTHS:-6} > "$OUT/trace.log" 2> "$OUT/trace.err"
 i=0
 for grp in "FETCH_SIZE" "WRITE_SIZE" "SQ_INSTS_VALU SQ_INSTS_LDS SQ_INSTS_SALU SQ_INSTS_VMEM_RD SQ_WAVES SQ_WAVE_CYCLES SQ_BUSY_CYCLES GRBM_GUI_ACTIVE" \
            "SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_ACTIVE_INST_LDS SQ_ACTIVE_INST_VALU SQ_WAIT_INST_LDS SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_LDS_ADDR_CONFLICT"; do
     i=$((i + 1))
     rocprofv3 --pmc $grp --output-format csv -d "$OUT/pmc_$i" -- python3 "$R/tools/jointbench.py" --tiles $TILES --rounds 1 \
-        --content vegetation --depths 6 > "$OUT/pmc_$i.log" 2> "$OUT/pmc_$i.err"
+        --content vegetation --depths ${DEPTHS:-6} > "$OUT/pmc_$i.log" 2> "$OUT/pmc_$i.err"
     echo "pmc group $i done: $grp"
 done
 python3 "$R/tools/pmc_summary.py" "$OUT" > "$OUT/pmc_summary.txt" || true

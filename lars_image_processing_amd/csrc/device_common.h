@@ -20,6 +20,9 @@ struct FusedParams {
     const unsigned int *sel_win;   // [ntiles][2]: first slot (int) of each stream's predicted window (select_q.hip, v2_device.h), or null
     unsigned int *sel_win_hist;    // [ntiles][2][SELQ_WIN_SLOTS]: slot counts inside the window
     unsigned int *sel_below;       // [ntiles][2]: values below the window
+    long long out_tile_stride;     // pixels between consecutive tiles of an index / RGBA plane (npix unless the planes are interleaved tile by tile)
+    long long out_group;           // laboratory: tiles per group (0 = off): tile t of a plane sits (t / out_group) * out_group_gap pixels further on
+    long long out_group_gap;
 };
 
 struct Acc {

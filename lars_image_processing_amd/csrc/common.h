@@ -104,8 +104,7 @@ struct Tuning {
     int last_fused_kernel = 0; // read-only: the kernel family lars_d_fused launched last -- 1 k_fused_u8c3, 2 k_fused_v2, 3 uint16, 4 generic, 5 RGBA uint8
     int u16_hist_impl = 2;     // uint16 percentiles: 2 one full pass (candidate bins from a subsample, u16.hip), 1 always two radix passes,
                                // 3 test hook (wrong candidates), 4 one full pass with round 3's slot look-ups instead of the window tests
-    int out_group = 0;         // laboratory: g > 0 = three planes interleaved in groups of g tiles (plane k's group j at (3 j + k) * g tiles)
-    int out_stride_planes = 0; // laboratory: k > 1 = the fused kernel steps k x npix from tile to tile in its index / RGBA planes (interleaved planes)
+    int out_stride_planes = 0; // laboratory build (LARS_LAB_LAYOUT) only: k > 1 = the fused kernel steps k x npix from tile to tile in its index planes
     int joint_depth = 6;       // joint.hip: 12-byte loads in flight per lane of the counting kernel (4 | 6 | 8 | 12)
 };
 Tuning &tuning();

@@ -20,9 +20,12 @@ struct FusedParams {
     const unsigned int *sel_win;   // [ntiles][2]: first slot (int) of each stream's predicted window (select_q.hip, v2_device.h), or null
     unsigned int *sel_win_hist;    // [ntiles][2][SELQ_WIN_SLOTS]: slot counts inside the window
     unsigned int *sel_below;       // [ntiles][2]: values below the window
-    long long out_tile_stride;     // pixels between consecutive tiles of an index / RGBA plane (npix unless the planes are interleaved tile by tile)
-    long long out_group;           // laboratory: tiles per group (0 = off): tile t of a plane sits (t / out_group) * out_group_gap pixels further on
-    long long out_group_gap;
+#ifdef LARS_LAB_LAYOUT
+    // laboratory build only (make lablayout; tools/lab/interleave.py): pixels between consecutive tiles of an index plane.  Kept out of
+    // the product build on purpose: three more scalars in the headline instantiation took it from 253 to 264 registers = from two
+    // resident waves per SIMD to one, and every arena then ran at the slow class's level (NOTES.md, round 4)
+    long long out_tile_stride;
+#endif
 };
 
 struct Acc {

@@ -397,15 +397,18 @@ __attribute__((amdgpu_waves_per_eu(1, (sizeof(PIX) == 1 && CH == 3 && MASK != 0u
     Acc acc[3];
     acc_init(acc[0]); acc_init(acc[1]); acc_init(acc[2]);
 
+#ifdef LARS_LAB_LAYOUT
     const long long ots = P.out_tile_stride;
-    const long long tile_off = tile * ots + (P.out_group > 0 ? (tile / P.out_group) * P.out_group_gap : 0);
-    float *const oi0 = P.out_index[0] ? P.out_index[0] + tile_off : nullptr;
-    float *const oi1 = P.out_index[1] ? P.out_index[1] + tile_off : nullptr;
-    float *const oi2 = P.out_index[2] ? P.out_index[2] + tile_off : nullptr;
+#else
+    const long long ots = npix;
+#endif
+    float *const oi0 = P.out_index[0] ? P.out_index[0] + tile * ots : nullptr;
+    float *const oi1 = P.out_index[1] ? P.out_index[1] + tile * ots : nullptr;
+    float *const oi2 = P.out_index[2] ? P.out_index[2] + tile * ots : nullptr;
     uint8_t *const owb = P.out_wb ? P.out_wb + tile * npix * CH : nullptr;
-    uint8_t *const oc0 = P.out_rgba[0] ? P.out_rgba[0] + tile * ots * 4 : nullptr;
-    uint8_t *const oc1 = P.out_rgba[1] ? P.out_rgba[1] + tile * ots * 4 : nullptr;
-    uint8_t *const oc2 = P.out_rgba[2] ? P.out_rgba[2] + tile * ots * 4 : nullptr;
+    uint8_t *const oc0 = P.out_rgba[0] ? P.out_rgba[0] + tile * npix * 4 : nullptr;
+    uint8_t *const oc1 = P.out_rgba[1] ? P.out_rgba[1] + tile * npix * 4 : nullptr;
+    uint8_t *const oc2 = P.out_rgba[2] ? P.out_rgba[2] + tile * npix * 4 : nullptr;
     const unsigned int *lut0 = reinterpret_cast<const unsigned int *>(P.cmap_lut[0]);
     const unsigned int *lut1 = reinterpret_cast<const unsigned int *>(P.cmap_lut[1]);
     const unsigned int *lut2 = reinterpret_cast<const unsigned int *>(P.cmap_lut[2]);
@@ -809,11 +812,9 @@ extern "C" int lars_d_fused(const lars_fused_args *a)
     }
     P.out_wb = a->out_wb; P.stats = a->stats; P.mask = mask; P.sel_hist = nullptr; P.sel_win = nullptr; P.sel_win_hist = nullptr; P.sel_below = nullptr;
     P.flags = (a->flags & 7u) | (tuning().nt_stores ? 0x20000000u : 0u);
-    // laboratory knob: tiles of a plane `out_stride_planes` x npix apart (planes interleaved tile by tile); the fast uint8 / uint16 kernels only
+#ifdef LARS_LAB_LAYOUT
     P.out_tile_stride = a->npix * (tuning().out_stride_planes > 1 ? tuning().out_stride_planes : 1);
-    // laboratory knob: groups of `out_group` tiles of a plane, a gap of 2 x out_group tiles between groups (three planes interleaved group by group)
-    P.out_group = tuning().out_group > 0 ? tuning().out_group : 0;
-    P.out_group_gap = 2ll * P.out_group * a->npix;
+#endif
 
     const long long nrec = a->ntiles * 3;
     const bool raw = (a->flags & LARS_F_RAW) != 0;        // the caller brackets the launches with lars_d_stats_begin / _end

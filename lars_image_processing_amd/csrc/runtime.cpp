@@ -263,7 +263,6 @@ int lars_set_tuning(const char *key, int value)
     else if (!strcmp(key, "selq_list_wgs")) t.selq_list_wgs = value;
     else if (!strcmp(key, "joint_depth")) t.joint_depth = value;
     else if (!strcmp(key, "out_stride_planes")) t.out_stride_planes = value;
-    else if (!strcmp(key, "out_group")) t.out_group = value;
     else if (!strcmp(key, "u16_hist_impl")) t.u16_hist_impl = value;
     else return fail(LARS_ERR_INVALID, "lars_set_tuning: unknown key %s", key);
     return LARS_OK;
@@ -280,7 +279,6 @@ int lars_get_tuning(const char *key, int *value)
     else if (!strcmp(key, "selq_list_wgs")) *value = t.selq_list_wgs;
     else if (!strcmp(key, "joint_depth")) *value = t.joint_depth;
     else if (!strcmp(key, "out_stride_planes")) *value = t.out_stride_planes;
-    else if (!strcmp(key, "out_group")) *value = t.out_group;
     else if (!strcmp(key, "u16_hist_impl")) *value = t.u16_hist_impl;
     else if (!strcmp(key, "last_fused_kernel")) *value = t.last_fused_kernel;
     else return fail(LARS_ERR_INVALID, "lars_get_tuning: unknown key %s", key);

@@ -1,5 +1,6 @@
 #!/usr/bin/env python3
-"""Does the LAYOUT of the three planes inside an output arena decide its speed class?  (laboratory; lars_set_tuning("out_stride_planes", 3))
+"""Does the LAYOUT of the three planes inside an output arena decide its speed class?  (laboratory build of the library with the
+plane-stride knob: make -C lars_image_processing_amd/csrc lablayout, then LARS_HIP_LIB=build/lablayout/liblars_layout.so python tools/lab/interleave.py)
 
 The product writes plane k of tile slot s at  arena + k * (slots * 64 MiB) + s * 64 MiB  ("planar": three streams 4 GiB apart).
 Interleaved:  arena + s * (3 * 64 MiB) + k * 64 MiB  (the three planes of a slot next to each other: 192 MiB per slot).
@@ -28,7 +29,6 @@ def main():
     ap.add_argument("--candidates", type=int, default=8)
     ap.add_argument("--tiles", type=int, default=1024)
     ap.add_argument("--ring", type=int, default=64)
-    ap.add_argument("--groups", action="store_true", help="sweep the group size of the interleaving, then region triples of one 24 GiB allocation")
     args = ap.parse_args()
     b = lars.TileBatch.synthetic(args.tiles, 4096, 4096, seed=1234, profile="vegetation")
     b.compute_wb_tables()
@@ -67,40 +67,6 @@ def main():
         burst(ls)
         return float(np.mean(burst(ls)[1:]))
 
-    if args.groups:
-        # three planes interleaved in groups of G tile slots: plane k's group j at (3 j + k) * G slots; G = ring is the planar layout
-        print(f"# group sweep: ms per 64-tile launch by group size G (distance between the planes' simultaneously written regions = G x 64 MiB)")
-        arenas = [_ffi.DeviceBuffer(nbytes) for _ in range(args.candidates)]
-        for j, arena in enumerate(arenas):
-            row = []
-            for G in (64, 32, 16, 8, 4, 2, 1, 64):
-                _ffi.set_tuning(out_group=0 if G == 64 else G)
-                outs.adopt_arena(arena)
-                ls = []
-                for st in range(0, b.ntiles, outs.slots):
-                    a = b.fused_args(IDX, True, stats, False, outs, None, st, min(outs.slots, b.ntiles - st), raw=True)
-                    if G != 64:
-                        for k in range(3):
-                            a.out_index[k] = arena.ptr + k * G * b.npix * 4
-                    ls.append(a)
-                row.append((G, level(ls)))
-            _ffi.set_tuning(out_group=0)
-            print(f"arena {j}: " + "  ".join(f"G={g}: {t:.3f}" for g, t in row), flush=True)
-        for a in arenas:
-            a.free()
-        # one big allocation, the three planes in chosen 4 GiB regions of it
-        big = _ffi.DeviceBuffer(6 * outs.plane_bytes)
-        print("# one 24 GiB allocation, planar planes in regions (i, j, k) of 4 GiB each")
-        for combo in ((0, 1, 2), (3, 4, 5), (0, 2, 4), (1, 3, 5), (0, 1, 5), (0, 4, 5), (2, 3, 4), (0, 3, 5), (0, 1, 2)):
-            ls = []
-            for st in range(0, b.ntiles, outs.slots):
-                a = b.fused_args(IDX, True, stats, False, outs, None, st, min(outs.slots, b.ntiles - st), raw=True) if outs.arena is not None else None
-                for k in range(3):
-                    a.out_index[k] = big.ptr + combo[k] * outs.plane_bytes
-                ls.append(a)
-            print(f"regions {combo}: {level(ls):.3f}", flush=True)
-        big.free()
-        return
     print(f"# {args.candidates} candidate arenas of {nbytes / 2**30:.0f} GiB; ms per 64-tile launch (mean of launches 2..16 of the second burst)")
     arenas = [_ffi.DeviceBuffer(nbytes) for _ in range(args.candidates)]
     for rnd in range(2):

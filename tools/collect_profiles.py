@@ -44,17 +44,19 @@ def headline_launches(rnd, src):
     ring_grid = max(set(grid(r) for r in rows), key=lambda g: sum(1 for r in rows if grid(r) == g))
     hist = [r for r in allrows if "k_chan_hist_u8c3_v2<3>" in r["Kernel_Name"]]
     hist_grid = max(set(grid(r) for r in hist), key=lambda g: int(g[1] or 1))        # grid.y = tiles: the pass over the whole batch
-    steps, search, left = [], [], 0
+    # groups of headline launches between a k_stats_init and the next k_stats_finalize: a step's group has exactly `launches_per_step`
+    # of them and a full-batch histogram pass since the previous group; the arena probe's groups are longer (untimed + timed passes)
+    steps, search, group, saw_hist = [], [], [], False
     for r in allrows:
-        if "k_chan_hist_u8c3_v2<3>" in r["Kernel_Name"] and grid(r) == hist_grid:
-            left = per_step
-        elif r["Kernel_Name"].startswith(head) and grid(r) == ring_grid:
-            d = int(r["End_Timestamp"]) - int(r["Start_Timestamp"])
-            if left > 0:
-                steps.append(d)
-                left -= 1
-            else:
-                search.append(d)
+        name = r["Kernel_Name"]
+        if "k_chan_hist_u8c3_v2<3>" in name and grid(r) == hist_grid:
+            saw_hist = True
+        elif name.startswith(head) and grid(r) == ring_grid:
+            group.append(int(r["End_Timestamp"]) - int(r["Start_Timestamp"]))
+        elif "k_stats_finalize" in name and group:
+            (steps if (len(group) == per_step and saw_hist) else search).extend(group)
+            group, saw_hist = [], False
+    search.extend(group)
     nbytes = line["roofline"]["bytes_per_launch"]
     out = f"{ROOT}/profiles/{rnd}_bench_headline_launches.csv"
     with open(out, "w") as fh:

@@ -22,10 +22,11 @@ from ._ffi import FusedArgs, INDEX_IDS, INDEX_NAMES, STATS_DTYPE, DeviceBuffer, 
 
 MAX_TILES_PER_LAUNCH = 65535      # grid.y limit
 ARENA_MIN_BYTES = 2 << 30         # smaller arenas run alike wherever they land
-ARENA_FULL_SEARCH_BYTES = 6 << 30  # arenas below this get at most four candidates
-ARENA_TRIALS = 16                 # candidate allocations of the default search at most (0.7^16: no fast one among them in 0.3 % of processes)
+ARENA_TRIALS = 4                  # allocations of the default search at most (each is tried with every placement of its planes)
 ARENA_CLASS_GAP = 0.93            # the search ends once its best candidate is 7 % under its worst: both classes seen (they are ~18 % apart)
 ARENA_WARM_MS = 30.0              # untimed launches before a candidate is timed: after an idle gap a fast arena needs ~22 ms to reach its level
+ARENA_SPAN_BYTES = 20 << 30       # how far from the first planes the last ones may be placed inside an allocation (the memory changes kind every 6-16 GiB)
+ARENA_SPAN_STEP = 4 << 30         # ... in steps of
 
 
 # How statistics-only passes over uint8 RGNir batches run (no output planes):
@@ -167,22 +168,23 @@ class TileBatch:
         tile slots (same HBM traffic, bounded footprint) -- see BatchOutputs.
 
         The float32 index planes (and RGBA8 planes) live in ONE allocation (an arena).  How fast the write-bound fused
-        kernel runs into a multi-GiB arena is a stable property of that allocation: two classes about 18 % apart (2.50-2.56
-        against 3.00-3.11 ms per 64-tile launch of the headline kernel; three of ten allocations fast), the same in every
-        round of bursts, with the other candidates alive or freed (profiles/r04_arena_probe_phases.txt).  ``arena``:
-          "auto"      multi-GiB arenas are CHOSEN: plain allocations are made one by one, each is timed with the batch's
-                      own launches (``_probe_arena``), and the search ends as soon as both classes have been seen (the best
-                      7 % under the worst) -- 3.3 candidates on average at three fast ones in ten -- or at
-                      ``placement_trials`` (default ARENA_TRIALS = 16) candidates or when less than arena + 8 GiB of
-                      device memory is free; the fastest is kept, the rest freed.  Candidates stay allocated until the
-                      choice is made (a freed arena would be handed out again), so the search transiently holds
-                      (candidates seen) x the arena's size.  Smaller arenas (they run alike wherever they land) are one
-                      plain allocation
-          "plain"     one plain allocation as it comes, unless ``placement_trials`` asks for a search
+        kernel runs into a multi-GiB arena depends on WHERE its planes lie: device memory comes in two kinds that alternate
+        along an allocation in stretches of 6-16 GiB, and a launch whose write streams are split between the kinds runs 18 %
+        faster than one whose planes all lie in one kind (2.49-2.52 against 3.01-3.15 ms per 64-tile launch of the headline
+        kernel; profiles/r04_arena_two_kinds.txt).  Three 4 GiB planes packed into 12 GiB see a change of kind in three
+        allocations of ten; with room to spare inside the allocation a placement that does can be found in three of four.
+        ``arena``:
+          "auto"      multi-GiB arenas: ONE allocation with up to ARENA_SPAN_BYTES of room beyond the first planes (24 GiB for
+                      three planes of 4 GiB, less if the device is short of memory), and the planes are tried in a handful of
+                      placements inside it -- packed, and with the last planes 8, 12, 16, 20 GiB from the start -- each timed
+                      with the batch's own launches (``_probe_arena``).  If no placement is 7 % faster than another the
+                      allocation is of one kind throughout: another one is taken (up to ``placement_trials``, default
+                      ARENA_TRIALS), and the search ends as soon as both classes have been seen.  The fastest (allocation,
+                      placement) is kept, other allocations are freed.  Smaller arenas (they run alike wherever they land)
+                      are one packed allocation
+          "plain"     one packed allocation as it comes, unless ``placement_trials`` asks for a search among packed ones
         ``pick="slowest"`` keeps the slowest candidate instead (a diagnostic: what a process without a fast arena sees).
-        (Arenas put together from timed groups of physical chunks were built and measured in round 3 --
-        profiles/r03_arena_assembled.txt: a group's probe time does not predict the arena's speed; removed again.)
-        ``outs.arena_report`` = {kind, search_ms, chosen_ms, post_free_ms, rejected, candidate_ms, malloc_ms, ...}."""
+        ``outs.arena_report`` = {kind, search_ms, chosen_ms, post_free_ms, rejected, candidate_ms, placements, ...}."""
         outs = BatchOutputs(self, indices, index, wb, rgba, ring, allocate=False)
         nplanes = len(outs._index_ids) + len(outs._rgba_ids)
         report = {"kind": "none"} if not nplanes else None
@@ -190,63 +192,90 @@ class TileBatch:
             raise ValueError("arena must be auto or plain")
         if pick not in ("fastest", "slowest"):
             raise ValueError("pick must be fastest or slowest")
+        packed_bytes = nplanes * outs.plane_bytes
         big = bool(nplanes) and nplanes * outs.slots * self.npix * 4 >= ARENA_MIN_BYTES
+        spread = arena == "auto" and big and nplanes >= 2                  # room inside the allocation, several placements
         if placement_trials is None:
-            # the classes have shown for 8 and 12 GiB arenas; a 4 GiB single-plane arena gave sixteen candidates within 1 % of each
-            # other (profiles/r04_ndvi_plane_step_ways.txt), so smaller arenas get a short search
-            nbytes_arena = nplanes * outs.slots * self.npix * 4
-            placement_trials = 0 if not (arena == "auto" and big) else (ARENA_TRIALS if nbytes_arena >= ARENA_FULL_SEARCH_BYTES else 4)
-        if nplanes and report is None:
-            t0 = time.perf_counter()
-            outs.adopt_arena(DeviceBuffer(nplanes * outs.plane_bytes))
-            first_malloc_ms = (time.perf_counter() - t0) * 1e3
-            report = {"kind": "plain hipMalloc", "search_ms": 0.0, "chosen_ms": None, "post_free_ms": None, "rejected": 0}
-        outs.arena_report = report
-        if placement_trials <= 1 or outs.arena is None or report.get("kind") != "plain hipMalloc":
+            # one plane: nothing to split -- sixteen 4 GiB single-plane arenas measured within 1 % of each other (profiles/r04_ndvi_plane_step_ways.txt)
+            placement_trials = ARENA_TRIALS if spread else 0
+        if not nplanes or (placement_trials <= 1 and not spread):
+            if nplanes:
+                outs.adopt_arena(DeviceBuffer(packed_bytes))
+                report = {"kind": "plain hipMalloc", "search_ms": 0.0, "chosen_ms": None, "post_free_ms": None, "rejected": 0}
+            outs.arena_report = report
             return outs
         t_search = time.perf_counter()
-        stats = self.new_stats()
-        arenas, timings, malloc_ms = [outs.arena], [self._probe_arena(outs, indices, stats)], [first_malloc_ms]
         free_b, total_b = C.c_size_t(), C.c_size_t()
+        n_first = (nplanes + 1) // 2                                       # planes of the first cluster; the rest form the second
+        first_bytes, second_bytes = n_first * outs.plane_bytes, (nplanes - n_first) * outs.plane_bytes
+
+        def placements_for(nbytes):
+            """Offsets of the planes inside an allocation of ``nbytes``: packed, then the second cluster further and further out."""
+            packed = tuple(j * outs.plane_bytes for j in range(nplanes))
+            out = [packed]
+            start = ((first_bytes + ARENA_SPAN_STEP - 1) // ARENA_SPAN_STEP) * ARENA_SPAN_STEP
+            for s0 in range(start, ARENA_SPAN_BYTES + 1, ARENA_SPAN_STEP):
+                if s0 > first_bytes and s0 + second_bytes <= nbytes:
+                    out.append(packed[:n_first] + tuple(s0 + j * outs.plane_bytes for j in range(nplanes - n_first)))
+            return out
+
+        stats = self.new_stats()
+        cands = []                                                         # (ms, allocation index, offsets)
+        arenas, malloc_ms = [], []
         stopped = "placement_trials"
-        while len(arenas) < int(placement_trials):
-            if len(arenas) >= 2 and min(timings) <= ARENA_CLASS_GAP * max(timings):
-                stopped = "both classes seen"
-                break
+        while len(arenas) < max(1, int(placement_trials)):
             _ffi.call("lars_mem_info", C.byref(free_b), C.byref(total_b))
-            if free_b.value < outs.arena.nbytes + (8 << 30):       # keep 8 GiB of headroom for the caller
-                stopped = "device memory"
-                break
+            want = packed_bytes
+            if spread:
+                want = max(packed_bytes, min(ARENA_SPAN_BYTES + second_bytes, free_b.value - (16 << 30)))
+            if free_b.value < want + (8 << 30):                            # keep 8 GiB of headroom for the caller
+                if arenas:
+                    stopped = "device memory"
+                    break
+                want = packed_bytes                                        # the first arena must exist whatever the headroom
             t0 = time.perf_counter()
             try:
-                cand = DeviceBuffer(outs.arena.nbytes)
+                buf = DeviceBuffer(want)
             except _ffi.LarsError:
+                if not arenas:
+                    stats.free()
+                    raise
                 stopped = "device memory"
-                break                                               # out of memory: choose among what fits
+                break
             malloc_ms.append((time.perf_counter() - t0) * 1e3)
-            arenas.append(cand)
-            outs.adopt_arena(cand)
-            timings.append(self._probe_arena(outs, indices, stats))
-        best = int(np.argmin(timings) if pick == "fastest" else np.argmax(timings))
-        outs.adopt_arena(arenas[best])
-        for j, cand in enumerate(arenas):
-            if j != best:
-                cand.free()
+            arenas.append(buf)
+            for k, offsets in enumerate(placements_for(want)):
+                outs.adopt_arena(buf, offsets)
+                cands.append((self._probe_arena(outs, indices, stats, warm_ms=ARENA_WARM_MS if k == 0 else 5.0), len(arenas) - 1, offsets))
+            times = [c[0] for c in cands]
+            if len(cands) >= 2 and min(times) <= ARENA_CLASS_GAP * max(times):
+                stopped = "both classes seen"
+                break
+        times = [c[0] for c in cands]
+        best = int(np.argmin(times) if pick == "fastest" else np.argmax(times))
+        chosen_ms, chosen_alloc, chosen_offsets = cands[best]
+        outs.adopt_arena(arenas[chosen_alloc], chosen_offsets)
+        for j, buf in enumerate(arenas):
+            if j != chosen_alloc:
+                buf.free()
         _ffi.call("lars_synchronize", None)
-        # the survivor once more, now that the rejected candidates are gone: the figure the steps should reproduce
-        post_free = self._probe_arena(outs, indices, stats) if len(arenas) > 1 else float(timings[best])
+        # the survivor once more, now that the rejected allocations are gone: the figure the steps should reproduce
+        post_free = self._probe_arena(outs, indices, stats) if len(arenas) > 1 else float(chosen_ms)
         stats.free()
-        outs.placement_ms = {"arenas": [float(x) for x in timings], "chosen": float(timings[best])}
-        outs.arena_report = {"kind": f"plain hipMalloc, the {pick} of {len(arenas)} candidates timed with the batch's own launches "
-                                     f"(search ended by: {stopped})",
-                             "search_ms": (time.perf_counter() - t_search) * 1e3, "chosen_ms": float(timings[best]),
-                             "post_free_ms": float(post_free), "rejected": len(arenas) - 1,
-                             "candidate_ms": [float(x) for x in timings], "malloc_ms": [float(x) for x in malloc_ms],
-                             "transient_bytes": int(len(arenas) * outs.arena.nbytes),
-                             "probe": f">= {ARENA_WARM_MS:.0f} ms of untimed launches, then one timed pass of launches over the batch's chunks"}
+        gib = float(1 << 30)
+        outs.placement_ms = {"arenas": [float(x) for x in times], "chosen": float(chosen_ms)}
+        outs.arena_report = {
+            "kind": f"plain hipMalloc of {arenas[chosen_alloc].nbytes / gib:.1f} GiB, the {pick} of {len(cands)} placements of the planes in "
+                    f"{len(arenas)} allocation(s), timed with the batch's own launches (search ended by: {stopped})",
+            "search_ms": (time.perf_counter() - t_search) * 1e3, "chosen_ms": float(chosen_ms), "post_free_ms": float(post_free),
+            "rejected": len(arenas) - 1, "candidate_ms": [float(x) for x in times], "malloc_ms": [float(x) for x in malloc_ms],
+            "placements": [{"allocation": int(a), "offsets_gib": [round(o / gib, 3) for o in offs], "ms": float(t)} for t, a, offs in cands],
+            "chosen_offsets_gib": [round(o / gib, 3) for o in chosen_offsets],
+            "arena_bytes": int(arenas[chosen_alloc].nbytes), "transient_bytes": int(sum(b.nbytes for b in arenas)),
+            "probe": f">= {ARENA_WARM_MS:.0f} ms of untimed launches per allocation, then per placement one timed pass of launches over the batch's chunks"}
         return outs
 
-    def _probe_arena(self, outs, indices, stats):
+    def _probe_arena(self, outs, indices, stats, warm_ms=ARENA_WARM_MS):
         """Milliseconds per fused launch into ``outs`` at the level a step sees: the step's own launch sequence (one launch
         per ring of tile slots over the batch, LARS_F_RAW records; sixteen evenly spaced chunks of a longer sequence).
 
@@ -255,8 +284,9 @@ class TileBatch:
         2.7, 2.67, 2.63, 2.57, 2.53 -> 2.50 ms; slow arenas show no such ramp): profiles/r04_arena_probe_phases.txt, phases
         B and C.  Round 3's probe (one warm-up + three launches right after the allocation) therefore read 2.94-3.04 ms for
         every candidate whenever the allocations were slow, whatever their class.  Hence: untimed launches until
-        ARENA_WARM_MS of device time have passed, then one timed pass; and the pass covers every chunk of the batch because
-        the level also moves by 2-4 % with the input region a launch reads (launches 11-16 of a step against 1-10)."""
+        ``warm_ms`` of device time have passed (less for a further placement in an allocation that has just been probed), then
+        one timed pass; and the pass covers every chunk of the batch because the level also moves by 2-4 % with the input
+        region a launch reads (the input changes kind along its length too)."""
         count = min(outs.slots, self.ntiles)
         starts = list(range(0, self.ntiles, count))
         if len(starts) > 16:
@@ -283,7 +313,7 @@ class TileBatch:
             return float(ms.value)
 
         warmed, passes = 0.0, 0
-        while warmed < ARENA_WARM_MS and passes < 8:
+        while warmed < warm_ms and passes < 8:
             warmed += one_pass()
             passes += 1
         timed = one_pass()
@@ -707,14 +737,23 @@ class BatchOutputs:
                 self.luts[k].upload(colormap_lut(_colormap_for(t)))
         self.wb = DeviceBuffer(self.slots * batch.npix * batch.channels) if wb else None
 
-    def adopt_arena(self, arena):
-        """Point the index planes at ``arena`` (the caller frees whatever arena was in use before)."""
-        assert arena.nbytes >= (len(self._index_ids) + len(self._rgba_ids)) * self.plane_bytes
+    def adopt_arena(self, arena, offsets=None):
+        """Point the planes at ``arena`` (the caller frees whatever arena was in use before).  ``offsets``: byte offset of every
+        plane inside the arena (index planes in the order of INDEX_NAMES, then the RGBA planes; multiples of 256), packed
+        back to back when None."""
+        nplanes = len(self._index_ids) + len(self._rgba_ids)
+        if offsets is None:
+            offsets = tuple(j * self.plane_bytes for j in range(nplanes))
+        offsets = tuple(int(o) for o in offsets)
+        assert len(offsets) == nplanes and all(o % 256 == 0 and o + self.plane_bytes <= arena.nbytes for o in offsets)
+        order = sorted(offsets)
+        assert all(b - a >= self.plane_bytes for a, b in zip(order, order[1:])), "planes overlap"
         self.arena = arena
+        self.plane_offsets = offsets
         for j, k in enumerate(self._index_ids):
-            self.index[k] = DeviceSlice(arena, j * self.plane_bytes, self.plane_bytes)
+            self.index[k] = DeviceSlice(arena, offsets[j], self.plane_bytes)
         for j, k in enumerate(self._rgba_ids):
-            self.rgba[k] = DeviceSlice(arena, (len(self._index_ids) + j) * self.plane_bytes, self.plane_bytes)
+            self.rgba[k] = DeviceSlice(arena, offsets[len(self._index_ids) + j], self.plane_bytes)
 
     def host_index(self, index_type, slot=0, count=1):
         k = INDEX_IDS[index_type]

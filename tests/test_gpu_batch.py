@@ -464,6 +464,18 @@ def test_output_ring_placement_trials(lars):
     worst = b.make_outputs(index=True, ring=2, placement_trials=3, pick="slowest")
     assert worst.arena_report["chosen_ms"] == max(worst.arena_report["candidate_ms"])
     worst.free()
+    # planes may sit anywhere inside the arena (what the search over placements of multi-GiB arenas does): same results
+    from lars_image_processing_amd._ffi import DeviceBuffer
+    spaced = lars.batch.BatchOutputs(b, ("NDVI", "GNDVI", "NDWI"), True, False, False, 2, allocate=False)
+    pb = spaced.plane_bytes
+    spaced.adopt_arena(DeviceBuffer(7 * pb + 4096), (2 * pb + 256, 0, 5 * pb + 4096))
+    assert [spaced.index[k].ptr - spaced.arena.ptr for k in range(3)] == [2 * pb + 256, 0, 5 * pb + 4096]
+    rec_c = b.process(outputs=spaced)
+    assert rec_c.tobytes() == rec_a.tobytes()
+    np.testing.assert_array_equal(bits(spaced.host_index("NDVI", 1, 1)), bits(ndvi_a))
+    with pytest.raises(AssertionError):
+        spaced.adopt_arena(spaced.arena, (0, pb // 2 & ~255, 3 * pb))                    # overlapping planes
+    spaced.free()
     plain.free(); tuned.free(); wide.free(); b.free()
 
 

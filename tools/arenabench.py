@@ -41,7 +41,8 @@ def main():
         first = line["roofline"].get("first_step_launch_ms") or [0.0]
         print(f"run {i:2d}: frac {line['roofline']['frac']:.4f}  whole step {line['roofline']['whole_step_frac']:.4f}  steps {avg:.3f} ms per launch  "
               f"probe chosen {a.get('chosen_ms') or 0:.3f}  after freeing {post:.3f} ({100 * (post / avg - 1) if post else 0:+.1f} % vs steps)  "
-              f"first step {min(first):.3f}-{max(first):.3f}  search {a.get('search_ms') or 0:7.1f} ms  candidates [{cands}]  hipMalloc ms [{mallocs}]  {a.get('kind')}",
+              f"first step {min(first):.3f}-{max(first):.3f}  search {a.get('search_ms') or 0:7.1f} ms  candidates [{cands}]  planes at {a.get('chosen_offsets_gib')} GiB  "
+              f"hipMalloc ms [{mallocs}]  {a.get('kind')}",
               flush=True)
     if fracs:
         print(f"# {len(fracs)} processes: min {min(fracs):.4f}  median {sorted(fracs)[len(fracs) // 2]:.4f}  max {max(fracs):.4f}")

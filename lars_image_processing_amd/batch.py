@@ -206,6 +206,10 @@ class TileBatch:
             return outs
         t_search = time.perf_counter()
         free_b, total_b = C.c_size_t(), C.c_size_t()
+        # Two clusters: ceil(n / 2) planes at the start, the rest further out.  The other split of an odd number ((0, 16, 20) for three planes)
+        # was measured too: 1 % slower than (0, 4, 16) although it balances the launch's four streams, the read included, more often -- and
+        # the 28 GiB it needs came from one kind of memory throughout in three of six fresh processes, where 24 GiB changed kind at 16 GiB in
+        # fourteen of fourteen (profiles/r04_arena_fresh_processes.txt).
         n_first = (nplanes + 1) // 2                                       # planes of the first cluster; the rest form the second
         first_bytes, second_bytes = n_first * outs.plane_bytes, (nplanes - n_first) * outs.plane_bytes
 

@@ -386,6 +386,22 @@ def device_probe(runner):
             ts.append(ms.value)
         out[name] = nbytes * mult / float(np.median(ts[1:])) / 1e6
     dst.free()
+    # the same 12 B / 48 B mix with the three planes where the headline's output arena has them (its chosen placement: the planes split
+    # between the two kinds of device memory) and packed at the start of the same arena: the bare pattern's ceiling for the headline kernel
+    outs = runner.outputs.get(("NDVI", "GNDVI", "NDWI"))
+    if outs is not None and getattr(outs, "plane_offsets", None) is not None and hasattr(lablib, "probe_mix3"):
+        nquads = min(outs.slots, runner.batch.ntiles) * runner.batch.npix // 4
+        for name, offs in (("mix_12B_read_48B_write_planes_as_placed", outs.plane_offsets),
+                           ("mix_12B_read_48B_write_planes_packed", tuple(j * outs.plane_bytes for j in range(3)))):
+            ts = []
+            for _ in range(5):
+                ffi.call("lars_event_record", runner.ev[0], None)
+                lablib.probe_mix3(src, *(outs.arena.ptr + o for o in offs), nquads)
+                ffi.call("lars_event_record", runner.ev[1], None)
+                ms = C.c_float(0)
+                ffi.call("lars_event_elapsed_ms", runner.ev[0], runner.ev[1], C.byref(ms))
+                ts.append(ms.value)
+            out[name] = nquads * 60 / float(np.median(ts[2:])) / 1e6
     return out
 
 

@@ -686,3 +686,15 @@ extern "C" int lars_d_probe(int kind, int unroll, int blocks, const void *src, v
     }
     return launch_check("lars_d_probe");
 }
+
+extern "C" int lars_d_probe_mix3(const void *src, void *d0, void *d1, void *d2, int64_t nquads, int blocks, void *stream)
+{
+    ThreadCtx *c;
+    LARS_TRY(ensure_ctx(&c));
+    if (!src || !d0 || !d1 || !d2 || nquads <= 0 || blocks <= 0) return fail(LARS_ERR_INVALID, "lars_d_probe_mix3: bad arguments");
+    hipStream_t s = pick_stream(c, stream);
+    hipLaunchKernelGGL((k_probe_mix<false>), dim3(blocks), dim3(256), 0, s, static_cast<const unsigned int *>(src), static_cast<pu32x4 *>(d0),
+                       static_cast<pu32x4 *>(d1), static_cast<pu32x4 *>(d2), (long long)nquads);
+    return launch_check("lars_d_probe_mix3");
+}
+

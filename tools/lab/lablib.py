@@ -20,6 +20,7 @@ SIGNATURES = {
     "lars_lab_malloc": (_I, [C.POINTER(_P), _SZ, _I, _I, _I, _I]),
     "lars_lab_free": (_I, [_P]),
     "lars_d_probe": (_I, [_I, _I, _I, _P, _P, _I64, _P]),
+    "lars_d_probe_mix3": (_I, [_P, _P, _P, _P, _I64, _I, _P]),
 }
 _lib = None
 
@@ -73,3 +74,8 @@ class LabBuffer(_ffi._DeviceRange):
 def probe(kind, unroll, blocks, src, dst, nbytes, stream=None):
     call("lars_d_probe", int(kind), int(unroll), int(blocks), C.c_void_p(src) if src else None, C.c_void_p(dst) if dst else None,
          int(nbytes), stream)
+
+
+def probe_mix3(src, d0, d1, d2, nquads, blocks=65536, stream=None):
+    call("lars_d_probe_mix3", C.c_void_p(src), C.c_void_p(d0), C.c_void_p(d1), C.c_void_p(d2), int(nquads), int(blocks), stream)
+

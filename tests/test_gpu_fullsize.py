@@ -67,3 +67,33 @@ def test_chunked_ring_launches_at_bench_size():
     rec_j = b.process(route="joint")
     assert rec_j.tobytes() == rec.tobytes()
     outs.free(); stats.free(); b.free()
+
+
+def test_placement_search_of_a_multi_gib_arena():
+    """make_outputs(arena="auto") for an arena of 2 GiB and more with several planes: ONE allocation with room to spare, the planes
+    tried in several placements inside it (profiles/r04_arena_two_kinds.txt), the fastest kept -- and the planes it writes there
+    are the planes a packed arena gets, bit for bit."""
+    import lars_image_processing_amd as lars
+    from lars_image_processing_amd import _ffi
+    ntiles, ring, edge = 24, 12, 4096                                  # three planes of 12 slots: 2.25 GiB packed
+    b = lars.TileBatch.synthetic(ntiles, edge, edge, seed=77, profile="vegetation")
+    plain = b.make_outputs(index=True, ring=ring, arena="plain")
+    assert plain.arena_report["kind"] == "plain hipMalloc" and plain.arena.nbytes == 3 * plain.plane_bytes
+    auto = b.make_outputs(index=True, ring=ring)
+    rep = auto.arena_report
+    assert rep["rejected"] == len(rep["malloc_ms"]) - 1 and len(rep["candidate_ms"]) == len(rep["placements"]) >= 2
+    assert rep["arena_bytes"] == auto.arena.nbytes > 3 * auto.plane_bytes
+    assert rep["chosen_ms"] == min(rep["candidate_ms"]) and rep["post_free_ms"] > 0
+    offs = [int(round(o * (1 << 30))) for o in rep["chosen_offsets_gib"]]
+    assert [auto.index[k].ptr - auto.arena.ptr for k in range(3)] == list(auto.plane_offsets)
+    assert all(abs(a - b_) <= (1 << 20) for a, b_ in zip(offs, auto.plane_offsets))
+    assert {tuple(p["offsets_gib"]) for p in rep["placements"]} >= {tuple(round(j * auto.plane_bytes / (1 << 30), 3) for j in range(3))}   # packed is among them
+    rec_p = b.process(outputs=plain)
+    rec_a = b.process(outputs=auto)
+    assert rec_p.tobytes() == rec_a.tobytes()
+    for name in TYPES:
+        assert plain.host_index(name, 0, ring).tobytes() == auto.host_index(name, 0, ring).tobytes(), name
+    # one plane: nothing to split, one packed allocation
+    single = b.make_outputs(indices=("NDVI",), index=True, ring=ring)
+    assert single.arena_report["kind"] == "plain hipMalloc"
+    single.free(); plain.free(); auto.free(); b.free()

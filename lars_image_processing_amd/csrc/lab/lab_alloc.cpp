@@ -122,3 +122,21 @@ extern "C" int lars_lab_free(void *dptr)
     LARS_HIP_TRY(hipFree(dptr));
     return LARS_OK;
 }
+
+extern "C" int lars_lab_copy(int mode, int to_device, void *host, void *dev, size_t bytes)
+{
+    ThreadCtx *c;
+    LARS_TRY(ensure_ctx(&c));
+    if (!host || !dev) return fail(LARS_ERR_INVALID, "lars_lab_copy: NULL");
+    void *dst = to_device ? dev : host;
+    const void *src = to_device ? host : dev;
+    const hipMemcpyKind kind = to_device ? hipMemcpyHostToDevice : hipMemcpyDeviceToHost;
+    if (mode == 0) {
+        LARS_HIP_TRY(hipMemcpy(dst, src, bytes, kind));
+    } else {
+        LARS_HIP_TRY(hipMemcpyAsync(dst, src, bytes, kind, c->stream));
+        LARS_HIP_TRY(hipStreamSynchronize(c->stream));
+    }
+    return LARS_OK;
+}
+

@@ -21,6 +21,7 @@ SIGNATURES = {
     "lars_lab_free": (_I, [_P]),
     "lars_d_probe": (_I, [_I, _I, _I, _P, _P, _I64, _P]),
     "lars_d_probe_mix3": (_I, [_P, _P, _P, _P, _I64, _I, _P]),
+    "lars_lab_copy": (_I, [_I, _I, _P, _P, _SZ]),
 }
 _lib = None
 

@@ -176,8 +176,8 @@ class TileBatch:
         ``arena``:
           "auto"      multi-GiB arenas: ONE allocation with up to ARENA_SPAN_BYTES of room beyond the first planes (24 GiB for
                       three planes of 4 GiB, less if the device is short of memory), and the planes are tried in a handful of
-                      placements inside it -- packed, and with the last planes 8, 12, 16, 20 GiB from the start -- each timed
-                      with the batch's own launches (``_probe_arena``).  If no placement is 7 % faster than another the
+                      placements inside it -- packed, and with the second half of the planes further out in steps of 4 GiB up
+                      to 20 GiB from the start -- each timed with the batch's own launches (``_probe_arena``).  If no placement is 7 % faster than another the
                       allocation is of one kind throughout: another one is taken (up to ``placement_trials``, default
                       ARENA_TRIALS), and the search ends as soon as both classes have been seen.  The fastest (allocation,
                       placement) is kept, other allocations are freed.  Smaller arenas (they run alike wherever they land)
@@ -208,8 +208,8 @@ class TileBatch:
         free_b, total_b = C.c_size_t(), C.c_size_t()
         # Two clusters: ceil(n / 2) planes at the start, the rest further out.  The other split of an odd number ((0, 16, 20) for three planes)
         # was measured too: 1 % slower than (0, 4, 16) although it balances the launch's four streams, the read included, more often -- and
-        # the 28 GiB it needs came from one kind of memory throughout in three of six fresh processes, where 24 GiB changed kind at 16 GiB in
-        # fourteen of fourteen (profiles/r04_arena_fresh_processes.txt).
+        # the 28 GiB it needs came from one kind of memory throughout in three of six fresh processes, where the first 24 GiB of a fresh
+        # process showed both classes in eleven of thirteen (profiles/r04_arena_fresh_processes.txt).
         n_first = (nplanes + 1) // 2                                       # planes of the first cluster; the rest form the second
         first_bytes, second_bytes = n_first * outs.plane_bytes, (nplanes - n_first) * outs.plane_bytes
 

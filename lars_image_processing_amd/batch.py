@@ -63,6 +63,24 @@ def channels_of(indices, whole_image=False):
     return need
 
 
+def arena_placements(nplanes, plane_bytes, nbytes):
+    """Byte offsets of ``nplanes`` planes of ``plane_bytes`` inside an allocation of ``nbytes`` that ``TileBatch.make_outputs`` tries:
+    packed back to back, then the first ceil(n / 2) planes packed at the start and the rest packed from 8, 12, 16, 20 GiB on
+    (every multiple of ARENA_SPAN_STEP beyond the first cluster up to ARENA_SPAN_BYTES that still fits).  Device memory changes kind
+    every 6-16 GiB along an allocation and a launch is fast when its planes are split between the kinds (make_outputs)."""
+    n_first = (nplanes + 1) // 2
+    first_bytes, second_bytes = n_first * plane_bytes, (nplanes - n_first) * plane_bytes
+    packed = tuple(j * plane_bytes for j in range(nplanes))
+    out = [packed]
+    if nplanes < 2:
+        return out
+    start = ((first_bytes + ARENA_SPAN_STEP - 1) // ARENA_SPAN_STEP) * ARENA_SPAN_STEP
+    for s0 in range(start, ARENA_SPAN_BYTES + 1, ARENA_SPAN_STEP):
+        if s0 > first_bytes and s0 + second_bytes <= nbytes:
+            out.append(packed[:n_first] + tuple(s0 + j * plane_bytes for j in range(nplanes - n_first)))
+    return out
+
+
 def shard_range(ntiles, rank, world):
     """Contiguous block of tiles owned by ``rank`` (remainder to the low ranks)."""
     base, rem = divmod(int(ntiles), int(world))
@@ -214,14 +232,7 @@ class TileBatch:
         first_bytes, second_bytes = n_first * outs.plane_bytes, (nplanes - n_first) * outs.plane_bytes
 
         def placements_for(nbytes):
-            """Offsets of the planes inside an allocation of ``nbytes``: packed, then the second cluster further and further out."""
-            packed = tuple(j * outs.plane_bytes for j in range(nplanes))
-            out = [packed]
-            start = ((first_bytes + ARENA_SPAN_STEP - 1) // ARENA_SPAN_STEP) * ARENA_SPAN_STEP
-            for s0 in range(start, ARENA_SPAN_BYTES + 1, ARENA_SPAN_STEP):
-                if s0 > first_bytes and s0 + second_bytes <= nbytes:
-                    out.append(packed[:n_first] + tuple(s0 + j * outs.plane_bytes for j in range(nplanes - n_first)))
-            return out
+            return arena_placements(nplanes, outs.plane_bytes, nbytes)
 
         stats = self.new_stats()
         cands = []                                                         # (ms, allocation index, offsets)

@@ -135,3 +135,21 @@ def test_hist_edges_match_numpy_linspace():
     np.testing.assert_array_equal(e32, np.histogram_bin_edges(np.zeros(1, np.float32), bins=50, range=(-1, 1)))
     e64 = np.array([(1.0 if i >= 50 else np.float64(i) * (2.0 / 50.0) + (-1.0)) for i in range(51)])
     np.testing.assert_array_equal(e64, np.histogram_bin_edges(np.zeros(1, np.float64), bins=50, range=(-1, 1)))
+
+
+def test_arena_placements():
+    """The placements of the planes TileBatch.make_outputs tries inside one allocation (host logic, no GPU): packed first, then the second
+    half of the planes further out in steps of 4 GiB up to 20 GiB; planes never overlap, never leave the allocation."""
+    from lars_image_processing_amd import batch
+    gib = 1 << 30
+    got = batch.arena_placements(3, 4 * gib, 24 * gib)
+    assert [tuple(o // gib for o in p) for p in got] == [(0, 4, 8), (0, 4, 12), (0, 4, 16), (0, 4, 20)]
+    assert [tuple(o // gib for o in p) for p in batch.arena_placements(2, 4 * gib, 24 * gib)] == [(0, 4), (0, 8), (0, 12), (0, 16), (0, 20)]
+    assert batch.arena_placements(1, 4 * gib, 24 * gib) == [(0,)]
+    assert batch.arena_placements(3, 4 * gib, 12 * gib) == [(0, 4 * gib, 8 * gib)]                       # no room: packed only
+    six = batch.arena_placements(6, 4 * gib, 32 * gib)
+    assert [tuple(o // gib for o in p) for p in six] == [(0, 4, 8, 12, 16, 20), (0, 4, 8, 16, 20, 24), (0, 4, 8, 20, 24, 28)]
+    for n, pb, nb in ((3, 4 * gib, 24 * gib), (2, 3 * gib + 256, 24 * gib), (5, 700 << 20, 22 * gib), (6, 4 * gib, 32 * gib), (4, 256, 1 << 20)):
+        for p in batch.arena_placements(n, pb, nb):
+            assert len(p) == n and p[0] == 0 and all(o % 256 == 0 for o in p)
+            assert all(b - a >= pb for a, b in zip(p, p[1:])) and p[-1] + pb <= nb

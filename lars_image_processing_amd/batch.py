@@ -229,7 +229,7 @@ class TileBatch:
         # the 28 GiB it needs came from one kind of memory throughout in three of six fresh processes, where the first 24 GiB of a fresh
         # process showed both classes in eleven of thirteen (profiles/r04_arena_fresh_processes.txt).
         n_first = (nplanes + 1) // 2                                       # planes of the first cluster; the rest form the second
-        first_bytes, second_bytes = n_first * outs.plane_bytes, (nplanes - n_first) * outs.plane_bytes
+        second_bytes = (nplanes - n_first) * outs.plane_bytes
 
         def placements_for(nbytes):
             return arena_placements(nplanes, outs.plane_bytes, nbytes)

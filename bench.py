@@ -76,10 +76,11 @@ def parse():
     ap.add_argument("--no-probe", dest="probe", action="store_false", help="skip the streaming-roofline probes")
     ap.add_argument("--profile", default="vegetation", choices=["uniform", "vegetation"])
     ap.add_argument("--arena", default="auto", choices=["auto", "plain", "slowest"],
-                    help="output arena of the plane-writing modes.  auto: the library's default (TileBatch.make_outputs) -- for "
-                         "multi-GiB arenas candidate allocations are timed with the batch's own launches until both speed classes "
-                         "have been seen and the fastest is kept; plain: one allocation as it comes; slowest: the same search but "
-                         "the SLOWEST candidate is kept (a diagnostic: the line of a process that finds no fast arena)")
+                    help="output arena of the plane-writing modes.  auto: the library's default (TileBatch.make_outputs) -- a multi-GiB "
+                         "arena is ONE allocation with room to spare and the planes are tried in a handful of placements inside it, each "
+                         "timed with the batch's own launches (device memory comes in two kinds; the launch is fast when its planes are "
+                         "split between them); plain: one packed allocation as it comes; slowest: the same search but the SLOWEST "
+                         "placement is kept (a diagnostic: the line of a process that finds no fast placement)")
     ap.add_argument("--placement-trials", type=int, default=-1,
                     help="candidate arenas of the search (-1: the library's default, 0/1: take the first)")
     ap.add_argument("--stats-route", default="joint", choices=["joint", "classic"],

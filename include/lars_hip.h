@@ -266,7 +266,15 @@ int lars_d_quotient_median_pairs(const void *tiles, int64_t ntiles, int64_t npix
  *                 a->wb_table, if not NULL, is an OUTPUT here: [ntiles][3][256] tables of the channels the mask needs
  *                 (NIR and red for NDVI, NIR and green for GNDVI / NDWI)
  *   white_balance 0: indices of the raw samples (calculate_index without fix_white_balance); 1: percentile white balance
- *   percentiles   [ntiles][3][2] double or NULL, hist [ntiles][3][256] or NULL: outputs, same channels as the tables
+ *   percentiles   [ntiles][3][2] double or NULL, hist [ntiles][3][256] or NULL: outputs, same channels as the tables.
+ *                 With hist == NULL, white_balance != 0, both value streams in the mask and tiles of >= 2^20 pixels the call may
+ *                 count a tile on WINDOWED tables (csrc/joint_win.hip): red and green clamped to a window around their
+ *                 percentiles -- fix_white_balance maps everything at or below p2 to 0 and at or above p98 to 255
+ *                 (process-images.py:438), so the records, percentiles, tables and medians are the same bits -- which lets both pair
+ *                 tables of a tile chunk live in ONE workgroup's LDS: one reader per byte instead of two.  A subsample predicts
+ *                 the windows, the exact percentiles check them, a tile whose window missed is counted again on full tables
+ *                 (lars_set_tuning("joint_window", 0) = never windowed; 2 = windows that miss on purpose).  Channel histograms
+ *                 cannot be had from clamped counts: asking for hist keeps the full tables
  *   out_pairs     float[ntiles][2 streams: NDVI, GNDVI][2] or NULL: the two middle order statistics (median = their
  *                 float32 mean; NDWI's is -GNDVI's); a stream the mask does not need comes back as NaN
  *   scratch       scratch_bytes >= lars_joint_scratch_bytes(ntiles, npix, index_mask) bytes of device memory; its first word
@@ -275,6 +283,10 @@ int lars_d_quotient_median_pairs(const void *tiles, int64_t ntiles, int64_t npix
 size_t lars_joint_scratch_bytes(int64_t ntiles, int64_t npix, uint32_t index_mask);
 int lars_d_stats_joint(const lars_fused_args *a, int white_balance, int rgn_variant, double *percentiles, uint32_t *hist,
                        float *out_pairs, void *scratch, size_t scratch_bytes);
+/* How the last lars_d_stats_joint on `scratch` used windowed tables (csrc/joint_win.hip), once its stream has finished:
+ * *windowed = tiles counted by one reader on windowed tables, *recounted = tiles among them whose window missed a percentile's
+ * order statistic and which were counted again on full tables.  Both 0 after a call that did not qualify (see above). */
+int lars_joint_window_report(const void *scratch, int64_t ntiles, int64_t *windowed, int64_t *recounted);
 
 /* classification mask (see lars_h_threshold_mask_f32); x 16-byte, out_mask 4-byte aligned */
 int lars_d_threshold_mask_f32(const float *x, int64_t n, float threshold, uint8_t *out_mask, void *stream);
@@ -313,6 +325,7 @@ int lars_d_synth_u8(uint8_t *tiles, int64_t ntiles, int64_t first_tile, int64_t 
 
 /* Tuning knobs (per process): "fused_impl" 0 (auto)|1|2, "hist_impl" 1|2, "nt_stores" 0|1, "blocks_per_tile" 0 = automatic
  * (also the chunks per tile of lars_d_stats_joint), "joint_depth" 4|6 loads in flight per lane of the counting kernel,
+ * "joint_window" 1 (windowed pair tables where they fit: lars_d_stats_joint)|0 (never)|2 (windows that miss on purpose: exercises the recount),
  * "u16_hist_impl" 2 (uint16 percentiles usually from one full pass: candidate bins predicted from a subsample)|1 (always the two
  * radix passes)|3 (wrong candidates on purpose: exercises the recount),
  * "selq_window" 1 (one-pass medians)|0 (always two select passes)|2 (wrong windows: exercises the fallback), "selq_list_wgs"

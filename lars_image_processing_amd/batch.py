@@ -109,6 +109,7 @@ class TileBatch:
         self.table = None
         self.percentiles = None
         self._table_channels = set()       # channels whose tables are valid (a one-read pass fills only those its indices read)
+        self._hist_channels = set()        # channels whose 256-bin histograms are valid (a one-read pass fills them only on request)
         self._rgn_variant = 0              # flavour of the tables in force (process-rgn.py's extra inner clip = 1)
 
     # -- construction -----------------------------------------------------
@@ -152,6 +153,7 @@ class TileBatch:
             _ffi.call("lars_d_wb_prepare", C.c_void_p(self.tiles.ptr), self.ntiles, self.npix, self.channels,
                       self.code, C.c_void_p(self.table.ptr), C.c_void_p(self.percentiles.ptr), int(rgn_variant), stream)
         self._table_channels = {0, 1, 2}
+        self._hist_channels = {0, 1, 2} if self.code == _ffi.U8 else set()
         self._rgn_variant = int(rgn_variant)
         return self
 
@@ -175,8 +177,14 @@ class TileBatch:
         return self.percentiles.download(np.float64, (self.ntiles, 3, 2))
 
     def host_hist(self, partial=False):
-        """uint8 batches only (uint16 percentiles come from two radix levels, no full histogram)."""
+        """uint8 batches only (uint16 percentiles come from two radix levels, no full histogram).  After a one-read pass
+        (``run_joint`` / ``process`` without planes) the histograms exist only if it was asked for them (``channel_hist=True``):
+        without them the pass may count red and green clamped to a window around their percentiles (csrc/joint_win.hip)."""
         self._need_channels(partial)
+        if self.hist is None or (not partial and self._hist_channels != {0, 1, 2}):
+            missing = sorted({0, 1, 2} - self._hist_channels)
+            raise RuntimeError(f"channel histograms of channel(s) {missing} are not valid: the last one-read pass was not asked for them "
+                               f"(compute_wb_tables(), or run_joint(..., channel_hist=True); partial=True hands out what there is)")
         return self.hist.download(np.uint32, (self.ntiles, 3, 256))
 
     # -- pass 2: the fused kernel ------------------------------------------
@@ -428,11 +436,14 @@ class TileBatch:
         return self.code == _ffi.U8 and self.channels in (3, 4) and (self.ntiles == 1 or self.npix % 4 == 0)
 
     def run_joint(self, indices, white_balance, stats, hist=False, sumsq=False, pairs=None, stream=None, rgn_variant=0,
-                  tile_count=None):
+                  tile_count=None, channel_hist=False):
         """Enqueue ``lars_d_stats_joint``: final records into ``stats`` and, with ``pairs`` (a DeviceBuffer of
         ntiles * 4 floats), the two middle order statistics of every tile's NDVI / GNDVI values.  With white balance the
-        call also leaves ``self.hist`` / ``self.percentiles`` / ``self.table`` filled for the channels the indices read
-        (NIR and red for NDVI, NIR and green for GNDVI / NDWI), as ``compute_wb_tables`` would."""
+        call also leaves ``self.percentiles`` / ``self.table`` filled for the channels the indices read (NIR and red for
+        NDVI, NIR and green for GNDVI / NDWI), as ``compute_wb_tables`` would -- and, with ``channel_hist=True``,
+        ``self.hist``.  Without the histograms a pass over both value streams may count red and green clamped to windows
+        around their percentiles, both pair tables of a tile chunk in ONE workgroup (csrc/joint_win.hip): same records,
+        percentiles, tables and medians, one reader per byte instead of two."""
         mask = 0
         for t in indices:
             mask |= 1 << INDEX_IDS[t]
@@ -448,16 +459,20 @@ class TileBatch:
                 self.percentiles = DeviceBuffer(self.ntiles * 3 * 2 * 8)
                 self.table.zero(stream)
                 self.percentiles.zero(stream)
-            if self.hist is None:
+            if channel_hist and self.hist is None:
                 self.hist = DeviceBuffer(self.ntiles * 3 * 256 * 4)
                 self.hist.zero(stream)
+                self._hist_channels = set()
             if tile_count is None or int(tile_count) == self.ntiles:
                 # valid rows: those this pass writes, plus what an earlier pass of the same flavour left for the other channels
                 keep = self._table_channels if int(rgn_variant) == self._rgn_variant else set()
                 self._table_channels = keep | channels_of(indices)
                 self._rgn_variant = int(rgn_variant)
+                if channel_hist:
+                    self._hist_channels = self._hist_channels | channels_of(indices)
             else:
                 self._table_channels = set()                # a partial pass leaves the batch's tables in no usable state
+                self._hist_channels = set()
         a = FusedArgs()
         a.tiles = self.tiles.ptr
         a.ntiles, a.npix, a.channels, a.dtype = (self.ntiles if tile_count is None else int(tile_count)), self.npix, self.channels, self.code
@@ -468,8 +483,15 @@ class TileBatch:
         a.stream = stream
         _ffi.call("lars_d_stats_joint", C.byref(a), 1 if white_balance else 0, int(rgn_variant),
                   C.c_void_p(self.percentiles.ptr) if white_balance else None,
-                  C.c_void_p(self.hist.ptr) if white_balance else None,
+                  C.c_void_p(self.hist.ptr) if white_balance and channel_hist else None,
                   C.c_void_p(pairs.ptr) if pairs is not None else None, C.c_void_p(self._joint_scratch.ptr), self._joint_scratch.nbytes)
+
+    def joint_window_report(self):
+        """(tiles the last ``run_joint`` counted on windowed tables, tiles among them whose window missed and that were
+        counted again) -- after the pass's stream has finished."""
+        w, r = C.c_int64(0), C.c_int64(0)
+        _ffi.call("lars_joint_window_report", C.c_void_p(self._joint_scratch.ptr), self.ntiles, C.byref(w), C.byref(r))
+        return int(w.value), int(r.value)
 
     def check_joint(self, stream=None):
         """After a ``run_joint``: wait for ``stream`` and raise if the counting kernel reported a hand-over list overflow
@@ -498,9 +520,10 @@ class TileBatch:
         if sample * self.npix < int(min_pixels) or self.channels != 3:
             cache[key] = "joint"
             return "joint"
-        saved = (self.table, self.percentiles, self.hist, set(self._table_channels), self._rgn_variant)
+        saved = (self.table, self.percentiles, self.hist, set(self._table_channels), self._rgn_variant, set(self._hist_channels))
         self.table = self.percentiles = self.hist = None
         self._table_channels = set()
+        self._hist_channels = set()
         ev = [C.c_void_p() for _ in range(3)]
         for e in ev:
             _ffi.call("lars_event_create", C.byref(e))
@@ -512,6 +535,8 @@ class TileBatch:
                 self.run_joint(indices, white_balance, stats, tile_count=sample)
                 _ffi.call("lars_event_record", ev[1], None)
                 if white_balance:
+                    if self.hist is None:
+                        self.hist = DeviceBuffer(self.ntiles * 3 * 256 * 4)
                     _ffi.call("lars_d_channel_hist", C.c_void_p(self.tiles.ptr), sample, self.npix, self.channels, self.code,
                               C.c_void_p(self.hist.ptr), None)
                     _ffi.call("lars_d_wb_table", C.c_void_p(self.hist.ptr), sample, self.npix, self.code, C.c_void_p(self.table.ptr),
@@ -530,7 +555,7 @@ class TileBatch:
             for buf in (self.table, self.percentiles, self.hist):
                 if buf is not None:
                     buf.free()
-            self.table, self.percentiles, self.hist, self._table_channels, self._rgn_variant = saved
+            self.table, self.percentiles, self.hist, self._table_channels, self._rgn_variant, self._hist_channels = saved
         cache[key] = "joint" if ms["joint"] <= ms["classic"] else "classic"
         self._route_ms = dict(ms)
         return cache[key]

@@ -29,55 +29,11 @@
 // 25 DIFFERENT banks (and dwords), as do common shifts of both samples (shading: +6 per level) and shifts of one sample alone.
 // Round 3's n ^ 2x put such a neighbourhood into about six banks (tools/lab/banksim.py: 10-12 lanes on the fullest bank against
 // 5.4 for independent samples; the linear form: 5.5-5.7).
-#include <string.h>
+#include <vector>
 
-#include <type_traits>
-
-#include "v2_device.h"
+#include "joint_device.h"
 
 namespace lars {
-
-#define JH_K 5u                                          /* m = n + JH_K * x: odd, and 5 x 5 neighbourhoods tile 25 consecutive values */
-#define JH_DWORDS 32768
-#define JH_THREADS 1024
-#define JH_PERIOD_STEPS 12                    /* steps of 4096 pixels between two scans */
-#define JH_PROMOTE_MASK 0x0000C000u           /* a low half >= 16384 */
-#define JH_LIST_CAP 1024
-#define JH_MAX_WG_PIXELS (1ll << 24)
-
-struct JointCountParams {
-    const uint8_t *tiles;
-    long long npix;
-    long long ntiles;
-    long long chunk_quads;                    // quads per chunk: a multiple of 1024 (the last chunk of a tile takes the rest)
-    unsigned int *part;                       // [ntiles][S][K][32768][2] uint32: counts of the cells (D, 0), (D, 1)
-    unsigned int *error;                      // set to 1 if a list overflows (cannot happen: see JH_MAX_WG_PIXELS)
-    int K;                                    // chunks per tile
-    int S;                                    // streams counted: 1 or 2
-    unsigned int streams;                     // bit 0: (n, r) pairs, bit 1: (n, g) pairs
-};
-
-__device__ inline void jh_add(unsigned int addr, unsigned int val, char *tab)
-{
-    __hip_atomic_fetch_add(reinterpret_cast<unsigned int *>(tab + addr), val, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-}
-
-// nn + 5 px in one full-rate instruction (px < 2^24; the compiler's own choice for * 5 + is the quarter-rate v_mad_u64_u32)
-__device__ inline unsigned int jh_mad5(unsigned int px, unsigned int nn)
-{
-    unsigned int r;
-    asm("v_mad_u32_u24 %0, %1, 5, %2" : "=v"(r) : "v"(px), "v"(nn));
-    return r;
-}
-static_assert(JH_K == 5u, "jh_mad5 spells the factor out");
-
-// (D, h) of a pair of samples, and back
-__device__ inline unsigned int jh_m(unsigned int n, unsigned int x) { return (n + JH_K * x) & 255u; }
-__device__ inline unsigned int jh_n_of(unsigned int D, unsigned int h)
-{
-    const unsigned int x = D >> 7, m = (D & 127u) | (h << 7);
-    return (m - JH_K * x) & 255u;
-}
 
 // CH = 4: RGBA tiles, one 16-byte load per lane and step, repacked into the three dwords of an RGB quad.
 template <int DEPTH, int CH = 3>
@@ -105,6 +61,11 @@ __global__ __launch_bounds__(JH_THREADS, 4) void k_joint_count(JointCountParams 
     const long long tile = unit / P.K;
     const int chunk = (int)(unit - tile * P.K);
     if (tile >= P.ntiles) return;
+    if (P.win) {
+        // windowed tiles belong to k_joint_count_win; the second pass counts only the tiles whose window missed (k_joint_finish's flag)
+        const JointWin wn = P.win[tile];
+        if (P.pass == 0 ? wn.mode == 1u : wn.flag == 0u) return;
+    }
     const bool green = P.S == 2 ? role == 1 : (P.streams == 2u);                   // which sample pairs with NIR
 
     uint4 *tab4 = reinterpret_cast<uint4 *>(s_tab);
@@ -314,6 +275,8 @@ struct JointFinishParams {
     double *pcts_out;                         // [ntiles][3][2] or null
     unsigned int *hist_out;                   // [ntiles][3][256] or null
     float *out_pairs;                         // [ntiles][2 streams][2] or null: the two middle order statistics
+    JointWin *win;                            // [ntiles] or null: the windows the tiles were counted with (joint_win.hip)
+    int pass;                                 // 0: every tile, windows checked; 1: only the tiles flagged by pass 0 (now counted on full tables)
 };
 
 // Exclusive prefix of one value per thread over the first 256 threads of the block (4 waves): wave scans + one barrier.
@@ -393,6 +356,18 @@ __global__ __launch_bounds__(JH_THREADS) void k_joint_finish(JointFinishParams P
     const bool want_g = green && (P.mask & LARS_MASK_GNDVI);
     const bool want_w = green && (P.mask & LARS_MASK_NDWI);
     const bool medians = P.out_pairs != nullptr;
+    // Windowed counts (joint_win.hip): samples of this stream's channel below win_lo were counted as win_lo, above win_hi as win_hi.
+    bool windowed = false;
+    unsigned int win_lo = 0u, win_hi = 255u;
+    if (P.win) {
+        const JointWin wn = P.win[tile];                                 // pass 0: the other stream's block may set .flag meanwhile; nothing else changes
+        if (P.pass == 1 && wn.flag == 0u) return;
+        if (P.pass == 0 && wn.mode == 1u && P.wb) {
+            windowed = true;
+            win_lo = green ? wn.lo_g : wn.lo_r;
+            win_hi = win_lo + (green ? wn.ng : wn.nr) - 1u;
+        }
+    }
 
     if (tid < 256) { s_hn[tid] = 0; s_hx[tid] = 0; }
     for (int i = tid; i < SELQ_BINS; i += JH_THREADS) s_bucket[i] = 0;
@@ -405,37 +380,46 @@ __global__ __launch_bounds__(JH_THREADS) void k_joint_finish(JointFinishParams P
     // This thread's 64 cells: dwords D = j * 1024 + tid (j < 32), halves h = 0, 1; x = D >> 7 (the same for the 64 lanes of a
     // wave), n = ((D & 127 | h << 7) - 5 x) & 255 (jh_n_of).  Every pass below walks them in four groups of eight dwords, the next
     // group's loads (L2 hits: the counting kernel has just written them) in flight while the current one is worked on.
-    constexpr int NJ = JH_DWORDS / JH_THREADS;                       // 32
+    constexpr int NJ = JH_DWORDS / JH_THREADS;                       // 32 blocks of 1024 dwords = 8 rows each
     constexpr int GRP = 8;
+    // windowed counts: only the blocks that hold the window's rows were published (k_joint_count_win), everything else is zero
+    const int j_lo = windowed ? (int)(win_lo >> 3) : 0, j_hi = windowed ? (int)(win_hi >> 3) + 1 : NJ;
     auto for_cells = [&](auto &&f) {
         uint2 buf[2][GRP];
         auto fetch = [&](int g, uint2 (&dst)[GRP]) {
 #pragma unroll
-            for (int i = 0; i < GRP; ++i)
-                dst[i] = *reinterpret_cast<const uint2 *>(part + 2 * ((long long)(g * GRP + i) * JH_THREADS + tid));
+            for (int i = 0; i < GRP; ++i) {
+                const int j = j_lo + g * GRP + i;
+                dst[i] = j < j_hi ? *reinterpret_cast<const uint2 *>(part + 2 * ((long long)j * JH_THREADS + tid)) : make_uint2(0u, 0u);
+            }
             for (int k = 1; k < P.K; ++k) {
                 const unsigned int *pk = part + (long long)k * (2 * JH_DWORDS);
 #pragma unroll
                 for (int i = 0; i < GRP; ++i) {
-                    const uint2 v = *reinterpret_cast<const uint2 *>(pk + 2 * ((long long)(g * GRP + i) * JH_THREADS + tid));
-                    dst[i].x += v.x; dst[i].y += v.y;
+                    const int j = j_lo + g * GRP + i;
+                    if (j < j_hi) {
+                        const uint2 v = *reinterpret_cast<const uint2 *>(pk + 2 * ((long long)j * JH_THREADS + tid));
+                        dst[i].x += v.x; dst[i].y += v.y;
+                    }
                 }
             }
         };
         auto work = [&](int g, const uint2 (&src)[GRP]) {
 #pragma unroll
             for (int i = 0; i < GRP; ++i) {
-                f((unsigned)(g * GRP + i) * JH_THREADS + (unsigned)tid, src[i].x, src[i].y);
+                const int j = j_lo + g * GRP + i;
+                if (j < j_hi) f((unsigned)j * JH_THREADS + (unsigned)tid, src[i].x, src[i].y);       // uniform over the block
                 __builtin_amdgcn_sched_barrier(0);
             }
         };
+        const int ng = (j_hi - j_lo + GRP - 1) / GRP;
         fetch(0, buf[0]);
 #pragma unroll 1
-        for (int g = 0; g < NJ / GRP; g += 2) {
-            fetch(g + 1, buf[1]);
+        for (int g = 0; g < ng; g += 2) {
+            if (g + 1 < ng) fetch(g + 1, buf[1]);
             work(g, buf[0]);
-            if (g + 2 < NJ / GRP) fetch(g + 2, buf[0]);
-            work(g + 1, buf[1]);
+            if (g + 2 < ng) fetch(g + 2, buf[0]);
+            if (g + 1 < ng) work(g + 1, buf[1]);
         }
     };
     __syncthreads();
@@ -491,6 +475,22 @@ __global__ __launch_bounds__(JH_THREADS) void k_joint_finish(JointFinishParams P
             }
         }
         __syncthreads();
+        if (windowed) {
+            // The clamped channel's cumulative counts are exact from win_lo up to win_hi - 1, so an order statistic found strictly
+            // inside the window IS the tile's; one found on an edge (that is not the range's edge) may really lie beyond it.  All four
+            // inside: win_lo < p2 and p98 < win_hi, every clamped sample has the level of its edge (0 resp. 255, process-images.py:438)
+            // and the counts are the tile's statistics.  Otherwise: flag the tile, it is counted again on full tables.
+            bool missed = false;
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const unsigned int b = (unsigned int)s_ord[1][r];
+                if ((win_lo > 0u && b <= win_lo) || (win_hi < 255u && b >= win_hi)) missed = true;
+            }
+            if (missed) {
+                if (tid == 0) P.win[tile].flag = 1u;
+                return;
+            }
+        }
         if (tid < 4) {
             const int pc = tid >> 1, k = tid & 1;
             const double q = (k == 0 ? 2.0 : 98.0) / 100.0;
@@ -688,13 +688,28 @@ static long long joint_chunk_quads(long long npix, int K)
     return cq > 0 ? cq : 1024;
 }
 
+// Scratch: [256 B: error flag][JointWin x ntiles, padded to 256 B][moved-dword lists of the windowed workgroups][pair counts]
+struct JointScratch {
+    size_t win_off, list_off, part_off, total;
+};
+static JointScratch joint_scratch_layout(long long ntiles, int S, int K)
+{
+    JointScratch L;
+    L.win_off = 256;
+    L.list_off = L.win_off + (((size_t)ntiles * sizeof(JointWin) + 255) & ~(size_t)255);
+    const size_t list_bytes = S == 2 ? (size_t)ntiles * K * JW_LIST_CAP * sizeof(uint2) : 0;
+    L.part_off = L.list_off + list_bytes;
+    L.total = L.part_off + (size_t)ntiles * S * K * (2 * JH_DWORDS) * sizeof(unsigned int);
+    return L;
+}
+
 extern "C" size_t lars_joint_scratch_bytes(int64_t ntiles, int64_t npix, uint32_t index_mask)
 {
     if (ntiles <= 0 || npix <= 0) return 0;
     const int S = ((index_mask & 1u) ? 1 : 0) + ((index_mask & 6u) ? 1 : 0);
     if (S == 0) return 0;
     const int K = joint_chunks(ntiles, npix, S);
-    return (size_t)ntiles * S * K * (2 * JH_DWORDS) * sizeof(unsigned int) + 256;
+    return joint_scratch_layout(ntiles, S, K).total;
 }
 
 extern "C" int lars_d_stats_joint(const lars_fused_args *a, int white_balance, int rgn_variant, double *percentiles,
@@ -718,39 +733,84 @@ extern "C" int lars_d_stats_joint(const lars_fused_args *a, int white_balance, i
     const unsigned streams = ((mask & 1u) ? 1u : 0u) | ((mask & 6u) ? 2u : 0u);
     const int S = streams == 3u ? 2 : 1;
     const int K = joint_chunks(a->ntiles, a->npix, S);
-    const size_t need = (size_t)a->ntiles * S * K * (2 * JH_DWORDS) * sizeof(unsigned int) + 256;
-    if (scratch_bytes < need)
+    const JointScratch L = joint_scratch_layout(a->ntiles, S, K);
+    if (scratch_bytes < L.total)
         return fail(LARS_ERR_INVALID, "lars_d_stats_joint: scratch holds %zu bytes, %zu are needed (lars_joint_scratch_bytes, with the "
-                                      "tuning in force at the launch)", scratch_bytes, need);
+                                      "tuning in force at the launch)", scratch_bytes, L.total);
+    // Windowed tables, one reader per tile chunk (joint_win.hip): two streams, percentile white balance (the windows ARE its clipping),
+    // tiles large enough to pay for a window, and no channel histograms wanted -- those would come out clamped to the windows.
+    // lars_set_tuning("joint_window", 0) = never, 2 = windows that miss on purpose (exercises the recount).
+    const int window = tuning().joint_window;
+    const bool windowed = S == 2 && white_balance && !hist && window != 0 && a->npix >= JW_MIN_PIXELS;
 
-    unsigned int *error = reinterpret_cast<unsigned int *>(scratch);
+    char *base = static_cast<char *>(scratch);
+    unsigned int *error = reinterpret_cast<unsigned int *>(base);
+    JointWin *win = reinterpret_cast<JointWin *>(base + L.win_off);
     LARS_HIP_TRY(hipMemsetAsync(error, 0, 256, s));
+    const uint8_t *tiles = static_cast<const uint8_t *>(a->tiles);
+    if (windowed) {
+        joint_predict_launch(tiles, a->ntiles, a->npix, a->channels, win, window == 2 ? 1 : 0, s);
+        LARS_TRY(launch_check("lars_d_stats_joint (predict)"));
+    } else {
+        LARS_HIP_TRY(hipMemsetAsync(win, 0, (size_t)a->ntiles * sizeof(JointWin), s));        // lars_joint_window_report: nothing windowed
+    }
     JointCountParams C;
     memset(&C, 0, sizeof C);
-    C.tiles = static_cast<const uint8_t *>(a->tiles); C.npix = a->npix; C.ntiles = a->ntiles;
+    C.tiles = tiles; C.npix = a->npix; C.ntiles = a->ntiles;
     C.chunk_quads = joint_chunk_quads(a->npix, K);
-    C.part = error + 64; C.error = error; C.K = K; C.S = S; C.streams = streams;
+    C.part = reinterpret_cast<unsigned int *>(base + L.part_off); C.error = error; C.K = K; C.S = S; C.streams = streams;
+    C.win = windowed ? win : nullptr; C.pass = 0; C.list = reinterpret_cast<uint2 *>(base + L.list_off);
     const long long units = (long long)a->ntiles * K;
     const long long nwg = S == 2 ? ((units + 7) / 8) * 16 : units;
     if (nwg > 0x7FFFFFFFll) return fail(LARS_ERR_INVALID, "lars_d_stats_joint: too many workgroups");
     // joint_depth: 12-byte (RGBA: 16-byte) loads in flight per lane; 6 by default -- 4, 8 and 12 measure the same within noise
     // (profiles/r04_joint_depths.txt), although the bare two-reader pattern gains 5 % from 6 to 12 (profiles/r04_shared_readers_depths.txt)
     const int depth = tuning().joint_depth;
+    auto count_full = [&]() {
 #define LARS_JOINT(DD, CC) hipLaunchKernelGGL((k_joint_count<DD, CC>), dim3((unsigned)nwg), dim3(JH_THREADS), 0, s, C)
-    if (c4) LARS_JOINT(6, 4);
-    else if (depth == 4) LARS_JOINT(4, 3);
-    else if (depth == 8) LARS_JOINT(8, 3);
-    else if (depth == 12) LARS_JOINT(12, 3);
-    else LARS_JOINT(6, 3);
+        if (c4) LARS_JOINT(6, 4);
+        else if (depth == 4) LARS_JOINT(4, 3);
+        else if (depth == 8) LARS_JOINT(8, 3);
+        else if (depth == 12) LARS_JOINT(12, 3);
+        else LARS_JOINT(6, 3);
 #undef LARS_JOINT
-    LARS_TRY(launch_check("lars_d_stats_joint (count)"));
-
+    };
     JointFinishParams F;
     memset(&F, 0, sizeof F);
     F.part = C.part; F.npix = a->npix; F.K = K; F.S = S; F.streams = streams; F.mask = mask;
     F.flags = a->flags & (LARS_F_HIST | LARS_F_SUMSQ); F.wb = white_balance ? 1 : 0; F.rgn_variant = rgn_variant;
     F.stats = a->stats; F.table_out = white_balance ? const_cast<uint8_t *>(a->wb_table) : nullptr;
     F.pcts_out = white_balance ? percentiles : nullptr; F.hist_out = hist; F.out_pairs = out_pairs;
+    F.win = C.win; F.pass = 0;
+
+    if (windowed) {
+        joint_count_win_launch(C, a->channels, depth, s);
+        LARS_TRY(launch_check("lars_d_stats_joint (count, windowed)"));
+    }
+    count_full();                                          // the tiles without a window (every tile when nothing is windowed)
+    LARS_TRY(launch_check("lars_d_stats_joint (count)"));
     hipLaunchKernelGGL(k_joint_finish, dim3((unsigned)S, (unsigned)a->ntiles), dim3(JH_THREADS), 0, s, F);
-    return launch_check("lars_d_stats_joint (finish)");
+    LARS_TRY(launch_check("lars_d_stats_joint (finish)"));
+    if (windowed) {
+        // the tiles whose window missed a percentile: counted again on full tables -- workgroups of all other tiles leave at once
+        C.pass = 1; F.pass = 1;
+        count_full();
+        LARS_TRY(launch_check("lars_d_stats_joint (recount)"));
+        hipLaunchKernelGGL(k_joint_finish, dim3((unsigned)S, (unsigned)a->ntiles), dim3(JH_THREADS), 0, s, F);
+        LARS_TRY(launch_check("lars_d_stats_joint (finish of the recount)"));
+    }
+    return LARS_OK;
+}
+
+// How the last windowed lars_d_stats_joint on this scratch went (after its stream has finished): tiles counted on windowed
+// tables, and tiles among them whose window missed and which were counted again.  Laboratory / test helper.
+extern "C" int lars_joint_window_report(const void *scratch, int64_t ntiles, int64_t *windowed, int64_t *recounted)
+{
+    if (!scratch || ntiles <= 0 || !windowed || !recounted) return fail(LARS_ERR_INVALID, "lars_joint_window_report: bad arguments");
+    std::vector<JointWin> w((size_t)ntiles);
+    LARS_HIP_TRY(hipMemcpy(w.data(), static_cast<const char *>(scratch) + 256, (size_t)ntiles * sizeof(JointWin), hipMemcpyDeviceToHost));
+    int64_t nw = 0, nr = 0;
+    for (const JointWin &x : w) { nw += x.mode == 1u; nr += x.flag != 0u; }
+    *windowed = nw; *recounted = nr;
+    return LARS_OK;
 }

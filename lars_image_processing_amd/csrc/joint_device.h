@@ -1,0 +1,85 @@
+// Pieces shared by the one-read statistics kernels: the two-reader counting kernel and the finish kernel (joint.hip)
+// and the one-reader counting kernel over windowed tables with its window prediction (joint_win.hip).
+#pragma once
+#include <string.h>
+
+#include <type_traits>
+
+#include "v2_device.h"
+
+namespace lars {
+
+#define JH_K 5u                                          /* m = n + JH_K * x: odd, and 5 x 5 neighbourhoods tile 25 consecutive values */
+#define JH_DWORDS 32768
+#define JH_THREADS 1024
+#define JH_PERIOD_STEPS 12                    /* steps of 4096 pixels between two scans */
+#define JH_PROMOTE_MASK 0x0000C000u           /* a low half >= 16384 */
+#define JH_LIST_CAP 1024
+#define JH_MAX_WG_PIXELS (1ll << 24)
+
+struct JointWin;
+struct JointCountParams {
+    const uint8_t *tiles;
+    long long npix;
+    long long ntiles;
+    long long chunk_quads;                    // quads per chunk: a multiple of 1024 (the last chunk of a tile takes the rest)
+    unsigned int *part;                       // [ntiles][S][K][32768][2] uint32: counts of the cells (D, 0), (D, 1)
+    unsigned int *error;                      // set to 1 if a list overflows (cannot happen: see JH_MAX_WG_PIXELS)
+    int K;                                    // chunks per tile
+    int S;                                    // streams counted: 1 or 2
+    unsigned int streams;                     // bit 0: (n, r) pairs, bit 1: (n, g) pairs
+    struct JointWin *win;                     // [ntiles] or null: which tiles are counted on windowed tables (joint_win.hip)
+    int pass;                                 // 0: the first count (k_joint_count skips the windowed tiles); 1: the recount of the tiles whose window missed
+    uint2 *list;                              // k_joint_count_win: [ntiles * K][JW_LIST_CAP] moved dwords (dword, value)
+};
+
+__device__ inline void jh_add(unsigned int addr, unsigned int val, char *tab)
+{
+    __hip_atomic_fetch_add(reinterpret_cast<unsigned int *>(tab + addr), val, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+}
+
+// nn + 5 px in one full-rate instruction (px < 2^24; the compiler's own choice for * 5 + is the quarter-rate v_mad_u64_u32)
+__device__ inline unsigned int jh_mad5(unsigned int px, unsigned int nn)
+{
+    unsigned int r;
+    asm("v_mad_u32_u24 %0, %1, 5, %2" : "=v"(r) : "v"(px), "v"(nn));
+    return r;
+}
+static_assert(JH_K == 5u, "jh_mad5 spells the factor out");
+
+// (D, h) of a pair of samples, and back
+__device__ inline unsigned int jh_m(unsigned int n, unsigned int x) { return (n + JH_K * x) & 255u; }
+__device__ inline unsigned int jh_n_of(unsigned int D, unsigned int h)
+{
+    const unsigned int x = D >> 7, m = (D & 127u) | (h << 7);
+    return (m - JH_K * x) & 255u;
+}
+
+
+// ---- windowed tables (joint_win.hip) ------------------------------------------------------------------------------
+// After the percentile white balance every sample at or below p2 is level 0 and every sample at or above p98 is level 255
+// (process-images.py:438: clip((ch - p2) / (p98 - p2) * 255, 0, 255)), so for the statistics a pair table only has to tell the
+// samples INSIDE a window [lo, hi] with lo < p2 and p98 < hi apart: whatever lies below counts as lo, whatever lies above as hi.
+// Windows on red and green (NIR keeps its 256 values) shrink the two pair tables of a tile to (nr + ng) x 256 cells of 16 bits --
+// both fit ONE workgroup's LDS when nr + ng <= JW_MAX_ROWS, and the tile is then read by one CU instead of two.
+// The windows come from a subsample (k_joint_predict); the exact percentiles follow from the counted marginals as before and
+// k_joint_finish checks that they lie strictly inside the window -- a tile whose window missed is counted again on full tables.
+#define JW_PITCH 133u                          /* dwords per table row: 128 + 5, so that the LDS bank is (n + 5 x') mod 32 as in the full tables */
+#define JW_MAX_ROWS 306                        /* nr + ng: 306 x 133 dwords = 162792 bytes of the CU's 163840 */
+#define JW_TAB_DWORDS 40700                    /* JW_MAX_ROWS x JW_PITCH, rounded up to whole uint4 */
+#define JW_LIST_CAP 2048                       /* moved dwords of a workgroup: two tables x 2^24 pixels / 16384 */
+#define JW_MIN_PIXELS (1ll << 20)              /* smaller tiles are not worth a window (zeroing + publishing the tables) */
+
+struct JointWin {                              // per tile, in the scratch of lars_d_stats_joint
+    unsigned int mode;                         // 0: full tables, two readers (k_joint_count); 1: windowed tables, one reader (k_joint_count_win)
+    unsigned short lo_r, nr;                   // red window: samples lo_r .. lo_r + nr - 1 (rows 0 .. nr - 1 of table A)
+    unsigned short lo_g, ng;                   // green window (rows nr .. nr + ng - 1)
+    unsigned int flag;                         // set by k_joint_finish: an order statistic of np.percentile fell onto the window's edge
+};
+static_assert(sizeof(JointWin) == 16, "JointWin is addressed as 16-byte records");
+
+// joint_win.hip
+void joint_predict_launch(const uint8_t *tiles, long long ntiles, long long npix, int channels, JointWin *win, int test_wrong, hipStream_t s);
+void joint_count_win_launch(const JointCountParams &C, int channels, int depth, hipStream_t s);
+
+}  // namespace lars

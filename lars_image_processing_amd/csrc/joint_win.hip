@@ -1,0 +1,416 @@
+// One-read statistics, ONE reader per tile chunk: both byte-pair tables of a chunk in one workgroup's LDS (joint.hip has the
+// method; this file the windowed tables and their prediction).
+//
+// The two-stream launch of k_joint_count puts the (NIR, red) and the (NIR, green) table of a tile chunk into two workgroups on two
+// CUs, because 2 x 65536 counters of 16 bits are 256 KiB and a CU has 160: every byte of the tile then travels from the L2 into
+// two CUs, and that intake -- not HBM, not the LDS atomics -- set the launch's pace (profiles/r04_joint_hist_counters.txt).
+// But the white balance itself says which cells matter: process-images.py:438 maps every sample <= p2 to 0 and every sample >= p98
+// to 255, so below a window start lo < p2 and above a window end hi > p98 the samples need not be told apart -- they count as lo
+// resp. hi, and every statistic of the white-balanced quotients comes out the same.  With windows on red and green (NIR keeps its
+// 256 values; no clamp for it) the tables take (nr + ng) rows of 256 cells: both fit one CU when nr + ng <= 306.
+//
+//   k_joint_predict     per tile: channel histograms of a subsample (1024 segments of 128 pixels spread over the tile) ->
+//                       [lo, hi] per channel with a margin for the sampling error -> mode 1 (windowed) if the rows fit, else 0
+//   k_joint_count_win   one workgroup per (tile, chunk) of the mode-1 tiles: per pair of pixels 3 v_perm_b32 (n | n' << 16, r | r' << 16,
+//                       g | g' << 16), per window 2 packed clamps (v_pk_sub_u16 clamp, v_pk_min_u16) and 1 v_pk_mad_u16 for both dword
+//                       indices, 4 LDS atomics.  Publishes the counts in the FULL tables' layout (zeros outside the windows), so that
+//                       k_joint_finish reads one format
+//   k_joint_finish      derives the exact percentiles from the marginals as ever and checks that their order statistics lie strictly
+//                       inside the window (or the window's edge is the range's edge): then lo < p2 and p98 < hi hold and the clamped
+//                       counts ARE the tile's statistics.  Otherwise it flags the tile and k_joint_count counts it again on full tables.
+//
+// Layout in LDS: row x' (red rows 0 .. nr - 1, green rows nr .. nr + ng - 1) takes JW_PITCH = 133 dwords, dword x' * 133 + (n & 127)
+// holds the cells n & 127 (low half: both cells, as in joint.hip) and n | 128 (high half).  133 = 128 + 5: the bank of a dword is
+// (n + 5 x') mod 32, the full tables' bank pattern (smooth imagery: a 5 x 5 neighbourhood of pairs lands in 25 banks).
+#include "joint_device.h"
+
+namespace lars {
+
+struct JointPredictParams {
+    const uint8_t *tiles;
+    long long npix;
+    long long ntiles;
+    JointWin *win;
+    int test_wrong;                           // lars_set_tuning("joint_window", 2): one-row windows at the median, so that every tile misses
+};
+
+#define JP_SEGMENTS 1024                      /* of 32 quads = 128 pixels each: 1 / 128 of a 4096 x 4096 tile */
+
+__device__ inline unsigned int jp_mix(unsigned int x)
+{
+    x ^= x >> 16; x *= 0x7FEB352Du; x ^= x >> 15; x *= 0x846CA68Bu; x ^= x >> 16;
+    return x;
+}
+
+template <int CH>
+__global__ __launch_bounds__(JH_THREADS) void k_joint_predict(JointPredictParams P)
+{
+    // red and green histograms of the sample in 32 copies: lane l adds to copy l & 31, whose LDS bank is its own -- no bank conflict and no
+    // two lanes of a half-wave on one word, whatever the image (a smooth one puts all 64 lanes into two or three bins)
+    __shared__ unsigned int s_h[2 * 256 * 32];                 // 64 KiB: [channel][bin][copy]
+    const int tid = threadIdx.x;
+    const long long tile = blockIdx.x;
+    for (int i = tid; i < 2 * 256 * 32 / 4; i += JH_THREADS) reinterpret_cast<uint4 *>(s_h)[i] = make_uint4(0u, 0u, 0u, 0u);
+    __syncthreads();
+    const long long nquads = P.npix >> 2;
+    const uint8_t *base = P.tiles + tile * P.npix * CH;
+    const unsigned int copy = (unsigned)(tid & 31);
+    auto add = [&](unsigned int ch, unsigned int v) {
+        __hip_atomic_fetch_add(&s_h[(((ch << 8) | v) << 5) | copy], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+    };
+    auto count_quad = [&](unsigned int w0, unsigned int w1, unsigned int w2) {
+        // r0 g0 n0 r1 | g1 n1 r2 g2 | n2 r3 g3 n3
+        add(0u, w0 & 255u); add(1u, (w0 >> 8) & 255u); add(0u, w0 >> 24); add(1u, w1 & 255u);
+        add(0u, (w1 >> 16) & 255u); add(1u, w1 >> 24); add(0u, (w2 >> 8) & 255u); add(1u, (w2 >> 16) & 255u);
+    };
+    auto load_quad = [&](long long q, unsigned int &w0, unsigned int &w1, unsigned int &w2) {
+        if constexpr (CH == 4) {
+            const uint4 v = *reinterpret_cast<const uint4 *>(base + q * 16);
+            w0 = __builtin_amdgcn_perm(v.y, v.x, 0x04020100u); w1 = __builtin_amdgcn_perm(v.z, v.y, 0x05040201u);
+            w2 = __builtin_amdgcn_perm(v.w, v.z, 0x06050402u);
+        } else {
+            const unsigned int *p = reinterpret_cast<const unsigned int *>(base + q * 12);
+            w0 = p[0]; w1 = p[1]; w2 = p[2];
+        }
+    };
+    long long sampled;                                       // pixels in the histograms
+    if (nquads >= (long long)JP_SEGMENTS * 128) {
+        // segment i (32 quads = 128 pixels = 384 contiguous bytes; a wave reads two per load) starts somewhere inside its own
+        // stretch of nquads / 1024 quads; a lane's loads all go out before the first is counted (latency once, not 32 times)
+        const long long stretch = nquads / JP_SEGMENTS;
+        const unsigned int span = (unsigned int)(stretch - 31);            // npix < 2^32: a segment starts at stretch * i + [0, span)
+        const int wave = tid >> 6, lane = tid & 63;
+        constexpr int NJ = JP_SEGMENTS / 32, HALF = NJ / 2;
+        unsigned int w[HALF][3];
+#pragma unroll
+        for (int part = 0; part < 2; ++part) {
+#pragma unroll
+            for (int j = 0; j < HALF; ++j) {
+                const unsigned int i = (unsigned)(((part * HALF + j) * 16 + wave) * 2 + (lane >> 5));
+                const long long q = (long long)i * stretch + (long long)__umulhi(jp_mix(i + (unsigned)tile * 0x9E3779B9u), span) + (lane & 31);
+                load_quad(q, w[j][0], w[j][1], w[j][2]);
+            }
+#pragma unroll
+            for (int j = 0; j < HALF; ++j) count_quad(w[j][0], w[j][1], w[j][2]);
+        }
+        sampled = (long long)JP_SEGMENTS * 128;
+    } else {
+        for (long long q = tid; q < nquads; q += JH_THREADS) {
+            unsigned int w0, w1, w2;
+            load_quad(q, w0, w1, w2);
+            count_quad(w0, w1, w2);
+        }
+        sampled = nquads * 4;
+    }
+    __syncthreads();
+    // totals of the 32 copies, their running sums (wave scans + one barrier), and the two order statistics that bound the window
+    __shared__ unsigned int s_wsum[2][4];
+    __shared__ unsigned int s_lo[2], s_hi[2];
+    unsigned int tot = 0, inc = 0;
+    if (tid < 512) {
+#pragma unroll 8
+        for (int k = 0; k < 32; ++k) tot += s_h[tid * 32 + ((k + tid) & 31)];    // rotated: the 64 lanes read 32 banks
+        inc = tot;
+        const int lane = tid & 63;
+        for (int off = 1; off < 64; off <<= 1) {
+            const unsigned int o = __shfl_up(inc, off);
+            if (lane >= off) inc += o;
+        }
+        if (lane == 63) s_wsum[tid >> 8][(tid >> 6) & 3] = inc;
+    }
+    __syncthreads();
+    if (tid < 512 && sampled > 0) {
+        // The window of channel ch (red, green): from the sample's order statistics at 0.5 % and 99.5 %, one more value on either
+        // side.  The margin is for imagery, not for independent samples: the 128 pixels of a segment of a smooth image are nearly one
+        // observation, so the sample is worth its 1024 segments -- a value that truly holds 2 % of the tile below it shows fewer
+        // than 0.5 % of the sample there about once in 10^5 tiles even then.  (0.4 % of margin, enough for independent pixels,
+        // missed on 19 % of the tiles of tools/jointbench.py's smooth content: profiles/r05_joint_window_first.txt.)
+        const int ch = tid >> 8, bin = tid & 255;
+        unsigned int before = inc - tot;
+        for (int w = 0; w < ((tid >> 6) & 3); ++w) before += s_wsum[ch][w];
+        double dq = 0.015;
+        if (sampled == nquads * 4) dq = 0.0;                  // everything was counted (but the tile's last npix % 4 pixels)
+        double ql = 0.02 - dq, qh = 0.98 + dq;
+        if (P.test_wrong) ql = qh = 0.5;
+        const long long rl = (long long)floor((double)(sampled - 1) * ql), rh = (long long)ceil((double)(sampled - 1) * qh);
+        const int margin = P.test_wrong ? 0 : 1;
+        if (tot && rl >= (long long)before && rl < (long long)before + tot) s_lo[ch] = (unsigned)(bin - margin < 0 ? 0 : bin - margin);
+        if (tot && rh >= (long long)before && rh < (long long)before + tot) s_hi[ch] = (unsigned)(bin + margin > 255 ? 255 : bin + margin);
+    }
+    __syncthreads();
+    if (tid == 0) {
+        JointWin w;
+        w.flag = 0u;
+        if (sampled > 0) {
+            w.lo_r = (unsigned short)s_lo[0]; w.nr = (unsigned short)(s_hi[0] - s_lo[0] + 1u);
+            w.lo_g = (unsigned short)s_lo[1]; w.ng = (unsigned short)(s_hi[1] - s_lo[1] + 1u);
+            w.mode = (unsigned)w.nr + (unsigned)w.ng <= (unsigned)JW_MAX_ROWS ? 1u : 0u;
+        } else {
+            w.lo_r = w.lo_g = 0; w.nr = w.ng = 256; w.mode = 0u;
+        }
+        P.win[tile] = w;
+    }
+}
+
+// ---- packed 16-bit arithmetic the compiler is not left to choose ------------------------------------------------------------
+__device__ inline unsigned int jw_sub_sat(unsigned int a, unsigned int b)        // per half: max(a - b, 0)
+{
+    unsigned int r;
+    asm("v_pk_sub_u16 %0, %1, %2 clamp" : "=v"(r) : "v"(a), "s"(b));
+    return r;
+}
+__device__ inline unsigned int jw_min(unsigned int a, unsigned int b)
+{
+    unsigned int r;
+    asm("v_pk_min_u16 %0, %1, %2" : "=v"(r) : "v"(a), "s"(b));
+    return r;
+}
+__device__ inline unsigned int jw_mad(unsigned int a, unsigned int b, unsigned int c)   // per half: a * b + c
+{
+    unsigned int r;
+    asm("v_pk_mad_u16 %0, %1, %2, %3" : "=v"(r) : "v"(a), "s"(b), "v"(c));
+    return r;
+}
+// 1 | h0 << 16 for u = h0 << 7 | h1 << 23: the product's bit 32 falls off
+__device__ inline unsigned int jw_val0(unsigned int u)
+{
+    unsigned int r;
+    asm("v_mad_u32_u24 %0, %1, %2, 1" : "=v"(r) : "v"(u), "s"(512u));
+    return r;
+}
+
+// byte address of the dword whose index is the low (HALF = 0) or high (HALF = 1) 16 bits of d: one SDWA shift, the half selected by the operand
+template <int HALF>
+__device__ inline unsigned int jw_addr(unsigned int d, unsigned int two)
+{
+    unsigned int r;
+    if (HALF) asm("v_lshlrev_b32_sdwa %0, %1, %2 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:DWORD src1_sel:WORD_1" : "=v"(r) : "v"(two), "v"(d));
+    else asm("v_lshlrev_b32_sdwa %0, %1, %2 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:DWORD src1_sel:WORD_0" : "=v"(r) : "v"(two), "v"(d));
+    return r;
+}
+
+template <int DEPTH, int CH = 3>
+__global__ __launch_bounds__(JH_THREADS, 4) void k_joint_count_win(JointCountParams P)
+{
+    constexpr int PERIOD = (JH_PERIOD_STEPS % DEPTH == 0) ? JH_PERIOD_STEPS : DEPTH;
+    static_assert(PERIOD % DEPTH == 0 && PERIOD <= JH_PERIOD_STEPS, "a period is a whole number of ring turns, at most 12 steps");
+    __shared__ __attribute__((aligned(16))) unsigned int s_tab[JW_TAB_DWORDS];      // 159 KiB
+    __shared__ unsigned int s_nlist;
+
+    const int tid = threadIdx.x;
+    const long long unit = blockIdx.x;
+    const long long tile = unit / P.K;
+    const int chunk = (int)(unit - tile * P.K);
+    if (tile >= P.ntiles) return;
+    const JointWin win = P.win[tile];
+    if (win.mode != 1u) return;                                                    // k_joint_count's tile
+    const unsigned int nr = win.nr, ng = win.ng, lo_r = win.lo_r, lo_g = win.lo_g;
+    const unsigned int rows = nr + ng;
+    const int ntab4 = (int)((rows * JW_PITCH + 3u) >> 2);                          // uint4s in use
+
+    uint4 *tab4 = reinterpret_cast<uint4 *>(s_tab);
+    for (int i = tid; i < ntab4; i += JH_THREADS) tab4[i] = make_uint4(0u, 0u, 0u, 0u);
+    if (tid == 0) s_nlist = 0;
+    __syncthreads();
+    char *tab = reinterpret_cast<char *>(s_tab);
+
+    const long long nquads_tile = P.npix >> 2;
+    const long long q_begin = (long long)chunk * P.chunk_quads;
+    long long q_end = chunk == P.K - 1 ? nquads_tile : q_begin + P.chunk_quads;
+    if (q_end > nquads_tile) q_end = nquads_tile;
+    const long long nq = q_end > q_begin ? q_end - q_begin : 0;
+    const uint8_t *tile_base = P.tiles + tile * P.npix * CH;
+
+    // wave-uniform constants, both halves alike
+    const unsigned int lo_r2 = __builtin_amdgcn_readfirstlane(lo_r * 0x10001u), lo_g2 = __builtin_amdgcn_readfirstlane(lo_g * 0x10001u);
+    const unsigned int nr1_2 = __builtin_amdgcn_readfirstlane((nr - 1u) * 0x10001u), ng1_2 = __builtin_amdgcn_readfirstlane((ng - 1u) * 0x10001u);
+    const unsigned int pitch2 = JW_PITCH * 0x10001u;
+    const unsigned int base_g2 = __builtin_amdgcn_readfirstlane((nr * JW_PITCH) * 0x10001u);      // first dword of the green rows: < 2^16
+
+    // bytes of a quad r0 g0 n0 r1 | g1 n1 r2 g2 | n2 r3 g3 n3; pixels 0, 1 from perm(w1, w0), pixels 2, 3 from perm(w2, w1)
+    const unsigned int seln01 = 0x0c050c02u, selr01 = 0x0c030c00u, selg01 = 0x0c040c01u;
+    const unsigned int seln23 = 0x0c070c04u, selr23 = 0x0c050c02u, selg23 = 0x0c060c03u;
+
+    unsigned int two = 2u;
+    asm volatile("" : "+v"(two));                                                  // a VGPR that holds 2 (SDWA takes no constants)
+    // Two pixels at a time, one in each 16-bit half.  mul = 1 but for flat areas, where one lane adds the whole wave's count.
+    auto count_pair = [&](unsigned int nn, unsigned int rr, unsigned int gg, unsigned int mul) {
+        const unsigned int t = nn & 0x007F007Fu, u = nn & 0x00800080u;
+        unsigned int v0 = jw_val0(u);                                               // 1 | h << 16 of the low pixel
+        unsigned int v1 = (u >> 7) | 1u;                                            // of the high pixel (bit 0 is set either way)
+        if (mul != 1u) { v0 *= mul; v1 = (v1 & 0x10001u) * mul; }
+        const unsigned int da = jw_mad(jw_min(jw_sub_sat(rr, lo_r2), nr1_2), pitch2, t);
+        const unsigned int db = jw_mad(jw_min(jw_sub_sat(gg, lo_g2), ng1_2), pitch2, t + base_g2);
+        jh_add(jw_addr<0>(da, two), v0, tab);
+        jh_add(jw_addr<1>(da, two), v1, tab);
+        jh_add(jw_addr<0>(db, two), v0, tab);
+        jh_add(jw_addr<1>(db, two), v1, tab);
+    };
+    auto do_quad = [&](unsigned int w0, unsigned int w1, unsigned int w2) {
+        // flat areas (every lane of the wave holds the same four pixels) would queue 64 lanes on one LDS word per atomic: joint.hip
+        const unsigned int f0 = __builtin_amdgcn_readfirstlane(w0);
+        bool flat = __builtin_amdgcn_ballot_w64(w0 != f0) == 0ull;
+        if (flat) {
+            const unsigned int f1 = __builtin_amdgcn_readfirstlane(w1), f2 = __builtin_amdgcn_readfirstlane(w2);
+            flat = __builtin_amdgcn_ballot_w64(((w1 ^ f1) | (w2 ^ f2)) != 0u) == 0ull;
+            if (flat) {
+                const unsigned long long active = __builtin_amdgcn_ballot_w64(true);
+                if ((active & (0ull - active)) == (1ull << (tid & 63))) {             // the first active lane
+                    const unsigned int n = (unsigned int)__builtin_popcountll(active);
+                    count_pair(__builtin_amdgcn_perm(f1, f0, seln01), __builtin_amdgcn_perm(f1, f0, selr01), __builtin_amdgcn_perm(f1, f0, selg01), n);
+                    count_pair(__builtin_amdgcn_perm(f2, f1, seln23), __builtin_amdgcn_perm(f2, f1, selr23), __builtin_amdgcn_perm(f2, f1, selg23), n);
+                }
+                return;
+            }
+        }
+        count_pair(__builtin_amdgcn_perm(w1, w0, seln01), __builtin_amdgcn_perm(w1, w0, selr01), __builtin_amdgcn_perm(w1, w0, selg01), 1u);
+        count_pair(__builtin_amdgcn_perm(w2, w1, seln23), __builtin_amdgcn_perm(w2, w1, selr23), __builtin_amdgcn_perm(w2, w1, selg23), 1u);
+    };
+
+    // tail pixels of the tile (npix % 4): its last chunk, before the first period
+    if (chunk == P.K - 1 && tid < (int)(P.npix & 3)) {
+        const uint8_t *p = tile_base + (nquads_tile * 4 + tid) * CH;
+        const unsigned int n = p[2];
+        unsigned int r = p[0] > lo_r ? p[0] - lo_r : 0u, g = p[1] > lo_g ? p[1] - lo_g : 0u;
+        r = r < nr - 1u ? r : nr - 1u;
+        g = g < ng - 1u ? g : ng - 1u;
+        const unsigned int v = ((n >> 7) << 16) | 1u;
+        jh_add((r * JW_PITCH + (n & 127u)) << 2, v, tab);
+        jh_add(((nr + g) * JW_PITCH + (n & 127u)) << 2, v, tab);
+    }
+
+    // A scan: every dword whose sum (low half) has reached 16384 moves onto the workgroup's list (in global memory: the LDS is the
+    // tables').  Between the two barriers nobody adds.
+    uint2 *list = P.list + unit * JW_LIST_CAP;
+    auto scan = [&]() {
+        __syncthreads();
+#pragma unroll 1
+        for (int idx = tid; idx < ntab4; idx += JH_THREADS) {
+            const uint4 v = tab4[idx];
+            if ((v.x | v.y | v.z | v.w) & JH_PROMOTE_MASK) {
+                const unsigned int c[4] = {v.x, v.y, v.z, v.w};
+#pragma unroll
+                for (int k = 0; k < 4; ++k) {
+                    if (c[k] & JH_PROMOTE_MASK) {
+                        const unsigned int slot = atomicAdd(&s_nlist, 1u);
+                        if (slot < JW_LIST_CAP) list[slot] = make_uint2((unsigned)(idx * 4 + k), c[k]);
+                        else atomicExch(P.error, 1u);
+                        s_tab[idx * 4 + k] = 0u;
+                    }
+                }
+            }
+        }
+        __syncthreads();
+    };
+
+    const long long nfull = nq >> 10;
+    const int rem = (int)(nq & 1023);
+    if (nq > 0) {
+        const __amdgpu_buffer_rsrc_t rsrc =
+            __builtin_amdgcn_make_buffer_rsrc(const_cast<uint8_t *>(tile_base + q_begin * (CH * 4)), 0, (int)(nq * (CH * 4)), 0x00020000);
+        const unsigned int voff = (unsigned int)tid * (CH * 4u);
+        constexpr unsigned int STEP_B = JH_THREADS * CH * 4u;
+        typedef unsigned int u32x4j __attribute__((ext_vector_type(4)));
+        typename std::conditional<CH == 4, u32x4j, u32x3>::type w[DEPTH];
+        auto load = [&](unsigned int soff_b) {
+            if constexpr (CH == 4) return __builtin_amdgcn_raw_buffer_load_b128(rsrc, voff, soff_b, 0);
+            else return __builtin_amdgcn_raw_buffer_load_b96(rsrc, voff, soff_b, 0);
+        };
+        auto count = [&](const auto &v) {
+            if constexpr (CH == 4)
+                do_quad(__builtin_amdgcn_perm(v.y, v.x, 0x04020100u), __builtin_amdgcn_perm(v.z, v.y, 0x05040201u),
+                        __builtin_amdgcn_perm(v.w, v.z, 0x06050402u));
+            else do_quad(v.x, v.y, v.z);
+        };
+#pragma unroll
+        for (int k = 0; k < DEPTH; ++k) w[k] = load((unsigned)k * STEP_B);
+        long long it = 0;
+        unsigned int soff = DEPTH * STEP_B;
+        int since = 0;
+        for (; it + DEPTH <= nfull; it += DEPTH) {
+#pragma unroll
+            for (int k = 0; k < DEPTH; ++k) {
+                count(w[k]);
+                __builtin_amdgcn_sched_barrier(0);
+                w[k] = load(soff + (unsigned)k * STEP_B);                 // past the end: zeros, never counted
+                __builtin_amdgcn_sched_barrier(0);
+            }
+            soff += DEPTH * STEP_B;
+            since += DEPTH;
+            if (since == PERIOD) {
+                scan();
+                since = 0;
+            }
+        }
+#pragma unroll
+        for (int k = 0; k < DEPTH; ++k) {
+            const long long step = it + k;
+            if (step < nfull || (step == nfull && tid < rem)) count(w[k]);
+        }
+    }
+    __syncthreads();
+
+    // Publish in the full tables' layout (joint.hip): stream s, dword D = x << 7 | (m & 127) with m = (n + 5 x) & 255 holds the cells
+    // (D, 0), (D, 1) = the counts of n0 = (D & 127) - 5 x and of n0 ^ 128 -- the two halves of ONE windowed dword.  Rows outside the
+    // window are zero and, but for those that share a block of 8 rows with the window, not even written: k_joint_finish skips them.
+    auto full_cells = [&](unsigned int wd, unsigned int n0) {       // windowed dword -> (count of n0, count of n0 ^ 128)
+        const unsigned int v = s_tab[wd];
+        const unsigned int hi = v >> 16, lo = (v & 0xFFFFu) - hi;  // cells n & 127 (bit 7 clear) and n | 128
+        return (n0 & 128u) ? make_uint2(hi, lo) : make_uint2(lo, hi);
+    };
+#pragma unroll 1
+    for (int s = 0; s < 2; ++s) {
+        unsigned int *out = P.part + ((tile * 2 + s) * P.K + chunk) * (long long)(2 * JH_DWORDS);
+        const unsigned int lo = s ? lo_g : lo_r, nx = s ? ng : nr, row0 = s ? nr : 0u;
+        // only the blocks of 8 rows that touch the window: k_joint_finish walks exactly these
+        const int d_begin = (int)(lo >> 3) << 10, d_end = (int)(((lo + nx - 1u) >> 3) + 1u) << 10;
+        for (int D = d_begin + tid; D < d_end; D += JH_THREADS) {
+            const unsigned int x = (unsigned)D >> 7;
+            uint2 c = make_uint2(0u, 0u);
+            if (x >= lo && x < lo + nx) {
+                const unsigned int n0 = (((unsigned)D & 127u) - JH_K * x) & 255u;
+                c = full_cells((row0 + x - lo) * JW_PITCH + (n0 & 127u), n0);
+            }
+            *reinterpret_cast<uint2 *>(out + 2 * (long long)D) = c;
+        }
+    }
+    const unsigned int nlist = s_nlist < JW_LIST_CAP ? s_nlist : JW_LIST_CAP;
+    if (nlist) {
+        __threadfence();
+        __syncthreads();
+        for (unsigned int e = tid; e < nlist; e += JH_THREADS) {
+            const unsigned long long mv = __builtin_nontemporal_load(reinterpret_cast<const unsigned long long *>(&list[e]));   // past this CU's L1
+            const uint2 m = make_uint2((unsigned int)mv, (unsigned int)(mv >> 32));
+            const unsigned int row = m.x / JW_PITCH, nl = m.x - row * JW_PITCH;     // n & 127
+            const int s = row >= nr ? 1 : 0;
+            const unsigned int x = s ? lo_g + (row - nr) : lo_r + row;
+            unsigned int *out = P.part + ((tile * 2 + s) * P.K + chunk) * (long long)(2 * JH_DWORDS);
+            const unsigned int hi = m.y >> 16, lo = (m.y & 0xFFFFu) - hi;
+            // cell n = nl (count lo) and n = nl | 128 (count hi), each at (D, h) of the full layout
+            const unsigned int m0 = jh_m(nl, x), m1 = jh_m(nl | 128u, x);
+            if (lo) atomicAdd(&out[2 * (long long)((x << 7) | (m0 & 127u)) + (m0 >> 7)], lo);
+            if (hi) atomicAdd(&out[2 * (long long)((x << 7) | (m1 & 127u)) + (m1 >> 7)], hi);
+        }
+    }
+}
+
+// ---- launchers (called by lars_d_stats_joint, joint.hip) --------------------------------------------------------------------
+void joint_predict_launch(const uint8_t *tiles, long long ntiles, long long npix, int channels, JointWin *win, int test_wrong, hipStream_t s)
+{
+    JointPredictParams P;
+    P.tiles = tiles; P.npix = npix; P.ntiles = ntiles; P.win = win; P.test_wrong = test_wrong;
+    if (channels == 4) hipLaunchKernelGGL((k_joint_predict<4>), dim3((unsigned)ntiles), dim3(JH_THREADS), 0, s, P);
+    else hipLaunchKernelGGL((k_joint_predict<3>), dim3((unsigned)ntiles), dim3(JH_THREADS), 0, s, P);
+}
+void joint_count_win_launch(const JointCountParams &C, int channels, int depth, hipStream_t s)
+{
+    const long long units = C.ntiles * C.K;
+#define LARS_JOINT_WIN(DD, CC) hipLaunchKernelGGL((k_joint_count_win<DD, CC>), dim3((unsigned)units), dim3(JH_THREADS), 0, s, C)
+    if (channels == 4) LARS_JOINT_WIN(6, 4);
+    else if (depth == 4) LARS_JOINT_WIN(4, 3);
+    else if (depth == 12) LARS_JOINT_WIN(12, 3);
+    else LARS_JOINT_WIN(6, 3);
+#undef LARS_JOINT_WIN
+}
+
+}  // namespace lars

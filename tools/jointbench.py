@@ -84,6 +84,8 @@ def main():
     ap.add_argument("--content", default="vegetation,uniform")
     ap.add_argument("--depths", default="6,4")
     ap.add_argument("--blocks", default="0", help="chunks per tile of the counting kernel (blocks_per_tile), 0 = automatic")
+    ap.add_argument("--windows", default="1,0", help="joint_window settings to time: 1 windowed tables where they fit, 0 never, 2 windows that miss")
+    ap.add_argument("--skip-classic-medians", action="store_true")
     args = ap.parse_args()
     lib = _ffi.load()
     for content in args.content.split(","):
@@ -108,6 +110,7 @@ def main():
             report(f"classic {mname} statistics", ms, mn)
             _ffi.call("lars_synchronize", None)
             ref[mname] = stats.download(_ffi.STATS_DTYPE, (b.ntiles, 3)).copy()
+            ref["tables"], ref["pcts"] = b.host_tables().copy(), b.host_percentiles().copy()
 
             def classic_med():
                 b.compute_wb_tables()
@@ -118,20 +121,28 @@ def main():
             _ffi.call("lars_synchronize", None)
             ref[mname + "_med"] = pairs.download(np.float32, (b.ntiles, 2, 2)).copy()
         for depth in map(int, args.depths.split(",")):
-            for blocks in map(int, args.blocks.split(",")):
-                _ffi.set_tuning(joint_depth=depth, blocks_per_tile=blocks)
+          for blocks in map(int, args.blocks.split(",")):
+            for window in map(int, args.windows.split(",")):
+                _ffi.set_tuning(joint_depth=depth, blocks_per_tile=blocks, joint_window=window)
                 for mname, indices in MODES.items():
+                    if window != 1 and len(indices) == 1:
+                        continue                                    # one stream: never windowed
                     for med in (False, True):
                         ms, mn = timed(lambda: b.run_joint(indices, True, stats, pairs=pairs if med else None), args.rounds)
-                        report(f"joint   {mname} statistics{' + medians' if med else ''} depth {depth} blocks {blocks}", ms, mn)
                         b.check_joint()
+                        nw, nrec = b.joint_window_report()
+                        report(f"joint   {mname} statistics{' + medians' if med else ''} depth {depth} blocks {blocks} window {window} "
+                               f"[{nw} windowed, {nrec} recounted]", ms, mn)
                         rec = stats.download(_ffi.STATS_DTYPE, (b.ntiles, 3))
                         ids = [_ffi.INDEX_IDS[t] for t in indices]
                         assert rec[:, ids].tobytes() == ref[mname][:, ids].tobytes(), "records differ between the routes"
+                        chans = sorted(lars.batch.channels_of(indices))
+                        assert np.array_equal(b.host_tables(partial=True)[:, chans], ref["tables"][:, chans]), "tables differ between the routes"
+                        assert b.host_percentiles(partial=True)[:, chans].tobytes() == ref["pcts"][:, chans].tobytes(), "percentiles differ"
                         if med:
                             got = pairs.download(np.float32, (b.ntiles, 2, 2))
                             assert np.array_equal(got, ref[mname + "_med"], equal_nan=True), "medians differ between the routes"
-        _ffi.set_tuning(joint_depth=6, blocks_per_tile=0)
+        _ffi.set_tuning(joint_depth=6, blocks_per_tile=0, joint_window=1)
         stats.free(); pairs.free(); med_scratch.free(); b.free()
 
 

@@ -29,6 +29,7 @@
 // 25 DIFFERENT banks (and dwords), as do common shifts of both samples (shading: +6 per level) and shifts of one sample alone.
 // Round 3's n ^ 2x put such a neighbourhood into about six banks (tools/lab/banksim.py: 10-12 lanes on the fullest bank against
 // 5.4 for independent samples; the linear form: 5.5-5.7).
+#include <stdlib.h>
 #include <vector>
 
 #include "joint_device.h"
@@ -114,8 +115,8 @@ __global__ __launch_bounds__(JH_THREADS, 4) void k_joint_count(JointCountParams 
         jh_add(a1, v1, tab);
 #endif
     };
-    // Flat areas (nodata borders, saturated sky: every lane of the wave holds the same four pixels) would queue all 64 lanes on
-    // one LDS word per atomic.  Two v_readfirstlane + a compare per quad find them; one lane then adds the wave's whole count.
+    // Runs of equal pixels would queue the lanes of a wave on a few LDS words per atomic: the lanes that start a run add its whole count
+    // (joint_device.h).  For textured content the test is one v_mov_b32_dpp + one compare per quad.
     auto count_pair_n = [&](unsigned int nn, unsigned int px, unsigned int n) {
         const unsigned int m2 = jh_mad5(px, nn);
         const unsigned int W = (px << 7) | (m2 & 0x007F007Fu);
@@ -125,29 +126,14 @@ __global__ __launch_bounds__(JH_THREADS, 4) void k_joint_count(JointCountParams 
         jh_add(a1, v1, tab);
     };
     auto do_quad = [&](unsigned int w0, unsigned int w1, unsigned int w2) {
-        // the cheap test first: one v_readfirstlane + one compare on the quad's first dword settle it for any textured content
-        const unsigned int f0 = __builtin_amdgcn_readfirstlane(w0);
-        bool flat = __builtin_amdgcn_ballot_w64(w0 != f0) == 0ull;
-        if (flat) {
-            const unsigned int f1 = __builtin_amdgcn_readfirstlane(w1), f2 = __builtin_amdgcn_readfirstlane(w2);
-            flat = __builtin_amdgcn_ballot_w64(((w1 ^ f1) | (w2 ^ f2)) != 0u) == 0ull;
-            if (flat) {
-                const unsigned long long active = __builtin_amdgcn_ballot_w64(true);
-                if ((active & (0ull - active)) == (1ull << (tid & 63))) {             // the first active lane
-                    const unsigned int n = (unsigned int)__builtin_popcountll(active);
-                    const unsigned int nn01 = __builtin_amdgcn_perm(f1, f0, seln01), px01 = __builtin_amdgcn_perm(f1, f0, selx01);
-                    const unsigned int nn23 = __builtin_amdgcn_perm(f2, f1, seln23), px23 = __builtin_amdgcn_perm(f2, f1, selx23);
-                    if (nn01 == nn23 && px01 == px23 && (nn01 >> 16) == (nn01 & 0xFFFFu) && (px01 >> 16) == (px01 & 0xFFFFu)) {
-                        // one colour: one add for the whole 256 pixels
-                        const unsigned int m = jh_m(nn01 & 255u, px01 & 255u);
-                        jh_add((((px01 & 255u) << 7) | (m & 127u)) << 2, (((m >> 7) << 16) | 1u) * (4u * n), tab);
-                    } else {
-                        count_pair_n(nn01, px01, n);
-                        count_pair_n(nn23, px23, n);
-                    }
-                }
-                return;
+        if (jh_mostly_runs(w0)) {
+            const bool head = ((jh_prev_lane(w0) ^ w0) | (jh_prev_lane(w1) ^ w1) | (jh_prev_lane(w2) ^ w2)) != 0u;   // every lane takes part in the three DPP moves
+            const unsigned int n = jh_run_length(head, tid & 63);
+            if (head) {
+                count_pair_n(__builtin_amdgcn_perm(w1, w0, seln01), __builtin_amdgcn_perm(w1, w0, selx01), n);
+                count_pair_n(__builtin_amdgcn_perm(w2, w1, seln23), __builtin_amdgcn_perm(w2, w1, selx23), n);
             }
+            return;
         }
         count_pair(__builtin_amdgcn_perm(w1, w0, seln01), __builtin_amdgcn_perm(w1, w0, selx01));
         count_pair(__builtin_amdgcn_perm(w2, w1, seln23), __builtin_amdgcn_perm(w2, w1, selx23));
@@ -759,6 +745,7 @@ extern "C" int lars_d_stats_joint(const lars_fused_args *a, int white_balance, i
     C.tiles = tiles; C.npix = a->npix; C.ntiles = a->ntiles;
     C.chunk_quads = joint_chunk_quads(a->npix, K);
     C.part = reinterpret_cast<unsigned int *>(base + L.part_off); C.error = error; C.K = K; C.S = S; C.streams = streams;
+    C.lab_period = getenv("LARS_LAB_PERIOD") ? atoi(getenv("LARS_LAB_PERIOD")) : 0;
     C.win = windowed ? win : nullptr; C.pass = 0; C.list = reinterpret_cast<uint2 *>(base + L.list_off);
     const long long units = (long long)a->ntiles * K;
     const long long nwg = S == 2 ? ((units + 7) / 8) * 16 : units;
@@ -784,7 +771,7 @@ extern "C" int lars_d_stats_joint(const lars_fused_args *a, int white_balance, i
     F.win = C.win; F.pass = 0;
 
     if (windowed) {
-        joint_count_win_launch(C, a->channels, depth, s);
+        joint_count_win_launch(C, a->channels, tuning().joint_win_depth, s);
         LARS_TRY(launch_check("lars_d_stats_joint (count, windowed)"));
     }
     count_full();                                          // the tiles without a window (every tile when nothing is windowed)

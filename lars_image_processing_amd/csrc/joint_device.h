@@ -30,6 +30,7 @@ struct JointCountParams {
     unsigned int streams;                     // bit 0: (n, r) pairs, bit 1: (n, g) pairs
     struct JointWin *win;                     // [ntiles] or null: which tiles are counted on windowed tables (joint_win.hip)
     int pass;                                 // 0: the first count (k_joint_count skips the windowed tiles); 1: the recount of the tiles whose window missed
+    int lab_period;                           // TEMPORARY experiment: steps between scans (0 = PERIOD)
     uint2 *list;                              // k_joint_count_win: [ntiles * K][JW_LIST_CAP] moved dwords (dword, value)
 };
 
@@ -46,6 +47,26 @@ __device__ inline unsigned int jh_mad5(unsigned int px, unsigned int nn)
     return r;
 }
 static_assert(JH_K == 5u, "jh_mad5 spells the factor out");
+
+// Runs of equal pixels (nodata borders, saturated sky, flat fills): when at least half of a wave's lanes hold the same quad as the lane before
+// them, the lanes that START a run add the whole run's count and the others add nothing -- 64 lanes queueing on a few LDS words become
+// a few lanes.  jh_run_head: does this lane start a run (its quad differs from the previous lane's; rows of 16 lanes start one anyway)?
+// The cheap half of the test (first dword only) runs for every quad: one v_mov_b32_dpp + one compare.
+__device__ inline unsigned int jh_prev_lane(unsigned int w)
+{
+    return (unsigned int)__builtin_amdgcn_update_dpp((int)~w, (int)w, 0x111 /* row_shr:1 */, 0xF, 0xF, false);   // first lane of a row: ~w
+}
+__device__ inline bool jh_mostly_runs(unsigned int w0)
+{
+    return __builtin_popcountll(__builtin_amdgcn_ballot_w64(jh_prev_lane(w0) == w0)) >= 32;
+}
+// length of the run a head lane starts: up to the next head, the first inactive lane, or the wave's end
+__device__ inline unsigned int jh_run_length(bool head, int lane)
+{
+    const unsigned long long stops = __builtin_amdgcn_ballot_w64(head) | ~__builtin_amdgcn_ballot_w64(true);
+    const unsigned long long above = (stops >> lane) >> 1;
+    return above ? (unsigned int)__builtin_ctzll(above) + 1u : 64u - (unsigned int)lane;
+}
 
 // (D, h) of a pair of samples, and back
 __device__ inline unsigned int jh_m(unsigned int n, unsigned int x) { return (n + JH_K * x) & 255u; }

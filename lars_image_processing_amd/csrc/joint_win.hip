@@ -156,13 +156,13 @@ __global__ __launch_bounds__(JH_THREADS) void k_joint_predict(JointPredictParams
 __device__ inline unsigned int jw_sub_sat(unsigned int a, unsigned int b)        // per half: max(a - b, 0)
 {
     unsigned int r;
-    asm("v_pk_sub_u16 %0, %1, %2 clamp" : "=v"(r) : "v"(a), "s"(b));
+    asm("v_pk_sub_u16 %0, %1, %2 clamp" : "=v"(r) : "v"(a), "v"(b));
     return r;
 }
 __device__ inline unsigned int jw_min(unsigned int a, unsigned int b)
 {
     unsigned int r;
-    asm("v_pk_min_u16 %0, %1, %2" : "=v"(r) : "v"(a), "s"(b));
+    asm("v_pk_min_u16 %0, %1, %2" : "=v"(r) : "v"(a), "v"(b));
     return r;
 }
 __device__ inline unsigned int jw_mad(unsigned int a, unsigned int b, unsigned int c)   // per half: a * b + c
@@ -221,50 +221,54 @@ __global__ __launch_bounds__(JH_THREADS, 4) void k_joint_count_win(JointCountPar
     const long long nq = q_end > q_begin ? q_end - q_begin : 0;
     const uint8_t *tile_base = P.tiles + tile * P.npix * CH;
 
-    // wave-uniform constants, both halves alike
-    const unsigned int lo_r2 = __builtin_amdgcn_readfirstlane(lo_r * 0x10001u), lo_g2 = __builtin_amdgcn_readfirstlane(lo_g * 0x10001u);
-    const unsigned int nr1_2 = __builtin_amdgcn_readfirstlane((nr - 1u) * 0x10001u), ng1_2 = __builtin_amdgcn_readfirstlane((ng - 1u) * 0x10001u);
+    // Which table a lane's FIRST and which its SECOND add of a pixel goes to depends on the lane's parity: even lanes red then green, odd
+    // lanes green then red.  One LDS instruction then spreads its 64 lanes over both tables -- on smooth imagery, where the pixels of a
+    // wave fall into a 5 x 5 neighbourhood of cells per table, that halves the lanes per cell and bank.  It costs nothing but registers:
+    // the byte selectors of v_perm_b32 and the windows' constants are per-lane values instead of scalars.  Both halves of a dword alike.
+    const bool odd = (tid & 1) != 0;
+    const unsigned int lo_r2 = lo_r * 0x10001u, lo_g2 = lo_g * 0x10001u;
+    const unsigned int nr1_2 = (nr - 1u) * 0x10001u, ng1_2 = (ng - 1u) * 0x10001u;
+    const unsigned int base_g2 = (nr * JW_PITCH) * 0x10001u;                           // first dword of the green rows: < 2^16
+    const unsigned int lo_f = odd ? lo_g2 : lo_r2, lo_s = odd ? lo_r2 : lo_g2;
+    const unsigned int n1_f = odd ? ng1_2 : nr1_2, n1_s = odd ? nr1_2 : ng1_2;
+    const unsigned int base_f = odd ? base_g2 : 0u, base_s = odd ? 0u : base_g2;
     const unsigned int pitch2 = JW_PITCH * 0x10001u;
-    const unsigned int base_g2 = __builtin_amdgcn_readfirstlane((nr * JW_PITCH) * 0x10001u);      // first dword of the green rows: < 2^16
 
     // bytes of a quad r0 g0 n0 r1 | g1 n1 r2 g2 | n2 r3 g3 n3; pixels 0, 1 from perm(w1, w0), pixels 2, 3 from perm(w2, w1)
     const unsigned int seln01 = 0x0c050c02u, selr01 = 0x0c030c00u, selg01 = 0x0c040c01u;
     const unsigned int seln23 = 0x0c070c04u, selr23 = 0x0c050c02u, selg23 = 0x0c060c03u;
+    const unsigned int self01 = odd ? selg01 : selr01, sels01 = odd ? selr01 : selg01;
+    const unsigned int self23 = odd ? selg23 : selr23, sels23 = odd ? selr23 : selg23;
 
     unsigned int two = 2u;
     asm volatile("" : "+v"(two));                                                  // a VGPR that holds 2 (SDWA takes no constants)
-    // Two pixels at a time, one in each 16-bit half.  mul = 1 but for flat areas, where one lane adds the whole wave's count.
-    auto count_pair = [&](unsigned int nn, unsigned int rr, unsigned int gg, unsigned int mul) {
+    // Two pixels at a time, one in each 16-bit half; xf / xs: the samples paired with NIR in the lane's first and second table.
+    // mul = 1 but for flat areas, where one lane adds the whole wave's count.
+    auto count_pair = [&](unsigned int nn, unsigned int xf, unsigned int xs, unsigned int mul) {
         const unsigned int t = nn & 0x007F007Fu, u = nn & 0x00800080u;
         unsigned int v0 = jw_val0(u);                                               // 1 | h << 16 of the low pixel
         unsigned int v1 = (u >> 7) | 1u;                                            // of the high pixel (bit 0 is set either way)
         if (mul != 1u) { v0 *= mul; v1 = (v1 & 0x10001u) * mul; }
-        const unsigned int da = jw_mad(jw_min(jw_sub_sat(rr, lo_r2), nr1_2), pitch2, t);
-        const unsigned int db = jw_mad(jw_min(jw_sub_sat(gg, lo_g2), ng1_2), pitch2, t + base_g2);
-        jh_add(jw_addr<0>(da, two), v0, tab);
-        jh_add(jw_addr<1>(da, two), v1, tab);
-        jh_add(jw_addr<0>(db, two), v0, tab);
-        jh_add(jw_addr<1>(db, two), v1, tab);
+        const unsigned int df = jw_mad(jw_min(jw_sub_sat(xf, lo_f), n1_f), pitch2, t + base_f);
+        const unsigned int ds = jw_mad(jw_min(jw_sub_sat(xs, lo_s), n1_s), pitch2, t + base_s);
+        jh_add(jw_addr<0>(df, two), v0, tab);
+        jh_add(jw_addr<1>(df, two), v1, tab);
+        jh_add(jw_addr<0>(ds, two), v0, tab);
+        jh_add(jw_addr<1>(ds, two), v1, tab);
     };
     auto do_quad = [&](unsigned int w0, unsigned int w1, unsigned int w2) {
-        // flat areas (every lane of the wave holds the same four pixels) would queue 64 lanes on one LDS word per atomic: joint.hip
-        const unsigned int f0 = __builtin_amdgcn_readfirstlane(w0);
-        bool flat = __builtin_amdgcn_ballot_w64(w0 != f0) == 0ull;
-        if (flat) {
-            const unsigned int f1 = __builtin_amdgcn_readfirstlane(w1), f2 = __builtin_amdgcn_readfirstlane(w2);
-            flat = __builtin_amdgcn_ballot_w64(((w1 ^ f1) | (w2 ^ f2)) != 0u) == 0ull;
-            if (flat) {
-                const unsigned long long active = __builtin_amdgcn_ballot_w64(true);
-                if ((active & (0ull - active)) == (1ull << (tid & 63))) {             // the first active lane
-                    const unsigned int n = (unsigned int)__builtin_popcountll(active);
-                    count_pair(__builtin_amdgcn_perm(f1, f0, seln01), __builtin_amdgcn_perm(f1, f0, selr01), __builtin_amdgcn_perm(f1, f0, selg01), n);
-                    count_pair(__builtin_amdgcn_perm(f2, f1, seln23), __builtin_amdgcn_perm(f2, f1, selr23), __builtin_amdgcn_perm(f2, f1, selg23), n);
-                }
-                return;
+        // runs of equal pixels: the lanes that start a run add its whole count, the others nothing (joint_device.h)
+        if (jh_mostly_runs(w0)) {
+            const bool head = ((jh_prev_lane(w0) ^ w0) | (jh_prev_lane(w1) ^ w1) | (jh_prev_lane(w2) ^ w2)) != 0u;   // every lane takes part in the three DPP moves
+            const unsigned int n = jh_run_length(head, tid & 63);
+            if (head) {
+                count_pair(__builtin_amdgcn_perm(w1, w0, seln01), __builtin_amdgcn_perm(w1, w0, self01), __builtin_amdgcn_perm(w1, w0, sels01), n);
+                count_pair(__builtin_amdgcn_perm(w2, w1, seln23), __builtin_amdgcn_perm(w2, w1, self23), __builtin_amdgcn_perm(w2, w1, sels23), n);
             }
+            return;
         }
-        count_pair(__builtin_amdgcn_perm(w1, w0, seln01), __builtin_amdgcn_perm(w1, w0, selr01), __builtin_amdgcn_perm(w1, w0, selg01), 1u);
-        count_pair(__builtin_amdgcn_perm(w2, w1, seln23), __builtin_amdgcn_perm(w2, w1, selr23), __builtin_amdgcn_perm(w2, w1, selg23), 1u);
+        count_pair(__builtin_amdgcn_perm(w1, w0, seln01), __builtin_amdgcn_perm(w1, w0, self01), __builtin_amdgcn_perm(w1, w0, sels01), 1u);
+        count_pair(__builtin_amdgcn_perm(w2, w1, seln23), __builtin_amdgcn_perm(w2, w1, self23), __builtin_amdgcn_perm(w2, w1, sels23), 1u);
     };
 
     // tail pixels of the tile (npix % 4): its last chunk, before the first period
@@ -337,7 +341,7 @@ __global__ __launch_bounds__(JH_THREADS, 4) void k_joint_count_win(JointCountPar
             }
             soff += DEPTH * STEP_B;
             since += DEPTH;
-            if (since == PERIOD) {
+            if (since == (P.lab_period ? P.lab_period : PERIOD)) {
                 scan();
                 since = 0;
             }
@@ -408,8 +412,8 @@ void joint_count_win_launch(const JointCountParams &C, int channels, int depth, 
 #define LARS_JOINT_WIN(DD, CC) hipLaunchKernelGGL((k_joint_count_win<DD, CC>), dim3((unsigned)units), dim3(JH_THREADS), 0, s, C)
     if (channels == 4) LARS_JOINT_WIN(6, 4);
     else if (depth == 4) LARS_JOINT_WIN(4, 3);
-    else if (depth == 12) LARS_JOINT_WIN(12, 3);
-    else LARS_JOINT_WIN(6, 3);
+    else if (depth == 6) LARS_JOINT_WIN(6, 3);
+    else LARS_JOINT_WIN(12, 3);
 #undef LARS_JOINT_WIN
 }
 

@@ -263,6 +263,7 @@ int lars_set_tuning(const char *key, int value)
     else if (!strcmp(key, "selq_list_wgs")) t.selq_list_wgs = value;
     else if (!strcmp(key, "joint_depth")) t.joint_depth = value;
     else if (!strcmp(key, "joint_window")) t.joint_window = value;
+    else if (!strcmp(key, "joint_win_depth")) t.joint_win_depth = value;
     else if (!strcmp(key, "out_stride_planes")) t.out_stride_planes = value;
     else if (!strcmp(key, "u16_hist_impl")) t.u16_hist_impl = value;
     else return fail(LARS_ERR_INVALID, "lars_set_tuning: unknown key %s", key);
@@ -280,6 +281,7 @@ int lars_get_tuning(const char *key, int *value)
     else if (!strcmp(key, "selq_list_wgs")) *value = t.selq_list_wgs;
     else if (!strcmp(key, "joint_depth")) *value = t.joint_depth;
     else if (!strcmp(key, "joint_window")) *value = t.joint_window;
+    else if (!strcmp(key, "joint_win_depth")) *value = t.joint_win_depth;
     else if (!strcmp(key, "out_stride_planes")) *value = t.out_stride_planes;
     else if (!strcmp(key, "u16_hist_impl")) *value = t.u16_hist_impl;
     else if (!strcmp(key, "last_fused_kernel")) *value = t.last_fused_kernel;

@@ -561,7 +561,7 @@ class TileBatch:
         return cache[key]
 
     def process(self, indices=INDEX_NAMES, white_balance=True, hist=False, outputs=None, stream=None,
-                recompute_tables=True, medians=False, sumsq=False, route=None, rgn_variant=None):
+                recompute_tables=True, medians=False, sumsq=False, route=None, rgn_variant=None, channel_hist=False):
         """Both passes over the whole batch; returns per-tile records
         (structured ndarray ``[ntiles, 3]`` of STATS_DTYPE; rows of indices not
         requested are zero).  ``hist`` adds the 50-bin histograms, ``sumsq`` the sums of squares
@@ -574,7 +574,9 @@ class TileBatch:
         Tables: ``recompute_tables=False`` uses the white-balance tables the batch already holds (``compute_wb_tables``,
         any ``rgn_variant``) when they cover the channels this pass reads -- such a pass runs on the per-pixel route, the
         one-read route derives its tables from its own counts -- and computes them otherwise.  ``rgn_variant`` (None: 0
-        for tables computed here, whatever the reused tables are) selects the flavour of tables computed here."""
+        for tables computed here, whatever the reused tables are) selects the flavour of tables computed here.
+        ``channel_hist=True``: the 256-bin channel histograms (``host_hist``) are wanted too -- the per-pixel route always
+        leaves them, the one-read route only on request (and then counts on full tables: ``run_joint``)."""
         route = _STATS_ROUTE if route is None else route
         variant = 0 if rgn_variant is None else int(rgn_variant)
         need = channels_of(indices, outputs is not None and outputs.wb is not None)
@@ -591,7 +593,7 @@ class TileBatch:
             stats = self.new_stats()
             stats.zero(stream)
             pairs_dev = DeviceBuffer(self.ntiles * 4 * 4) if medians else None
-            self.run_joint(indices, white_balance, stats, hist, sumsq, pairs_dev, stream, rgn_variant=variant)
+            self.run_joint(indices, white_balance, stats, hist, sumsq, pairs_dev, stream, rgn_variant=variant, channel_hist=channel_hist)
             self.check_joint(stream)
             rec = stats.download(STATS_DTYPE, (self.ntiles, 3))
             stats.free()
@@ -612,7 +614,7 @@ class TileBatch:
             stats = self.new_stats()
             stats.zero(stream)
             pairs_dev = DeviceBuffer(self.ntiles * 4 * 4) if medians else None
-            self.run_joint(indices, white_balance, stats, hist, sumsq, pairs_dev, stream, rgn_variant=variant)
+            self.run_joint(indices, white_balance, stats, hist, sumsq, pairs_dev, stream, rgn_variant=variant, channel_hist=channel_hist)
             self.run_fused_chunks(indices, white_balance, None, False, outputs, stream)
             self.check_joint(stream)
             rec = stats.download(STATS_DTYPE, (self.ntiles, 3))

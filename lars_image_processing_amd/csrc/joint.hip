@@ -29,7 +29,6 @@
 // 25 DIFFERENT banks (and dwords), as do common shifts of both samples (shading: +6 per level) and shifts of one sample alone.
 // Round 3's n ^ 2x put such a neighbourhood into about six banks (tools/lab/banksim.py: 10-12 lanes on the fullest bank against
 // 5.4 for independent samples; the linear form: 5.5-5.7).
-#include <stdlib.h>
 #include <vector>
 
 #include "joint_device.h"
@@ -314,7 +313,9 @@ __device__ inline void jf_pick(const unsigned int *h, unsigned long long rank0, 
     __syncthreads();
 }
 
-__global__ __launch_bounds__(JH_THREADS) void k_joint_finish(JointFinishParams P)
+// 8 waves per SIMD = 64 registers: TWO of these 16-wave blocks share a CU.  Left to itself the compiler took 68 and the second half of the
+// blocks waited for the first (profiles/r05_finish_block_timeline.txt: 97 -> 74 us per 256 tiles, with medians 177 -> 129).
+__global__ __launch_bounds__(JH_THREADS, 8) void k_joint_finish(JointFinishParams P)
 {
     __shared__ unsigned int s_hn[256], s_hx[256];
     __shared__ float s_fn[256], s_fx[256];
@@ -725,9 +726,9 @@ extern "C" int lars_d_stats_joint(const lars_fused_args *a, int white_balance, i
                                       "tuning in force at the launch)", scratch_bytes, L.total);
     // Windowed tables, one reader per tile chunk (joint_win.hip): two streams, percentile white balance (the windows ARE its clipping),
     // tiles large enough to pay for a window, and no channel histograms wanted -- those would come out clamped to the windows.
-    // lars_set_tuning("joint_window", 0) = never, 2 = windows that miss on purpose (exercises the recount).
+    // lars_set_tuning("joint_window", 0) = never, 2 = windows that miss on purpose (exercises the recount), 3 = tiles of any size (tests).
     const int window = tuning().joint_window;
-    const bool windowed = S == 2 && white_balance && !hist && window != 0 && a->npix >= JW_MIN_PIXELS;
+    const bool windowed = S == 2 && white_balance && !hist && window != 0 && (a->npix >= JW_MIN_PIXELS || window >= 2);
 
     char *base = static_cast<char *>(scratch);
     unsigned int *error = reinterpret_cast<unsigned int *>(base);
@@ -745,7 +746,6 @@ extern "C" int lars_d_stats_joint(const lars_fused_args *a, int white_balance, i
     C.tiles = tiles; C.npix = a->npix; C.ntiles = a->ntiles;
     C.chunk_quads = joint_chunk_quads(a->npix, K);
     C.part = reinterpret_cast<unsigned int *>(base + L.part_off); C.error = error; C.K = K; C.S = S; C.streams = streams;
-    C.lab_period = getenv("LARS_LAB_PERIOD") ? atoi(getenv("LARS_LAB_PERIOD")) : 0;
     C.win = windowed ? win : nullptr; C.pass = 0; C.list = reinterpret_cast<uint2 *>(base + L.list_off);
     const long long units = (long long)a->ntiles * K;
     const long long nwg = S == 2 ? ((units + 7) / 8) * 16 : units;

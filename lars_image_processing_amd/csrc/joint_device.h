@@ -30,7 +30,6 @@ struct JointCountParams {
     unsigned int streams;                     // bit 0: (n, r) pairs, bit 1: (n, g) pairs
     struct JointWin *win;                     // [ntiles] or null: which tiles are counted on windowed tables (joint_win.hip)
     int pass;                                 // 0: the first count (k_joint_count skips the windowed tiles); 1: the recount of the tiles whose window missed
-    int lab_period;                           // TEMPORARY experiment: steps between scans (0 = PERIOD)
     uint2 *list;                              // k_joint_count_win: [ntiles * K][JW_LIST_CAP] moved dwords (dword, value)
 };
 

@@ -341,7 +341,7 @@ __global__ __launch_bounds__(JH_THREADS, 4) void k_joint_count_win(JointCountPar
             }
             soff += DEPTH * STEP_B;
             since += DEPTH;
-            if (since == (P.lab_period ? P.lab_period : PERIOD)) {
+            if (since == PERIOD) {
                 scan();
                 since = 0;
             }

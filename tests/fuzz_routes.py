@@ -14,6 +14,7 @@ import numpy as np
 
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import lars_image_processing_amd as lars  # noqa: E402
+from lars_image_processing_amd import _ffi as _lars_ffi  # noqa: E402,F401
 
 TYPES = ("NDVI", "GNDVI", "NDWI")
 SUBSETS = [c for r in (1, 2, 3) for c in itertools.combinations(TYPES, r)]
@@ -58,7 +59,7 @@ def main():
     ap.add_argument("--max-edge", type=int, default=200)
     args = ap.parse_args()
     rng = np.random.default_rng(args.seed)
-    seen = {}
+    seen, windowed, recounted = {}, {}, {}
     for case in range(args.cases):
         ntiles = int(rng.integers(1, 6))
         h, w = int(rng.integers(1, args.max_edge)), int(rng.integers(1, args.max_edge))
@@ -68,8 +69,11 @@ def main():
         kind, tiles = content(rng, ntiles, h, w, ch)
         indices = SUBSETS[int(rng.integers(0, len(SUBSETS)))]
         wb, hist, sumsq, med = (bool(rng.integers(0, 2)) for _ in range(4))
+        # the one-read route's tables: 0 full, 3 windowed where they fit (tiles of any size), 2 windows that miss on purpose (recount)
+        window = int(rng.choice([0, 3, 3, 2]))
+        _lars_ffi.set_tuning(joint_window=window)
         b = lars.TileBatch.from_host(tiles)
-        what = f"case {case}: {kind} {ntiles}x{h}x{w}x{ch} {indices} wb={wb} hist={hist} sumsq={sumsq} medians={med}"
+        what = f"case {case}: {kind} {ntiles}x{h}x{w}x{ch} {indices} wb={wb} hist={hist} sumsq={sumsq} medians={med} window={window}"
         try:
             if not b.can_joint():
                 raise AssertionError("can_joint() is False")
@@ -77,7 +81,12 @@ def main():
             if wb:
                 tab_c, pct_c, hist_c = b.host_tables(), b.host_percentiles(), b.host_hist()
                 b.table.zero(); b.percentiles.zero(); b.hist.zero()
-            rj = b.process(indices=indices, white_balance=wb, hist=hist, sumsq=sumsq, medians=med, route="joint")
+            rj = b.process(indices=indices, white_balance=wb, hist=hist, sumsq=sumsq, medians=med, route="joint", channel_hist=window == 0)
+            nwin, nrec = b.joint_window_report()
+            windowed[window] = windowed.get(window, 0) + nwin
+            recounted[window] = recounted.get(window, 0) + nrec
+            assert window != 0 or nwin == 0
+            assert window != 2 or nrec == nwin
             (rec_c, med_c), (rec_j, med_j) = (rc if med else (rc, None)), (rj if med else (rj, None))
             a, c = rec_c.copy(), rec_j.copy()
             np.testing.assert_allclose(a["sumsq"], c["sumsq"], rtol=1e-12, atol=2.0 ** -26)   # rounded to 2^-32 per workgroup / per tile
@@ -87,9 +96,10 @@ def main():
                 assert np.array_equal(med_c, med_j, equal_nan=True), ("medians differ", med_c, med_j)
             if wb:
                 chans = sorted({2} | ({0} if "NDVI" in indices else set()) | ({1} if set(indices) & {"GNDVI", "NDWI"} else set()))
-                tab_j, pct_j, hist_j = b.host_tables(partial=True), b.host_percentiles(partial=True), b.host_hist(partial=True)
+                tab_j, pct_j = b.host_tables(partial=True), b.host_percentiles(partial=True)
+                hist_j = b.host_hist(partial=True) if window == 0 else None
                 for k in chans:
-                    assert np.array_equal(hist_j[:, k], hist_c[:, k]), f"channel histogram {k}"
+                    assert hist_j is None or np.array_equal(hist_j[:, k], hist_c[:, k]), f"channel histogram {k}"
                     assert pct_j[:, k].tobytes() == pct_c[:, k].tobytes(), f"percentiles {k}"
                     assert np.array_equal(tab_j[:, k], tab_c[:, k]), f"table {k}"
         except Exception as e:
@@ -101,7 +111,9 @@ def main():
         seen[kind] = seen.get(kind, 0) + 1
         if case % 50 == 49:
             print(f"{case + 1} cases ok", flush=True)
-    print(f"{args.cases} random batches (seed {args.seed}): one-read route == per-pixel route; contents {dict((str(k), v) for k, v in seen.items())}")
+    _lars_ffi.set_tuning(joint_window=1)
+    print(f"{args.cases} random batches (seed {args.seed}): one-read route == per-pixel route; contents {dict((str(k), v) for k, v in seen.items())}; "
+          f"tiles counted on windowed tables by joint_window setting {windowed}, recounted {recounted}")
     return 0
 
 

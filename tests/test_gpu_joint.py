@@ -35,9 +35,23 @@ def subsets():
         yield from itertools.combinations(TYPES, r)
 
 
+@pytest.fixture
+def window(request):
+    """lars_set_tuning("joint_window", ...) for the test's duration: 0 full tables only, 3 windowed tables for tiles of any size
+    (csrc/joint_win.hip; the default, 1, needs 2^20 pixels per tile), 2 windows that miss on purpose (every tile is recounted)."""
+    from lars_image_processing_amd import _ffi
+    _ffi.set_tuning(joint_window=request.param)
+    yield request.param
+    _ffi.set_tuning(joint_window=1)
+
+
+WINDOWS = pytest.mark.parametrize("window", [0, 3, 2], indirect=True)
+
+
+@WINDOWS
 @pytest.mark.parametrize("profile", ["uniform", "vegetation"])
 @pytest.mark.parametrize("shape,ntiles", [((64, 64), 5), ((96, 160), 3), ((33, 35), 1), ((128, 130), 2)])
-def test_joint_route_equals_classic_route(lars, profile, shape, ntiles):
+def test_joint_route_equals_classic_route(lars, profile, shape, ntiles, window):
     b = lars.TileBatch.synthetic(ntiles, shape[0], shape[1], seed=77, profile=profile)
     tiles = b.host_tiles()
     for wb in (True, False):
@@ -46,7 +60,17 @@ def test_joint_route_equals_classic_route(lars, profile, shape, ntiles):
             if wb:
                 want_tab, want_pct, want_hist = b.host_tables(), b.host_percentiles(), b.host_hist()
                 b.table.zero(); b.percentiles.zero(); b.hist.zero()
-            rec_j, med_j = b.process(indices=indices, white_balance=wb, hist=True, sumsq=True, medians=True, route="joint")
+            # the channel histograms are a by-product only full tables can give: asked for with window 0, not with the others
+            rec_j, med_j = b.process(indices=indices, white_balance=wb, hist=True, sumsq=True, medians=True, route="joint",
+                                     channel_hist=window == 0)
+            nwin, nrec = b.joint_window_report()
+            two_streams = "NDVI" in indices and len(indices) > 1
+            if window == 0 or not wb or not two_streams:
+                assert (nwin, nrec) == (0, 0)
+            elif window == 2:
+                assert nwin > 0 and nrec == nwin                 # one-row windows at the median: every windowed tile is counted again
+            elif profile == "vegetation":
+                assert (nwin, nrec) == (ntiles, 0)               # 96 + 128 values: both tables fit one workgroup
             same_records(rec_c, rec_j)
             np.testing.assert_array_equal(med_c, med_j)
             # without the optional parts: sums of squares and bins stay zero
@@ -57,9 +81,12 @@ def test_joint_route_equals_classic_route(lars, profile, shape, ntiles):
             if wb:
                 # the by-products: channel histograms, percentiles and tables of the channels the indices read
                 chans = sorted({2} | ({0} if "NDVI" in indices else set()) | ({1} if set(indices) & {"GNDVI", "NDWI"} else set()))
-                got_tab, got_pct, got_hist = b.host_tables(partial=True), b.host_percentiles(partial=True), b.host_hist(partial=True)
+                got_tab, got_pct = b.host_tables(partial=True), b.host_percentiles(partial=True)
+                if window == 0:
+                    got_hist = b.host_hist(partial=True)
                 for c in chans:
-                    np.testing.assert_array_equal(got_hist[:, c], want_hist[:, c])
+                    if window == 0:
+                        np.testing.assert_array_equal(got_hist[:, c], want_hist[:, c])
                     np.testing.assert_array_equal(got_pct[:, c], want_pct[:, c])
                     np.testing.assert_array_equal(got_tab[:, c], want_tab[:, c])
     # and against the oracle / NumPy directly (all three indices, white balance)
@@ -84,8 +111,9 @@ def _tile_from(fn, h, w):
     return np.stack([fn(yy, xx, c).astype(np.uint8) for c in range(3)], axis=-1)
 
 
+@WINDOWS
 @pytest.mark.parametrize("blocks", [0, 1, 3])
-def test_joint_counters_never_overflow(lars, blocks):
+def test_joint_counters_never_overflow(lars, blocks, window):
     """Tiles that pile hundreds of thousands of pixels onto single cells: the 16-bit counters are emptied onto the
     workgroup's list before they can wrap (constant tiles, two-level tiles, flat areas with a textured rim)."""
     from lars_image_processing_amd import _ffi
@@ -132,12 +160,15 @@ def test_joint_full_size_tiles(lars):
     rec_c, med_c = b.process(hist=True, medians=True, route="classic")
     try:
         for blocks in (1, 0, 5):
-            _ffi.set_tuning(blocks_per_tile=blocks)
-            rec_j, med_j = b.process(hist=True, medians=True, route="joint")
-            assert rec_j.tobytes() == rec_c.tobytes(), blocks
-            np.testing.assert_array_equal(med_j, med_c)
+            for window in (1, 0, 2):
+                _ffi.set_tuning(blocks_per_tile=blocks, joint_window=window)
+                rec_j, med_j = b.process(hist=True, medians=True, route="joint")
+                # the default: all six tiles on windowed tables (96 + 128 values; the one-colour tile: 3 + 3), nothing recounted
+                assert b.joint_window_report() == {1: (6, 0), 0: (0, 0), 2: (6, 6)}[window]
+                assert rec_j.tobytes() == rec_c.tobytes(), (blocks, window)
+                np.testing.assert_array_equal(med_j, med_c)
     finally:
-        _ffi.set_tuning(blocks_per_tile=0)
+        _ffi.set_tuning(blocks_per_tile=0, joint_window=1)
     n = 4096 * 4096
     assert (rec_j["count"] == n).all() and (rec_j["hist"].sum(axis=2) == n).all()
     tile = b.host_tiles(3, 1)[0]
@@ -279,8 +310,9 @@ def _hot_tiles(kind, n, h, w, seed=3):
     return t
 
 
+@WINDOWS
 @pytest.mark.parametrize("kind", ["iid", "three_colours_by_quad", "mostly_one_colour", "two_colours_by_pixel", "one_colour"])
-def test_hot_cells_survive_the_16_bit_counters(lars, kind):
+def test_hot_cells_survive_the_16_bit_counters(lars, kind, window):
     """Content whose pixels pile onto a few counter pairs moves those pairs onto the hand-over list thousands of times (plain
     adds, flat-wave adds of up to 256 at once, one and two streams, one workgroup per tile and several): records, medians
     and tables stay identical to the per-pixel route."""
@@ -291,12 +323,103 @@ def test_hot_cells_survive_the_16_bit_counters(lars, kind):
             want, want_med = b.process(indices=indices, hist=True, medians=True, route="classic")
             want_tab = b.host_tables()
             for blocks, depth in ((0, 6), (1, 6), (0, 12), (3, 8)):
-                _ffi.set_tuning(blocks_per_tile=blocks, joint_depth=depth)
+                _ffi.set_tuning(blocks_per_tile=blocks, joint_depth=depth, joint_win_depth=depth if depth != 8 else 4)
                 got, got_med = b.process(indices=indices, hist=True, medians=True, route="joint")
                 assert got.tobytes() == want.tobytes(), (kind, indices, blocks, depth)
                 np.testing.assert_array_equal(got_med, want_med)
                 for c in sorted(lars.batch.channels_of(indices)):
                     np.testing.assert_array_equal(b.host_tables(partial=True)[:, c], want_tab[:, c])
     finally:
-        _ffi.set_tuning(blocks_per_tile=0, joint_depth=6)
+        _ffi.set_tuning(blocks_per_tile=0, joint_depth=6, joint_win_depth=12)
+        b.free()
+
+
+def _narrow(rng, h, w, lo, hi, ch=3):
+    return rng.integers(lo, hi, (h, w, ch), dtype=np.uint8)
+
+
+@pytest.mark.parametrize("channels", [3, 4])
+def test_windowed_and_full_tiles_in_one_batch(lars, channels):
+    """A batch in which some tiles get windows (narrow red and green) and others do not (full-range samples): each tile takes its own
+    way through ONE call -- k_joint_count_win for the first kind, k_joint_count for the second -- RGB and RGBA."""
+    from lars_image_processing_amd import _ffi
+    rng = np.random.default_rng(11)
+    h, w = 512, 640
+    tiles = np.stack([
+        _narrow(rng, h, w, 40, 160, channels),                                          # 120 + 120 rows: fits
+        rng.integers(0, 256, (h, w, channels), dtype=np.uint8),                          # 250 + 250: does not
+        np.clip(rng.normal(90, 12, (h, w, channels)), 0, 255).astype(np.uint8),          # bell-shaped: fits
+        np.concatenate([_narrow(rng, h, w // 2, 0, 256, channels), _narrow(rng, h, w // 2, 100, 110, channels)], axis=1),   # wide half
+        _narrow(rng, h, w, 250, 256, channels),                                          # up against the range's end
+        _narrow(rng, h, w, 0, 3, channels),                                              # and its start
+    ])
+    tiles[2, :, :, 2] = rng.integers(0, 256, (h, w), dtype=np.uint8)                     # NIR keeps all 256 values either way
+    b = lars.TileBatch.from_host(tiles)
+    try:
+        want, want_med = b.process(hist=True, medians=True, route="classic")
+        want_tab, want_pct = b.host_tables(), b.host_percentiles()
+        for window, expect in ((3, (4, 0)), (2, None), (0, (0, 0))):
+            for blocks in (0, 1, 3):
+                _ffi.set_tuning(joint_window=window, blocks_per_tile=blocks)
+                got, got_med = b.process(hist=True, medians=True, route="joint")
+                report = b.joint_window_report()
+                assert expect is None or report == expect, (window, report)
+                if window == 2:
+                    assert report[0] >= 4 and report[1] == report[0]
+                assert got.tobytes() == want.tobytes(), (window, blocks)
+                np.testing.assert_array_equal(got_med, want_med)
+                np.testing.assert_array_equal(b.host_tables(), want_tab)
+                assert b.host_percentiles().tobytes() == want_pct.tobytes()
+    finally:
+        _ffi.set_tuning(joint_window=1, blocks_per_tile=0)
+        b.free()
+
+
+def test_windowed_ragged_single_tile_and_flavours(lars):
+    """One tile whose pixel count is not a multiple of four (the tail pixels take the scalar path of the windowed kernel), the
+    process-rgn.py flavour of the tables, the sum of squares and the 50 bins -- windowed against full tables against per pixel."""
+    from lars_image_processing_amd import _ffi
+    rng = np.random.default_rng(5)
+    tile = np.clip(rng.normal(120, 20, (1, 333, 335, 3)), 0, 255).astype(np.uint8)
+    tile[0, -1, -3:, :] = (0, 255, 7)                                                     # the tail: values outside every window
+    b = lars.TileBatch.from_host(tile)
+    try:
+        for variant in (0, 1):
+            b.compute_wb_tables(rgn_variant=variant)
+            want = b.process(hist=True, sumsq=True, recompute_tables=False, route="classic")
+            want_tab = b.host_tables()
+            for window in (3, 0, 2):
+                _ffi.set_tuning(joint_window=window)
+                got = b.process(hist=True, sumsq=True, rgn_variant=variant, route="joint")
+                assert b.joint_window_report() == {3: (1, 0), 0: (0, 0), 2: (1, 1)}[window]
+                same_records(want, got)
+                np.testing.assert_array_equal(b.host_tables(), want_tab)
+    finally:
+        _ffi.set_tuning(joint_window=1)
+        b.free()
+
+
+def test_window_report_and_channel_histograms(lars):
+    """Asking for the channel histograms keeps the full tables (clamped counts cannot give them); not asking leaves host_hist()
+    invalid instead of handing out clamped histograms."""
+    b = lars.TileBatch.synthetic(2, 1024, 1024, seed=9, profile="vegetation")
+    stats = b.new_stats()
+    try:
+        b.run_joint(TYPES, True, stats)                                                    # 2^20 pixels: windowed by default
+        b.check_joint()
+        assert b.joint_window_report() == (2, 0)
+        with pytest.raises(RuntimeError):
+            b.host_hist()
+        rec_w = stats.download(lars.batch.STATS_DTYPE, (2, 3)).copy()
+        b.run_joint(TYPES, True, stats, channel_hist=True)
+        b.check_joint()
+        assert b.joint_window_report() == (0, 0)
+        assert stats.download(lars.batch.STATS_DTYPE, (2, 3)).tobytes() == rec_w.tobytes()
+        hist = b.host_hist()
+        tiles = b.host_tiles()
+        for i in range(2):
+            for c in range(3):
+                np.testing.assert_array_equal(hist[i, c], np.bincount(tiles[i, :, :, c].ravel(), minlength=256))
+    finally:
+        stats.free()
         b.free()

@@ -530,17 +530,23 @@ def smooth_leg(tiles=256, edge=4096, rounds=4):
                 b.run_fused(a)
         c_ms = timed(classic)
         _ffi.call("lars_synchronize", None)
-        want = stats.download(_ffi.STATS_DTYPE, (1, 3)).tobytes()
+        want = stats.download(_ffi.STATS_DTYPE, (tiles, 3)).tobytes()             # every tile's records, not only the first's
+        want_med = pairs.download(np.float32, (tiles, 2, 2)).tobytes() if med else None
         j_ms = timed(lambda: b.run_joint(indices, True, stats, pairs=pairs if med else None))
         b.check_joint()
-        same = stats.download(_ffi.STATS_DTYPE, (1, 3)).tobytes() == want
+        windowed, recounted = b.joint_window_report()
+        same = stats.download(_ffi.STATS_DTYPE, (tiles, 3)).tobytes() == want
+        if med:
+            same = same and pairs.download(np.float32, (tiles, 2, 2)).tobytes() == want_med
         b.__dict__.pop("_route_cache", None)
         auto = "joint" if med else b.pick_stats_route(indices, True)
         chosen = j_ms if auto == "joint" else c_ms
         out[name] = {"one_read_ms": j_ms, "per_pixel_ms": c_ms, "auto_route": "one read" if auto == "joint" else "per pixel",
                      "ms_per_step": chosen, "whole_step_frac": npix * 3 / (chosen * 1e-3) / 1e9 / HBM_PEAK_GBS,
                      "one_read_frac": npix * 3 / (j_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, "per_pixel_frac": npix * 3 / (c_ms * 1e-3) / 1e9 / HBM_PEAK_GBS,
-                     "records_identical": bool(same)}
+                     "records_identical": bool(same), "tiles_on_windowed_tables": windowed, "tiles_recounted": recounted}
+    for e in ev:
+        _ffi.call("lars_event_destroy", e)
     stats.free(); pairs.free(); scratch.free(); b.free()
     return out
 
@@ -612,6 +618,11 @@ def launch_ranks(args):
     rdzv_dir = tempfile.mkdtemp(prefix="lars_rdzv_")
     base = dict(os.environ, WORLD_SIZE=str(n), MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port),
                 LARS_RDZV_TOKEN=secrets.token_hex(16), LARS_RDZV_DIR=rdzv_dir, LARS_BENCH_LAUNCHER="self")
+    # The ranks of one node share device memory through dmabuf IPC handles (RCCL's intra-node transports, and any device buffer a
+    # rank hands to another).  This image's host driver supports ONLY dmabuf IPC: with the legacy mode (the runtime's default when the
+    # variable is unset) hipIpcGetMemHandle fails with "invalid argument" and ncclCommInitRank with nranks > 1 never comes up.  The
+    # image exports the variable already; a launcher that builds its ranks' environment itself has to keep it.
+    # setdefault: an operator's own setting wins.
     base.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
     try:
         out = run_rank_processes(n, [sys.executable, os.path.abspath(__file__), *sys.argv[1:]], base)
@@ -722,14 +733,20 @@ def main():
                 "Mpix_s": npix_rank * world * k_steps / d / 1e6,
                 "ms_per_step": m_step_ms,
                 "whole_step_frac": npix_rank * MODES[base][3] / (m_step_ms * 1e-3) / 1e9 / HBM_PEAK_GBS,
-                "route": ("one read: joint byte-pair histograms (k_joint_count + k_joint_finish)" if one_read else
-                          "one-read statistics pass (k_joint_count + k_joint_finish), then k_fused_u8c3 planes only"
+                "route": ("one read: joint byte-pair histograms (windowed tables, one reader per tile chunk: k_joint_predict + "
+                          "k_joint_count_win + k_joint_finish; full tables, two readers, where the windows do not fit or one value "
+                          "stream is counted: k_joint_count)" if one_read else
+                          "one-read statistics pass (k_joint_count_win / k_joint_count + k_joint_finish), then k_fused_u8c3 planes only"
                           if (base == "wb3idx_out_stats_medians" or (base == "wb_ndvi_out_stats" and args.stats_route == "joint" and runner.batch.can_joint())) else
                           "channel-histogram pass + tables, then the fused kernel"),
                 "fused_ms": f_ms, "hist_pass_ms": float(np.mean([t[0] for t in tm])),
                 "fused_GBs_algorithmic": npix_rank * MODES[base][3] / (f_ms * 1e-3) / 1e9,
                 "fused_frac_of_8TBs": npix_rank * MODES[base][3] / (f_ms * 1e-3) / 1e9 / HBM_PEAK_GBS,
             }
+            if one_read:
+                # how the one-read pass counted this rank's tiles: on windowed pair tables (one reader per tile chunk), and how many
+                # of those had to be counted again on full tables because a window missed
+                extra[m]["tiles_on_windowed_tables"], extra[m]["tiles_recounted"] = runner.batch.joint_window_report()
 
     # self-check, after the timed region: the timed configuration's records / planes against single-tile runs, and the
     # global statistics of every mode that ran against each other
@@ -792,6 +809,19 @@ def main():
                 "stats_route": args.stats_route,
                 "parallelism": f"tile-sharded x{world}",
                 "collective": collective, "ranks_seen": ranks_seen,
+                # True only when the exchange of the global statistics ran on the library's own RCCL communicator (csrc/comm.cpp:
+                # ncclAllGather over xGMI) -- a fall-back to torch.distributed or the gloo rehearsal shows here, not only in the text above
+                "rccl_used": collective.startswith("RCCL ncclAllGather"),
+                # which BASELINE.json configuration the line is: [1] per GPU by default (1024 tiles); [3] is 16384 tiles over 8 GPUs
+                "baseline_config": ("configs[3]: 16384 tiles over 8 GPUs" if world == 8 and args.tiles == 2048 and args.mode == "wb3idx_out_stats"
+                                    else f"configs[1] per GPU ({args.tiles} tiles each; configs[3] = --gpus 8 --tiles 2048)"
+                                    if args.mode == "wb3idx_out_stats" else f"mode {args.mode} (the headline is wb3idx_out_stats)"),
+                "build_flags": int(_ffi.load().lars_build_flags()),
+                # the headline's output arena, flat (the nested report above may be dropped by a recorder): allocations taken,
+                # bytes held during the search, bytes kept
+                "arena_allocations": (arena_report or {}).get("allocations"),
+                "arena_transient_bytes": (arena_report or {}).get("transient_bytes"),
+                "arena_bytes": (arena_report or {}).get("arena_bytes"),
                 "statistics_fold": "per-index fold on the device (lars_d_stats_fold), 3 x 472 B per rank exchanged",
                 "launcher": os.environ.get("LARS_BENCH_LAUNCHER", "external" if world > 1 else "none"),
                 "device": _ffi.device_name(),
@@ -827,6 +857,9 @@ def main():
         if probe:
             line["device_probe_GBs"] = probe
         print(json.dumps(line))
+    for e in runner.launch_ev:
+        _ffi.call("lars_event_destroy", e)
+    runner.launch_ev = []
     comm.destroy()
     if verified is not None and not verified["ok_on_every_rank"]:
         print(f"[bench rank {rank}] self-check FAILED: {verified}", file=sys.stderr)

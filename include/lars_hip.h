@@ -336,6 +336,16 @@ int lars_d_synth_u8(uint8_t *tiles, int64_t ntiles, int64_t first_tile, int64_t 
 int lars_set_tuning(const char *key, int value);
 int lars_get_tuning(const char *key, int *value);
 
+/* Build-time switches of the kernel sources this library was compiled with: 0 for the product (what `make` builds and the
+ * package loads).  Laboratory builds (csrc/Makefile `lablayout`, `EXTRA=-D...`) report what they changed: the plane-layout knob
+ * (one more kernel argument: other register counts), IEEE division instead of rcp + fma (same results, slower), vector instead of
+ * scalar coverage counters (same results), another geometry of the statistics-only kernels.  Needs no device. */
+#define LARS_BUILD_LAB_LAYOUT 1u
+#define LARS_BUILD_IEEE_DIV 2u
+#define LARS_BUILD_COUNT_MODE 4u
+#define LARS_BUILD_STATS_GEOMETRY 8u
+unsigned int lars_build_flags(void);
+
 /* Device self-check: number of (num, den) pairs, 1 <= den <= max_den, |num| <= den,
  * for which the kernels' rcp+fma quotient differs from IEEE float32 division
  * (must be 0; tests run it for the uint8 and the uint16 operand ranges). */

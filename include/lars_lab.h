@@ -25,12 +25,12 @@ int lars_lab_free(void *dptr);
  * tile interleaved tile by tile in one launch (unroll = read-only blocks per tile, blocks = plane-writing blocks per tile,
  * bytes = ntiles x 48 MiB of source, dst = 64 tile slots x 3 planes x 64 MiB; tools/lab/twopass.py). */
 int lars_d_probe(int kind, int unroll, int blocks, const void *src, void *dst, int64_t bytes, void *stream);
-/* The fused kernel's traffic mix with the three planes WHERE THE CALLER PUTS THEM (kind 5 packs them behind one another): nquads
- * quads of 12 bytes read from src, one 16-byte vector written to each of d0, d1, d2 per quad.  Device memory comes in two kinds
- * (profiles/r04_arena_two_kinds.txt); this is the probe for a placement that splits the planes between them. */
 /* One host <-> device copy two ways (tools/pciebench.py): mode 0 hipMemcpy, 1 hipMemcpyAsync on the calling thread's (non-blocking) library
  * stream + hipStreamSynchronize -- what the host entry points do.  to_device != 0: host -> device. */
 int lars_lab_copy(int mode, int to_device, void *host, void *dev, size_t bytes);
+/* The fused kernel's traffic mix with the three planes WHERE THE CALLER PUTS THEM (kind 5 packs them behind one another): nquads
+ * quads of 12 bytes read from src, one 16-byte vector written to each of d0, d1, d2 per quad.  Device memory comes in two kinds
+ * (profiles/r04_arena_two_kinds.txt); this is the probe for a placement that splits the planes between them. */
 int lars_d_probe_mix3(const void *src, void *d0, void *d1, void *d2, int64_t nquads, int blocks, void *stream);
 
 

@@ -117,6 +117,7 @@ SIGNATURES = {
     "lars_d_synth_u8": (_I, [_P, _I64, _I64, _I64, _I, _U32, _I, _P]),
     "lars_stats_merge": (_I, [_P, _I64, _P]),
     "lars_d_stats_fold": (_I, [_P, _I64, _U32, _P, _P]),
+    "lars_build_flags": (C.c_uint, []),
     "lars_set_tuning": (_I, [C.c_char_p, _I]),
     "lars_get_tuning": (_I, [C.c_char_p, C.POINTER(_I)]),
     "lars_d_quot_selfcheck": (_I, [_U32, C.POINTER(C.c_uint64), C.POINTER(_U32 * 2)]),

@@ -22,6 +22,7 @@ from ._ffi import FusedArgs, INDEX_IDS, INDEX_NAMES, STATS_DTYPE, DeviceBuffer, 
 
 MAX_TILES_PER_LAUNCH = 65535      # grid.y limit
 ARENA_MIN_BYTES = 2 << 30         # smaller arenas run alike wherever they land
+ARENA_SPREAD_PLANE_BYTES = 2 << 30  # planes from this size on are worth a placement search (and its spare room)
 ARENA_TRIALS = 4                  # allocations of the default search at most (each is tried with every placement of its planes)
 ARENA_CLASS_GAP = 0.93            # the search ends once its best candidate is 7 % under its worst: both classes seen (they are ~18 % apart)
 ARENA_WARM_MS = 30.0              # untimed launches before a candidate is timed: after an idle gap a fast arena needs ~22 ms to reach its level
@@ -220,7 +221,12 @@ class TileBatch:
             raise ValueError("pick must be fastest or slowest")
         packed_bytes = nplanes * outs.plane_bytes
         big = bool(nplanes) and nplanes * outs.slots * self.npix * 4 >= ARENA_MIN_BYTES
-        spread = arena == "auto" and big and nplanes >= 2                  # room inside the allocation, several placements
+        # Room inside the allocation and several placements: only where it can pay -- two or more planes of ARENA_SPREAD_PLANE_BYTES
+        # (2 GiB) or more each (planes of 1 GiB show no difference between placements: profiles/r04_arena_two_kinds.txt) -- and only
+        # if the caller did not ask for one trial at most.  Such an arena KEEPS its spare room while the outputs live:
+        # report["arena_bytes"] against the packed size (24 instead of 12 GiB for three planes of 4 GiB).
+        spread = (arena == "auto" and big and nplanes >= 2 and outs.plane_bytes >= ARENA_SPREAD_PLANE_BYTES
+                  and (placement_trials is None or int(placement_trials) > 1))
         if placement_trials is None:
             # one plane: nothing to split -- sixteen 4 GiB single-plane arenas measured within 1 % of each other (profiles/r04_ndvi_plane_step_ways.txt)
             placement_trials = ARENA_TRIALS if spread else 0
@@ -246,34 +252,42 @@ class TileBatch:
         cands = []                                                         # (ms, allocation index, offsets)
         arenas, malloc_ms = [], []
         stopped = "placement_trials"
-        while len(arenas) < max(1, int(placement_trials)):
-            _ffi.call("lars_mem_info", C.byref(free_b), C.byref(total_b))
-            want = packed_bytes
-            if spread:
-                want = max(packed_bytes, min(ARENA_SPAN_BYTES + second_bytes, free_b.value - (16 << 30)))
-            if free_b.value < want + (8 << 30):                            # keep 8 GiB of headroom for the caller
-                if arenas:
+        try:
+            while len(arenas) < max(1, int(placement_trials)):
+                _ffi.call("lars_mem_info", C.byref(free_b), C.byref(total_b))
+                want = packed_bytes
+                if spread:
+                    want = max(packed_bytes, min(ARENA_SPAN_BYTES + second_bytes, free_b.value - (16 << 30)))
+                if free_b.value < want + (8 << 30):                        # keep 8 GiB of headroom for the caller
+                    if arenas:
+                        stopped = "device memory"
+                        break
+                    want = packed_bytes                                    # the first arena must exist whatever the headroom
+                t0 = time.perf_counter()
+                try:
+                    buf = DeviceBuffer(want)
+                except _ffi.LarsError:
+                    if not arenas:
+                        raise
                     stopped = "device memory"
                     break
-                want = packed_bytes                                        # the first arena must exist whatever the headroom
-            t0 = time.perf_counter()
-            try:
-                buf = DeviceBuffer(want)
-            except _ffi.LarsError:
-                if not arenas:
-                    stats.free()
-                    raise
-                stopped = "device memory"
-                break
-            malloc_ms.append((time.perf_counter() - t0) * 1e3)
-            arenas.append(buf)
-            for k, offsets in enumerate(placements_for(want)):
-                outs.adopt_arena(buf, offsets)
-                cands.append((self._probe_arena(outs, indices, stats, warm_ms=ARENA_WARM_MS if k == 0 else 5.0), len(arenas) - 1, offsets))
-            times = [c[0] for c in cands]
-            if len(cands) >= 2 and min(times) <= ARENA_CLASS_GAP * max(times):
-                stopped = "both classes seen"
-                break
+                malloc_ms.append((time.perf_counter() - t0) * 1e3)
+                arenas.append(buf)
+                for k, offsets in enumerate(placements_for(want)):
+                    outs.adopt_arena(buf, offsets)
+                    cands.append((self._probe_arena(outs, indices, stats, warm_ms=ARENA_WARM_MS if k == 0 else 5.0), len(arenas) - 1, offsets))
+                times = [c[0] for c in cands]
+                if len(cands) >= 2 and min(times) <= ARENA_CLASS_GAP * max(times):
+                    stopped = "both classes seen"
+                    break
+        except BaseException:
+            # a failed probe launch or allocation: nothing of the search may stay behind, and `outs` must not point into a freed arena
+            _ffi.call("lars_synchronize", None)
+            outs.arena = None
+            for buf in arenas:
+                buf.free()
+            stats.free()
+            raise
         times = [c[0] for c in cands]
         best = int(np.argmin(times) if pick == "fastest" else np.argmax(times))
         chosen_ms, chosen_alloc, chosen_offsets = cands[best]
@@ -294,7 +308,8 @@ class TileBatch:
             "rejected": len(arenas) - 1, "candidate_ms": [float(x) for x in times], "malloc_ms": [float(x) for x in malloc_ms],
             "placements": [{"allocation": int(a), "offsets_gib": [round(o / gib, 3) for o in offs], "ms": float(t)} for t, a, offs in cands],
             "chosen_offsets_gib": [round(o / gib, 3) for o in chosen_offsets],
-            "arena_bytes": int(arenas[chosen_alloc].nbytes), "transient_bytes": int(sum(b.nbytes for b in arenas)),
+            "arena_bytes": int(arenas[chosen_alloc].nbytes), "packed_bytes": int(packed_bytes), "allocations": len(arenas),
+            "transient_bytes": int(sum(b.nbytes for b in arenas)),
             "probe": f">= {ARENA_WARM_MS:.0f} ms of untimed launches per allocation, then per placement one timed pass of launches over the batch's chunks"}
         return outs
 
@@ -324,7 +339,6 @@ class TileBatch:
         ev = [C.c_void_p(), C.c_void_p()]
         for e in ev:
             _ffi.call("lars_event_create", C.byref(e))
-        _ffi.call("lars_d_stats_begin", C.c_void_p(stats.ptr), self.ntiles, mask, None)
         ms = C.c_float(0)
 
         def one_pass():
@@ -335,15 +349,18 @@ class TileBatch:
             _ffi.call("lars_event_elapsed_ms", ev[0], ev[1], C.byref(ms))     # synchronises on ev[1]
             return float(ms.value)
 
-        warmed, passes = 0.0, 0
-        while warmed < warm_ms and passes < 8:
-            warmed += one_pass()
-            passes += 1
-        timed = one_pass()
-        _ffi.call("lars_d_stats_end", C.c_void_p(stats.ptr), self.ntiles, mask, self.npix, None)
-        _ffi.call("lars_synchronize", None)
-        for e in ev:
-            _ffi.call("lars_event_destroy", e)
+        try:
+            _ffi.call("lars_d_stats_begin", C.c_void_p(stats.ptr), self.ntiles, mask, None)
+            warmed, passes = 0.0, 0
+            while warmed < warm_ms and passes < 8:
+                warmed += one_pass()
+                passes += 1
+            timed = one_pass()
+            _ffi.call("lars_d_stats_end", C.c_void_p(stats.ptr), self.ntiles, mask, self.npix, None)
+            _ffi.call("lars_synchronize", None)
+        finally:
+            for e in ev:                                                      # also when a launch failed: the events do not leak
+                _ffi.call("lars_event_destroy", e)
         return timed / len(launches)
 
     def fused_args(self, indices=INDEX_NAMES, white_balance=True, stats=None, hist=False, outputs=None,

@@ -253,22 +253,16 @@ __device__ inline void fcount2(f32x2 &counter, f32x2 x, f32x2 k, f32x2 b)
     counter += c;
 }
 
-// LARS_ABLATE (build-time, timing experiments only -- `make abl`, tools/ablbench.py; results are wrong): leave out
-// 1 minimum / maximum, 2 the float64 sums, 4 the coverage counters of the statistics-only kernels, 8 the correction step of
-// the quotient (v2_device.h); 64 keeps every value alive through one integer xor instead.
-#ifndef LARS_ABLATE
-#define LARS_ABLATE 0
-#endif
+// (Round 2 timed this kernel with single ingredients compiled out -- minimum / maximum, the float64 sums, the coverage counters, the
+// quotient's correction step: profiles/r02_ablation_stats_kernel.txt.  Those builds gave wrong results by construction; the switch
+// left the sources in round 5.)
 template <int STATS, bool COUNT = true>
 __device__ inline void push(WaveAcc &a, unsigned int &above, float x, float thr)
 {
-    if (!(LARS_ABLATE & 1)) {
-        a.mn = fminf(a.mn, x);
-        a.mx = fmaxf(a.mx, x);
-    }
-    if (LARS_ABLATE & 64) above ^= __builtin_bit_cast(unsigned int, x);
+    a.mn = fminf(a.mn, x);
+    a.mx = fmaxf(a.mx, x);
     const double xd = (double)x;
-    if (!(LARS_ABLATE & 2)) a.sum += xd;
+    a.sum += xd;
     if (STATS >= 3) a.sumsq += xd * xd;
     if (COUNT) {
         if (LARS_COUNT_MODE == 0) count_gt(above, x, thr);           // wave-uniform scalar counter
@@ -477,13 +471,10 @@ __global__ __launch_bounds__(V2Block<OUT>::threads, OUT ? 4 : LARS_V2_STATS_WAVE
             if (NEED_G) {
                 const float x = v1[px];
                 if (STATS >= 1) {
-                    if (!(LARS_ABLATE & 1)) {
-                        acc_g.mn = fminf(acc_g.mn, x);
-                        acc_g.mx = fmaxf(acc_g.mx, x);
-                    }
-                    if (LARS_ABLATE & 64) above_g ^= __builtin_bit_cast(unsigned int, x);
+                    acc_g.mn = fminf(acc_g.mn, x);
+                    acc_g.mx = fmaxf(acc_g.mx, x);
                     const double xd = (double)x;
-                    if (!(LARS_ABLATE & 2)) acc_g.sum += xd;
+                    acc_g.sum += xd;
                     if (STATS >= 3) acc_g.sumsq += xd * xd;
                     if (CM == 1) {
                         if (WANT_GNDVI) vcount_gt(above_g, x, 0.2f);
@@ -495,7 +486,7 @@ __global__ __launch_bounds__(V2Block<OUT>::threads, OUT ? 4 : LARS_V2_STATS_WAVE
                 }
             }
         }
-        if (STATS >= 1 && CM == 0 && !(LARS_ABLATE & 4)) {
+        if (STATS >= 1 && CM == 0) {
             if (WANT_NDVI) count4_gt(above_v, v0, 0.2f);
             if (WANT_GNDVI) count4_gt(above_g, v1, 0.2f);
             if (WANT_NDWI) count4_lt(above_w, v1, 0.0f);                   // -x > 0

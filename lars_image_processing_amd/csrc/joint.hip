@@ -90,29 +90,15 @@ __global__ __launch_bounds__(JH_THREADS, 4) void k_joint_count(JointCountParams 
     const unsigned int seln23 = 0x04u | (0x0cu << 8) | (0x07u << 16) | (0x0cu << 24);           // n2 0 n3 0
     const unsigned int selx23 = (2u + xo) | (0x0cu << 8) | ((5u + xo) << 16) | (0x0cu << 24);
 
-#ifdef LARS_JOINT_NO_ADDS
-    unsigned int lab_sink = 0;
-#endif
     // Two pixels at a time, one in each 16-bit half: nn = n | n' << 16, px = x | x' << 16.  m2 = nn + 5 px holds n + 5 x (< 2048) in
     // each half, W = px << 7 | (m2 & 0x7F007F) the two dword indices D; the half bit h is bit 7 of each m.
     auto count_pair = [&](unsigned int nn, unsigned int px) {
         const unsigned int m2 = jh_mad5(px, nn);                                // v_mad_u32_u24: px < 2^24
         const unsigned int W = (px << 7) | (m2 & 0x007F007Fu);
-        unsigned int a0 = (W << 2) & 0x1FFFCu, a1 = (W >> 14) & 0x1FFFCu;
+        const unsigned int a0 = (W << 2) & 0x1FFFCu, a1 = (W >> 14) & 0x1FFFCu;
         const unsigned int v0 = ((m2 << 9) & 0x10000u) | 1u, v1 = ((m2 >> 7) & 0x10000u) | 1u;
-#ifdef LARS_JOINT_FAKE_BANKS
-        // laboratory build only (wrong counts by construction): every lane adds inside its own bank -- what would the launch cost without
-        // LDS bank conflicts?  The row (bits 7..16) stays data-dependent, the bank (bits 2..6) becomes the lane's.
-        a0 = (a0 & 0x1FF80u) | ((unsigned)(tid & 31) << 2);
-        a1 = (a1 & 0x1FF80u) | ((unsigned)(tid & 31) << 2);
-#endif
-#ifdef LARS_JOINT_NO_ADDS
-        // laboratory build only (wrong counts): the addresses and addends are computed but nothing is added -- what do the LDS atomics cost at all?
-        lab_sink ^= a0 ^ v0 ^ a1 ^ v1;
-#else
         jh_add(a0, v0, tab);
         jh_add(a1, v1, tab);
-#endif
     };
     // Runs of equal pixels would queue the lanes of a wave on a few LDS words per atomic: the lanes that start a run add its whole count
     // (joint_device.h).  For textured content the test is one v_mov_b32_dpp + one compare per quad.
@@ -218,10 +204,6 @@ __global__ __launch_bounds__(JH_THREADS, 4) void k_joint_count(JointCountParams 
     }
     __syncthreads();
 
-#ifdef LARS_JOINT_NO_ADDS
-    if (lab_sink == 0x12345677u) s_tab[tid] = lab_sink;
-    __syncthreads();
-#endif
     // publish: (cell (D, 0), cell (D, 1)) = (low - high, high), 32 bytes per lane and trip
     unsigned int *out = P.part + ((tile * P.S + role) * P.K + chunk) * (long long)(2 * JH_DWORDS);
     for (int i = tid; i < JH_DWORDS / 4; i += JH_THREADS) {

@@ -251,6 +251,26 @@ int lars_event_elapsed_ms(void *start, void *stop, float *ms)
     return LARS_OK;
 }
 
+// Which build-time switches of the kernel sources this library was compiled with: 0 for the product.  A laboratory build
+// (csrc/Makefile: lablayout, EXTRA=-D...) answers with the bits of what it changed, so that no measurement or test can mistake it.
+unsigned int lars_build_flags(void)
+{
+    unsigned int f = 0;
+#ifdef LARS_LAB_LAYOUT
+    f |= LARS_BUILD_LAB_LAYOUT;
+#endif
+#ifdef LARS_IEEE_DIV
+    f |= LARS_BUILD_IEEE_DIV;
+#endif
+#if defined(LARS_COUNT_MODE) && LARS_COUNT_MODE != 0
+    f |= LARS_BUILD_COUNT_MODE;
+#endif
+#if LARS_V2_STATS_THREADS != 1024 || LARS_V2_STATS_WAVES != 8
+    f |= LARS_BUILD_STATS_GEOMETRY;
+#endif
+    return f;
+}
+
 int lars_set_tuning(const char *key, int value)
 {
     if (!key) return fail(LARS_ERR_INVALID, "lars_set_tuning: NULL key");
@@ -261,10 +281,25 @@ int lars_set_tuning(const char *key, int value)
     else if (!strcmp(key, "blocks_per_tile")) t.blocks_per_tile = value;
     else if (!strcmp(key, "selq_window")) t.selq_window = value;
     else if (!strcmp(key, "selq_list_wgs")) t.selq_list_wgs = value;
-    else if (!strcmp(key, "joint_depth")) t.joint_depth = value;
-    else if (!strcmp(key, "joint_window")) t.joint_window = value;
-    else if (!strcmp(key, "joint_win_depth")) t.joint_win_depth = value;
-    else if (!strcmp(key, "out_stride_planes")) t.out_stride_planes = value;
+    else if (!strcmp(key, "joint_depth")) {
+        if (value != 4 && value != 6 && value != 8 && value != 12) return fail(LARS_ERR_INVALID, "lars_set_tuning: joint_depth is 4, 6, 8 or 12 (got %d)", value);
+        t.joint_depth = value;
+    }
+    else if (!strcmp(key, "joint_window")) {
+        if (value < 0 || value > 3) return fail(LARS_ERR_INVALID, "lars_set_tuning: joint_window is 0, 1, 2 or 3 (got %d)", value);
+        t.joint_window = value;
+    }
+    else if (!strcmp(key, "joint_win_depth")) {
+        if (value != 4 && value != 6 && value != 12) return fail(LARS_ERR_INVALID, "lars_set_tuning: joint_win_depth is 4, 6 or 12 (got %d)", value);
+        t.joint_win_depth = value;
+    }
+    else if (!strcmp(key, "out_stride_planes")) {
+#ifdef LARS_LAB_LAYOUT
+        t.out_stride_planes = value;
+#else
+        return fail(LARS_ERR_INVALID, "lars_set_tuning: out_stride_planes exists in the laboratory build only (make lablayout); this library would ignore it");
+#endif
+    }
     else if (!strcmp(key, "u16_hist_impl")) t.u16_hist_impl = value;
     else return fail(LARS_ERR_INVALID, "lars_set_tuning: unknown key %s", key);
     return LARS_OK;

@@ -35,9 +35,6 @@ __device__ inline f32x2 exact_quot2(f32x2 num, f32x2 den)
     r.x = __builtin_amdgcn_rcpf(den.x);
     r.y = __builtin_amdgcn_rcpf(den.y);
     const f32x2 q0 = num * r;
-#if defined(LARS_ABLATE) && (LARS_ABLATE & 8)
-    return q0;
-#endif
     const f32x2 e = __builtin_elementwise_fma(-q0, den, num);
     return __builtin_elementwise_fma(e, r, q0);
 }

@@ -153,6 +153,40 @@ def stats_timeseries_row(index_array, index_type, date):
     }
 
 
+def timeframe_rows(image_data_list, index_type):
+    """process-images.py:619-667 ``calculate_index_statistics_by_timeframe`` up to the DataFrame: the list of row dicts.
+    The cached ``corrected_array`` is used where the dict holds one (:636-637), the white balance is computed otherwise
+    (:639); an image whose index comes back as ``None`` (empty array: :427-428, :452-453) leaves no row (:649)."""
+    rows = []
+    for img_data in image_data_list:
+        date = img_data["metadata"]["upload_date"]                                   # :632
+        if "corrected_array" in img_data and img_data["corrected_array"] is not None:
+            corrected = img_data["corrected_array"]
+        else:
+            arr = img_data["array"]
+            corrected = None if arr is None or arr.size == 0 else wb_app(arr)
+        index_array = None if corrected is None or corrected.size == 0 else index_app(corrected, index_type)   # :644
+        if index_array is not None:
+            rows.append(stats_timeseries_row(index_array, index_type, date))          # :650-660
+    return rows
+
+
+def timeseries_points(image_data_list, index_type):
+    """process-images.py:814-832: the lists ``create_time_series_plot`` draws -- dates, means, maxima, minima."""
+    dates, means, maxs, mins = [], [], [], []
+    for img_data in image_data_list:
+        dates.append(img_data["metadata"]["upload_date"])                            # :815-816
+        if "corrected_array" in img_data and img_data["corrected_array"] is not None:
+            corrected = img_data["corrected_array"]
+        else:
+            corrected = wb_app(img_data["array"])
+        index_array = index_app(corrected, index_type)                               # :825
+        means.append(float(np.mean(index_array)))                                    # :830
+        maxs.append(float(np.max(index_array)))                                      # :831
+        mins.append(float(np.min(index_array)))                                      # :832
+    return dates, means, maxs, mins
+
+
 def stats_ndvi(ndvi_array):
     """process-ndvi.py:50-73 ``analyze_ndvi_statistics(ndvi_array)``."""
     out = {

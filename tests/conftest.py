@@ -42,3 +42,20 @@ def golden_case_names(kind=None):
     if kind:
         names = [n for n in names if n.startswith(kind)]
     return names
+
+
+def golden_series():
+    """The image_data dicts of tools/gen_golden.py's time series (tests/golden/timeframe_inputs.npz + the dates in
+    reference_dicts.json), as the reference received them."""
+    import datetime
+    import json
+    arrays = np.load(os.path.join(GOLDEN_DIR, "timeframe_inputs.npz"))
+    with open(os.path.join(GOLDEN_DIR, "reference_dicts.json")) as fh:
+        dicts = json.load(fh)["dicts"]
+    series = []
+    for i, (date, has_key) in enumerate(zip(dicts["timeframe/dates"], dicts["timeframe/has_corrected_key"])):
+        d = {"metadata": {"upload_date": datetime.datetime.fromisoformat(date)}, "original": None, "array": arrays[f"img{i}/array"]}
+        if has_key:
+            d["corrected_array"] = arrays[f"img{i}/corrected_array"] if f"img{i}/corrected_array" in arrays.files else None
+        series.append(d)
+    return series

@@ -54,6 +54,20 @@ def test_product_exports_are_exactly_the_documented_set():
         assert exported_symbols(lab) == declared, set(exported_symbols(lab)) ^ set(declared)
 
 
+def test_the_loaded_library_is_the_product_build():
+    """Laboratory builds of the kernel sources (plane-layout knob, IEEE division, other counter forms or launch geometries:
+    csrc/Makefile `lablayout`, `EXTRA=-D...`) announce themselves through lars_build_flags(); what the package loads answers 0.
+    The switches that produced wrong results on purpose (round 2's ablations, round 4's no-adds / fake-banks counting kernel) are
+    gone from the sources altogether."""
+    assert _ffi.load().lars_build_flags() == 0
+    src = os.path.join(ROOT, "lars_image_processing_amd", "csrc")
+    for name in os.listdir(src):
+        if name.endswith((".hip", ".h", ".cpp")):
+            text = open(os.path.join(src, name)).read()
+            for gone in ("LARS_ABLATE", "LARS_JOINT_NO_ADDS", "LARS_JOINT_FAKE_BANKS"):
+                assert gone not in text or name == "fused_v2.hip" and "#if" not in "".join(l for l in text.splitlines() if gone in l), (name, gone)
+
+
 def test_struct_layouts_match_header():
     assert C.sizeof(_ffi.Stats) == 472 == _ffi.STATS_DTYPE.itemsize
     for name, _ in _ffi.Stats._fields_:

@@ -185,6 +185,29 @@ def test_timeframe_table_matches_reference_rows(lars, index_type):
     assert maxs == list(df["Max"]) and mins == list(df["Min"]) and means == list(df["Mean"])
 
 
+@pytest.mark.parametrize("index_type", ["NDVI", "GNDVI", "NDWI"])
+def test_timeframe_table_and_points_match_the_reference_itself(lars, golden_dicts, index_type):
+    """The DataFrame the reference's calculate_index_statistics_by_timeframe returned for tools/gen_golden.py's series (cached
+    corrected_array that is not the white balance of its array, the key missing, the key None, RGBA, an empty image: no row) and
+    the lists its create_time_series_plot drew, against api.calculate_index_statistics_by_timeframe / api.time_series_points:
+    columns, dates, median, min, max and coverage exact, the mean within 1e-6 (the reference's float32 pairwise sum)."""
+    from conftest import golden_series
+    series = golden_series()
+    want = golden_dicts["dicts"][f"timeframe/table_{index_type}"]
+    df = lars.calculate_index_statistics_by_timeframe(series, index_type)
+    assert list(df.columns) == want["columns"] and len(df) == len(want["rows"]) == 4
+    for k, ref in enumerate(want["rows"]):
+        row = df.iloc[k]
+        assert row["Date"].isoformat() == ref[0]
+        assert abs(row["Mean"] - ref[1]) <= 1e-6 * max(abs(ref[1]), 0.25)          # mean |x| of these images is 0.4 .. 0.6
+        assert [row[c] for c in want["columns"][2:]] == ref[2:], (k, list(row), ref)
+    pts = golden_dicts["dicts"][f"timeframe/points_{index_type}"]
+    dates, means, maxs, mins = lars.time_series_points(series[:4], index_type)
+    assert [d.isoformat() for d in dates] == pts["dates"] and maxs == pts["max"] and mins == pts["min"]
+    assert all(abs(a - b) <= 1e-6 * max(abs(b), 0.25) for a, b in zip(means, pts["mean"]))
+    assert list(df["Mean"]) == means                                               # one computation behind both entry points
+
+
 def test_no_figure_plumbing_in_the_package(lars):
     """Figure rendering is out of scope: the package hands the reference's own figure
     functions their numbers and imports no matplotlib; the per-pixel colormap of an index stays available."""

@@ -423,3 +423,49 @@ def test_window_report_and_channel_histograms(lars):
     finally:
         stats.free()
         b.free()
+
+
+@pytest.mark.parametrize("channels", [3, 4])
+def test_plane_writing_calls_that_take_the_one_read_statistics(lars, channels):
+    """process(outputs=...) sends two kinds of plane-writing calls through the one-read statistics pass followed by a fused launch
+    WITHOUT statistics (batch.py): planes of one value stream, and any planes with medians.  Records, planes and medians against
+    route="classic" -- packed outputs and a ring, RGB and RGBA; the optional sum of squares within its documented few units of
+    2^-32; and the tables the batch holds afterwards cover only the channels the indices read."""
+    rng = np.random.default_rng(21)
+    tiles = np.clip(rng.normal((90, 120, 150, 255)[:channels], (30, 25, 40, 0)[:channels], (5, 192, 256, channels)), 0, 255).astype(np.uint8)
+    b = lars.TileBatch.from_host(tiles)
+    try:
+        for ring in (None, 2):
+            for indices, kw in ((("NDVI",), dict(hist=True, sumsq=True)), (TYPES, dict(medians=True)), (("GNDVI", "NDWI"), dict(hist=True))):
+                oc = b.make_outputs(indices=indices, index=True, ring=ring, arena="plain")
+                oj = b.make_outputs(indices=indices, index=True, ring=ring, arena="plain")
+                got_c = b.process(indices=indices, outputs=oc, route="classic", **kw)
+                got_j = b.process(indices=indices, outputs=oj, **kw)                       # the default route
+                rec_c, med_c = got_c if kw.get("medians") else (got_c, None)
+                rec_j, med_j = got_j if kw.get("medians") else (got_j, None)
+                same_records(rec_c, rec_j)
+                if med_c is not None:
+                    np.testing.assert_array_equal(med_c, med_j)
+                for t in indices:
+                    pc, pj = oc.host_index(t, 0, oc.slots), oj.host_index(t, 0, oj.slots)
+                    assert pc.view(np.uint32).tobytes() == pj.view(np.uint32).tobytes(), (ring, indices, t)
+                assert b.host_tables().shape == (5, 3, 256)            # the classic pass before left all three channels' rows valid
+                oc.free(); oj.free()
+        # on a batch that has seen nothing else, such a call leaves only the rows of the channels its indices read
+        fresh = lars.TileBatch.from_host(tiles)
+        of = fresh.make_outputs(indices=("NDVI",), index=True, arena="plain")
+        fresh.process(indices=("NDVI",), outputs=of)
+        with pytest.raises(RuntimeError):
+            fresh.host_tables()
+        assert fresh._table_channels == {0, 2} and fresh.host_tables(partial=True).shape == (5, 3, 256)
+        of.free(); fresh.free()
+    finally:
+        b.free()
+
+
+def test_tuning_rejects_values_the_kernels_do_not_have(lars):
+    from lars_image_processing_amd import _ffi
+    for key, bad in (("joint_depth", 5), ("joint_win_depth", 8), ("joint_window", 4), ("out_stride_planes", 3)):
+        with pytest.raises(_ffi.LarsError):
+            _ffi.set_tuning(**{key: bad})
+    assert _ffi.get_tuning("joint_depth") == 6 and _ffi.get_tuning("joint_win_depth") == 12 and _ffi.get_tuning("joint_window") == 1

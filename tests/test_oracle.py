@@ -10,7 +10,7 @@ import warnings
 import numpy as np
 import pytest
 
-from conftest import GOLDEN_DIR, golden_case_names
+from conftest import GOLDEN_DIR, golden_case_names, golden_series
 from oracle import index_oracle as orc
 
 CASES = golden_case_names()
@@ -222,3 +222,23 @@ def test_wb_of_other_sample_types(case):
     assert want.dtype == np.uint8 and want.shape == img.shape
     if img.shape[2] > 3:
         assert (want[:, :, 3:] == 0).all()
+
+
+@pytest.mark.parametrize("t", ["NDVI", "GNDVI", "NDWI"])
+def test_timeframe_table_and_plotted_points(golden_dicts, t):
+    """process-images.py:619-667 and :814-832 on a series of image_data dicts -- no 'corrected_array' key, the key holding None, a
+    cached array that is NOT the white balance of its 'array', an RGBA image, an empty image (no row) -- against the DataFrame the
+    reference itself returned and the lists its create_time_series_plot handed to errorbar (tools/gen_golden.py)."""
+    import warnings
+    series = golden_series()
+    want = golden_dicts["dicts"][f"timeframe/table_{t}"]
+    with warnings.catch_warnings():
+        warnings.simplefilter("ignore")
+        rows = orc.timeframe_rows(series, t)
+        dates, means, maxs, mins = orc.timeseries_points(series[:4], t)
+    assert [list(r.keys()) for r in rows] == [want["columns"]] * len(want["rows"]) and len(rows) == 4      # the empty image leaves no row
+    for got, ref in zip(rows, want["rows"]):
+        assert [got["Date"].isoformat()] + [got[c] for c in want["columns"][1:]] == ref                      # exact: the same NumPy calls
+    pts = golden_dicts["dicts"][f"timeframe/points_{t}"]
+    assert [d.isoformat() for d in dates] == pts["dates"] and means == pts["mean"] and maxs == pts["max"] and mins == pts["min"]
+    assert golden_dicts["dicts"]["contract/timeseries_plot_short"] == "None"

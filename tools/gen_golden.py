@@ -245,10 +245,60 @@ def main():
         resize[f"{name}/same_object"] = np.array(out is img)
     dicts["contract/resize_none"] = repr(app.preprocess_large_image(None))
 
+
+    # ---- time series (process-images.py:619-667 calculate_index_statistics_by_timeframe, :801-883 create_time_series_plot): the
+    # reference's own DataFrame for a series of image_data dicts -- one without the 'corrected_array' key, one with it None, one with
+    # a cached array (deliberately NOT the white balance of its 'array': only the cached branch :636-637 gives these numbers), an RGBA
+    # image and an empty one (fix_white_balance -> None -> calculate_index -> None: the row is skipped, :649) -- and the three lists
+    # create_time_series_plot hands to errorbar (:830-832), read from the function's own frame when it returns.
+    import datetime as dt
+    g = np.random.default_rng(41)
+    def _ts_img(h, w, ch, centre, spread):
+        return np.clip(g.normal(centre, spread, (h, w, ch)), 0, 255).astype(np.uint8)
+    series = [
+        {"metadata": {"upload_date": dt.datetime(2025, 1, 5, 10, 30)}, "original": None, "array": _ts_img(48, 64, 3, (70, 90, 150), (25, 25, 40))},
+        {"metadata": {"upload_date": dt.datetime(2025, 2, 9, 11, 0)}, "original": None, "array": _ts_img(57, 33, 3, (120, 100, 90), (50, 40, 30)),
+         "corrected_array": None},
+        {"metadata": {"upload_date": dt.datetime(2025, 3, 16, 9, 15)}, "original": None, "array": _ts_img(40, 40, 3, (60, 60, 60), (10, 10, 10)),
+         "corrected_array": g.integers(0, 256, (40, 40, 3), dtype=np.uint8)},
+        {"metadata": {"upload_date": dt.datetime(2025, 4, 20, 14, 45)}, "original": None, "array": _ts_img(31, 45, 4, (90, 140, 60, 255), (30, 30, 20, 0))},
+        {"metadata": {"upload_date": dt.datetime(2025, 5, 25, 8, 0)}, "original": None, "array": np.zeros((0, 0, 3), np.uint8)},
+    ]
+    timeframe = {}
+    for i, d in enumerate(series):
+        timeframe[f"img{i}/array"] = d["array"]
+        if d.get("corrected_array") is not None:
+            timeframe[f"img{i}/corrected_array"] = d["corrected_array"]
+    dicts["timeframe/dates"] = [d["metadata"]["upload_date"].isoformat() for d in series]
+    dicts["timeframe/has_corrected_key"] = ["corrected_array" in d for d in series]
+    with warnings.catch_warnings():
+        warnings.simplefilter("ignore")
+        for t in ("NDVI", "GNDVI", "NDWI"):
+            df = app.calculate_index_statistics_by_timeframe(series, t)
+            dicts[f"timeframe/table_{t}"] = {
+                "columns": [str(c) for c in df.columns],
+                "rows": [[v.isoformat() if hasattr(v, "isoformat") else float(v) for v in row] for row in df.itertuples(index=False, name=None)],
+            }
+            caught = {}
+            def _hook(frame, event, arg, caught=caught):
+                if event == "return" and frame.f_code.co_name == "create_time_series_plot":
+                    for key in ("dates", "mean_values", "max_values", "min_values"):
+                        caught[key] = list(frame.f_locals[key])
+            sys.setprofile(_hook)
+            try:
+                picture = app.create_time_series_plot(series[:4], t)        # with the empty image its lists would differ in length (:814 / :829)
+            finally:
+                sys.setprofile(None)
+            assert picture is not None and len(caught["dates"]) == 4
+            dicts[f"timeframe/points_{t}"] = {"dates": [v.isoformat() for v in caught["dates"]], "mean": caught["mean_values"],
+                                              "max": caught["max_values"], "min": caught["min_values"]}
+    dicts["contract/timeseries_plot_short"] = repr(app.create_time_series_plot(series[:1], "NDVI"))     # fewer than two images: None (:803)
+
     meta = {
         "numpy": np.__version__,
         "matplotlib": matplotlib.__version__,
         "pillow": PIL.__version__,
+        "pandas": __import__("pandas").__version__,
         "python": sys.version.split()[0],
         "reference": "lars-uav/lars-image-processing snapshot 2025-03-28 (mounted at /root/reference)",
         "generator": "tools/gen_golden.py",
@@ -257,6 +307,7 @@ def main():
     np.savez_compressed(os.path.join(args.out, "reference_outputs.npz"), **arrays)
     np.savez_compressed(os.path.join(args.out, "resize_outputs.npz"), **resize)
     np.savez_compressed(os.path.join(args.out, "wb_dtypes.npz"), **dtypes)
+    np.savez_compressed(os.path.join(args.out, "timeframe_inputs.npz"), **timeframe)
     with open(os.path.join(args.out, "reference_dicts.json"), "w") as fh:
         json.dump({"meta": meta, "dicts": dicts}, fh, indent=1)   # insertion order kept: key order is contract
     total = sum(a.nbytes for a in arrays.values())

@@ -123,7 +123,7 @@ def main():
         for depth in map(int, args.depths.split(",")):
           for blocks in map(int, args.blocks.split(",")):
             for window in map(int, args.windows.split(",")):
-                _ffi.set_tuning(joint_depth=depth if depth != 12 else 6, joint_win_depth=depth, blocks_per_tile=blocks, joint_window=window)
+                _ffi.set_tuning(joint_depth=depth, joint_win_depth=depth if depth in (4, 6, 12) else 12, blocks_per_tile=blocks, joint_window=window)
                 for mname, indices in MODES.items():
                     if window != 1 and len(indices) == 1:
                         continue                                    # one stream: never windowed

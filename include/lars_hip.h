@@ -295,6 +295,8 @@ int lars_d_threshold_mask_f32(const float *x, int64_t n, float threshold, uint8_
  * mapping of imshow(cmap, vmin=-1, vmax=1) (process-images.py:695). */
 int lars_d_colormap_f32(const float *x, int64_t n, const uint8_t *lut_rgba, uint8_t *out_rgba,
                         void *stream);
+/* ... and only the entry min(int((x + 1f) * 128f), 255) of every sample, one byte each (x 16-byte, out_entry 4-byte aligned). */
+int lars_d_colormap_entry_f32(const float *x, int64_t n, uint8_t *out_entry, void *stream);
 
 /* ---- registration and change detection ---- */
 /* skimage.color.rgb2gray of a uint8 [npix][3] image (process-images.py:538-546) into the real parts of a
@@ -396,7 +398,9 @@ int lars_h_analyze_f64(const double *x, int64_t n, double threshold, int want_hi
 
 /* Whole reference pipeline for one host image in one upload:
  * white balance -> requested indices -> statistics (+ medians) -> optional
- * RGBA8 colormaps.  Any output pointer may be NULL. */
+ * RGBA8 colormaps.  Any output pointer may be NULL.  out_rgba[k] with cmap_lut[k] == NULL (or cmap_lut == NULL) receives the
+ * colormap ENTRY of every pixel instead -- [h][w] uint8, min(int((x + 1f) * 128f), 255): the pixels of a palette image whose
+ * palette is the colormap (backend-process.py:40-47, process-images.py:690-695 per pixel) -- one byte per pixel over PCIe. */
 int lars_h_process_image(const void *img, int64_t h, int64_t w, int channels, int dtype,
                          int apply_wb, uint32_t index_mask, int want_hist,
                          uint8_t *out_wb, float *const out_index[3],

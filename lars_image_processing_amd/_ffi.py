@@ -105,6 +105,7 @@ SIGNATURES = {
     "lars_d_median_pair_f64": (_I, [_P, _I64, _P, _P, _P]),
     "lars_d_median_pair_batch_f32": (_I, [_P, _I64, _I64, _I64, _P, _P, _P]),
     "lars_d_colormap_f32": (_I, [_P, _I64, _P, _P, _P]),
+    "lars_d_colormap_entry_f32": (_I, [_P, _I64, _P, _P]),
     "lars_quotient_median_scratch_bytes": (_SZ, [_I64]),
     "lars_d_stats_medians": (_I, [C.POINTER(FusedArgs), _P, _P]),
     "lars_d_quotient_median_pairs": (_I, [_P, _I64, _I64, _I, _I, _P, _U32, _P, _P, _P]),

@@ -369,14 +369,19 @@ def colorize_index(index_array, index_type):
 
 
 def process_image(img_array, indices=INDEX_NAMES, white_balance=True, want_arrays=True, want_hist=False,
-                  want_rgba=False):
+                  want_rgba=False, want_entries=False):
     """White balance -> indices -> statistics of one image in ONE upload.
 
     What the Streamlit comparison path does with three separate calls per index
     (process-images.py:1457, :1522, :1525).  Returns a dict with
     ``corrected`` (uint8), and per index ``index`` (float32), ``stats`` (the
-    ``analyze_index`` dict), ``hist`` (50 bins) and ``rgba``.
+    ``analyze_index`` dict), ``hist`` (50 bins) and ``rgba``.  ``want_entries=True`` (instead of
+    ``want_rgba``) returns ``entry``: the colormap entry of every pixel, uint8 ``[h, w]``, computed on the
+    device -- ``colormap_lut(name)[entry]`` is the RGBA image, and a palette PNG needs nothing else
+    (one byte per pixel crosses PCIe; backend-process.py:40-47 per pixel).
     """
+    if want_rgba and want_entries:
+        raise ValueError("process_image: want_rgba or want_entries, not both (they share the output slot of the C ABI)")
     arr = _as_image(img_array, "process_image")
     code = _ffi.dtype_code(arr.dtype)
     if code is None:
@@ -397,6 +402,8 @@ def process_image(img_array, indices=INDEX_NAMES, white_balance=True, want_array
         if want_rgba:
             rgbas[k] = _empty((h, w, 4), dtype=np.uint8)
             luts[k] = colormap_lut(_colormap_for(t))
+        elif want_entries:
+            rgbas[k] = _empty((h, w), dtype=np.uint8)          # no table: the entry plane comes back in the RGBA slot
     stats = (Stats * 3)()
     med = np.zeros((3, 2), dtype=np.float32)
     p_out, p_rgba, p_lut = _ffi.ptr3(outs), _ffi.ptr3(rgbas), _ffi.ptr3(luts)
@@ -410,7 +417,8 @@ def process_image(img_array, indices=INDEX_NAMES, white_balance=True, want_array
         median = float(np.float32(np.float32(med[k, 0] + med[k, 1]) / 2))
         result["indices"][t] = {
             "index": outs[k],
-            "rgba": rgbas[k],
+            "rgba": rgbas[k] if want_rgba else None,
+            "entry": rgbas[k] if want_entries else None,
             "hist": np.array(list(st.hist), dtype=np.int64) if want_hist else None,
             "stats": {
                 f"Mean {t}": st.sum / st.count,

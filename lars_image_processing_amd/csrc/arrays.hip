@@ -336,6 +336,19 @@ __global__ __launch_bounds__(256) void k_colormap(const float *__restrict__ x, l
     }
 }
 
+// The colormap ENTRY of every sample -- min(int((x + 1f) * 128f), 255), what Normalize(-1, 1) + Colormap.__call__ look up
+// (process-images.py:690-695, backend-process.py:40-47) -- one byte per pixel: a palette image's pixels.
+// Four samples per lane: one 16-byte load, one 4-byte store.  x must be 16-byte aligned, out 4-byte aligned.
+__global__ __launch_bounds__(256) void k_colormap_entry(const float *__restrict__ x, long long n, uint8_t *__restrict__ out)
+{
+    const long long nvec = n >> 2;
+    for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < nvec; i += (long long)gridDim.x * 256) {
+        const float4 v = reinterpret_cast<const float4 *>(x)[i];
+        reinterpret_cast<unsigned int *>(out)[i] = cmap_index(v.x) | (cmap_index(v.y) << 8) | (cmap_index(v.z) << 16) | (cmap_index(v.w) << 24);
+    }
+    if (blockIdx.x == 0 && threadIdx.x < (n & 3)) out[nvec * 4 + threadIdx.x] = (uint8_t)cmap_index(x[nvec * 4 + threadIdx.x]);
+}
+
 }  // namespace lars
 
 using namespace lars;
@@ -516,4 +529,16 @@ extern "C" int lars_d_colormap_f32(const float *x, int64_t n, const uint8_t *lut
     hipLaunchKernelGGL(k_colormap, dim3(grid_for(n)), dim3(256), 0, s, x, (long long)n,
                        reinterpret_cast<const unsigned int *>(lut_rgba), reinterpret_cast<unsigned int *>(out_rgba));
     return launch_check("lars_d_colormap_f32");
+}
+
+extern "C" int lars_d_colormap_entry_f32(const float *x, int64_t n, uint8_t *out_entry, void *stream)
+{
+    ThreadCtx *c;
+    LARS_TRY(ensure_ctx(&c));
+    if (!x || !out_entry || n <= 0) return fail(LARS_ERR_INVALID, "lars_d_colormap_entry_f32: bad arguments");
+    if ((reinterpret_cast<uintptr_t>(x) & 15) || (reinterpret_cast<uintptr_t>(out_entry) & 3))
+        return fail(LARS_ERR_INVALID, "lars_d_colormap_entry_f32: x on a 16-byte, out_entry on a 4-byte boundary");
+    hipStream_t s = pick_stream(c, stream);
+    hipLaunchKernelGGL(k_colormap_entry, dim3(grid_for((n + 3) / 4)), dim3(256), 0, s, x, (long long)n, out_entry);
+    return launch_check("lars_d_colormap_entry_f32");
 }

@@ -44,6 +44,7 @@ struct ImageJob {
 struct Layout {
     uint8_t *img; uint32_t *hist; uint8_t *table; double *pcts; uint8_t *wb;
     float *idx[3]; lars_stats *stats; float *med; char *sel; uint8_t *rgba[3]; uint8_t *cmap[3];
+    uint8_t *entry[3];             // colormap entry planes (out_rgba[k] without a cmap_lut[k]): one byte per pixel
     float *pairs; char *selq;      // statistics + medians without planes (lars_d_stats_medians)
     size_t total;
 };
@@ -82,9 +83,11 @@ Layout plan(const ImageJob &j, void *base)
     const bool select = select_route(j);
     for (int k = 0; k < 3; ++k) {
         const bool on = (j.mask >> k) & 1u;
-        L.idx[k] = (on && (j.out_index[k] || (j.want_median && !select))) ? c.take<float>(npix) : nullptr;
-        L.rgba[k] = (on && j.out_rgba[k]) ? c.take<uint8_t>(npix * 4) : nullptr;
-        L.cmap[k] = (on && j.out_rgba[k]) ? c.take<uint8_t>(1024) : nullptr;
+        const bool entries = on && j.out_rgba[k] && !j.cmap[k];             // the entry plane is derived from the float32 plane on the device
+        L.idx[k] = (on && (j.out_index[k] || entries || (j.want_median && !select))) ? c.take<float>(npix) : nullptr;
+        L.rgba[k] = (on && j.out_rgba[k] && j.cmap[k]) ? c.take<uint8_t>(npix * 4) : nullptr;
+        L.cmap[k] = (on && j.out_rgba[k] && j.cmap[k]) ? c.take<uint8_t>(1024) : nullptr;
+        L.entry[k] = entries ? c.take<uint8_t>(npix + 4) : nullptr;
     }
     L.stats = c.take<lars_stats>(3);
     L.med = c.take<float>(6);
@@ -158,6 +161,10 @@ int run_image(const ImageJob &j)
         if (!((j.mask >> k) & 1u)) continue;
         if (j.out_index[k]) LARS_HIP_TRY(hipMemcpyAsync(j.out_index[k], L.idx[k], npix * 4, hipMemcpyDeviceToHost, s));
         if (L.rgba[k]) LARS_HIP_TRY(hipMemcpyAsync(j.out_rgba[k], L.rgba[k], npix * 4, hipMemcpyDeviceToHost, s));
+        if (L.entry[k]) {                                   // one byte per pixel crosses PCIe instead of four (or a float32 plane)
+            LARS_TRY(lars_d_colormap_entry_f32(L.idx[k], (int64_t)npix, L.entry[k], s));
+            LARS_HIP_TRY(hipMemcpyAsync(j.out_rgba[k], L.entry[k], npix, hipMemcpyDeviceToHost, s));
+        }
     }
     lars_stats hstats[3];
     float hmed[6];
@@ -259,7 +266,6 @@ int lars_h_process_image(const void *img, int64_t h, int64_t w, int channels, in
         j.out_index[k] = out_index ? out_index[k] : nullptr;
         j.out_rgba[k] = out_rgba ? out_rgba[k] : nullptr;
         j.cmap[k] = cmap_lut ? cmap_lut[k] : nullptr;
-        if (j.out_rgba[k] && !j.cmap[k]) return fail(LARS_ERR_INVALID, "lars_h_process_image: out_rgba needs cmap_lut");
     }
     j.stats = stats; j.want_stats = stats != nullptr; j.want_hist = want_hist;
     j.medians = medians; j.want_median = medians != nullptr;

@@ -27,15 +27,6 @@ EXTENSIONS = {".tif", ".tiff", ".png", ".jpg", ".jpeg"}      # backend-process.p
 LUT_PNG_LEVEL = 1
 
 
-def colormap_entry(index_array):
-    """The colormap entry (0..255) of every pixel of a float32 index plane: ``Normalize(-1, 1)`` + ``Colormap.__call__`` of
-    matplotlib in the closed form the kernels use (``min(int((x + 1f) * 128f), 255)``, float32 arithmetic) --
-    ``colormap_lut(name)[colormap_entry(x)]`` is the RGBA image ``want_rgba`` returns."""
-    x = np.asarray(index_array, dtype=np.float32)
-    e = ((x + np.float32(1)) * np.float32(128)).astype(np.int32)
-    return np.clip(e, 0, 255).astype(np.uint8)
-
-
 def process_image(image_path, output_dir, process_wb=False, indices=None, full_depth=False, lut_format="png"):
     """One file: same outputs as backend-process.py:49-73.  Returns the statistics dicts.
     ``full_depth=True`` reads three-sample 16-bit TIFFs at their full depth (``tiffio.read_image``; Pillow, hence the
@@ -55,7 +46,9 @@ def process_image(image_path, output_dir, process_wb=False, indices=None, full_d
         raise ValueError(f"{image_path.name}: expected an image with at least 3 channels, got shape {arr.shape}")
     indices = list(indices or [])
     palette = lut_format == "png8"
-    res = api.process_image(arr, indices=indices, white_balance=True, want_arrays=palette, want_rgba=not palette) if indices else None
+    # palette files: the colormap entry of every pixel comes from the device, one byte per pixel (lars_h_process_image)
+    res = api.process_image(arr, indices=indices, white_balance=True, want_arrays=False, want_rgba=not palette,
+                            want_entries=palette) if indices else None
     corrected = res["corrected"] if res else api.fix_white_balance(arr)
     if process_wb:
         (output_dir / "white_balanced").mkdir(parents=True, exist_ok=True)
@@ -70,7 +63,7 @@ def process_image(image_path, output_dir, process_wb=False, indices=None, full_d
             from .tiffio import write_tiff
             write_tiff(out.with_suffix(".tif"), entry["rgba"])
         elif palette:
-            im = Image.fromarray(colormap_entry(entry["index"]), "P")
+            im = Image.fromarray(entry["entry"], "P")
             im.putpalette(api.colormap_lut(api._colormap_for(t)).tobytes(), rawmode="RGBA")
             im.save(out, compress_level=LUT_PNG_LEVEL)
         else:

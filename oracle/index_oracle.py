@@ -349,6 +349,14 @@ def colormap_closed_form(index_array, lut_rgba8):
     return np.asarray(lut_rgba8, dtype=np.uint8)[idx]
 
 
+def colormap_entry_closed_form(index_array):
+    """The colormap entry of every sample: ``min(int((x + 1f) * 128f), 255)`` in float32 -- ``lut[entry]`` is
+    ``colormap_closed_form`` (matplotlib's Normalize(-1, 1) + Colormap.__call__; process-images.py:690-695)."""
+    x = np.asarray(index_array, dtype=np.float32)
+    scaled = (x + np.float32(1)) * np.float32(128)
+    return np.clip(scaled.astype(np.int32), 0, 255).astype(np.uint8)
+
+
 def hist50_edges(dtype=np.float32):
     """The 51 bin edges numpy.histogram builds for bins=50, range=(-1, 1).
 

@@ -30,7 +30,8 @@ def test_an_empty_directory_is_an_empty_result(tmp_path):
 
 
 def test_palette_png_decodes_to_the_rgba_pixels():
-    """lut_format="png8": entry plane + colormap palette == the per-pixel RGBA image (oracle's closed form of matplotlib)."""
+    """lut_format="png8": entry plane + colormap palette == the per-pixel RGBA image (oracle's closed form of matplotlib).  The
+    entry plane itself comes from the device in the product (lars_h_process_image; tests/test_gpu_driver.py) -- here the oracle's."""
     import io
     import numpy as np
     from PIL import Image
@@ -41,7 +42,7 @@ def test_palette_png_decodes_to_the_rgba_pixels():
     x[0, :4] = [1.0, -1.0, 0.0, np.float32(0.9999999)]
     for name in ("RdYlGn", "RdYlBu"):
         lut = api.colormap_lut(name)
-        im = Image.fromarray(driver.colormap_entry(x), "P")
+        im = Image.fromarray(orc.colormap_entry_closed_form(x), "P")
         im.putpalette(lut.tobytes(), rawmode="RGBA")
         buf = io.BytesIO()
         im.save(buf, format="PNG", compress_level=1)

@@ -45,6 +45,12 @@ def check_line(line, tiles=6, tile=512):
     else:
         assert roof["traffic_source"].startswith("profiles/traffic.json@") and roof["traffic"] > 0
     assert line["config"]["ranks_seen"] == line["n_gpus"]
+    # what the line is and what ran it: the library's own RCCL communicator or not, which BASELINE configuration, a product build
+    cfg = line["config"]
+    assert cfg["rccl_used"] is cfg["collective"].startswith("RCCL ncclAllGather") and cfg["build_flags"] == 0
+    assert cfg["baseline_config"].startswith("configs[1] per GPU") and "configs[3] = --gpus 8 --tiles 2048" in cfg["baseline_config"]
+    for key in ("arena_allocations", "arena_transient_bytes", "arena_bytes"):
+        assert key in cfg, key
     for name in ("NDVI", "GNDVI", "NDWI"):
         assert line["global_stats"][name]["count"] == tiles * tile * tile
     # the self-check after the timed region: records (and ring planes) of sampled tiles against single-tile runs
@@ -92,6 +98,12 @@ def test_bench_all_modes_and_their_self_check():
                  "wb3idx_out_stats_medians", "wb3idx_stats_only_classic", "wb_ndvi_stats_only_classic", "wb3idx_stats_medians_classic"):
         assert name in modes and modes[name]["Mpix_s"] > 0 and 0 < modes[name]["whole_step_frac"] < 1, name
     assert "one read" in modes["wb_ndvi_stats_only"]["route"] and "histogram pass" in modes["wb_ndvi_stats_only_classic"]["route"]
+    for name in ("wb3idx_stats_only", "wb3idx_stats_medians"):
+        # the bench's own (vegetation) tiles go on windowed tables, none is counted again -- from 2^20 pixels per tile on (the
+        # default 4096 x 4096: every tile; this test's 512 x 512: none)
+        big = line["config"]["tile"][0] * line["config"]["tile"][1] >= 1 << 20
+        assert modes[name]["tiles_on_windowed_tables"] == (line["config"]["tiles_per_gpu"] if big else 0) and modes[name]["tiles_recounted"] == 0
+    assert modes["wb_ndvi_stats_only"]["tiles_on_windowed_tables"] == 0
     for name in ("wb3idx_stats_medians", "wb3idx_out_stats_medians"):
         assert line["verified"][name] == {"records": True, "planes": (True if name == "wb3idx_out_stats_medians" else None), "medians": True, "ok": True}
     assert len(line["verified"]["modes_compared"]) == 10
@@ -114,6 +126,7 @@ def test_bench_statistics_fold_transports_agree(transport):
     line = run_bench({"LARS_FORCE_RCCL": "1", **({} if transport == "auto" else {"LARS_COMM": transport})}, "--no-cpu-baseline")
     check_line(line)
     assert ("torch.distributed" in line["config"]["collective"]) == (transport == "torch")
+    assert line["config"]["rccl_used"] is (transport != "torch") and base["config"]["rccl_used"] is False
     assert line["global_stats"] == base["global_stats"]
 
 
@@ -143,6 +156,7 @@ def test_ranks_on_one_gpu_equal_one_process_over_all_tiles(tmp_path, ranks, all_
     assert out1.returncode == 0, out1.stderr[-2000:]
     one = json.loads([ln for ln in out1.stdout.splitlines() if ln.startswith("{")][0])
     assert two["n_gpus"] == ranks and two["scaling"] == "weak" and "gloo" in two["config"]["collective"]
+    assert two["config"]["rccl_used"] is False and two["config"]["baseline_config"].startswith("configs[1] per GPU")   # a rehearsal says so
     assert [r["rank"] for r in two["ranks"]] == list(range(ranks)) and two["verified"]["ok_on_every_rank"] is True
     assert abs(max(r["ms_per_step"] for r in two["ranks"]) - two["ms_per_step"]) <= 1e-6 * two["ms_per_step"]
     assert two["config"]["tiles_per_gpu"] == per_rank and one["config"]["tiles_per_gpu"] == 12

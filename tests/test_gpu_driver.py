@@ -65,6 +65,38 @@ def test_batch_process_directory(tmp_path):
     assert not (tmp_path / "ser" / "white_balanced").exists() and "Water Coverage (%)" in res2["a.png"]["NDWI"]
 
 
+def test_colormap_entries_come_from_the_device():
+    """process_image(want_entries=True): the uint8 colormap entry of every pixel (one byte per pixel over PCIe) -- the palette
+    of lut_format="png8" applied to it is the RGBA image of want_rgba=True; lars_d_colormap_entry_f32 on arbitrary float32 data,
+    ragged lengths included, equals the closed form of matplotlib's Normalize(-1, 1) + Colormap.__call__."""
+    import ctypes as C
+    import lars_image_processing_amd as lars
+    from lars_image_processing_amd import _ffi
+    for shape in ((257, 263, 3), (64, 65, 4), (1, 1, 3)):
+        img = np.random.default_rng(shape[0]).integers(0, 256, shape, dtype=np.uint8)
+        ent = lars.process_image(img, want_arrays=False, want_entries=True)
+        full = lars.process_image(img, want_arrays=True, want_rgba=True)
+        for t in ("NDVI", "GNDVI", "NDWI"):
+            e, f = ent["indices"][t], full["indices"][t]
+            assert e["entry"].dtype == np.uint8 and e["entry"].shape == shape[:2] and e["rgba"] is None and e["index"] is None
+            np.testing.assert_array_equal(e["entry"], orc.colormap_entry_closed_form(f["index"]))
+            np.testing.assert_array_equal(lars.colormap_lut(lars.api._colormap_for(t))[e["entry"]], f["rgba"])
+            assert e["stats"] == f["stats"]
+        np.testing.assert_array_equal(ent["corrected"], full["corrected"])
+    with pytest.raises(ValueError):
+        lars.process_image(img, want_rgba=True, want_entries=True)
+    rng = np.random.default_rng(3)
+    for n in (1, 3, 4, 1001, 65536 + 2):
+        x = np.concatenate([rng.uniform(-1, 1, n).astype(np.float32)[: max(0, n - 6)],
+                            np.array([-1.0, 1.0, 0.0, -0.0, np.nextafter(np.float32(1), np.float32(0)), 0.9921875], np.float32)])[:n]
+        dx, de = _ffi.DeviceBuffer(x.nbytes + 16), _ffi.DeviceBuffer(n + 8)
+        dx.upload(x)
+        _ffi.call("lars_d_colormap_entry_f32", C.c_void_p(dx.ptr), n, C.c_void_p(de.ptr), None)
+        _ffi.call("lars_synchronize", None)
+        np.testing.assert_array_equal(de.download(np.uint8, (n,)), orc.colormap_entry_closed_form(x))
+        dx.free(); de.free()
+
+
 def test_sixteen_bit_tiff_at_reference_depth_and_at_full_depth(tmp_path):
     """A three-sample 16-bit TIFF: by default it is read as the reference reads it (Pillow keeps the high bytes);
     full_depth=True processes the uint16 samples (BASELINE configs[4])."""

@@ -406,7 +406,8 @@ def device_probe(runner):
     return out
 
 
-KERNEL_SOURCES = ("fused.hip", "fused_device.h", "fused_v2.hip", "joint.hip", "select_q.hip", "device_common.h", "v2_device.h", "common.h")
+KERNEL_SOURCES = ("fused.hip", "fused_device.h", "fused_v2.hip", "joint.hip", "joint_win.hip", "joint_device.h", "select_q.hip", "device_common.h",
+                  "v2_device.h", "common.h")
 
 
 def kernel_sources_sha():

@@ -70,17 +70,23 @@ def test_chunked_ring_launches_at_bench_size():
 
 
 def test_placement_search_of_a_multi_gib_arena():
-    """make_outputs(arena="auto") for an arena of 2 GiB and more with several planes: ONE allocation with room to spare, the planes
-    tried in several placements inside it (profiles/r04_arena_two_kinds.txt), the fastest kept -- and the planes it writes there
-    are the planes a packed arena gets, bit for bit."""
+    """make_outputs(arena="auto") for several planes of 2 GiB and more each: ONE allocation with room to spare, the planes tried in
+    several placements inside it (profiles/r04_arena_two_kinds.txt), the fastest kept -- and the planes it writes there are the
+    planes a packed arena gets, bit for bit.  Smaller planes (they run alike wherever they lie) and callers that ask for one trial
+    at most get one packed allocation: no spare room is held for them."""
     import lars_image_processing_amd as lars
     from lars_image_processing_amd import _ffi
-    ntiles, ring, edge = 24, 12, 4096                                  # three planes of 12 slots: 2.25 GiB packed
+    ntiles, ring, edge = 32, 32, 4096                                  # three planes of 32 slots: 2 GiB each, 6 GiB packed
     b = lars.TileBatch.synthetic(ntiles, edge, edge, seed=77, profile="vegetation")
     plain = b.make_outputs(index=True, ring=ring, arena="plain")
     assert plain.arena_report["kind"] == "plain hipMalloc" and plain.arena.nbytes == 3 * plain.plane_bytes
+    for kw in (dict(ring=12), dict(ring=ring, placement_trials=1), dict(ring=ring, placement_trials=0)):
+        small = b.make_outputs(index=True, **kw)                         # 0.75 GiB planes; one trial at most: packed, nothing held back
+        assert small.arena_report["kind"] == "plain hipMalloc" and small.arena.nbytes == 3 * small.plane_bytes, kw
+        small.free()
     auto = b.make_outputs(index=True, ring=ring)
     rep = auto.arena_report
+    assert rep["allocations"] == len(rep["malloc_ms"]) and rep["packed_bytes"] == 3 * auto.plane_bytes
     assert rep["rejected"] == len(rep["malloc_ms"]) - 1 and len(rep["candidate_ms"]) == len(rep["placements"]) >= 2
     assert rep["arena_bytes"] == auto.arena.nbytes > 3 * auto.plane_bytes
     assert rep["chosen_ms"] == min(rep["candidate_ms"]) and rep["post_free_ms"] > 0

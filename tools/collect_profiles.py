@@ -90,11 +90,13 @@ def main():
         "wb3idx_out_stats_hist": ("k_fused_u8c3<unsigned char, 7u, true, 2, 3>", px64),
         "wb_ndvi_out_stats": ("k_fused_u8c3<unsigned char, 1u, true, 1, 3>", px64),
         "wb3idx_out_stats_medians": ("k_fused_u8c3<unsigned char, 7u, true, 0, 3>", px64),      # planes only; its statistics pass is k_joint_count
-        # the one-read statistics route: one counting launch per step over the whole batch, whatever the indices (the second
-        # stream's reads are served by the XCD's L2); the per-tile finish kernel reads the counts back
-        "wb3idx_stats_only": ("k_joint_count<6, 3>", px256),
+        # the one-read statistics route: one counting launch per step over the whole batch.  Two value streams on the bench's tiles:
+        # windowed tables, one reader per tile chunk (k_joint_count_win); one stream: the full table (k_joint_count).  The launches of
+        # lars_d_stats_joint whose workgroups find nothing to do are left out of the means (tools/pmc_summary.py)
+        "wb3idx_stats_only": ("k_joint_count_win<12, 3>", px256),
         "wb_ndvi_stats_only": ("k_joint_count<6, 3>", px256),
-        "wb3idx_stats_medians": ("k_joint_count<6, 3>", px256),
+        "wb3idx_stats_medians": ("k_joint_count_win<12, 3>", px256),
+        "joint_predict": ("k_joint_predict<3>", px256),
         "joint_finish": ("k_joint_finish", px256),
         "wb3idx_stats_only_classic": ("k_fused_v2<7u, true, 1, false, false, 0,", px256),
         "wb_ndvi_stats_only_classic": ("k_fused_v2<1u, true, 1, false, false, 0,", px256),

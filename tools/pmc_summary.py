@@ -2,6 +2,11 @@
 """Summarise rocprofv3 --pmc CSV output: mean counter value per kernel name.
 
     python tools/pmc_summary.py gpurun_out/pmc_dir [substring filter]
+
+lars_d_stats_joint launches its counting and finish kernels a second time for the tiles whose window missed (and the full-table
+counting kernel once for the tiles without a window): launches whose workgroups find nothing to do and leave at once.  A dispatch
+is counted as such -- and left out of its kernel's mean -- when its value is below 1 % of the largest dispatch of the same kernel,
+grid and counter; their number is printed.
 """
 import csv, glob, os, sys
 from collections import defaultdict
@@ -23,7 +28,10 @@ def main():
         print(f"{key[0]} grid={key[1]} lds={key[2]} vgpr={key[3]}")
         for c in sorted(acc[key]):
             v = acc[key][c]
-            print(f"    {c:28s} mean={sum(v)/len(v):16.1f} n={len(v)}")
+            top = max(v)
+            work = [x for x in v if x >= 0.01 * top] if top > 0 and "k_joint" in key[0] else v
+            idle = len(v) - len(work)
+            print(f"    {c:28s} mean={sum(work)/len(work):16.1f} n={len(work)}" + (f"  (+{idle} launches that found nothing to do)" if idle else ""))
 
 if __name__ == "__main__":
     main()

@@ -328,7 +328,7 @@ int lars_d_synth_u8(uint8_t *tiles, int64_t ntiles, int64_t first_tile, int64_t 
 /* Tuning knobs (per process): "fused_impl" 0 (auto)|1|2, "hist_impl" 1|2, "nt_stores" 0|1, "blocks_per_tile" 0 = automatic
  * (also the chunks per tile of lars_d_stats_joint), "joint_depth" 4|6 loads in flight per lane of the counting kernel,
  * "joint_window" 1 (windowed pair tables where they fit: lars_d_stats_joint)|0 (never)|2 (windows that miss on purpose: exercises the
- * recount; tiles of any size)|3 (as 1 for tiles of any size), "joint_win_depth" 4|6|12 loads in flight per lane of the windowed counting kernel,
+ * recount; tiles of any size)|3 (as 1 for tiles of any size), "joint_win_depth" 4|5|6|12|15 loads in flight per lane of the windowed counting kernel,
  * "u16_hist_impl" 2 (uint16 percentiles usually from one full pass: candidate bins predicted from a subsample)|1 (always the two
  * radix passes)|3 (wrong candidates on purpose: exercises the recount),
  * "selq_window" 1 (one-pass medians)|0 (always two select passes)|2 (wrong windows: exercises the fallback), "selq_list_wgs"

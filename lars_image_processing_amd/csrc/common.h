@@ -106,7 +106,7 @@ struct Tuning {
                                // 3 test hook (wrong candidates), 4 one full pass with round 3's slot look-ups instead of the window tests
     int out_stride_planes = 0; // laboratory build (LARS_LAB_LAYOUT) only: k > 1 = the fused kernel steps k x npix from tile to tile in its index planes
     int joint_depth = 6;       // joint.hip: 12-byte loads in flight per lane of the counting kernel (4 | 6 | 8 | 12)
-    int joint_win_depth = 12;  // joint_win.hip: loads in flight per lane of the windowed counting kernel (4 | 6 | 12; profiles/r05_joint_window_depths.txt)
+    int joint_win_depth = 15;  // joint_win.hip: loads in flight per lane of the windowed counting kernel: 5 | 15 (a sweep every 15 steps), 4 | 6 | 12 (every 12)
     int joint_window = 1;      // joint_win.hip: 1 windowed pair tables (one reader per tile chunk) where they fit, 0 never, 2 test hook (windows that miss)
 };
 Tuning &tuning();

@@ -87,7 +87,12 @@ __device__ inline unsigned int jh_n_of(unsigned int D, unsigned int h)
 #define JW_PITCH 133u                          /* dwords per table row: 128 + 5, so that the LDS bank is (n + 5 x') mod 32 as in the full tables */
 #define JW_MAX_ROWS 306                        /* nr + ng: 306 x 133 dwords = 162792 bytes of the CU's 163840 */
 #define JW_TAB_DWORDS 40700                    /* JW_MAX_ROWS x JW_PITCH, rounded up to whole uint4 */
-#define JW_LIST_CAP 2048                       /* moved dwords of a workgroup: two tables x 2^24 pixels / 16384 */
+// The windowed kernel sweeps its 16-bit counters every 15 steps of 4096 pixels and moves a dword onto the list from 4096 on: 4095 + 15 x 4096
+// = 65535.  (The full-table kernel: every 12 steps, from 16384 on.)  A fifth fewer sweeps -- each reads the tables in use from the LDS, which
+// is this kernel's busiest unit (profiles/r05_joint_window_scan_period.txt) -- for a longer list: two tables x 2^24 pixels / 4096.
+#define JW_PERIOD_STEPS 15
+#define JW_PROMOTE_MASK 0x0000F000u            /* a low half >= 4096 */
+#define JW_LIST_CAP 8192                       /* moved dwords of a workgroup, in global memory */
 #define JW_MIN_PIXELS (1ll << 20)              /* smaller tiles are not worth a window (zeroing + publishing the tables) */
 
 struct JointWin {                              // per tile, in the scratch of lars_d_stats_joint

@@ -192,8 +192,9 @@ __device__ inline unsigned int jw_addr(unsigned int d, unsigned int two)
 template <int DEPTH, int CH = 3>
 __global__ __launch_bounds__(JH_THREADS, 4) void k_joint_count_win(JointCountParams P)
 {
-    constexpr int PERIOD = (JH_PERIOD_STEPS % DEPTH == 0) ? JH_PERIOD_STEPS : DEPTH;
-    static_assert(PERIOD % DEPTH == 0 && PERIOD <= JH_PERIOD_STEPS, "a period is a whole number of ring turns, at most 12 steps");
+    // a period is a whole number of ring turns and adds at most 65535 - 4095 = 61440 pixels (15 steps) to any one dword
+    constexpr int PERIOD = (JW_PERIOD_STEPS % DEPTH == 0) ? JW_PERIOD_STEPS : ((12 % DEPTH == 0) ? 12 : DEPTH);
+    static_assert(PERIOD % DEPTH == 0 && PERIOD <= JW_PERIOD_STEPS, "a period is a whole number of ring turns, at most 15 steps");
     __shared__ __attribute__((aligned(16))) unsigned int s_tab[JW_TAB_DWORDS];      // 159 KiB
     __shared__ unsigned int s_nlist;
 
@@ -283,7 +284,7 @@ __global__ __launch_bounds__(JH_THREADS, 4) void k_joint_count_win(JointCountPar
         jh_add(((nr + g) * JW_PITCH + (n & 127u)) << 2, v, tab);
     }
 
-    // A scan: every dword whose sum (low half) has reached 16384 moves onto the workgroup's list (in global memory: the LDS is the
+    // A scan: every dword whose sum (low half) has reached 4096 moves onto the workgroup's list (in global memory: the LDS is the
     // tables').  Between the two barriers nobody adds.
     uint2 *list = P.list + unit * JW_LIST_CAP;
     auto scan = [&]() {
@@ -291,11 +292,11 @@ __global__ __launch_bounds__(JH_THREADS, 4) void k_joint_count_win(JointCountPar
 #pragma unroll 1
         for (int idx = tid; idx < ntab4; idx += JH_THREADS) {
             const uint4 v = tab4[idx];
-            if ((v.x | v.y | v.z | v.w) & JH_PROMOTE_MASK) {
+            if ((v.x | v.y | v.z | v.w) & JW_PROMOTE_MASK) {
                 const unsigned int c[4] = {v.x, v.y, v.z, v.w};
 #pragma unroll
                 for (int k = 0; k < 4; ++k) {
-                    if (c[k] & JH_PROMOTE_MASK) {
+                    if (c[k] & JW_PROMOTE_MASK) {
                         const unsigned int slot = atomicAdd(&s_nlist, 1u);
                         if (slot < JW_LIST_CAP) list[slot] = make_uint2((unsigned)(idx * 4 + k), c[k]);
                         else atomicExch(P.error, 1u);
@@ -410,10 +411,12 @@ void joint_count_win_launch(const JointCountParams &C, int channels, int depth, 
 {
     const long long units = C.ntiles * C.K;
 #define LARS_JOINT_WIN(DD, CC) hipLaunchKernelGGL((k_joint_count_win<DD, CC>), dim3((unsigned)units), dim3(JH_THREADS), 0, s, C)
-    if (channels == 4) LARS_JOINT_WIN(6, 4);
+    if (channels == 4) LARS_JOINT_WIN(5, 4);
     else if (depth == 4) LARS_JOINT_WIN(4, 3);
+    else if (depth == 5) LARS_JOINT_WIN(5, 3);
     else if (depth == 6) LARS_JOINT_WIN(6, 3);
-    else LARS_JOINT_WIN(12, 3);
+    else if (depth == 12) LARS_JOINT_WIN(12, 3);
+    else LARS_JOINT_WIN(15, 3);
 #undef LARS_JOINT_WIN
 }
 

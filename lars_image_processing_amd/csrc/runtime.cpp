@@ -290,7 +290,8 @@ int lars_set_tuning(const char *key, int value)
         t.joint_window = value;
     }
     else if (!strcmp(key, "joint_win_depth")) {
-        if (value != 4 && value != 6 && value != 12) return fail(LARS_ERR_INVALID, "lars_set_tuning: joint_win_depth is 4, 6 or 12 (got %d)", value);
+        if (value != 4 && value != 5 && value != 6 && value != 12 && value != 15)
+            return fail(LARS_ERR_INVALID, "lars_set_tuning: joint_win_depth is 4, 5, 6, 12 or 15 (got %d)", value);
         t.joint_win_depth = value;
     }
     else if (!strcmp(key, "out_stride_planes")) {

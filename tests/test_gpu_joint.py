@@ -323,14 +323,14 @@ def test_hot_cells_survive_the_16_bit_counters(lars, kind, window):
             want, want_med = b.process(indices=indices, hist=True, medians=True, route="classic")
             want_tab = b.host_tables()
             for blocks, depth in ((0, 6), (1, 6), (0, 12), (3, 8)):
-                _ffi.set_tuning(blocks_per_tile=blocks, joint_depth=depth, joint_win_depth=depth if depth != 8 else 4)
+                _ffi.set_tuning(blocks_per_tile=blocks, joint_depth=depth, joint_win_depth={6: 15, 12: 12, 8: 5}[depth] if blocks else 4)
                 got, got_med = b.process(indices=indices, hist=True, medians=True, route="joint")
                 assert got.tobytes() == want.tobytes(), (kind, indices, blocks, depth)
                 np.testing.assert_array_equal(got_med, want_med)
                 for c in sorted(lars.batch.channels_of(indices)):
                     np.testing.assert_array_equal(b.host_tables(partial=True)[:, c], want_tab[:, c])
     finally:
-        _ffi.set_tuning(blocks_per_tile=0, joint_depth=6, joint_win_depth=12)
+        _ffi.set_tuning(blocks_per_tile=0, joint_depth=6, joint_win_depth=15)
         b.free()
 
 
@@ -468,4 +468,4 @@ def test_tuning_rejects_values_the_kernels_do_not_have(lars):
     for key, bad in (("joint_depth", 5), ("joint_win_depth", 8), ("joint_window", 4), ("out_stride_planes", 3)):
         with pytest.raises(_ffi.LarsError):
             _ffi.set_tuning(**{key: bad})
-    assert _ffi.get_tuning("joint_depth") == 6 and _ffi.get_tuning("joint_win_depth") == 12 and _ffi.get_tuning("joint_window") == 1
+    assert _ffi.get_tuning("joint_depth") == 6 and _ffi.get_tuning("joint_win_depth") == 15 and _ffi.get_tuning("joint_window") == 1

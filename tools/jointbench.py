@@ -123,7 +123,7 @@ def main():
         for depth in map(int, args.depths.split(",")):
           for blocks in map(int, args.blocks.split(",")):
             for window in map(int, args.windows.split(",")):
-                _ffi.set_tuning(joint_depth=depth, joint_win_depth=depth if depth in (4, 6, 12) else 12, blocks_per_tile=blocks, joint_window=window)
+                _ffi.set_tuning(joint_depth=depth if depth in (4, 6, 8, 12) else 6, joint_win_depth=depth if depth in (4, 5, 6, 12, 15) else 15, blocks_per_tile=blocks, joint_window=window)
                 for mname, indices in MODES.items():
                     if window != 1 and len(indices) == 1:
                         continue                                    # one stream: never windowed
@@ -142,7 +142,7 @@ def main():
                         if med:
                             got = pairs.download(np.float32, (b.ntiles, 2, 2))
                             assert np.array_equal(got, ref[mname + "_med"], equal_nan=True), "medians differ between the routes"
-        _ffi.set_tuning(joint_depth=6, joint_win_depth=12, blocks_per_tile=0, joint_window=1)
+        _ffi.set_tuning(joint_depth=6, joint_win_depth=15, blocks_per_tile=0, joint_window=1)
         stats.free(); pairs.free(); med_scratch.free(); b.free()
 
 

@@ -9,7 +9,7 @@
 // resp. hi, and every statistic of the white-balanced quotients comes out the same.  With windows on red and green (NIR keeps its
 // 256 values; no clamp for it) the tables take (nr + ng) rows of 256 cells: both fit one CU when nr + ng <= 306.
 //
-//   k_joint_predict     per tile: channel histograms of a subsample (1024 segments of 128 pixels spread over the tile) ->
+//   k_joint_predict     per tile: channel histograms of a subsample (1024 segments of 64 pixels spread over the tile) ->
 //                       [lo, hi] per channel with a margin for the sampling error -> mode 1 (windowed) if the rows fit, else 0
 //   k_joint_count_win   one workgroup per (tile, chunk) of the mode-1 tiles: per pair of pixels 3 v_perm_b32 (n | n' << 16, r | r' << 16,
 //                       g | g' << 16), per window 2 packed clamps (v_pk_sub_u16 clamp, v_pk_min_u16) and 1 v_pk_mad_u16 for both dword
@@ -34,7 +34,7 @@ struct JointPredictParams {
     int test_wrong;                           // lars_set_tuning("joint_window", 2): one-row windows at the median, so that every tile misses
 };
 
-#define JP_SEGMENTS 1024                      /* of 32 quads = 128 pixels each: 1 / 128 of a 4096 x 4096 tile */
+#define JP_SEGMENTS 1024                      /* of 16 quads = 64 pixels each: 1 / 256 of a 4096 x 4096 tile */
 
 __device__ inline unsigned int jp_mix(unsigned int x)
 {
@@ -45,18 +45,19 @@ __device__ inline unsigned int jp_mix(unsigned int x)
 template <int CH>
 __global__ __launch_bounds__(JH_THREADS) void k_joint_predict(JointPredictParams P)
 {
-    // red and green histograms of the sample in 32 copies: lane l adds to copy l & 31, whose LDS bank is its own -- no bank conflict and no
-    // two lanes of a half-wave on one word, whatever the image (a smooth one puts all 64 lanes into two or three bins)
-    __shared__ unsigned int s_h[2 * 256 * 32];                 // 64 KiB: [channel][bin][copy]
+    // red and green histograms of the sample in 16 copies: lane l adds to copy l & 15 -- at most two lanes of a half-wave on one word, whatever
+    // the image (a smooth one puts all 64 lanes into two or three bins), and 32 KiB per workgroup: four workgroups share a CU, so that the
+    // 1024 workgroups of a 1024-tile batch are resident at once and wait for their loads together (110 -> 60 us; 32 copies: two per CU)
+    __shared__ unsigned int s_h[2 * 256 * 16];                 // 32 KiB: [channel][bin][copy]
     const int tid = threadIdx.x;
     const long long tile = blockIdx.x;
-    for (int i = tid; i < 2 * 256 * 32 / 4; i += JH_THREADS) reinterpret_cast<uint4 *>(s_h)[i] = make_uint4(0u, 0u, 0u, 0u);
+    for (int i = tid; i < 2 * 256 * 16 / 4; i += JH_THREADS) reinterpret_cast<uint4 *>(s_h)[i] = make_uint4(0u, 0u, 0u, 0u);
     __syncthreads();
     const long long nquads = P.npix >> 2;
     const uint8_t *base = P.tiles + tile * P.npix * CH;
-    const unsigned int copy = (unsigned)(tid & 31);
+    const unsigned int copy = (unsigned)(tid & 15);
     auto add = [&](unsigned int ch, unsigned int v) {
-        __hip_atomic_fetch_add(&s_h[(((ch << 8) | v) << 5) | copy], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+        __hip_atomic_fetch_add(&s_h[(((ch << 8) | v) << 4) | copy], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
     };
     auto count_quad = [&](unsigned int w0, unsigned int w1, unsigned int w2) {
         // r0 g0 n0 r1 | g1 n1 r2 g2 | n2 r3 g3 n3
@@ -75,25 +76,24 @@ __global__ __launch_bounds__(JH_THREADS) void k_joint_predict(JointPredictParams
     };
     long long sampled;                                       // pixels in the histograms
     if (nquads >= (long long)JP_SEGMENTS * 128) {
-        // segment i (32 quads = 128 pixels = 384 contiguous bytes; a wave reads two per load) starts somewhere inside its own
-        // stretch of nquads / 1024 quads; a lane's loads all go out before the first is counted (latency once, not 32 times)
+        // segment i (16 quads = 64 pixels = 192 contiguous bytes; a wave reads four per load) starts somewhere inside its own stretch of
+        // nquads / 1024 quads; a lane's loads all go out before the first is counted (latency once, not 16 times).  The pass is bound by
+        // its scattered reads (0.4 % of the batch, but in pieces of two or three 128-byte lines: 95 us per 1024 tiles with segments of
+        // 128 pixels, what 550 MB cost at HBM rate); what a smooth image needs is many segments, not long ones.
         const long long stretch = nquads / JP_SEGMENTS;
-        const unsigned int span = (unsigned int)(stretch - 31);            // npix < 2^32: a segment starts at stretch * i + [0, span)
+        const unsigned int span = (unsigned int)(stretch - 15);            // npix < 2^32: a segment starts at stretch * i + [0, span)
         const int wave = tid >> 6, lane = tid & 63;
-        constexpr int NJ = JP_SEGMENTS / 32, HALF = NJ / 2;
-        unsigned int w[HALF][3];
+        constexpr int NJ = JP_SEGMENTS / 64;                               // 16 loads per lane
+        unsigned int w[NJ][3];
 #pragma unroll
-        for (int part = 0; part < 2; ++part) {
-#pragma unroll
-            for (int j = 0; j < HALF; ++j) {
-                const unsigned int i = (unsigned)(((part * HALF + j) * 16 + wave) * 2 + (lane >> 5));
-                const long long q = (long long)i * stretch + (long long)__umulhi(jp_mix(i + (unsigned)tile * 0x9E3779B9u), span) + (lane & 31);
-                load_quad(q, w[j][0], w[j][1], w[j][2]);
-            }
-#pragma unroll
-            for (int j = 0; j < HALF; ++j) count_quad(w[j][0], w[j][1], w[j][2]);
+        for (int j = 0; j < NJ; ++j) {
+            const unsigned int i = (unsigned)((j * 16 + wave) * 4 + (lane >> 4));
+            const long long q = (long long)i * stretch + (long long)__umulhi(jp_mix(i + (unsigned)tile * 0x9E3779B9u), span) + (lane & 15);
+            load_quad(q, w[j][0], w[j][1], w[j][2]);
         }
-        sampled = (long long)JP_SEGMENTS * 128;
+#pragma unroll
+        for (int j = 0; j < NJ; ++j) count_quad(w[j][0], w[j][1], w[j][2]);
+        sampled = (long long)JP_SEGMENTS * 64;
     } else {
         for (long long q = tid; q < nquads; q += JH_THREADS) {
             unsigned int w0, w1, w2;
@@ -103,13 +103,13 @@ __global__ __launch_bounds__(JH_THREADS) void k_joint_predict(JointPredictParams
         sampled = nquads * 4;
     }
     __syncthreads();
-    // totals of the 32 copies, their running sums (wave scans + one barrier), and the two order statistics that bound the window
+    // totals of the 16 copies, their running sums (wave scans + one barrier), and the two order statistics that bound the window
     __shared__ unsigned int s_wsum[2][4];
     __shared__ unsigned int s_lo[2], s_hi[2];
     unsigned int tot = 0, inc = 0;
     if (tid < 512) {
 #pragma unroll 8
-        for (int k = 0; k < 32; ++k) tot += s_h[tid * 32 + ((k + tid) & 31)];    // rotated: the 64 lanes read 32 banks
+        for (int k = 0; k < 16; ++k) tot += s_h[tid * 16 + ((k + tid) & 15)];    // rotated: fewer lanes per bank
         inc = tot;
         const int lane = tid & 63;
         for (int off = 1; off < 64; off <<= 1) {
@@ -121,7 +121,7 @@ __global__ __launch_bounds__(JH_THREADS) void k_joint_predict(JointPredictParams
     __syncthreads();
     if (tid < 512 && sampled > 0) {
         // The window of channel ch (red, green): from the sample's order statistics at 0.5 % and 99.5 %, one more value on either
-        // side.  The margin is for imagery, not for independent samples: the 128 pixels of a segment of a smooth image are nearly one
+        // side.  The margin is for imagery, not for independent samples: the 64 pixels of a segment of a smooth image are nearly one
         // observation, so the sample is worth its 1024 segments -- a value that truly holds 2 % of the tile below it shows fewer
         // than 0.5 % of the sample there about once in 10^5 tiles even then.  (0.4 % of margin, enough for independent pixels,
         // missed on 19 % of the tiles of tools/jointbench.py's smooth content: profiles/r05_joint_window_first.txt.)

@@ -71,6 +71,40 @@ def headline_launches(rnd, src):
     print(open(out).read())
 
 
+def joint_launches(rnd, src):
+    """The one-read statistics route's launches of the profiled bench run, by kernel and grid (= batch size): count, mean and
+    extreme durations, and for the counting kernels the algorithmic rate (3 B per pixel: every input byte once).  Launches whose
+    workgroups found nothing to do (the recount of tiles whose window missed, when none did; the full-table kernel beside a
+    fully windowed batch) are listed on a line of their own.  -> profiles/<round>_joint_launches.csv"""
+    import csv
+    trace = max(glob.glob(f"{src}/trace/**/*kernel_trace.csv", recursive=True), key=os.path.getmtime)
+    groups = {}
+    for r in csv.DictReader(open(trace)):
+        name = r["Kernel_Name"]
+        if "k_joint_" not in name:
+            continue
+        short = name.split("(")[0].replace("void lars::", "").replace("lars::", "")
+        wgs = int(r.get("Grid_Size_X", r.get("Grid_Size", 0))) // max(1, int(r.get("Workgroup_Size_X", r.get("Workgroup_Size", 1))))
+        wgs *= max(1, int(r.get("Grid_Size_Y", 1) or 1))
+        groups.setdefault((short, wgs), []).append(int(r["End_Timestamp"]) - int(r["Start_Timestamp"]))
+    out = f"{ROOT}/profiles/{rnd}_joint_launches.csv"
+    with open(out, "w") as fh:
+        fh.write("kernel,workgroups,launches,mean_us,min_us,max_us,idle_launches,GBs_algorithmic,frac_of_8TBs\n")
+        for (short, wgs), d in sorted(groups.items()):
+            top = max(d)
+            work = [x for x in d if x >= 0.05 * top]
+            mean = sum(work) / len(work)
+            rate = ""
+            if short.startswith("k_joint_count"):
+                # tiles of 4096 x 4096: windowed kernel one workgroup per (tile, chunk); full-table kernel two per unit with two streams
+                tiles = {1024: 1024, 512: 256, 2048: 1024}.get(wgs)
+                if tiles and top > 1e6:
+                    gbs = tiles * 4096 * 4096 * 3 / mean
+                    rate = f"{gbs:.1f},{gbs / 8000:.4f}"
+            fh.write(f"{short},{wgs},{len(work)},{mean / 1e3:.1f},{min(work) / 1e3:.1f},{max(work) / 1e3:.1f},{len(d) - len(work)},{rate or ','}\n")
+    print(open(out).read())
+
+
 def main():
     rnd = sys.argv[1] if len(sys.argv) > 1 else "r01"
     src = f"{ROOT}/gpurun_out/prof_{rnd}"
@@ -82,20 +116,21 @@ def main():
     shutil.copy(stats, f"{ROOT}/profiles/{rnd}_bench_kernel_stats.csv")
     shutil.copy(f"{src}/bench_under_rocprof.json", f"{ROOT}/profiles/{rnd}_bench_under_rocprof.json")
     headline_launches(rnd, src)
+    joint_launches(rnd, src)
     f, w = read(rnd, "FETCH_SIZE"), read(rnd, "WRITE_SIZE")
     px64, px256 = 64 * 4096 * 4096, 256 * 4096 * 4096
     # kernel names as rocprofv3 prints them, up to the template arguments that only tuning knobs change (matched by prefix)
     rows = {
         "wb3idx_out_stats": ("k_fused_u8c3<unsigned char, 7u, true, 1, 3>", px64),
         "wb3idx_out_stats_hist": ("k_fused_u8c3<unsigned char, 7u, true, 2, 3>", px64),
-        "wb_ndvi_out_stats": ("k_fused_u8c3<unsigned char, 1u, true, 1, 3>", px64),
+        "wb_ndvi_out_stats": ("k_fused_u8c3<unsigned char, 1u, true, 0, 3>", px64),       # planes only; its statistics pass is k_joint_count
         "wb3idx_out_stats_medians": ("k_fused_u8c3<unsigned char, 7u, true, 0, 3>", px64),      # planes only; its statistics pass is k_joint_count
         # the one-read statistics route: one counting launch per step over the whole batch.  Two value streams on the bench's tiles:
         # windowed tables, one reader per tile chunk (k_joint_count_win); one stream: the full table (k_joint_count).  The launches of
         # lars_d_stats_joint whose workgroups find nothing to do are left out of the means (tools/pmc_summary.py)
-        "wb3idx_stats_only": ("k_joint_count_win<12, 3>", px256),
+        "wb3idx_stats_only": ("k_joint_count_win<", px256),
         "wb_ndvi_stats_only": ("k_joint_count<6, 3>", px256),
-        "wb3idx_stats_medians": ("k_joint_count_win<12, 3>", px256),
+        "wb3idx_stats_medians": ("k_joint_count_win<", px256),
         "joint_predict": ("k_joint_predict<3>", px256),
         "joint_finish": ("k_joint_finish", px256),
         "wb3idx_stats_only_classic": ("k_fused_v2<7u, true, 1, false, false, 0,", px256),

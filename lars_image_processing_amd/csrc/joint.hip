@@ -45,6 +45,7 @@ __global__ __launch_bounds__(JH_THREADS, 4) void k_joint_count(JointCountParams 
     __shared__ __attribute__((aligned(16))) unsigned int s_tab[JH_DWORDS];          // 128 KiB
     __shared__ uint2 s_list[JH_LIST_CAP];                                          // moved dwords: (D, value)
     __shared__ unsigned int s_nlist;
+    __shared__ unsigned int s_jlo, s_jhi;                                          // blocks of 8 rows (1024 dwords) that hold a count
 
     const int tid = threadIdx.x;
     // unit = (tile, chunk); with two streams the two workgroups of a unit are 8 apart in dispatch order
@@ -70,7 +71,7 @@ __global__ __launch_bounds__(JH_THREADS, 4) void k_joint_count(JointCountParams 
 
     uint4 *tab4 = reinterpret_cast<uint4 *>(s_tab);
     for (int i = tid; i < JH_DWORDS / 4; i += JH_THREADS) tab4[i] = make_uint4(0u, 0u, 0u, 0u);
-    if (tid == 0) s_nlist = 0;
+    if (tid == 0) { s_nlist = 0; s_jlo = JH_DWORDS / JH_THREADS; s_jhi = 0u; }
     __syncthreads();
     char *tab = reinterpret_cast<char *>(s_tab);
 
@@ -204,13 +205,20 @@ __global__ __launch_bounds__(JH_THREADS, 4) void k_joint_count(JointCountParams 
     }
     __syncthreads();
 
-    // publish: (cell (D, 0), cell (D, 1)) = (low - high, high), 32 bytes per lane and trip
-    unsigned int *out = P.part + ((tile * P.S + role) * P.K + chunk) * (long long)(2 * JH_DWORDS);
+    // publish: (cell (D, 0), cell (D, 1)) = (low - high, high), 32 bytes per lane and trip -- and which blocks of 8 rows (1024 dwords: the unit
+    // k_joint_finish walks) hold a count at all: a tile's samples seldom span all 256 values, and the finish kernel skips the rest
+    const long long slot = (tile * P.S + role) * P.K + chunk;
+    unsigned int *out = P.part + slot * (long long)(2 * JH_DWORDS);
     for (int i = tid; i < JH_DWORDS / 4; i += JH_THREADS) {
         const uint4 v = tab4[i];
         uint4 *o = reinterpret_cast<uint4 *>(out + (long long)i * 8);
         o[0] = make_uint4((v.x & 0xFFFFu) - (v.x >> 16), v.x >> 16, (v.y & 0xFFFFu) - (v.y >> 16), v.y >> 16);
         o[1] = make_uint4((v.z & 0xFFFFu) - (v.z >> 16), v.z >> 16, (v.w & 0xFFFFu) - (v.w >> 16), v.w >> 16);
+        const unsigned int jb = (unsigned)i >> 8;                                  // the same for the 64 lanes of a wave
+        if (__builtin_amdgcn_ballot_w64((v.x | v.y | v.z | v.w) != 0u) != 0ull && (tid & 63) == 0) {
+            atomicMin(&s_jlo, jb);
+            atomicMax(&s_jhi, jb + 1u);
+        }
     }
     const unsigned int nlist = s_nlist < JH_LIST_CAP ? s_nlist : JH_LIST_CAP;
     if (nlist) {
@@ -221,8 +229,12 @@ __global__ __launch_bounds__(JH_THREADS, 4) void k_joint_count(JointCountParams 
             const unsigned int hi = m.y >> 16, lo = (m.y & 0xFFFFu) - hi;
             if (lo) atomicAdd(&out[2 * (long long)m.x], lo);
             if (hi) atomicAdd(&out[2 * (long long)m.x + 1], hi);
+            atomicMin(&s_jlo, m.x >> 10);
+            atomicMax(&s_jhi, (m.x >> 10) + 1u);
         }
     }
+    __syncthreads();
+    if (tid == 0) P.rows[slot] = make_uint2(s_jlo, s_jhi);
 }
 
 // ---------------------------------------------------------------------------
@@ -230,6 +242,7 @@ __global__ __launch_bounds__(JH_THREADS, 4) void k_joint_count(JointCountParams 
 // ---------------------------------------------------------------------------
 struct JointFinishParams {
     const unsigned int *part;
+    const uint2 *rows;                        // [ntiles][S][K]: blocks of 8 rows that hold counts (see JointCountParams)
     long long npix;
     int K, S;
     unsigned int streams;                     // as JointCountParams
@@ -351,8 +364,15 @@ __global__ __launch_bounds__(JH_THREADS, 8) void k_joint_finish(JointFinishParam
     // group's loads (L2 hits: the counting kernel has just written them) in flight while the current one is worked on.
     constexpr int NJ = JH_DWORDS / JH_THREADS;                       // 32 blocks of 1024 dwords = 8 rows each
     constexpr int GRP = 8;
-    // windowed counts: only the blocks that hold the window's rows were published (k_joint_count_win), everything else is zero
-    const int j_lo = windowed ? (int)(win_lo >> 3) : 0, j_hi = windowed ? (int)(win_hi >> 3) + 1 : NJ;
+    // only the blocks of 8 rows in which some chunk of the tile counted something (windowed counts: the blocks of the window, the only ones
+    // k_joint_count_win published): a tile whose samples span 96 of the 256 values is walked in 13 blocks instead of 32
+    int j_lo = NJ, j_hi = 0;
+    for (int k = 0; k < P.K; ++k) {
+        const uint2 rr = P.rows[(tile * P.S + role) * P.K + k];
+        j_lo = min(j_lo, (int)rr.x);
+        j_hi = max(j_hi, (int)rr.y);
+    }
+    if (j_hi > NJ) j_hi = NJ;
     auto for_cells = [&](auto &&f) {
         uint2 buf[2][GRP];
         auto fetch = [&](int g, uint2 (&dst)[GRP]) {
@@ -657,15 +677,17 @@ static long long joint_chunk_quads(long long npix, int K)
     return cq > 0 ? cq : 1024;
 }
 
-// Scratch: [256 B: error flag][JointWin x ntiles, padded to 256 B][moved-dword lists of the windowed workgroups][pair counts]
+// Scratch: [256 B: error flag][JointWin x ntiles, padded to 256 B][occupied row blocks per (tile, stream, chunk)][moved-dword lists of the
+// windowed workgroups][pair counts]
 struct JointScratch {
-    size_t win_off, list_off, part_off, total;
+    size_t win_off, rows_off, list_off, part_off, total;
 };
 static JointScratch joint_scratch_layout(long long ntiles, int S, int K)
 {
     JointScratch L;
     L.win_off = 256;
-    L.list_off = L.win_off + (((size_t)ntiles * sizeof(JointWin) + 255) & ~(size_t)255);
+    L.rows_off = L.win_off + (((size_t)ntiles * sizeof(JointWin) + 255) & ~(size_t)255);
+    L.list_off = L.rows_off + (((size_t)ntiles * S * K * sizeof(uint2) + 255) & ~(size_t)255);
     const size_t list_bytes = S == 2 ? (size_t)ntiles * K * JW_LIST_CAP * sizeof(uint2) : 0;
     L.part_off = L.list_off + list_bytes;
     L.total = L.part_off + (size_t)ntiles * S * K * (2 * JH_DWORDS) * sizeof(unsigned int);
@@ -729,6 +751,7 @@ extern "C" int lars_d_stats_joint(const lars_fused_args *a, int white_balance, i
     C.chunk_quads = joint_chunk_quads(a->npix, K);
     C.part = reinterpret_cast<unsigned int *>(base + L.part_off); C.error = error; C.K = K; C.S = S; C.streams = streams;
     C.win = windowed ? win : nullptr; C.pass = 0; C.list = reinterpret_cast<uint2 *>(base + L.list_off);
+    C.rows = reinterpret_cast<uint2 *>(base + L.rows_off);
     const long long units = (long long)a->ntiles * K;
     const long long nwg = S == 2 ? ((units + 7) / 8) * 16 : units;
     if (nwg > 0x7FFFFFFFll) return fail(LARS_ERR_INVALID, "lars_d_stats_joint: too many workgroups");
@@ -746,7 +769,7 @@ extern "C" int lars_d_stats_joint(const lars_fused_args *a, int white_balance, i
     };
     JointFinishParams F;
     memset(&F, 0, sizeof F);
-    F.part = C.part; F.npix = a->npix; F.K = K; F.S = S; F.streams = streams; F.mask = mask;
+    F.part = C.part; F.rows = C.rows; F.npix = a->npix; F.K = K; F.S = S; F.streams = streams; F.mask = mask;
     F.flags = a->flags & (LARS_F_HIST | LARS_F_SUMSQ); F.wb = white_balance ? 1 : 0; F.rgn_variant = rgn_variant;
     F.stats = a->stats; F.table_out = white_balance ? const_cast<uint8_t *>(a->wb_table) : nullptr;
     F.pcts_out = white_balance ? percentiles : nullptr; F.hist_out = hist; F.out_pairs = out_pairs;

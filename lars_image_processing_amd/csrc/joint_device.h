@@ -30,6 +30,7 @@ struct JointCountParams {
     unsigned int streams;                     // bit 0: (n, r) pairs, bit 1: (n, g) pairs
     struct JointWin *win;                     // [ntiles] or null: which tiles are counted on windowed tables (joint_win.hip)
     int pass;                                 // 0: the first count (k_joint_count skips the windowed tiles); 1: the recount of the tiles whose window missed
+    uint2 *rows;                              // [ntiles][S][K]: (first, one past the last) block of 8 table rows that holds a count -- what k_joint_finish walks
     uint2 *list;                              // k_joint_count_win: [ntiles * K][JW_LIST_CAP] moved dwords (dword, value)
 };
 

@@ -369,6 +369,7 @@ __global__ __launch_bounds__(JH_THREADS, 4) void k_joint_count_win(JointCountPar
         const unsigned int lo = s ? lo_g : lo_r, nx = s ? ng : nr, row0 = s ? nr : 0u;
         // only the blocks of 8 rows that touch the window: k_joint_finish walks exactly these
         const int d_begin = (int)(lo >> 3) << 10, d_end = (int)(((lo + nx - 1u) >> 3) + 1u) << 10;
+        if (tid == 0) P.rows[(tile * 2 + s) * P.K + chunk] = make_uint2(lo >> 3, ((lo + nx - 1u) >> 3) + 1u);
         for (int D = d_begin + tid; D < d_end; D += JH_THREADS) {
             const unsigned int x = (unsigned)D >> 7;
             uint2 c = make_uint2(0u, 0u);

@@ -469,3 +469,48 @@ def test_tuning_rejects_values_the_kernels_do_not_have(lars):
         with pytest.raises(_ffi.LarsError):
             _ffi.set_tuning(**{key: bad})
     assert _ffi.get_tuning("joint_depth") == 6 and _ffi.get_tuning("joint_win_depth") == 15 and _ffi.get_tuning("joint_window") == 1
+
+
+def _sampled_pixels(tile_index, npix):
+    """The pixels k_joint_predict samples of tile `tile_index` of a call (csrc/joint_win.hip): 1024 segments of 16 quads, segment i
+    somewhere inside its own stretch of nquads / 1024 quads, placed by the counter hash the synthetic tiles use."""
+    nquads = npix >> 2
+    stretch = nquads // 1024
+    span = stretch - 15
+    i = np.arange(1024, dtype=np.uint64)
+    with np.errstate(over="ignore"):
+        h = orc._mix32(((i + np.uint64((tile_index * 0x9E3779B9) & 0xFFFFFFFF)) & np.uint64(0xFFFFFFFF)).astype(np.uint32)).astype(np.uint64)
+    start = i * np.uint64(stretch) + ((h * np.uint64(span)) >> np.uint64(32))
+    quads = (start[:, None] + np.arange(16, dtype=np.uint64)[None, :]).ravel()
+    return (quads[:, None] * np.uint64(4) + np.arange(4, dtype=np.uint64)[None, :]).ravel().astype(np.int64)
+
+
+def test_a_window_that_misses_by_itself_is_recounted(lars):
+    """No test hook: a tile whose darkest 3 % of red samples all lie where the prediction's subsample does not look.  The sample sees
+    none of them, the red window starts above the tile's 2nd percentile, k_joint_finish finds the percentile's order statistics on
+    the window's edge, flags the tile, and the recount on full tables delivers what the per-pixel route delivers.  The neighbouring
+    tile (same values, dark pixels spread evenly) keeps its window."""
+    h = w = 1024
+    npix = h * w
+    rng = np.random.default_rng(17)
+    tiles = rng.integers(100, 160, (2, npix, 3), dtype=np.uint8)
+    dark = rng.integers(5, 30, (2, npix), dtype=np.uint8)
+    seen = np.zeros(npix, bool)
+    seen[_sampled_pixels(0, npix)] = True
+    hidden = np.flatnonzero(~seen)[: int(0.03 * npix)]                   # 3 % of the tile, none of it sampled (the sample is 1 / 16)
+    tiles[0, hidden, 0] = dark[0, hidden]
+    even = np.arange(0, npix, 33)[: int(0.03 * npix)]
+    tiles[1, even, 0] = dark[1, even]
+    b = lars.TileBatch.from_host(tiles.reshape(2, h, w, 3))
+    try:
+        want, want_med = b.process(hist=True, medians=True, route="classic")
+        want_tab, want_pct = b.host_tables(), b.host_percentiles()
+        assert want_pct[0, 0, 0] < 30 and want_pct[1, 0, 0] < 30            # the 2nd percentile of red lies among the dark pixels
+        got, got_med = b.process(hist=True, medians=True, route="joint")
+        assert b.joint_window_report() == (2, 1)                             # both tiles windowed, the first one counted again
+        assert got.tobytes() == want.tobytes()
+        np.testing.assert_array_equal(got_med, want_med)
+        np.testing.assert_array_equal(b.host_tables(), want_tab)
+        assert b.host_percentiles().tobytes() == want_pct.tobytes()
+    finally:
+        b.free()

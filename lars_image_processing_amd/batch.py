@@ -498,6 +498,7 @@ class TileBatch:
         a.flags = _ffi.F_STATS | (_ffi.F_HIST if hist else 0) | (_ffi.F_SUMSQ if sumsq else 0)
         a.stats = stats.ptr
         a.stream = stream
+        self._joint_tiles = int(a.ntiles)                   # what the call covers: joint_window_report() reads that many window records
         _ffi.call("lars_d_stats_joint", C.byref(a), 1 if white_balance else 0, int(rgn_variant),
                   C.c_void_p(self.percentiles.ptr) if white_balance else None,
                   C.c_void_p(self.hist.ptr) if white_balance and channel_hist else None,
@@ -507,7 +508,9 @@ class TileBatch:
         """(tiles the last ``run_joint`` counted on windowed tables, tiles among them whose window missed and that were
         counted again) -- after the pass's stream has finished."""
         w, r = C.c_int64(0), C.c_int64(0)
-        _ffi.call("lars_joint_window_report", C.c_void_p(self._joint_scratch.ptr), self.ntiles, C.byref(w), C.byref(r))
+        if getattr(self, "_joint_scratch", None) is None:
+            return 0, 0
+        _ffi.call("lars_joint_window_report", C.c_void_p(self._joint_scratch.ptr), getattr(self, "_joint_tiles", self.ntiles), C.byref(w), C.byref(r))
         return int(w.value), int(r.value)
 
     def check_joint(self, stream=None):

@@ -38,3 +38,34 @@ def test_plane_writing_kernels_keep_their_resident_waves(tmp_path):
         assert hits, f"instantiation {frag} not found"
         for name, vgprs in hits.items():
             assert vgprs <= budget, f"{name}: {vgprs} registers > {budget}: it loses a resident wave per SIMD"
+
+
+@pytest.mark.skipif(not os.path.exists(HIPCC), reason="hipcc not installed")
+def test_one_read_kernels_keep_their_residency(tmp_path):
+    """The one-read statistics kernels live by what fits a CU (profiles/r05_finish_block_timeline.txt): k_joint_finish must stay within 64
+    registers so that TWO of its 16-wave blocks share a CU (at 68 its launch ran in two rounds: 97 instead of 74 us per 256 tiles); the
+    counting kernels within 128 (16 waves of one workgroup per CU) and within the CU's 160 KiB of LDS: the full-table kernel 128 KiB + its
+    list, the windowed kernel 306 rows of 133 dwords."""
+    for src in ("joint.hip", "joint_win.hip"):
+        out = tmp_path / (src + ".s")
+        cmd = [HIPCC, "-O3", "-std=c++17", "--offload-arch=gfx950", "-ffp-contract=off", "-fno-fast-math", f"-I{ROOT}/include",
+               "-Wno-pass-failed", "-S", "--cuda-device-only", f"{ROOT}/lars_image_processing_amd/csrc/{src}", "-o", str(out)]
+        subprocess.run(cmd, check=True, capture_output=True, timeout=600)
+    meta = {}
+    for src in ("joint.hip", "joint_win.hip"):
+        text = (tmp_path / (src + ".s")).read_text()
+        for m in re.finditer(r"- \.agpr_count:.*?\n((?:    .*\n)+)", text):
+            block = m.group(1)
+            name = re.search(r"\.name:\s+(\S+)", block)
+            if name:
+                meta[name.group(1)] = {k: int(v) for k, v in re.findall(r"\.(vgpr_count|group_segment_fixed_size|private_segment_fixed_size):\s+(\d+)", block)}
+    finish = [v for k, v in meta.items() if "k_joint_finish" in k]
+    assert len(finish) == 1 and finish[0]["vgpr_count"] <= 64 and finish[0]["group_segment_fixed_size"] <= 24 * 1024, finish
+    assert finish[0]["private_segment_fixed_size"] <= 16, finish                       # a register or two spilled, not an array
+    full = {k: v for k, v in meta.items() if "k_joint_countILi" in k}
+    win = {k: v for k, v in meta.items() if "k_joint_count_winILi" in k}
+    assert len(full) >= 4 and len(win) >= 5, (sorted(full), sorted(win))
+    for name, v in {**full, **win}.items():
+        assert v["vgpr_count"] <= 128 and v["private_segment_fixed_size"] == 0, (name, v)
+        assert v["group_segment_fixed_size"] <= 160 * 1024, (name, v)
+    assert all(v["group_segment_fixed_size"] >= 306 * 133 * 4 for v in win.values())

@@ -329,8 +329,9 @@ int lars_d_synth_u8(uint8_t *tiles, int64_t ntiles, int64_t first_tile, int64_t 
  * (also the chunks per tile of lars_d_stats_joint), "joint_depth" 4|6 loads in flight per lane of the counting kernel,
  * "joint_window" 1 (windowed pair tables where they fit: lars_d_stats_joint)|0 (never)|2 (windows that miss on purpose: exercises the
  * recount; tiles of any size)|3 (as 1 for tiles of any size), "joint_win_depth" 4|5|6|12|15 loads in flight per lane of the windowed counting kernel,
- * "u16_hist_impl" 2 (uint16 percentiles usually from one full pass: candidate bins predicted from a subsample)|1 (always the two
- * radix passes)|3 (wrong candidates on purpose: exercises the recount),
+ * "u16_hist_impl" 5 (uint16 percentiles usually from ONE full pass: per channel and mark the count of the samples below a window
+ * predicted from a subsample and the histogram inside it; a tile whose window missed takes the two radix passes)|1 (always the two
+ * radix passes)|3 (windows that miss on purpose: exercises the fall-back),
  * "selq_window" 1 (one-pass medians)|0 (always two select passes)|2 (wrong windows: exercises the fallback), "selq_list_wgs"
  * workgroups per select pass over the tiles a window missed (0 = 2048).  Results never depend on them.  Read-only:
  * "last_fused_kernel" = the kernel family the last lars_d_fused launched (1 k_fused_u8c3, 2 k_fused_v2, 3 its uint16 form,

@@ -102,8 +102,8 @@ struct Tuning {
     int selq_window = 1;       // one-pass medians (select_q.hip): 1 predicted window, 0 always two passes, 2 wrong windows (test)
     int selq_list_wgs = 0;     // workgroups per launch of the classic select passes over the tiles a window missed (0 = 2048)
     int last_fused_kernel = 0; // read-only: the kernel family lars_d_fused launched last -- 1 k_fused_u8c3, 2 k_fused_v2, 3 uint16, 4 generic, 5 RGBA uint8
-    int u16_hist_impl = 2;     // uint16 percentiles: 2 one full pass (candidate bins from a subsample, u16.hip), 1 always two radix passes,
-                               // 3 test hook (wrong candidates), 4 one full pass with round 3's slot look-ups instead of the window tests
+    int u16_hist_impl = 5;     // uint16 percentiles (u16.hip): 5 one full pass on value windows (counts below + histograms inside), 1 always two
+                               // radix passes, 3 test hook (value windows that miss: every tile is flagged and takes the two passes as well)
     int out_stride_planes = 0; // laboratory build (LARS_LAB_LAYOUT) only: k > 1 = the fused kernel steps k x npix from tile to tile in its index planes
     int joint_depth = 6;       // joint.hip: 12-byte loads in flight per lane of the counting kernel (4 | 6 | 8 | 12)
     int joint_win_depth = 15;  // joint_win.hip: loads in flight per lane of the windowed counting kernel: 5 | 15 (a sweep every 15 steps), 4 | 6 | 12 (every 12)

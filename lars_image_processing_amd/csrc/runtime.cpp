@@ -301,7 +301,10 @@ int lars_set_tuning(const char *key, int value)
         return fail(LARS_ERR_INVALID, "lars_set_tuning: out_stride_planes exists in the laboratory build only (make lablayout); this library would ignore it");
 #endif
     }
-    else if (!strcmp(key, "u16_hist_impl")) t.u16_hist_impl = value;
+    else if (!strcmp(key, "u16_hist_impl")) {
+        if (value != 1 && value != 3 && value != 5) return fail(LARS_ERR_INVALID, "lars_set_tuning: u16_hist_impl is 5, 1 or 3 (got %d)", value);
+        t.u16_hist_impl = value;
+    }
     else return fail(LARS_ERR_INVALID, "lars_set_tuning: unknown key %s", key);
     return LARS_OK;
 }

@@ -14,11 +14,11 @@
 // Both data passes stream the tile once at HBM rate; a 3 x 65536-bin histogram would need one
 // global atomic per sample instead.
 //
-// Round 3: usually ONE full pass.  A 1/16 subsample of the high-byte histograms predicts, per channel, the bins that will
-// hold the order statistics (each predicted bin and its two neighbours: up to six candidates); the full pass then counts the
-// high bytes of every sample AND the low bytes of the samples in candidate bins (k_hist_u16_both).  The exact high-byte
-// histogram settles which bins were needed; a tile whose bins were not all among its candidates (a percentile within a sample
-// error of a bin boundary, or a 16-bit image that is not smooth at the 2 % / 98 % marks) is recounted by the classic second pass.
+// Usually ONE full pass instead of those two (round 5: value windows, see k_u16_count_win below).  Rounds 3-4 predicted candidate high-byte
+// BINS from a subsample and counted all high bytes plus the candidates' low bytes in one pass (k_hist_u16_both: 127 vector instructions
+// per wave-quad, bound by instruction issue at 0.61 of 8 TB/s; profiles/r04_u16_prepass_counters.txt, r05_u16_prepare_ab.txt) -- removed
+// when the value-window pass reached the HBM rate.  The two radix passes stay: as `u16_hist_impl` 1, for tiles the fast path does not
+// serve, and as the fall-back of a tile whose window missed.
 #include "common.h"
 #include "device_common.h"
 
@@ -37,11 +37,13 @@ struct U16Pick {
 // ---- pass 1: high-byte histograms --------------------------------------------------------
 // lane owns 4 pixels = 24 bytes (6 dwords: r0g0 n0r1 g1n1 r2g2 n2r3 g3n3, two samples per dword)
 // every > 1: only every `every`-th grid stride is counted (the subsample that predicts the candidate bins)
+// only: null, or flags per tile -- tiles whose flag is 0 are skipped (the classic passes as the fall-back of the one-pass forms)
 __global__ __launch_bounds__(1024) void k_hist_u16_hi(const uint16_t *__restrict__ tiles, long long npix,
-                                                      unsigned int *__restrict__ hist, int every)
+                                                      unsigned int *__restrict__ hist, int every, const unsigned int *__restrict__ only = nullptr)
 {
     __shared__ unsigned int s_h[3 * 256 * 32];             // [channel][bin][copy = lane % 32]
     const int tid = threadIdx.x;
+    if (only && !only[blockIdx.y]) return;
     for (int i = tid; i < 3 * 256 * 32; i += 1024) s_h[i] = 0;
     __syncthreads();
     const long long tile = blockIdx.y;
@@ -100,11 +102,12 @@ __global__ __launch_bounds__(256) void k_hist_u16_hi_generic(const uint16_t *__r
 
 // ---- pick: which high bytes hold the order statistics -------------------------------------
 __global__ __launch_bounds__(256) void k_u16_pick(const unsigned int *__restrict__ hist, long long npix,
-                                                  U16Pick *__restrict__ picks)
+                                                  U16Pick *__restrict__ picks, const unsigned int *__restrict__ only = nullptr)
 {
     __shared__ unsigned long long s_scan[256];
     __shared__ U16Pick s_pick;
     const int tid = threadIdx.x;
+    if (only && !only[blockIdx.y]) return;
     const long long slot = (long long)blockIdx.y * 3 + blockIdx.x;
     const unsigned long long c = hist[slot * 256 + tid];
     s_scan[tid] = c;
@@ -148,12 +151,14 @@ __global__ __launch_bounds__(256) void k_u16_pick(const unsigned int *__restrict
 // ---- pass 2: low-byte histograms of the samples in the picked high-byte bins ---------------
 template <bool FAST>
 __global__ __launch_bounds__(1024) void k_hist_u16_lo(const uint16_t *__restrict__ tiles, long long npix, int channels,
-                                                      const U16Pick *__restrict__ picks, unsigned int *__restrict__ lohist)
+                                                      const U16Pick *__restrict__ picks, unsigned int *__restrict__ lohist,
+                                                      const unsigned int *__restrict__ only = nullptr)
 {
     __shared__ unsigned int s_h[3 * 4 * 256];
     __shared__ unsigned char s_slot[3 * 256];
     const int tid = threadIdx.x;
     const long long tile = blockIdx.y;
+    if (only && !only[tile]) return;
     for (int i = tid; i < 3 * 4 * 256; i += 1024) s_h[i] = 0;
     if (tid < 768) s_slot[tid] = 0xFF;
     __syncthreads();
@@ -202,26 +207,76 @@ __global__ __launch_bounds__(1024) void k_hist_u16_lo(const uint16_t *__restrict
         if (s_h[i]) atomicAdd(&g[i], s_h[i]);
 }
 
-// ---- one full pass: candidate bins from a subsample, high bytes + low bytes of the candidates together --------------------
-#define U16_CAND 6                  /* candidate high-byte bins per channel: each predicted bin and its two neighbours */
 #define U16_DEPTH 3                 /* quads per lane in flight in the one-pass count */
-struct U16Cand { unsigned char bin[U16_CAND]; unsigned char n; unsigned char pad; };
 
-// From the subsample's high-byte histogram: the bin holding the 2 % resp. the 98 % mark of the sample, and a neighbour only where the
-// mark sits within six standard deviations of its sampling error from that side of its bin (sigma = sqrt(n q (1 - q)) ranks of the
-// subsample, as a fraction of the bin's count).  Round 3 took both neighbours always: six candidate bins per channel = 2.3 % of random
-// samples, and the one-pass count -- bound by instruction issue -- pays for every sample position at which ANY lane of a wave holds a
-// candidate (profiles/r04_u16_prepass_counters.txt).  A mark that lands outside its candidates costs that tile a recount, never a wrong
-// percentile: the exact high-byte histogram of the full pass decides (k_u16_resolve).
-__global__ __launch_bounds__(256) void k_u16_predict(const unsigned int *__restrict__ sample_hist, U16Cand *__restrict__ cand)
+// ---- one full pass on VALUE windows (round 5): no histogram per sample at all ---------------------------------------------------
+// np.percentile needs, per channel, the order statistics at ranks floor((n - 1) q) and the next one for q = 2 % and 98 %.  A 1/64
+// subsample (12-bit histograms: k_u16_sample12) says where in the 16-bit range each mark lies to within a few dozen values
+// (k_u16_window: the sample's order statistics six standard deviations of the sampling error either side of the mark, rounded outwards
+// to the sample histogram's 16-value bins); the full pass then only has to know, per channel and mark, HOW MANY samples lie below the
+// window and the histogram of the samples INSIDE it (k_u16_count_win).  Below: the borrow of one subtraction, added to the lane's
+// counter -- v_subrev_co_u32 d, vcc, lo << 16, key; v_addc_co_u32 -- where key is the dword itself for its high sample and the dword
+// shifted left by 16 for its low one (no extraction: the other sample sits below the compared bits).  Inside: d < width << 16, true for
+// one sample in a thousand, so the block behind it is entered at about one sample position in eight per wave (the candidate BINS of
+// round 3-4's pass, 2.3 % of the samples, put some lane of 64 into it at three positions in four: 127 vector instructions per
+// wave-quad, 94 of which ran at HBM rate).  A rank that falls outside its window (k_u16_pick_win) flags the tile, and only flagged
+// tiles take the two classic radix passes.
+#define U16_WIN_MAX 1024            /* values per window: 64 bins of the sample histogram */
+#define U16_SAMPLE_BITS 12
+#define U16_SAMPLE_BINS 4096        /* v >> 4 */
+#define U16_SAMPLE_SPAN 16          /* values per bin of the sample histogram */
+struct U16Win { unsigned int lo[2], wd[2]; };     // per (tile, channel): mark m's window = values [lo, lo + wd); wd == 0: none (the tile is flagged)
+
+__global__ __launch_bounds__(1024) void k_u16_sample12(const uint16_t *__restrict__ tiles, long long npix, unsigned int *__restrict__ hist12, int every)
 {
+    __shared__ unsigned int s_h[3 * U16_SAMPLE_BINS];
+    const int tid = threadIdx.x;
+    for (int i = tid; i < 3 * U16_SAMPLE_BINS; i += 1024) s_h[i] = 0;
+    __syncthreads();
+    const long long tile = blockIdx.y;
+    const uint16_t *base = tiles + tile * npix * 3;
+    const long long nquads = npix >> 2;
+#define SADD(word, half, ch) atomicAdd(&s_h[(ch) * U16_SAMPLE_BINS + (((word) >> ((half) * 16 + 4)) & 0xFFFu)], 1u)
+    const long long step = (long long)gridDim.x * 1024 * every;
+    if (nquads > 0) {
+        const __amdgpu_buffer_rsrc_t rsrc =
+            __builtin_amdgcn_make_buffer_rsrc(const_cast<uint16_t *>(base), 0, (int)(nquads * 24), 0x00020000);
+        // two quads of every lane in flight (quads past the tile read as zero and are skipped)
+        for (long long q = (long long)blockIdx.x * 1024 + tid; q < nquads; q += 2 * step) {
+            const unsigned int off = (unsigned int)q * 24u, off2 = (unsigned int)(q + step) * 24u;
+            const u32x4v a = __builtin_amdgcn_raw_buffer_load_b128(rsrc, off, 0, 0);
+            const u32x2v b = __builtin_amdgcn_raw_buffer_load_b64(rsrc, off + 16u, 0, 0);
+            const u32x4v a2 = __builtin_amdgcn_raw_buffer_load_b128(rsrc, off2, 0, 0);
+            const u32x2v b2 = __builtin_amdgcn_raw_buffer_load_b64(rsrc, off2 + 16u, 0, 0);
+            SADD(a.x, 0, 0); SADD(a.x, 1, 1); SADD(a.y, 0, 2); SADD(a.y, 1, 0); SADD(a.z, 0, 1); SADD(a.z, 1, 2);
+            SADD(a.w, 0, 0); SADD(a.w, 1, 1); SADD(b.x, 0, 2); SADD(b.x, 1, 0); SADD(b.y, 0, 1); SADD(b.y, 1, 2);
+            if (q + step < nquads) {
+                SADD(a2.x, 0, 0); SADD(a2.x, 1, 1); SADD(a2.y, 0, 2); SADD(a2.y, 1, 0); SADD(a2.z, 0, 1); SADD(a2.z, 1, 2);
+                SADD(a2.w, 0, 0); SADD(a2.w, 1, 1); SADD(b2.x, 0, 2); SADD(b2.x, 1, 0); SADD(b2.y, 0, 1); SADD(b2.y, 1, 2);
+            }
+        }
+    }
+#undef SADD
+    __syncthreads();
+    unsigned int *g = hist12 + tile * (3 * U16_SAMPLE_BINS);
+    for (int i = tid; i < 3 * U16_SAMPLE_BINS; i += 1024)
+        if (s_h[i]) atomicAdd(&g[i], s_h[i]);
+}
+
+// test_wrong (lars_set_tuning("u16_hist_impl", 3)): windows of 64 values at 0, so that (almost) every tile is flagged
+__global__ __launch_bounds__(256) void k_u16_window(const unsigned int *__restrict__ hist12, U16Win *__restrict__ win, int test_wrong)
+{
+    constexpr int PER = U16_SAMPLE_BINS / 256;              // 16 bins per thread
     __shared__ unsigned long long s_scan[256];
-    __shared__ int s_t[2];
-    __shared__ int s_side[2][2];                           // [mark][0: take the bin below, 1: the bin above]
+    __shared__ unsigned int s_b[2][2];                     // [mark][first, last] bin of the sample histogram
     const int tid = threadIdx.x;
     const long long slot = (long long)blockIdx.y * 3 + blockIdx.x;
-    const unsigned long long c = sample_hist[slot * 256 + tid];
-    s_scan[tid] = c;
+    const unsigned int *h = hist12 + slot * U16_SAMPLE_BINS;
+    unsigned int mine[PER];
+    unsigned long long local = 0;
+#pragma unroll
+    for (int j = 0; j < PER; ++j) { mine[j] = h[tid * PER + j]; local += mine[j]; }
+    s_scan[tid] = local;
     __syncthreads();
     for (int off = 1; off < 256; off <<= 1) {
         unsigned long long v = (tid >= off) ? s_scan[tid - off] : 0;
@@ -229,122 +284,107 @@ __global__ __launch_bounds__(256) void k_u16_predict(const unsigned int *__restr
         s_scan[tid] += v;
         __syncthreads();
     }
-    const unsigned long long total = s_scan[255], before = s_scan[tid] - c;
-    if (tid < 2) { s_t[tid] = tid == 0 ? 0 : 255; s_side[tid][0] = 1; s_side[tid][1] = 1; }
+    const unsigned long long total = s_scan[255], before = s_scan[tid] - local;
+    if (tid < 4) s_b[tid >> 1][tid & 1] = (tid & 1) ? 0u : (unsigned)U16_SAMPLE_BINS;       // first = 4096, last = 0: no window
     __syncthreads();
     if (total > 0) {
         for (int k = 0; k < 2; ++k) {
+            // four standard deviations of the sampling error either side of the mark (a miss costs that tile the two classic passes,
+            // never a wrong percentile: about one tile in ten thousand)
             const double q = k == 0 ? 0.02 : 0.98;
-            const unsigned long long r = (unsigned long long)((double)(total - 1) * q);
-            if (c && r >= before && r < before + c) {
-                s_t[k] = tid;
-                const double margin = 6.0 * sqrt((double)total * q * (1.0 - q)) + 2.0;        // ranks of the subsample
-                s_side[k][0] = (double)(r - before) < margin ? 1 : 0;
-                s_side[k][1] = (double)(before + c - 1 - r) < margin ? 1 : 0;
+            const double spread = 4.0 * sqrt((double)total * q * (1.0 - q)) + 2.0;          // ranks of the subsample
+            const double centre = (double)(total - 1) * q;
+            double rl = floor(centre - spread), rh = ceil(centre + spread + 1.0);          // + 1: the mark's upper neighbour rank
+            if (rl < 0.0) rl = 0.0;
+            if (rh > (double)(total - 1)) rh = (double)(total - 1);
+            const unsigned long long ranks[2] = {(unsigned long long)rl, (unsigned long long)rh};
+            for (int e = 0; e < 2; ++e) {
+                const unsigned long long r = ranks[e];
+                if (local && r >= before && r < before + local) {
+                    unsigned long long cum = before;
+#pragma unroll
+                    for (int j = 0; j < PER; ++j) {
+                        if (r >= cum && r < cum + mine[j]) s_b[k][e] = (unsigned)(tid * PER + j);
+                        cum += mine[j];
+                    }
+                }
             }
         }
     }
     __syncthreads();
     if (tid == 0) {
-        U16Cand out;
-        out.n = 0; out.pad = 0;
-        for (int j = 0; j < U16_CAND; ++j) out.bin[j] = 0;
+        U16Win w;
+        unsigned int widest = 0;
+        for (int k = 0; k < 2; ++k) {
+            // one more bin on either side: the subsample's bin edges are the window's edges, and a rank may sit on one
+            const int first = (int)s_b[k][0] - 1 < 0 ? 0 : (int)s_b[k][0] - 1;
+            const int last = (int)s_b[k][1] + 1 > U16_SAMPLE_BINS - 1 ? U16_SAMPLE_BINS - 1 : (int)s_b[k][1] + 1;
+            const int nb = last - first + 1;
+            const bool ok = s_b[k][0] < (unsigned)U16_SAMPLE_BINS && nb >= 1 && nb * U16_SAMPLE_SPAN <= U16_WIN_MAX;
+            w.lo[k] = ok ? (unsigned)first * U16_SAMPLE_SPAN : 0u;
+            w.wd[k] = ok ? (unsigned)nb * U16_SAMPLE_SPAN : 0u;
+            if (test_wrong) { w.lo[k] = 0u; w.wd[k] = U16_SAMPLE_SPAN; }
+            widest = w.wd[k] > widest ? w.wd[k] : widest;
+        }
+        // both windows of a channel as wide as the wider one (the counting pass tests "inside either" with ONE compare: min of the two
+        // distances against one width); a window without a prediction keeps width 0 and the tile is flagged by the pick
         for (int k = 0; k < 2; ++k)
-            for (int d = -1; d <= 1; ++d) {
-                if ((d < 0 && !s_side[k][0]) || (d > 0 && !s_side[k][1])) continue;
-                const int b = s_t[k] + d;
-                if (b < 0 || b > 255) continue;
-                bool have = false;
-                for (int j = 0; j < out.n; ++j) have |= out.bin[j] == (unsigned char)b;
-                if (!have) out.bin[out.n++] = (unsigned char)b;
-            }
-        // ascending order: the full pass reads the list as two windows of consecutive bins
-        for (int i = 1; i < out.n; ++i)
-            for (int j = i; j > 0 && out.bin[j] < out.bin[j - 1]; --j) { const unsigned char t = out.bin[j]; out.bin[j] = out.bin[j - 1]; out.bin[j - 1] = t; }
-        cand[slot] = out;
+            if (w.wd[k]) w.wd[k] = widest;
+        win[slot] = w;
     }
 }
 
-// test hook (lars_set_tuning("u16_hist_impl", 3)): every channel's candidates = {bin 0}, so that (almost) every tile misses and
-// takes the recount
-__global__ void k_u16_spoil(U16Cand *cand, long long n)
+// key: the sample in bits 16..31.  d = key - (lo << 16); the lane's counter takes the borrow (sample < lo): v_subrev_co_u32 + v_addc_co_u32,
+// nothing for the scalar unit.  (A scalar count -- s_bcnt1_i32_b64 of the borrow mask + s_add per sample and mark, with a branch per
+// sample and mark behind it -- made the pass wait for the CU's one scalar pipe: 150 scalar instructions per wave-quad, 2.46-2.55 ms per 32
+// tiles of 8192 x 8192 against 2.66 for round 4's pass.)
+__device__ inline unsigned int u16_below(unsigned int key, unsigned int lo16, unsigned int &count)
 {
-    const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= n) return;
-    U16Cand c;
-    c.n = 1; c.pad = 0;
-    for (int j = 0; j < U16_CAND; ++j) c.bin[j] = 0;
-    cand[i] = c;
+    unsigned int d;
+    asm volatile("v_subrev_co_u32 %0, vcc, %2, %3\n\tv_addc_co_u32 %1, vcc, 0, %1, vcc" : "=&v"(d), "+v"(count) : "s"(lo16), "v"(key) : "vcc");
+    return d;
 }
 
-// ONLY_FLAGGED: the recount of the tiles whose candidates missed (low bytes only, candidates = the exact bins by then)
-template <bool ONLY_FLAGGED>
-__global__ __launch_bounds__(1024) void k_hist_u16_both(const uint16_t *__restrict__ tiles, long long npix, const U16Cand *__restrict__ cand,
-                                                        const unsigned int *__restrict__ flags, unsigned int *__restrict__ hist,
-                                                        unsigned int *__restrict__ lohist, int allow_windows)
+__global__ __launch_bounds__(1024) void k_u16_count_win(const uint16_t *__restrict__ tiles, long long npix, const U16Win *__restrict__ win,
+                                                        unsigned int *__restrict__ below_out /*[ntiles][3][2]*/,
+                                                        unsigned int *__restrict__ winhist /*[ntiles][3][2][U16_WIN_MAX]*/)
 {
-    __shared__ unsigned int s_h[ONLY_FLAGGED ? 32 : 3 * 256 * 32];       // high bytes: [channel][bin][copy = lane % 32]
-    __shared__ unsigned int s_lo[3 * U16_CAND * 256];
-    __shared__ unsigned char s_slot[3 * 256];
-    // The candidates of a channel as two windows of consecutive bins [A0, A0 + la) and [B0, B0 + lb), slots 0 .. la - 1 and la .. la + lb - 1:
-    // what k_u16_predict produces (each predicted bin and its neighbours).  A sample is then tested with two subtractions and two compares
-    // in registers instead of a byte look-up in LDS per sample (twelve random ds_read_u8 per quad were 70 % of this kernel's LDS time).
-    // s_win[c] = {A0, la, B0, lb}; s_windows = 0 if some channel's list is not of that form (the recount's exact bins need not be):
-    // then the look-up table decides, as before.
-    __shared__ unsigned int s_win[3][4];
-    __shared__ int s_windows;
+    __shared__ unsigned int s_w[3 * 2 * U16_WIN_MAX];          // 24 KiB
+    __shared__ unsigned int s_below[6];
     const int tid = threadIdx.x;
     const long long tile = blockIdx.y;
-    if (ONLY_FLAGGED && !flags[tile]) return;
-    if (!ONLY_FLAGGED)
-        for (int i = tid; i < 3 * 256 * 32; i += 1024) s_h[i] = 0;
-    for (int i = tid; i < 3 * U16_CAND * 256; i += 1024) s_lo[i] = 0;
-    if (tid < 768) s_slot[tid] = 0xFF;
-    if (tid == 0) s_windows = (ONLY_FLAGGED || !allow_windows) ? 0 : 1;
+    for (int i = tid; i < 3 * 2 * U16_WIN_MAX; i += 1024) s_w[i] = 0;
+    if (tid < 6) s_below[tid] = 0;
     __syncthreads();
-    if (tid < 3 * U16_CAND) {
-        const int c = tid / U16_CAND, j = tid % U16_CAND;
-        const U16Cand cd = cand[tile * 3 + c];
-        if (j < cd.n) s_slot[c * 256 + cd.bin[j]] = (unsigned char)j;
-        if (!ONLY_FLAGGED && j == 0) {
-            int la = 1;
-            while (la < cd.n && cd.bin[la] == cd.bin[0] + la) ++la;
-            int lb = 0;
-            while (la + lb < cd.n && (lb == 0 || cd.bin[la + lb] == cd.bin[la] + lb)) ++lb;
-            if (cd.n < 1 || la + lb != cd.n) atomicExch(&s_windows, 0);
-            s_win[c][0] = cd.n ? cd.bin[0] : 0u; s_win[c][1] = cd.n ? (unsigned)la : 0u;
-            s_win[c][2] = lb ? cd.bin[la] : 0u;  s_win[c][3] = (unsigned)lb;
-        }
+    // the windows, wave-uniform: lo << 16 per channel and mark, one width << 16 per channel (k_u16_window made a channel's two alike)
+    unsigned int lo16[3][2], wd16[3];
+#pragma unroll
+    for (int c = 0; c < 3; ++c) {
+        const U16Win w = win[tile * 3 + c];
+        lo16[c][0] = __builtin_amdgcn_readfirstlane(w.lo[0] << 16);
+        lo16[c][1] = __builtin_amdgcn_readfirstlane(w.lo[1] << 16);
+        wd16[c] = __builtin_amdgcn_readfirstlane((w.wd[0] > w.wd[1] ? w.wd[0] : w.wd[1]) << 16);          // <= 1024 << 16
     }
-    __syncthreads();
+    // a mark without a window (width 0) must not catch samples through the other mark's width
+    const bool no_win[3][2] = {{win[tile * 3].wd[0] == 0, win[tile * 3].wd[1] == 0}, {win[tile * 3 + 1].wd[0] == 0, win[tile * 3 + 1].wd[1] == 0},
+                               {win[tile * 3 + 2].wd[0] == 0, win[tile * 3 + 2].wd[1] == 0}};
+    unsigned int below[3][2] = {{0u, 0u}, {0u, 0u}, {0u, 0u}};                     // per lane
     const uint16_t *base = tiles + tile * npix * 3;
     const long long nquads = npix >> 2;
-    const unsigned int lane_off = (tid & 31) << 2;
-    char *hb = reinterpret_cast<char *>(s_h);
-#define BADD(sample, ch)                                                                               \
-    {                                                                                                  \
-        const unsigned int s_ = (sample);                                                              \
-        if (!ONLY_FLAGGED)                                                                             \
-            atomicAdd(reinterpret_cast<unsigned int *>(hb + (ch) * 32768 + ((s_ >> 8) << 7) + lane_off), 1u); \
-        const unsigned int sl_ = s_slot[(ch) * 256 + (s_ >> 8)];                                       \
-        if (sl_ != 0xFFu) atomicAdd(&s_lo[((ch) * U16_CAND + sl_) * 256 + (s_ & 0xFFu)], 1u);         \
-    }
     const long long step = (long long)gridDim.x * 1024;
+    auto one_sample = [&](unsigned int key, int ch) {
+        const unsigned int d0 = u16_below(key, lo16[ch][0], below[ch][0]);
+        const unsigned int d1 = u16_below(key, lo16[ch][1], below[ch][1]);
+        if (min(d0, d1) < wd16[ch]) {                                              // inside either window: about one sample in a thousand
+            if (d0 < wd16[ch] && !no_win[ch][0]) atomicAdd(&s_w[(ch * 2 + 0) * U16_WIN_MAX + (d0 >> 16)], 1u);
+            if (d1 < wd16[ch] && !no_win[ch][1]) atomicAdd(&s_w[(ch * 2 + 1) * U16_WIN_MAX + (d1 >> 16)], 1u);
+        }
+    };
     if (nquads > 0) {
         const __amdgpu_buffer_rsrc_t rsrc =
             __builtin_amdgcn_make_buffer_rsrc(const_cast<uint16_t *>(base), 0, (int)(nquads * 24), 0x00020000);
-        // U16_DEPTH quads of every lane in flight: with one, a CU's 16 waves keep 24 KB on the way, which bounds the pass
-        // at about half of what HBM delivers.  Offsets past the tile (the ring's last turns) read as zero and are not counted.
         u32x4v ra[U16_DEPTH];
         u32x2v rb[U16_DEPTH];
-        // the windows, wave-uniform (scalar registers)
-        const bool use_windows = !ONLY_FLAGGED && __builtin_amdgcn_readfirstlane(s_windows) != 0;
-        unsigned int wA0[3], wla[3], wB0[3], wlb[3];
-#pragma unroll
-        for (int c = 0; c < 3; ++c) {
-            wA0[c] = __builtin_amdgcn_readfirstlane(s_win[c][0]); wla[c] = __builtin_amdgcn_readfirstlane(s_win[c][1]);
-            wB0[c] = __builtin_amdgcn_readfirstlane(s_win[c][2]); wlb[c] = __builtin_amdgcn_readfirstlane(s_win[c][3]);
-        }
         long long q = (long long)blockIdx.x * 1024 + tid;
 #pragma unroll
         for (int d = 0; d < U16_DEPTH; ++d) {
@@ -359,112 +399,112 @@ __global__ __launch_bounds__(1024) void k_hist_u16_both(const uint16_t *__restri
                 const u32x4v a = ra[d];
                 const u32x2v b = rb[d];
                 const unsigned int off = (unsigned int)(qq + U16_DEPTH * step) * 24u;
-                ra[d] = __builtin_amdgcn_raw_buffer_load_b128(rsrc, off, 0, 0);
+                ra[d] = __builtin_amdgcn_raw_buffer_load_b128(rsrc, off, 0, 0);      // past the tile: zeros, never counted
                 rb[d] = __builtin_amdgcn_raw_buffer_load_b64(rsrc, off + 16u, 0, 0);
-                if (qq < nquads && use_windows) {
+                if (qq < nquads) {
                     const unsigned int w[6] = {a.x, a.y, a.z, a.w, b.x, b.y};
 #pragma unroll
-                    for (int i = 0; i < 12; ++i) {
-                        const int ch = i % 3;
-                        const unsigned int hi = (w[i >> 1] >> ((i & 1) * 16 + 8)) & 0xFFu;
-                        atomicAdd(reinterpret_cast<unsigned int *>(hb + ch * 32768 + (hi << 7) + lane_off), 1u);
-                        const unsigned int ra = hi - wA0[ch], rb = hi - wB0[ch];
-                        if ((ra < wla[ch]) | (rb < wlb[ch])) {
-                            const unsigned int slot = ra < wla[ch] ? ra : wla[ch] + rb;
-                            atomicAdd(&s_lo[(ch * U16_CAND + slot) * 256 + ((w[i >> 1] >> ((i & 1) * 16)) & 0xFFu)], 1u);
-                        }
-                    }
-                } else if (qq < nquads) {
-                    // all twelve slot look-ups first, then the twelve counts, then the (rare) candidates: one LDS round trip
-                    // per quad instead of one per sample
-                    const unsigned int w[6] = {a.x, a.y, a.z, a.w, b.x, b.y};
-                    unsigned int sl[12];
-#pragma unroll
-                    for (int i = 0; i < 12; ++i)
-                        sl[i] = s_slot[(i % 3) * 256 + ((w[i >> 1] >> ((i & 1) * 16 + 8)) & 0xFFu)];
-                    if (!ONLY_FLAGGED) {
-#pragma unroll
-                        for (int i = 0; i < 12; ++i)
-                            atomicAdd(reinterpret_cast<unsigned int *>(hb + (i % 3) * 32768 + (((w[i >> 1] >> ((i & 1) * 16 + 8)) & 0xFFu) << 7) + lane_off), 1u);
-                    }
-#pragma unroll
-                    for (int i = 0; i < 12; ++i)
-                        if (sl[i] != 0xFFu)
-                            atomicAdd(&s_lo[((i % 3) * U16_CAND + sl[i]) * 256 + ((w[i >> 1] >> ((i & 1) * 16)) & 0xFFu)], 1u);
+                    for (int i = 0; i < 12; ++i) one_sample((i & 1) ? w[i >> 1] : (w[i >> 1] << 16), i % 3);
                 }
             }
         }
     }
     if (blockIdx.x == 0 && tid < (int)(npix & 3)) {
         const uint16_t *p = base + (nquads * 4 + tid) * 3;
-        BADD((unsigned)p[0], 0) BADD((unsigned)p[1], 1) BADD((unsigned)p[2], 2)
+        for (int ch = 0; ch < 3; ++ch) one_sample((unsigned int)p[ch] << 16, ch);
     }
-#undef BADD
+    // the lanes' six counts -> the wave's (shuffles) -> the block's -> the tile's
+#pragma unroll
+    for (int c = 0; c < 3; ++c)
+#pragma unroll
+        for (int m = 0; m < 2; ++m) {
+            unsigned int v = below[c][m];
+            for (int off = 32; off >= 1; off >>= 1) v += __shfl_xor(v, off);
+            if ((tid & 63) == 0 && v) atomicAdd(&s_below[c * 2 + m], v);
+        }
     __syncthreads();
-    if (!ONLY_FLAGGED && tid < 768) {
-        const unsigned int *row = s_h + tid * 32;
-        unsigned int v = 0;
-        for (int j = 0; j < 32; ++j) v += row[(j + tid) & 31];
-        if (v) atomicAdd(&hist[tile * 768 + tid], v);
-    }
-    unsigned int *g = lohist + tile * (3 * U16_CAND * 256);
-    for (int i = tid; i < 3 * U16_CAND * 256; i += 1024)
-        if (s_lo[i]) atomicAdd(&g[i], s_lo[i]);
+    if (tid < 6 && s_below[tid]) atomicAdd(&below_out[tile * 6 + tid], s_below[tid]);
+    unsigned int *g = winhist + tile * (3 * 2 * U16_WIN_MAX);
+    for (int i = tid; i < 3 * 2 * U16_WIN_MAX; i += 1024)
+        if (s_w[i]) atomicAdd(&g[i], s_w[i]);
 }
 
-// After the exact pick: point each rank at its candidate's low-byte histogram; a tile with a rank outside its candidates is
-// flagged, gets the exact bins as its candidates and its low-byte histograms zeroed (the recount follows).  One block per tile.
-__global__ __launch_bounds__(256) void k_u16_resolve(U16Pick *__restrict__ picks, U16Cand *__restrict__ cand, unsigned int *__restrict__ lohist,
-                                                     unsigned int *__restrict__ flags)
+// ranks -> values -> percentiles -> table, or the tile's flag.  One block per (channel, tile); a flagged tile keeps whatever the other
+// channels wrote: the classic passes overwrite all three.
+__global__ __launch_bounds__(256) void k_u16_pick_win(const U16Win *__restrict__ win, const unsigned int *__restrict__ below_in,
+                                                      const unsigned int *__restrict__ winhist, long long npix, unsigned int *__restrict__ flags,
+                                                      uint8_t *__restrict__ blobs, double *__restrict__ pcts, int rgn_variant)
 {
-    __shared__ int s_miss;
+    __shared__ unsigned long long s_scan[256];
+    __shared__ double s_val[4];
+    __shared__ int s_found[4];
+    __shared__ double s_p[2];
+    __shared__ unsigned int s_thr[260];
     const int tid = threadIdx.x;
-    const long long tile = blockIdx.x;
-    if (tid == 0) s_miss = 0;
+    const int c = blockIdx.x;
+    const long long tile = blockIdx.y;
+    const long long slot = tile * 3 + c;
+    const U16Win w = win[slot];
+    if (tid < 4) s_found[tid] = 0;
     __syncthreads();
-    if (tid < 3) {
-        U16Pick p = picks[tile * 3 + tid];
-        const U16Cand cd = cand[tile * 3 + tid];
-        bool miss = false;
-        for (int r = 0; r < 4; ++r) {
-            int j = 0;
-            for (; j < cd.n; ++j)
-                if (cd.bin[j] == p.target[r]) break;
-            if (j == cd.n) miss = true;
-            p.slot[r] = (unsigned)j;
+    const double nm1 = (double)(npix - 1);
+    double tq[2];
+    for (int k = 0; k < 2; ++k) {
+        const double q = (k == 0 ? 2.0 : 98.0) / 100.0;
+        const double vi = nm1 * q;
+        const double fl = floor(vi);
+        tq[k] = vi - fl;
+        long long lo = (long long)fl, hi = lo + 1;
+        if (hi > npix - 1) hi = npix - 1;
+        const unsigned long long below = below_in[tile * 6 + c * 2 + k];
+        const unsigned int *h = winhist + ((tile * 3 + c) * 2 + k) * U16_WIN_MAX;
+        unsigned int mine[4];
+        unsigned long long local = 0;
+        for (int j = 0; j < 4; ++j) { mine[j] = h[tid * 4 + j]; local += mine[j]; }
+        __syncthreads();
+        s_scan[tid] = local;
+        __syncthreads();
+        for (int off = 1; off < 256; off <<= 1) {
+            unsigned long long v = (tid >= off) ? s_scan[tid - off] : 0;
+            __syncthreads();
+            s_scan[tid] += v;
+            __syncthreads();
         }
-        if (miss) atomicExch(&s_miss, 1);
-        else picks[tile * 3 + tid] = p;
+        const unsigned long long before = below + s_scan[tid] - local;
+        const long long rank[2] = {lo, hi};
+        for (int j2 = 0; j2 < 2; ++j2) {
+            const unsigned long long r = (unsigned long long)rank[j2];
+            if (local && r >= before && r < before + local) {
+                unsigned long long cum = before;
+                for (int j = 0; j < 4; ++j) {
+                    if (r >= cum && r < cum + mine[j]) { s_val[2 * k + j2] = (double)(w.lo[k] + (unsigned)(tid * 4 + j)); s_found[2 * k + j2] = 1; }
+                    cum += mine[j];
+                }
+            }
+        }
     }
     __syncthreads();
-    if (!s_miss) {
-        if (tid == 0) flags[tile] = 0;
+    if (!(s_found[0] && s_found[1] && s_found[2] && s_found[3])) {
+        if (tid == 0) flags[tile] = 1u;                    // a rank outside its window (or no window): the classic passes take this tile
         return;
     }
-    if (tid < 3) {
-        U16Pick p = picks[tile * 3 + tid];
-        U16Cand cd;
-        cd.n = 0; cd.pad = 0;
-        for (int j = 0; j < U16_CAND; ++j) cd.bin[j] = 0;
-        for (int r = 0; r < 4; ++r) {
-            int j = 0;
-            for (; j < cd.n; ++j)
-                if (cd.bin[j] == p.target[r]) break;
-            if (j == cd.n) cd.bin[cd.n++] = (unsigned char)p.target[r];
-            p.slot[r] = (unsigned)j;
-        }
-        cand[tile * 3 + tid] = cd;
-        picks[tile * 3 + tid] = p;
+    if (tid < 2) {
+        const double a = s_val[2 * tid], b = s_val[2 * tid + 1], t = tq[tid];
+        const double d = b - a;
+        double r = a + d * t;
+        if (t >= 0.5) r = b - d * (1.0 - t);
+        s_p[tid] = r;
+        if (pcts) pcts[slot * 2 + tid] = r;
     }
-    unsigned int *g = lohist + tile * (3 * U16_CAND * 256);
-    for (int i = tid; i < 3 * U16_CAND * 256; i += 256) g[i] = 0;
-    if (tid == 0) flags[tile] = 1;
+    __syncthreads();
+    u16_fill_blob(blobs + tile * LARS_U16_BLOB_BYTES, c, s_p[0], s_p[1], rgn_variant, s_thr, tid);
 }
 
 // ---- table: order statistics -> percentiles -> 65536-entry table + thresholds ----------------
-// nslots: low-byte histograms per channel in lohist (4: the classic second pass, U16_CAND: the candidate layout)
+// nslots: low-byte histograms per channel in lohist (4: one per order statistic; ranks that share a high byte share a slot)
 __global__ __launch_bounds__(256) void k_wb_table_u16(const unsigned int *__restrict__ lohist, const U16Pick *__restrict__ picks,
-                                                      uint8_t *__restrict__ blobs, double *__restrict__ pcts, int rgn_variant, int nslots)
+                                                      uint8_t *__restrict__ blobs, double *__restrict__ pcts, int rgn_variant, int nslots,
+                                                      const unsigned int *__restrict__ only = nullptr)
 {
     __shared__ unsigned long long s_scan[256];
     __shared__ double s_val[4];
@@ -473,6 +513,7 @@ __global__ __launch_bounds__(256) void k_wb_table_u16(const unsigned int *__rest
     const int tid = threadIdx.x;
     const int c = blockIdx.x;
     const long long tile = blockIdx.y;
+    if (only && !only[tile]) return;
     const long long slot = tile * 3 + c;
     const U16Pick pk = picks[slot];
 
@@ -531,18 +572,21 @@ extern "C" int lars_d_wb_prepare(const void *tiles, int64_t ntiles, int64_t npix
     }
     if (dtype != LARS_U16) return fail(LARS_ERR_INVALID, "lars_d_wb_prepare: dtype");
     const size_t hi_bytes = (size_t)ntiles * 768 * 4, pick_bytes = (size_t)ntiles * 3 * sizeof(U16Pick),
-                 lo_bytes = (size_t)ntiles * 3 * U16_CAND * 256 * 4, cand_bytes = (size_t)ntiles * 3 * sizeof(U16Cand),
-                 flag_bytes = (size_t)ntiles * 4;
+                 lo_bytes = (size_t)ntiles * 3 * 4 * 256 * 4,
+                 flag_bytes = (size_t)ntiles * 4, s12_bytes = (size_t)ntiles * 3 * U16_SAMPLE_BINS * 4,
+                 below_bytes = (size_t)ntiles * 6 * 4, wh_bytes = (size_t)ntiles * 3 * 2 * U16_WIN_MAX * 4, win_bytes = (size_t)ntiles * 3 * sizeof(U16Win);
     auto up = [](size_t b) { return (b + 255) & ~(size_t)255; };
-    LARS_TRY(scratch_reserve(c, 2 * up(hi_bytes) + up(pick_bytes) + up(lo_bytes) + up(cand_bytes) + up(flag_bytes) + 512));
+    LARS_TRY(scratch_reserve(c, up(hi_bytes) + up(pick_bytes) + up(lo_bytes) + up(flag_bytes) + up(s12_bytes) + up(below_bytes) +
+                                    up(wh_bytes) + up(win_bytes) + 512));
     char *p = static_cast<char *>(c->scratch);
     unsigned int *hi = reinterpret_cast<unsigned int *>(p);                  p += up(hi_bytes);
-    unsigned int *hi_sample = reinterpret_cast<unsigned int *>(p);           p += up(hi_bytes);
     unsigned int *lo = reinterpret_cast<unsigned int *>(p);                  p += up(lo_bytes);
     unsigned int *flags = reinterpret_cast<unsigned int *>(p);               p += up(flag_bytes);
+    unsigned int *s12 = reinterpret_cast<unsigned int *>(p);                 p += up(s12_bytes);
+    unsigned int *below = reinterpret_cast<unsigned int *>(p);               p += up(below_bytes);
+    unsigned int *winhist = reinterpret_cast<unsigned int *>(p);             p += up(wh_bytes);
     U16Pick *picks = reinterpret_cast<U16Pick *>(p);                         p += up(pick_bytes);
-    U16Cand *cand = reinterpret_cast<U16Cand *>(p);
-    LARS_HIP_TRY(hipMemsetAsync(hi, 0, 2 * up(hi_bytes) + up(lo_bytes) + up(flag_bytes), s));     // hi, hi_sample, lo, flags are contiguous
+    U16Win *win = reinterpret_cast<U16Win *>(p);
     const uint16_t *t16 = static_cast<const uint16_t *>(tiles);
     const bool fast = channels == 3 && (ntiles == 1 || (npix & 3) == 0) && ((reinterpret_cast<uintptr_t>(tiles) & 3) == 0) &&
                       (long long)npix * 6 < (1ll << 30);
@@ -552,26 +596,27 @@ extern "C" int lars_d_wb_prepare(const void *tiles, int64_t ntiles, int64_t npix
     if (want < 1) want = 1;
     dim3 grid((unsigned)want, (unsigned)ntiles);
     const dim3 per_channel(3, (unsigned)ntiles);
-    if (fast && tuning().u16_hist_impl != 1 && cap >= 64) {
-        // ONE full pass: candidates from a 1/16 subsample, then high bytes + low bytes of the candidate bins together; the exact
-        // pick decides which tiles (if any) need the classic recount
-        hipLaunchKernelGGL(k_hist_u16_hi, grid, dim3(1024), 0, s, t16, (long long)npix, hi_sample, 16);
-        hipLaunchKernelGGL(k_u16_predict, per_channel, dim3(256), 0, s, hi_sample, cand);
-        if (tuning().u16_hist_impl == 3)
-            hipLaunchKernelGGL(k_u16_spoil, dim3((unsigned)((ntiles * 3 + 255) / 256)), dim3(256), 0, s, cand, (long long)ntiles * 3);
-        // u16_hist_impl 4: the same pass with a slot look-up in LDS per sample instead of the window tests in registers (round 3's form)
-        hipLaunchKernelGGL((k_hist_u16_both<false>), grid, dim3(1024), 0, s, t16, (long long)npix, cand, flags, hi, lo, tuning().u16_hist_impl == 4 ? 0 : 1);
-        hipLaunchKernelGGL(k_u16_pick, per_channel, dim3(256), 0, s, hi, (long long)npix, picks);
-        hipLaunchKernelGGL(k_u16_resolve, dim3((unsigned)ntiles), dim3(256), 0, s, picks, cand, lo, flags);
-        hipLaunchKernelGGL((k_hist_u16_both<true>), grid, dim3(1024), 0, s, t16, (long long)npix, cand, flags, hi, lo, 0);
-        hipLaunchKernelGGL(k_wb_table_u16, per_channel, dim3(256), 0, s, lo, picks, table, percentiles, rgn_variant, U16_CAND);
-        return launch_check("lars_d_wb_prepare (one pass)");
+    const int impl = tuning().u16_hist_impl;
+    if (fast && cap >= 64 && impl != 1) {
+        // ONE full pass on value windows (round 5): per channel and mark the count of the samples below a predicted window and the histogram
+        // inside it; a rank outside its window flags the tile, and only flagged tiles take the two classic passes (all of them with impl 3)
+        LARS_HIP_TRY(hipMemsetAsync(hi, 0, up(hi_bytes) + up(lo_bytes) + up(flag_bytes) + up(s12_bytes) + up(below_bytes) + up(wh_bytes), s));
+        hipLaunchKernelGGL(k_u16_sample12, grid, dim3(1024), 0, s, t16, (long long)npix, s12, 64);     // 1 / 64 of the samples: 1 M per 8192 x 8192 tile and channel
+        hipLaunchKernelGGL(k_u16_window, per_channel, dim3(256), 0, s, s12, win, impl == 3 ? 1 : 0);
+        hipLaunchKernelGGL(k_u16_count_win, grid, dim3(1024), 0, s, t16, (long long)npix, win, below, winhist);
+        hipLaunchKernelGGL(k_u16_pick_win, per_channel, dim3(256), 0, s, win, below, winhist, (long long)npix, flags, table, percentiles, rgn_variant);
+        hipLaunchKernelGGL(k_hist_u16_hi, grid, dim3(1024), 0, s, t16, (long long)npix, hi, 1, flags);
+        hipLaunchKernelGGL(k_u16_pick, per_channel, dim3(256), 0, s, hi, (long long)npix, picks, flags);
+        hipLaunchKernelGGL((k_hist_u16_lo<true>), grid, dim3(1024), 0, s, t16, (long long)npix, channels, picks, lo, flags);
+        hipLaunchKernelGGL(k_wb_table_u16, per_channel, dim3(256), 0, s, lo, picks, table, percentiles, rgn_variant, 4, flags);
+        return launch_check("lars_d_wb_prepare (value windows)");
     }
-    if (fast) hipLaunchKernelGGL(k_hist_u16_hi, grid, dim3(1024), 0, s, t16, (long long)npix, hi, 1);
+    LARS_HIP_TRY(hipMemsetAsync(hi, 0, up(hi_bytes) + up(lo_bytes) + up(flag_bytes), s));     // hi, lo, flags are contiguous
+    if (fast) hipLaunchKernelGGL(k_hist_u16_hi, grid, dim3(1024), 0, s, t16, (long long)npix, hi, 1, (const unsigned int *)nullptr);
     else hipLaunchKernelGGL(k_hist_u16_hi_generic, dim3((unsigned)want * 4, (unsigned)ntiles), dim3(256), 0, s, t16, (long long)npix, channels, hi);
-    hipLaunchKernelGGL(k_u16_pick, per_channel, dim3(256), 0, s, hi, (long long)npix, picks);
-    if (fast) hipLaunchKernelGGL((k_hist_u16_lo<true>), grid, dim3(1024), 0, s, t16, (long long)npix, channels, picks, lo);
-    else hipLaunchKernelGGL((k_hist_u16_lo<false>), grid, dim3(1024), 0, s, t16, (long long)npix, channels, picks, lo);
-    hipLaunchKernelGGL(k_wb_table_u16, per_channel, dim3(256), 0, s, lo, picks, table, percentiles, rgn_variant, 4);
+    hipLaunchKernelGGL(k_u16_pick, per_channel, dim3(256), 0, s, hi, (long long)npix, picks, (const unsigned int *)nullptr);
+    if (fast) hipLaunchKernelGGL((k_hist_u16_lo<true>), grid, dim3(1024), 0, s, t16, (long long)npix, channels, picks, lo, (const unsigned int *)nullptr);
+    else hipLaunchKernelGGL((k_hist_u16_lo<false>), grid, dim3(1024), 0, s, t16, (long long)npix, channels, picks, lo, (const unsigned int *)nullptr);
+    hipLaunchKernelGGL(k_wb_table_u16, per_channel, dim3(256), 0, s, lo, picks, table, percentiles, rgn_variant, 4, (const unsigned int *)nullptr);
     return launch_check("lars_d_wb_prepare");
 }

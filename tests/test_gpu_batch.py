@@ -347,10 +347,9 @@ def test_uint16_batch_against_oracle(lars, kind):
 
 
 def test_uint16_percentiles_one_pass_and_its_recount(lars):
-    """lars_d_wb_prepare for uint16 tiles: candidate high-byte bins predicted from a subsample, one full pass counting high bytes
-    and the candidates' low bytes, exact pick, recount only where a candidate set missed -- against the two radix passes and
-    np.percentile; with wrong candidates on purpose every tile takes the recount.  Heavy-tailed, constant and few-level
-    channels included."""
+    """lars_d_wb_prepare for uint16 tiles: ONE full pass on value windows predicted from a subsample (the count of the samples below
+    each window and the histogram inside it), the two radix passes, and np.percentile; with windows that miss on purpose every tile
+    takes the two passes after the one.  Heavy-tailed, constant and few-level channels included, and marks next to a bin boundary."""
     from lars_image_processing_amd import _ffi
     rng = np.random.default_rng(21)
     h, w = 512, 768
@@ -363,20 +362,23 @@ def test_uint16_percentiles_one_pass_and_its_recount(lars):
         (rng.integers(0, 4, (h, w, 3)) * 21845).astype(np.uint16),
         np.clip(rng.normal(255.6 * 50, 40, (h, w, 3)), 0, 65535).astype(np.uint16),      # the marks sit next to a bin boundary
         ramp,
+        (rng.integers(0, 4096, (h, w, 3)) * 16).astype(np.uint16),                         # 12-bit samples in the high bits
+        np.clip(rng.normal(800, 300, (h, w, 3)), 0, 4095).astype(np.uint16),                # 12-bit samples in the low bits, clipped at 0
+        np.where(rng.random((h, w, 3)) < 0.5, rng.integers(0, 65536, (h, w, 3)), 30000).astype(np.uint16),   # half the samples on one value
     ])
     b = lars.TileBatch.from_host(tiles)
     b.compute_wb_tables()                                            # allocates the blobs (their padding is never written)
     got = {}
     try:
-        for impl in (2, 1, 3):
+        for impl in (5, 1, 3):
             _ffi.set_tuning(u16_hist_impl=impl)
             b.table.zero(); b.percentiles.zero()
             b.compute_wb_tables()
             _ffi.call("lars_synchronize", None)
             got[impl] = (b.host_percentiles().tobytes(), b.table.download(np.uint8, (b.ntiles, b.table_bytes)).tobytes())
     finally:
-        _ffi.set_tuning(u16_hist_impl=2)
-    assert got[1] == got[2] == got[3]
+        _ffi.set_tuning(u16_hist_impl=5)
+    assert got[1] == got[3] == got[5]
     pcts = b.host_percentiles()
     for i in range(len(tiles)):
         for c in range(3):

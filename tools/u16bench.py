@@ -23,13 +23,15 @@ def main():
         return float(np.median(ts[1:]))
     npix = tiles * edge * edge
     res = {}
-    for impl, name in ((2, "wb_prepare (one full pass: candidate bins from a subsample)"), (4, "wb_prepare (one full pass, slot look-ups in LDS: round 3)"),
+    for impl, name in ((5, "wb_prepare (one full pass on VALUE windows: counts below + histograms inside; round 5)"),
                        (1, "wb_prepare (2 radix passes + tables)"),
-                       (3, "wb_prepare (wrong candidates on purpose: full pass + recount)")):
+                       (3, "wb_prepare (windows that miss on purpose: full pass + the two radix passes)"),
+                       (50, "wb_prepare (value windows once more)")):
+        impl = 5 if impl == 50 else impl
         _ffi.set_tuning(u16_hist_impl=impl)
         t = timed(lambda: b.compute_wb_tables())
         res[name] = {"ms": t, "GBs_input_once": npix * 6 / t / 1e6, "frac_8TBs": npix * 6 / t / 1e6 / 8000}
-    _ffi.set_tuning(u16_hist_impl=2)
+    _ffi.set_tuning(u16_hist_impl=5)
     stats = b.new_stats()
     outs = b.make_outputs(indices=("NDVI",), index=True, rgba=True)
     for name, kw, bpp in (("ndvi_f32+rgba+stats (configs[4])", dict(indices=("NDVI",), outputs=outs), 14),
@@ -38,7 +40,7 @@ def main():
         t = timed(lambda: b.run_fused(b.fused_args(kw["indices"], True, stats, False, kw["outputs"])))
         res[name] = {"ms": t, "GBs": npix * bpp / t / 1e6, "frac_8TBs": npix * bpp / t / 1e6 / 8000, "Gpix_s": npix / t / 1e6}
     for k, v in res.items():
-        print(f"{k:66s} " + "  ".join(f"{kk}={vv:9.3f}" for kk, vv in v.items()))
+        print(f"{k:96s} " + "  ".join(f"{kk}={vv:9.3f}" for kk, vv in v.items()))
     print(json.dumps(res))
 
 if __name__ == "__main__":

@@ -237,20 +237,27 @@ __global__ __launch_bounds__(1024) void k_u16_sample12(const uint16_t *__restric
     const uint16_t *base = tiles + tile * npix * 3;
     const long long nquads = npix >> 2;
 #define SADD(word, half, ch) atomicAdd(&s_h[(ch) * U16_SAMPLE_BINS + (((word) >> ((half) * 16 + 4)) & 0xFFFu)], 1u)
-    const long long step = (long long)gridDim.x * 1024 * every;
     if (nquads > 0) {
         const __amdgpu_buffer_rsrc_t rsrc =
             __builtin_amdgcn_make_buffer_rsrc(const_cast<uint16_t *>(base), 0, (int)(nquads * 24), 0x00020000);
-        // two quads of every lane in flight (quads past the tile read as zero and are skipped)
-        for (long long q = (long long)blockIdx.x * 1024 + tid; q < nquads; q += 2 * step) {
-            const unsigned int off = (unsigned int)q * 24u, off2 = (unsigned int)(q + step) * 24u;
+        // Every `every`-th stretch of 1024 quads of the tile is sampled, whatever the grid: workgroup b takes the sampled stretches b,
+        // b + gridDim.x, ... (two in flight per lane; quads past the tile read as zero and are skipped).  A stride that depended on the
+        // grid would sample only the head of a tile that has many workgroups to itself.
+        const long long nstretch = (nquads + 1023) >> 10;
+        const long long nsampled = (nstretch + every - 1) / every;
+        for (long long sidx = blockIdx.x; sidx < nsampled; sidx += 2 * (long long)gridDim.x) {
+            const long long q = sidx * every * 1024 + tid, q2 = (sidx + gridDim.x) * every * 1024 + tid;
+            const unsigned int off = (unsigned int)q * 24u, off2 = (unsigned int)q2 * 24u;
+            const bool second = sidx + gridDim.x < nsampled;
             const u32x4v a = __builtin_amdgcn_raw_buffer_load_b128(rsrc, off, 0, 0);
             const u32x2v b = __builtin_amdgcn_raw_buffer_load_b64(rsrc, off + 16u, 0, 0);
-            const u32x4v a2 = __builtin_amdgcn_raw_buffer_load_b128(rsrc, off2, 0, 0);
-            const u32x2v b2 = __builtin_amdgcn_raw_buffer_load_b64(rsrc, off2 + 16u, 0, 0);
-            SADD(a.x, 0, 0); SADD(a.x, 1, 1); SADD(a.y, 0, 2); SADD(a.y, 1, 0); SADD(a.z, 0, 1); SADD(a.z, 1, 2);
-            SADD(a.w, 0, 0); SADD(a.w, 1, 1); SADD(b.x, 0, 2); SADD(b.x, 1, 0); SADD(b.y, 0, 1); SADD(b.y, 1, 2);
-            if (q + step < nquads) {
+            const u32x4v a2 = __builtin_amdgcn_raw_buffer_load_b128(rsrc, second ? off2 : off, 0, 0);
+            const u32x2v b2 = __builtin_amdgcn_raw_buffer_load_b64(rsrc, (second ? off2 : off) + 16u, 0, 0);
+            if (q < nquads) {
+                SADD(a.x, 0, 0); SADD(a.x, 1, 1); SADD(a.y, 0, 2); SADD(a.y, 1, 0); SADD(a.z, 0, 1); SADD(a.z, 1, 2);
+                SADD(a.w, 0, 0); SADD(a.w, 1, 1); SADD(b.x, 0, 2); SADD(b.x, 1, 0); SADD(b.y, 0, 1); SADD(b.y, 1, 2);
+            }
+            if (second && q2 < nquads) {
                 SADD(a2.x, 0, 0); SADD(a2.x, 1, 1); SADD(a2.y, 0, 2); SADD(a2.y, 1, 0); SADD(a2.z, 0, 1); SADD(a2.z, 1, 2);
                 SADD(a2.w, 0, 0); SADD(a2.w, 1, 1); SADD(b2.x, 0, 2); SADD(b2.x, 1, 0); SADD(b2.y, 0, 1); SADD(b2.y, 1, 2);
             }

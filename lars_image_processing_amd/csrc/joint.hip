@@ -29,6 +29,13 @@
 // 25 DIFFERENT banks (and dwords), as do common shifts of both samples (shading: +6 per level) and shifts of one sample alone.
 // Round 3's n ^ 2x put such a neighbourhood into about six banks (tools/lab/banksim.py: 10-12 lanes on the fullest bank against
 // 5.4 for independent samples; the linear form: 5.5-5.7).
+//
+// Since round 5 this file is one of two counting kernels.  With both value streams, white balance and no channel histograms wanted,
+// lars_d_stats_joint first asks k_joint_predict (joint_win.hip) for windows on red and green; tiles whose windows fit are counted by
+// k_joint_count_win -- both tables in ONE workgroup, one reader per byte -- and published in this file's layout; everything else
+// (one value stream, windows that do not fit, channel histograms, and the recount of a tile whose window missed) is counted here.
+// k_joint_finish serves both: it walks only the blocks of 8 table rows the counting kernels report as occupied, and for windowed
+// counts it checks that np.percentile's order statistics fell strictly inside the window before it writes a record.
 #include <vector>
 
 #include "joint_device.h"

@@ -46,8 +46,9 @@ template <int CH>
 __global__ __launch_bounds__(JH_THREADS) void k_joint_predict(JointPredictParams P)
 {
     // red and green histograms of the sample in 16 copies: lane l adds to copy l & 15 -- at most two lanes of a half-wave on one word, whatever
-    // the image (a smooth one puts all 64 lanes into two or three bins), and 32 KiB per workgroup: four workgroups share a CU, so that the
-    // 1024 workgroups of a 1024-tile batch are resident at once and wait for their loads together (110 -> 60 us; 32 copies: two per CU)
+    // the image (a smooth one puts all 64 lanes into two or three bins); 32 KiB per workgroup, so that four workgroups share a CU and the
+    // 1024 workgroups of a 1024-tile batch are resident at once (32 copies, two workgroups per CU, measured the same: the pass is bound by
+    // its scattered reads)
     __shared__ unsigned int s_h[2 * 256 * 16];                 // 32 KiB: [channel][bin][copy]
     const int tid = threadIdx.x;
     const long long tile = blockIdx.x;
@@ -244,7 +245,7 @@ __global__ __launch_bounds__(JH_THREADS, 4) void k_joint_count_win(JointCountPar
     unsigned int two = 2u;
     asm volatile("" : "+v"(two));                                                  // a VGPR that holds 2 (SDWA takes no constants)
     // Two pixels at a time, one in each 16-bit half; xf / xs: the samples paired with NIR in the lane's first and second table.
-    // mul = 1 but for flat areas, where one lane adds the whole wave's count.
+    // mul = 1 but in runs of equal quads, where the lane that starts a run adds the run's length.
     auto count_pair = [&](unsigned int nn, unsigned int xf, unsigned int xs, unsigned int mul) {
         const unsigned int t = nn & 0x007F007Fu, u = nn & 0x00800080u;
         unsigned int v0 = jw_val0(u);                                               // 1 | h << 16 of the low pixel

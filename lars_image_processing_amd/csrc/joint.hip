@@ -229,13 +229,16 @@ __global__ __launch_bounds__(JH_THREADS, 4) void k_joint_count(JointCountParams 
     }
     const unsigned int nlist = s_nlist < JH_LIST_CAP ? s_nlist : JH_LIST_CAP;
     if (nlist) {
-        __threadfence();
+        // the stores above have to be in the L2 before the adds to the same words: the barrier's own workgroup-scope release (stores
+        // acknowledged) orders them, and the adds are workgroup-scope too -- every access stays in this XCD's L2.  (A device-scope
+        // __threadfence here writes the XCD's L2 back for every workgroup that has a list: + 40 % on the launch of any batch whose
+        // chunks hold a cell of 16384 pixels: profiles/r05_joint_publish_fence.txt.)
         __syncthreads();
         for (unsigned int e = tid; e < nlist; e += JH_THREADS) {
             const uint2 m = s_list[e];
             const unsigned int hi = m.y >> 16, lo = (m.y & 0xFFFFu) - hi;
-            if (lo) atomicAdd(&out[2 * (long long)m.x], lo);
-            if (hi) atomicAdd(&out[2 * (long long)m.x + 1], hi);
+            if (lo) jh_publish_add(&out[2 * (long long)m.x], lo);
+            if (hi) jh_publish_add(&out[2 * (long long)m.x + 1], hi);
             atomicMin(&s_jlo, m.x >> 10);
             atomicMax(&s_jhi, (m.x >> 10) + 1u);
         }

@@ -39,6 +39,13 @@ __device__ inline void jh_add(unsigned int addr, unsigned int val, char *tab)
     __hip_atomic_fetch_add(reinterpret_cast<unsigned int *>(tab + addr), val, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
 }
 
+// The hand-over of a moved dword at publish time: an add to a word of the workgroup's OWN published table, after a barrier behind the
+// stores that wrote it.  Workgroup scope: stores and adds meet in this XCD's L2; the next kernel sees them through the launch boundary.
+__device__ inline void jh_publish_add(unsigned int *word, unsigned int val)
+{
+    __hip_atomic_fetch_add(word, val, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+}
+
 // nn + 5 px in one full-rate instruction (px < 2^24; the compiler's own choice for * 5 + is the quarter-rate v_mad_u64_u32)
 __device__ inline unsigned int jh_mad5(unsigned int px, unsigned int nn)
 {

@@ -106,7 +106,7 @@ __global__ __launch_bounds__(JH_THREADS) void k_joint_predict(JointPredictParams
     __syncthreads();
     // totals of the 16 copies, their running sums (wave scans + one barrier), and the two order statistics that bound the window
     __shared__ unsigned int s_wsum[2][4];
-    __shared__ unsigned int s_lo[2], s_hi[2];
+    __shared__ unsigned int s_lo[2][2], s_hi[2][2];          // [margin][channel]
     unsigned int tot = 0, inc = 0;
     if (tid < 512) {
 #pragma unroll 8
@@ -126,28 +126,33 @@ __global__ __launch_bounds__(JH_THREADS) void k_joint_predict(JointPredictParams
         // observation, so the sample is worth its 1024 segments -- a value that truly holds 2 % of the tile below it shows fewer
         // than 0.5 % of the sample there about once in 10^5 tiles even then.  (0.4 % of margin, enough for independent pixels,
         // missed on 19 % of the tiles of tools/jointbench.py's smooth content: profiles/r05_joint_window_first.txt.)
+        // A second, tight pair of windows (1.5 % and 98.5 %) is for the tiles whose safe windows do not fit: a photograph with 1 % of
+        // overexposed pixels has its 99.5 % order statistic at 255 and its p98 a hundred values below.  A tight window misses more
+        // often, and a miss costs a second count -- but not fitting costs the second READER for certain.
         const int ch = tid >> 8, bin = tid & 255;
         unsigned int before = inc - tot;
         for (int w = 0; w < ((tid >> 6) & 3); ++w) before += s_wsum[ch][w];
-        double dq = 0.015;
-        if (sampled == nquads * 4) dq = 0.0;                  // everything was counted (but the tile's last npix % 4 pixels)
-        double ql = 0.02 - dq, qh = 0.98 + dq;
-        if (P.test_wrong) ql = qh = 0.5;
-        const long long rl = (long long)floor((double)(sampled - 1) * ql), rh = (long long)ceil((double)(sampled - 1) * qh);
-        const int margin = P.test_wrong ? 0 : 1;
-        if (tot && rl >= (long long)before && rl < (long long)before + tot) s_lo[ch] = (unsigned)(bin - margin < 0 ? 0 : bin - margin);
-        if (tot && rh >= (long long)before && rh < (long long)before + tot) s_hi[ch] = (unsigned)(bin + margin > 255 ? 255 : bin + margin);
+#pragma unroll
+        for (int m = 0; m < 2; ++m) {
+            double dq = m ? 0.005 : 0.015;
+            if (sampled == nquads * 4) dq = 0.0;              // everything was counted (but the tile's last npix % 4 pixels)
+            double ql = 0.02 - dq, qh = 0.98 + dq;
+            if (P.test_wrong) ql = qh = 0.5;
+            const long long rl = (long long)floor((double)(sampled - 1) * ql), rh = (long long)ceil((double)(sampled - 1) * qh);
+            const int margin = P.test_wrong ? 0 : 1;
+            if (tot && rl >= (long long)before && rl < (long long)before + tot) s_lo[m][ch] = (unsigned)(bin - margin < 0 ? 0 : bin - margin);
+            if (tot && rh >= (long long)before && rh < (long long)before + tot) s_hi[m][ch] = (unsigned)(bin + margin > 255 ? 255 : bin + margin);
+        }
     }
     __syncthreads();
     if (tid == 0) {
         JointWin w;
         w.flag = 0u;
-        if (sampled > 0) {
-            w.lo_r = (unsigned short)s_lo[0]; w.nr = (unsigned short)(s_hi[0] - s_lo[0] + 1u);
-            w.lo_g = (unsigned short)s_lo[1]; w.ng = (unsigned short)(s_hi[1] - s_lo[1] + 1u);
+        w.lo_r = w.lo_g = 0; w.nr = w.ng = 256; w.mode = 0u;
+        for (int m = 0; m < 2 && sampled > 0 && w.mode == 0u; ++m) {
+            w.lo_r = (unsigned short)s_lo[m][0]; w.nr = (unsigned short)(s_hi[m][0] - s_lo[m][0] + 1u);
+            w.lo_g = (unsigned short)s_lo[m][1]; w.ng = (unsigned short)(s_hi[m][1] - s_lo[m][1] + 1u);
             w.mode = (unsigned)w.nr + (unsigned)w.ng <= (unsigned)JW_MAX_ROWS ? 1u : 0u;
-        } else {
-            w.lo_r = w.lo_g = 0; w.nr = w.ng = 256; w.mode = 0u;
         }
         P.win[tile] = w;
     }
@@ -383,7 +388,10 @@ __global__ __launch_bounds__(JH_THREADS, 4) void k_joint_count_win(JointCountPar
     }
     const unsigned int nlist = s_nlist < JW_LIST_CAP ? s_nlist : JW_LIST_CAP;
     if (nlist) {
-        __threadfence();
+        // the stores above have to be in the L2 before the adds to the same words: the barrier's own workgroup-scope release (stores
+        // acknowledged) orders them, and the adds are workgroup-scope too -- every access stays in this XCD's L2.  (A device-scope
+        // __threadfence here writes the XCD's L2 back for every workgroup that has a list: + 40 % on the launch of any batch whose
+        // chunks hold a cell of 16384 pixels: profiles/r05_joint_publish_fence.txt.)
         __syncthreads();
         for (unsigned int e = tid; e < nlist; e += JH_THREADS) {
             const unsigned long long mv = __builtin_nontemporal_load(reinterpret_cast<const unsigned long long *>(&list[e]));   // past this CU's L1
@@ -395,8 +403,8 @@ __global__ __launch_bounds__(JH_THREADS, 4) void k_joint_count_win(JointCountPar
             const unsigned int hi = m.y >> 16, lo = (m.y & 0xFFFFu) - hi;
             // cell n = nl (count lo) and n = nl | 128 (count hi), each at (D, h) of the full layout
             const unsigned int m0 = jh_m(nl, x), m1 = jh_m(nl | 128u, x);
-            if (lo) atomicAdd(&out[2 * (long long)((x << 7) | (m0 & 127u)) + (m0 >> 7)], lo);
-            if (hi) atomicAdd(&out[2 * (long long)((x << 7) | (m1 & 127u)) + (m1 >> 7)], hi);
+            if (lo) jh_publish_add(&out[2 * (long long)((x << 7) | (m0 & 127u)) + (m0 >> 7)], lo);
+            if (hi) jh_publish_add(&out[2 * (long long)((x << 7) | (m1 & 127u)) + (m1 >> 7)], hi);
         }
     }
 }

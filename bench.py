@@ -93,7 +93,7 @@ def parse():
                          "worker holds about 1 GiB of NumPy temporaries for a 4096 x 4096 tile)")
     ap.add_argument("--no-u16-leg", dest="u16_leg", action="store_false", help="skip the BASELINE configs[4] shape (uint16 8192 x 8192 tiles)")
     ap.add_argument("--no-smooth-leg", dest="smooth_leg", action="store_false",
-                    help="skip the statistics-only modes on image-like (smooth) content")
+                    help="skip the statistics-only modes on image-like (smooth, natural) content")
     ap.add_argument("--no-verify", dest="verify", action="store_false", help="skip the self-check after the timed region")
     return ap.parse_args()
 
@@ -488,16 +488,39 @@ def smooth_tile(edge, seed=7):
     return out
 
 
-def smooth_leg(tiles=256, edge=4096, rounds=4):
+def natural_tile(edge, seed=7):
+    """One photograph-like tile (tools/jointbench.py's `natural`): 1 / f noise -- structure at every scale --, channels that share most
+    of it, sensor noise on top, stretched over the whole 8-bit range so that both ends clip (0.3-0.7 % of the pixels sit on the
+    (255, 255) byte pairs): broad histograms with piled-up ends, what a processed JPEG looks like to the counting kernels."""
+    rng = np.random.default_rng(seed)
+    fy, fx = np.meshgrid(np.fft.fftfreq(edge), np.fft.rfftfreq(edge), indexing="ij")
+    amp = 1.0 / np.maximum(np.hypot(fy, fx), 1.0 / edge)
+    common = np.fft.irfft2(amp * np.exp(2j * np.pi * rng.random(amp.shape)), s=(edge, edge))
+    out = np.empty((edge, edge, 3), np.uint8)
+    for c in range(3):
+        own = np.fft.irfft2(amp * np.exp(2j * np.pi * rng.random(amp.shape)), s=(edge, edge))
+        f = 0.8 * common + 0.6 * own
+        f = (f - f.mean()) / f.std()
+        out[:, :, c] = np.clip(120.0 + 15 * c + 55.0 * f + rng.normal(0, 1.5, (edge, edge)), 0, 255).astype(np.uint8)
+    return out
+
+
+def smooth_leg(tiles=256, edge=4096, rounds=4, kind="smooth"):
     """The statistics-only jobs on IMAGE-LIKE content (the reference's inputs are photographs, process-images.py:1441-1457; the
     bench's counter-hash tiles are iid): both routes timed, and what ``route="auto"`` picks (TileBatch.pick_stats_route; with
-    medians the library always takes the one-read route).  One smooth tile replicated over the batch."""
+    medians the library always takes the one-read route).  One tile (``kind``: "smooth" gradients or a "natural" 1 / f scene); every
+    other tile of the batch is that tile rolled by a pseudo-random number of rows."""
     import lars_image_processing_amd as lars
     from lars_image_processing_amd import _ffi
     b = lars.TileBatch(tiles, edge, edge, 3, np.uint8)
-    b.tiles.upload(smooth_tile(edge)[None])
+    b.tiles.upload((smooth_tile(edge) if kind == "smooth" else natural_tile(edge))[None])
+    row = edge * 3
     for i in range(1, tiles):
-        _ffi.call("lars_memcpy_d2d", C.c_void_p(b.tiles.ptr + i * b.tile_bytes), C.c_void_p(b.tiles.ptr), b.tile_bytes, None)
+        r = (i * 997) % edge
+        dst = b.tiles.ptr + i * b.tile_bytes
+        _ffi.call("lars_memcpy_d2d", C.c_void_p(dst), C.c_void_p(b.tiles.ptr + r * row), b.tile_bytes - r * row, None)
+        if r:
+            _ffi.call("lars_memcpy_d2d", C.c_void_p(dst + b.tile_bytes - r * row), C.c_void_p(b.tiles.ptr), r * row, None)
     _ffi.call("lars_synchronize", None)
     stats = b.new_stats()
     pairs = _ffi.DeviceBuffer(b.ntiles * 4 * 4)
@@ -518,8 +541,10 @@ def smooth_leg(tiles=256, edge=4096, rounds=4):
         return float(np.median(ts[1:]))
 
     npix = tiles * edge * edge
-    out = {"workload": f"{tiles} copies of one {edge}x{edge} uint8 tile: gradients + two levels of noise per channel (image-like; "
-                       "the headline's tiles are iid)", "algorithmic_bytes_per_pixel": 3}
+    what = ("gradients + two levels of noise per channel" if kind == "smooth" else
+            "1/f noise with correlated channels + sensor noise over the whole 8-bit range, clipped at both ends")
+    out = {"workload": f"{tiles} row-rolled copies of one {edge}x{edge} uint8 tile: {what} (image-like; the headline's tiles are iid)",
+           "algorithmic_bytes_per_pixel": 3}
     for name, indices, med in (("wb_ndvi_stats_only", ("NDVI",), False), ("wb3idx_stats_only", ("NDVI", "GNDVI", "NDWI"), False),
                                ("wb3idx_stats_medians", ("NDVI", "GNDVI", "NDWI"), True)):
         def classic():
@@ -786,6 +811,7 @@ def main():
         extra["u16_8192_ndvi_rgba_out_stats"] = config4_leg()
     if args.all_modes and world == 1 and args.smooth_leg:
         extra["smooth_content"] = smooth_leg(tiles=min(256, args.tiles), edge=args.tile)
+        extra["natural_content"] = smooth_leg(tiles=min(256, args.tiles), edge=args.tile, kind="natural")
     if rank == 0:
         cpu = None if args.no_cpu_baseline or world > 1 else cpu_baseline(args)
         g = {t: runner.lb.summarize(glob[_ffi.INDEX_IDS[t]]) for t in indices}

@@ -60,7 +60,12 @@ def main():
     ap.add_argument("--profile", default="vegetation")
     args = ap.parse_args()
 
-    b = lars.TileBatch.synthetic(args.tiles, args.tile, args.tile, seed=1234, profile=args.profile)
+    if args.profile in ("uniform", "vegetation"):
+        b = lars.TileBatch.synthetic(args.tiles, args.tile, args.tile, seed=1234, profile=args.profile)
+    else:                                           # the hand-made contents of tools/jointbench.py (natural, smooth, flat, steps ...)
+        sys.path.insert(0, os.path.join(ROOT, "tools"))
+        import jointbench
+        b = jointbench.make_batch(args.profile, args.tiles, args.tile)
     b.compute_wb_tables()
     stats = b.new_stats()
     timer = Timer()

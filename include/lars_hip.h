@@ -273,8 +273,11 @@ int lars_d_quotient_median_pairs(const void *tiles, int64_t ntiles, int64_t npix
  *                 (process-images.py:438), so the records, percentiles, tables and medians are the same bits -- which lets both pair
  *                 tables of a tile chunk live in ONE workgroup's LDS: one reader per byte instead of two.  A subsample predicts
  *                 the windows, the exact percentiles check them, a tile whose window missed is counted again on full tables
- *                 (lars_set_tuning("joint_window", 0) = never windowed; 2 = windows that miss on purpose).  Channel histograms
- *                 cannot be had from clamped counts: asking for hist keeps the full tables
+ *                 (lars_set_tuning("joint_window", 0) = never windowed; 2 = windows that miss on purpose).  Where red and green
+ *                 windows with NIR whole do not fit (more than 306 rows) NIR gets a window too -- it is white-balanced through
+ *                 its own percentiles like the others -- and rows shrink to its width: three windows of up to about 196 values
+ *                 each still share one workgroup.  Channel histograms cannot be had from clamped counts: asking for hist keeps
+ *                 the full tables
  *   out_pairs     float[ntiles][2 streams: NDVI, GNDVI][2] or NULL: the two middle order statistics (median = their
  *                 float32 mean; NDWI's is -GNDVI's); a stream the mask does not need comes back as NaN
  *   scratch       scratch_bytes >= lars_joint_scratch_bytes(ntiles, npix, index_mask) bytes of device memory; its first word
@@ -287,6 +290,9 @@ int lars_d_stats_joint(const lars_fused_args *a, int white_balance, int rgn_vari
  * *windowed = tiles counted by one reader on windowed tables, *recounted = tiles among them whose window missed a percentile's
  * order statistic and which were counted again on full tables.  Both 0 after a call that did not qualify (see above). */
 int lars_joint_window_report(const void *scratch, int64_t ntiles, int64_t *windowed, int64_t *recounted);
+/* ... and by table form: counts[0] = tiles counted on full tables (two readers), counts[1] = on windowed red and green rows with NIR
+ * whole, counts[2] = on three windows (recounted tiles are listed under the form they were first counted on). */
+int lars_joint_window_modes(const void *scratch, int64_t ntiles, int64_t counts[3]);
 
 /* classification mask (see lars_h_threshold_mask_f32); x 16-byte, out_mask 4-byte aligned */
 int lars_d_threshold_mask_f32(const float *x, int64_t n, float threshold, uint8_t *out_mask, void *stream);
@@ -328,7 +334,8 @@ int lars_d_synth_u8(uint8_t *tiles, int64_t ntiles, int64_t first_tile, int64_t 
 /* Tuning knobs (per process): "fused_impl" 0 (auto)|1|2, "hist_impl" 1|2, "nt_stores" 0|1, "blocks_per_tile" 0 = automatic
  * (also the chunks per tile of lars_d_stats_joint), "joint_depth" 4|6 loads in flight per lane of the counting kernel,
  * "joint_window" 1 (windowed pair tables where they fit: lars_d_stats_joint)|0 (never)|2 (windows that miss on purpose: exercises the
- * recount; tiles of any size)|3 (as 1 for tiles of any size), "joint_win_depth" 4|5|6|12|15 loads in flight per lane of the windowed counting kernel,
+ * recount; tiles of any size)|3 (as 1 for tiles of any size)|4 (three windows -- NIR as well -- wherever they fit, before two are tried; tiles
+ * of any size)|5 (as 4 with NIR windows that miss on purpose), "joint_win_depth" 4|5|6|12|15 loads in flight per lane of the windowed counting kernel,
  * "u16_hist_impl" 5 (uint16 percentiles usually from ONE full pass: per channel and mark the count of the samples below a window
  * predicted from a subsample and the histogram inside it; a tile whose window missed takes the two radix passes)|1 (always the two
  * radix passes)|3 (windows that miss on purpose: exercises the fall-back),

@@ -112,6 +112,7 @@ SIGNATURES = {
     "lars_joint_scratch_bytes": (_SZ, [_I64, _I64, _U32]),
     "lars_d_stats_joint": (_I, [C.POINTER(FusedArgs), _I, _I, _P, _P, _P, _P, _SZ]),
     "lars_joint_window_report": (_I, [_P, _I64, C.POINTER(_I64), C.POINTER(_I64)]),
+    "lars_joint_window_modes": (_I, [_P, _I64, C.POINTER(_I64)]),
     "lars_h_tiff_lzw_decode": (_I, [_P, _I64, _P, _I64, C.POINTER(_I64)]),
     "lars_h_tiff_lzw_decode_chunks": (_I, [_P, _I64, _P, _P, _I64, _P, _I64, _P, _I]),
     "lars_d_quotient_select_hist": (_I, [_P, _I64, _I64, _I, _I, _P, _U32, _I, _P, _P, _P]),

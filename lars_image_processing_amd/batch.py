@@ -513,6 +513,15 @@ class TileBatch:
         _ffi.call("lars_joint_window_report", C.c_void_p(self._joint_scratch.ptr), getattr(self, "_joint_tiles", self.ntiles), C.byref(w), C.byref(r))
         return int(w.value), int(r.value)
 
+    def joint_window_modes(self):
+        """(tiles the last ``run_joint`` counted on full tables by two readers, on windowed red and green rows with NIR whole, on three
+        windows) -- after the pass's stream has finished."""
+        if getattr(self, "_joint_scratch", None) is None:
+            return 0, 0, 0
+        counts = (C.c_int64 * 3)()
+        _ffi.call("lars_joint_window_modes", C.c_void_p(self._joint_scratch.ptr), getattr(self, "_joint_tiles", self.ntiles), counts)
+        return int(counts[0]), int(counts[1]), int(counts[2])
+
     def check_joint(self, stream=None):
         """After a ``run_joint``: wait for ``stream`` and raise if the counting kernel reported a hand-over list overflow
         (its published counts would be truncated; cannot happen while a workgroup counts at most 2^24 pixels, which the

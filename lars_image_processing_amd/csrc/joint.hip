@@ -72,7 +72,7 @@ __global__ __launch_bounds__(JH_THREADS, 4) void k_joint_count(JointCountParams 
     if (P.win) {
         // windowed tiles belong to k_joint_count_win; the second pass counts only the tiles whose window missed (k_joint_finish's flag)
         const JointWin wn = P.win[tile];
-        if (P.pass == 0 ? wn.mode == 1u : wn.flag == 0u) return;
+        if (P.pass == 0 ? wn.mode != 0u : wn.flag == 0u) return;
     }
     const bool green = P.S == 2 ? role == 1 : (P.streams == 2u);                   // which sample pairs with NIR
 
@@ -350,14 +350,16 @@ __global__ __launch_bounds__(JH_THREADS, 8) void k_joint_finish(JointFinishParam
     const bool medians = P.out_pairs != nullptr;
     // Windowed counts (joint_win.hip): samples of this stream's channel below win_lo were counted as win_lo, above win_hi as win_hi.
     bool windowed = false;
-    unsigned int win_lo = 0u, win_hi = 255u;
+    unsigned int win_lo = 0u, win_hi = 255u, win_nlo = 0u, win_nhi = 255u;
     if (P.win) {
         const JointWin wn = P.win[tile];                                 // pass 0: the other stream's block may set .flag meanwhile; nothing else changes
         if (P.pass == 1 && wn.flag == 0u) return;
-        if (P.pass == 0 && wn.mode == 1u && P.wb) {
+        if (P.pass == 0 && wn.mode != 0u && P.wb) {
             windowed = true;
             win_lo = green ? wn.lo_g : wn.lo_r;
             win_hi = win_lo + (green ? wn.ng : wn.nr) - 1u;
+            win_nlo = wn.lo_n;                                            // NIR whole (mode 1): 0 .. 255, nothing to check
+            win_nhi = wn.lo_n + wn.nn - 1u;
         }
     }
 
@@ -482,8 +484,9 @@ __global__ __launch_bounds__(JH_THREADS, 8) void k_joint_finish(JointFinishParam
             bool missed = false;
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
-                const unsigned int b = (unsigned int)s_ord[1][r];
+                const unsigned int b = (unsigned int)s_ord[1][r], bn = (unsigned int)s_ord[0][r];
                 if ((win_lo > 0u && b <= win_lo) || (win_hi < 255u && b >= win_hi)) missed = true;
+                if ((win_nlo > 0u && bn <= win_nlo) || (win_nhi < 255u && bn >= win_nhi)) missed = true;
             }
             if (missed) {
                 if (tid == 0) P.win[tile].flag = 1u;
@@ -741,6 +744,7 @@ extern "C" int lars_d_stats_joint(const lars_fused_args *a, int white_balance, i
     // Windowed tables, one reader per tile chunk (joint_win.hip): two streams, percentile white balance (the windows ARE its clipping),
     // tiles large enough to pay for a window, and no channel histograms wanted -- those would come out clamped to the windows.
     // lars_set_tuning("joint_window", 0) = never, 2 = windows that miss on purpose (exercises the recount), 3 = tiles of any size (tests).
+    // 4 = three windows (NIR as well) wherever they fit, before two are tried, tiles of any size; 5 = as 4 with NIR windows that miss (tests).
     const int window = tuning().joint_window;
     const bool windowed = S == 2 && white_balance && !hist && window != 0 && (a->npix >= JW_MIN_PIXELS || window >= 2);
 
@@ -750,7 +754,7 @@ extern "C" int lars_d_stats_joint(const lars_fused_args *a, int white_balance, i
     LARS_HIP_TRY(hipMemsetAsync(error, 0, 256, s));
     const uint8_t *tiles = static_cast<const uint8_t *>(a->tiles);
     if (windowed) {
-        joint_predict_launch(tiles, a->ntiles, a->npix, a->channels, win, window == 2 ? 1 : 0, s);
+        joint_predict_launch(tiles, a->ntiles, a->npix, a->channels, win, window == 2 ? 1 : window == 4 ? 2 : window == 5 ? 3 : 0, s);
         LARS_TRY(launch_check("lars_d_stats_joint (predict)"));
     } else {
         LARS_HIP_TRY(hipMemsetAsync(win, 0, (size_t)a->ntiles * sizeof(JointWin), s));        // lars_joint_window_report: nothing windowed
@@ -812,7 +816,18 @@ extern "C" int lars_joint_window_report(const void *scratch, int64_t ntiles, int
     std::vector<JointWin> w((size_t)ntiles);
     LARS_HIP_TRY(hipMemcpy(w.data(), static_cast<const char *>(scratch) + 256, (size_t)ntiles * sizeof(JointWin), hipMemcpyDeviceToHost));
     int64_t nw = 0, nr = 0;
-    for (const JointWin &x : w) { nw += x.mode == 1u; nr += x.flag != 0u; }
+    for (const JointWin &x : w) { nw += x.mode != 0u; nr += x.flag != 0u; }
     *windowed = nw; *recounted = nr;
+    return LARS_OK;
+}
+
+// ... and by table form: counts[0] tiles on full tables (two readers), [1] on windowed red and green rows with NIR whole, [2] on three windows.
+extern "C" int lars_joint_window_modes(const void *scratch, int64_t ntiles, int64_t counts[3])
+{
+    if (!scratch || ntiles <= 0 || !counts) return fail(LARS_ERR_INVALID, "lars_joint_window_modes: bad arguments");
+    std::vector<JointWin> w((size_t)ntiles);
+    LARS_HIP_TRY(hipMemcpy(w.data(), static_cast<const char *>(scratch) + 256, (size_t)ntiles * sizeof(JointWin), hipMemcpyDeviceToHost));
+    counts[0] = counts[1] = counts[2] = 0;
+    for (const JointWin &x : w) counts[x.mode < 3u ? x.mode : 0u] += 1;
     return LARS_OK;
 }

@@ -31,7 +31,9 @@ struct JointPredictParams {
     long long npix;
     long long ntiles;
     JointWin *win;
-    int test_wrong;                           // lars_set_tuning("joint_window", 2): one-row windows at the median, so that every tile misses
+    int test_mode;                            // lars_set_tuning("joint_window", ..): 0 as measured; 1 (setting 2): one-row red and green windows at the
+                                              // median, so that every tile misses; 2 (setting 4): three windows wherever they fit, before two are tried;
+                                              // 3 (setting 5): as 2 with a one-row NIR window at the median (its check in k_joint_finish misses)
 };
 
 #define JP_SEGMENTS 1024                      /* of 16 quads = 64 pixels each: 1 / 256 of a 4096 x 4096 tile */
@@ -45,14 +47,13 @@ __device__ inline unsigned int jp_mix(unsigned int x)
 template <int CH>
 __global__ __launch_bounds__(JH_THREADS) void k_joint_predict(JointPredictParams P)
 {
-    // red and green histograms of the sample in 16 copies: lane l adds to copy l & 15 -- at most two lanes of a half-wave on one word, whatever
-    // the image (a smooth one puts all 64 lanes into two or three bins); 32 KiB per workgroup, so that four workgroups share a CU and the
-    // 1024 workgroups of a 1024-tile batch are resident at once (32 copies, two workgroups per CU, measured the same: the pass is bound by
-    // its scattered reads)
-    __shared__ unsigned int s_h[2 * 256 * 16];                 // 32 KiB: [channel][bin][copy]
+    // red, green and NIR histograms of the sample in 16 copies: lane l adds to copy l & 15 -- at most two lanes of a half-wave on one word,
+    // whatever the image (a smooth one puts all 64 lanes into two or three bins); 48 KiB per workgroup, three workgroups per CU (two and
+    // four measured the same: the pass is bound by its scattered reads)
+    __shared__ unsigned int s_h[3 * 256 * 16];                 // 48 KiB: [channel][bin][copy]
     const int tid = threadIdx.x;
     const long long tile = blockIdx.x;
-    for (int i = tid; i < 2 * 256 * 16 / 4; i += JH_THREADS) reinterpret_cast<uint4 *>(s_h)[i] = make_uint4(0u, 0u, 0u, 0u);
+    for (int i = tid; i < 3 * 256 * 16 / 4; i += JH_THREADS) reinterpret_cast<uint4 *>(s_h)[i] = make_uint4(0u, 0u, 0u, 0u);
     __syncthreads();
     const long long nquads = P.npix >> 2;
     const uint8_t *base = P.tiles + tile * P.npix * CH;
@@ -64,6 +65,7 @@ __global__ __launch_bounds__(JH_THREADS) void k_joint_predict(JointPredictParams
         // r0 g0 n0 r1 | g1 n1 r2 g2 | n2 r3 g3 n3
         add(0u, w0 & 255u); add(1u, (w0 >> 8) & 255u); add(0u, w0 >> 24); add(1u, w1 & 255u);
         add(0u, (w1 >> 16) & 255u); add(1u, w1 >> 24); add(0u, (w2 >> 8) & 255u); add(1u, (w2 >> 16) & 255u);
+        add(2u, (w0 >> 16) & 255u); add(2u, (w1 >> 8) & 255u); add(2u, w2 & 255u); add(2u, w2 >> 24);
     };
     auto load_quad = [&](long long q, unsigned int &w0, unsigned int &w1, unsigned int &w2) {
         if constexpr (CH == 4) {
@@ -104,11 +106,11 @@ __global__ __launch_bounds__(JH_THREADS) void k_joint_predict(JointPredictParams
         sampled = nquads * 4;
     }
     __syncthreads();
-    // totals of the 16 copies, their running sums (wave scans + one barrier), and the two order statistics that bound the window
-    __shared__ unsigned int s_wsum[2][4];
-    __shared__ unsigned int s_lo[2][2], s_hi[2][2];          // [margin][channel]
+    // totals of the 16 copies, their running sums (wave scans + one barrier), and the order statistics that bound the windows
+    __shared__ unsigned int s_wsum[3][4];
+    __shared__ unsigned int s_lo[2][3], s_hi[2][3];          // [margin][channel]
     unsigned int tot = 0, inc = 0;
-    if (tid < 512) {
+    if (tid < 768) {
 #pragma unroll 8
         for (int k = 0; k < 16; ++k) tot += s_h[tid * 16 + ((k + tid) & 15)];    // rotated: fewer lanes per bank
         inc = tot;
@@ -120,39 +122,57 @@ __global__ __launch_bounds__(JH_THREADS) void k_joint_predict(JointPredictParams
         if (lane == 63) s_wsum[tid >> 8][(tid >> 6) & 3] = inc;
     }
     __syncthreads();
-    if (tid < 512 && sampled > 0) {
-        // The window of channel ch (red, green): from the sample's order statistics at 0.5 % and 99.5 %, one more value on either
-        // side.  The margin is for imagery, not for independent samples: the 64 pixels of a segment of a smooth image are nearly one
-        // observation, so the sample is worth its 1024 segments -- a value that truly holds 2 % of the tile below it shows fewer
-        // than 0.5 % of the sample there about once in 10^5 tiles even then.  (0.4 % of margin, enough for independent pixels,
-        // missed on 19 % of the tiles of tools/jointbench.py's smooth content: profiles/r05_joint_window_first.txt.)
-        // A second, tight pair of windows (1.5 % and 98.5 %) is for the tiles whose safe windows do not fit: a photograph with 1 % of
+    if (tid < 768 && sampled > 0) {
+        // The window of a channel: from the sample's order statistics at 0.5 % and 99.5 %, one more value on either side.  The margin is
+        // for imagery, not for independent samples: the 64 pixels of a segment of a smooth image are nearly one observation, so the
+        // sample is worth its 1024 segments -- a value that truly holds 2 % of the tile below it shows fewer than 0.5 % of the sample
+        // there about once in 10^5 tiles even then.  (0.4 % of margin, enough for independent pixels, missed on 19 % of the tiles of
+        // tools/jointbench.py's smooth content: profiles/r05_joint_window_first.txt.)
+        // A second, tight set of windows (1.5 % and 98.5 %) is for the tiles whose safe windows do not fit: a photograph with 1 % of
         // overexposed pixels has its 99.5 % order statistic at 255 and its p98 a hundred values below.  A tight window misses more
         // often, and a miss costs a second count -- but not fitting costs the second READER for certain.
         const int ch = tid >> 8, bin = tid & 255;
         unsigned int before = inc - tot;
         for (int w = 0; w < ((tid >> 6) & 3); ++w) before += s_wsum[ch][w];
+        const bool wrong = ch < 2 ? P.test_mode == 1 : P.test_mode == 3;
 #pragma unroll
         for (int m = 0; m < 2; ++m) {
             double dq = m ? 0.005 : 0.015;
             if (sampled == nquads * 4) dq = 0.0;              // everything was counted (but the tile's last npix % 4 pixels)
             double ql = 0.02 - dq, qh = 0.98 + dq;
-            if (P.test_wrong) ql = qh = 0.5;
+            if (wrong) ql = qh = 0.5;
             const long long rl = (long long)floor((double)(sampled - 1) * ql), rh = (long long)ceil((double)(sampled - 1) * qh);
-            const int margin = P.test_wrong ? 0 : 1;
+            const int margin = wrong ? 0 : 1;
             if (tot && rl >= (long long)before && rl < (long long)before + tot) s_lo[m][ch] = (unsigned)(bin - margin < 0 ? 0 : bin - margin);
             if (tot && rh >= (long long)before && rh < (long long)before + tot) s_hi[m][ch] = (unsigned)(bin + margin > 255 ? 255 : bin + margin);
         }
     }
     __syncthreads();
     if (tid == 0) {
+        // Which tables the tile is counted on: windows on red and green with NIR whole where they fit -- safe margins, then tight ones: that
+        // kernel is 10 % faster than the next, which outweighs the tight windows' misses on all but the smoothest content (and smooth
+        // content has narrow windows) --, else windows on all three channels, else full tables and two readers.
         JointWin w;
         w.flag = 0u;
-        w.lo_r = w.lo_g = 0; w.nr = w.ng = 256; w.mode = 0u;
-        for (int m = 0; m < 2 && sampled > 0 && w.mode == 0u; ++m) {
-            w.lo_r = (unsigned short)s_lo[m][0]; w.nr = (unsigned short)(s_hi[m][0] - s_lo[m][0] + 1u);
-            w.lo_g = (unsigned short)s_lo[m][1]; w.ng = (unsigned short)(s_hi[m][1] - s_lo[m][1] + 1u);
-            w.mode = (unsigned)w.nr + (unsigned)w.ng <= (unsigned)JW_MAX_ROWS ? 1u : 0u;
+        w.lo_r = w.lo_g = w.lo_n = 0; w.nr = w.ng = w.nn = 256; w.pitch = (unsigned short)JW_PITCH; w.half = 128; w.mode = 0u;
+        auto two = [&](int m) {
+            const unsigned int nr = s_hi[m][0] - s_lo[m][0] + 1u, ng = s_hi[m][1] - s_lo[m][1] + 1u;
+            if (nr + ng > (unsigned)JW_MAX_ROWS) return false;
+            w.lo_r = (unsigned short)s_lo[m][0]; w.nr = (unsigned short)nr; w.lo_g = (unsigned short)s_lo[m][1]; w.ng = (unsigned short)ng;
+            w.lo_n = 0; w.nn = 256; w.pitch = (unsigned short)JW_PITCH; w.half = 128; w.mode = 1u;
+            return true;
+        };
+        auto three = [&](int m) {
+            const unsigned int nr = s_hi[m][0] - s_lo[m][0] + 1u, ng = s_hi[m][1] - s_lo[m][1] + 1u, nn = s_hi[m][2] - s_lo[m][2] + 1u;
+            const unsigned int half = (nn + 1u) >> 1, pitch = jw_pitch_for(half);
+            if ((nr + ng) * pitch + 3u > (unsigned)JW_TAB_DWORDS) return false;
+            w.lo_r = (unsigned short)s_lo[m][0]; w.nr = (unsigned short)nr; w.lo_g = (unsigned short)s_lo[m][1]; w.ng = (unsigned short)ng;
+            w.lo_n = (unsigned short)s_lo[m][2]; w.nn = (unsigned short)nn; w.pitch = (unsigned short)pitch; w.half = (unsigned short)half; w.mode = 2u;
+            return true;
+        };
+        if (sampled > 0) {
+            if (P.test_mode >= 2) { three(0) || three(1) || two(0) || two(1); }
+            else { two(0) || two(1) || three(0) || three(1); }
         }
         P.win[tile] = w;
     }
@@ -195,7 +215,9 @@ __device__ inline unsigned int jw_addr(unsigned int d, unsigned int two)
     return r;
 }
 
-template <int DEPTH, int CH = 3>
+// NWIN: NIR has a window as well (JointWin mode 2): rows of win.pitch dwords, cell n' = clamp(n - lo_n) in dword n' mod half, half n' >= half.
+// Three more packed instructions per pixel pair than the NIR-whole form, whose rows are 128 + 5 dwords and whose half is bit 7 of n.
+template <int DEPTH, int CH = 3, bool NWIN = false>
 __global__ __launch_bounds__(JH_THREADS, 4) void k_joint_count_win(JointCountParams P)
 {
     // a period is a whole number of ring turns and adds at most 65535 - 4095 = 61440 pixels (15 steps) to any one dword
@@ -210,10 +232,12 @@ __global__ __launch_bounds__(JH_THREADS, 4) void k_joint_count_win(JointCountPar
     const int chunk = (int)(unit - tile * P.K);
     if (tile >= P.ntiles) return;
     const JointWin win = P.win[tile];
-    if (win.mode != 1u) return;                                                    // k_joint_count's tile
+    if (win.mode != (NWIN ? 2u : 1u)) return;                                      // another kernel's tile
     const unsigned int nr = win.nr, ng = win.ng, lo_r = win.lo_r, lo_g = win.lo_g;
+    const unsigned int lo_n = NWIN ? win.lo_n : 0u, nn = NWIN ? win.nn : 256u;
+    const unsigned int pitch = NWIN ? win.pitch : JW_PITCH, half = NWIN ? win.half : 128u;
     const unsigned int rows = nr + ng;
-    const int ntab4 = (int)((rows * JW_PITCH + 3u) >> 2);                          // uint4s in use
+    const int ntab4 = (int)((rows * pitch + 3u) >> 2);                             // uint4s in use
 
     uint4 *tab4 = reinterpret_cast<uint4 *>(s_tab);
     for (int i = tid; i < ntab4; i += JH_THREADS) tab4[i] = make_uint4(0u, 0u, 0u, 0u);
@@ -235,11 +259,13 @@ __global__ __launch_bounds__(JH_THREADS, 4) void k_joint_count_win(JointCountPar
     const bool odd = (tid & 1) != 0;
     const unsigned int lo_r2 = lo_r * 0x10001u, lo_g2 = lo_g * 0x10001u;
     const unsigned int nr1_2 = (nr - 1u) * 0x10001u, ng1_2 = (ng - 1u) * 0x10001u;
-    const unsigned int base_g2 = (nr * JW_PITCH) * 0x10001u;                           // first dword of the green rows: < 2^16
+    const unsigned int base_g2 = (nr * pitch) * 0x10001u;                              // first dword of the green rows: < 2^16
     const unsigned int lo_f = odd ? lo_g2 : lo_r2, lo_s = odd ? lo_r2 : lo_g2;
     const unsigned int n1_f = odd ? ng1_2 : nr1_2, n1_s = odd ? nr1_2 : ng1_2;
     const unsigned int base_f = odd ? base_g2 : 0u, base_s = odd ? 0u : base_g2;
-    const unsigned int pitch2 = JW_PITCH * 0x10001u;
+    const unsigned int pitch2 = pitch * 0x10001u;
+    const unsigned int lo_n2 = lo_n * 0x10001u, nn1_2 = (nn - 1u) * 0x10001u;          // NWIN: the NIR clamp,
+    const unsigned int halfm1_2 = (half - 1u) * 0x10001u, neghalf_2 = ((0x10000u - half) & 0xFFFFu) * 0x10001u;   // ... and n' -> (dword, half)
 
     // bytes of a quad r0 g0 n0 r1 | g1 n1 r2 g2 | n2 r3 g3 n3; pixels 0, 1 from perm(w1, w0), pixels 2, 3 from perm(w2, w1)
     const unsigned int seln01 = 0x0c050c02u, selr01 = 0x0c030c00u, selg01 = 0x0c040c01u;
@@ -251,10 +277,20 @@ __global__ __launch_bounds__(JH_THREADS, 4) void k_joint_count_win(JointCountPar
     asm volatile("" : "+v"(two));                                                  // a VGPR that holds 2 (SDWA takes no constants)
     // Two pixels at a time, one in each 16-bit half; xf / xs: the samples paired with NIR in the lane's first and second table.
     // mul = 1 but in runs of equal quads, where the lane that starts a run adds the run's length.
-    auto count_pair = [&](unsigned int nn, unsigned int xf, unsigned int xs, unsigned int mul) {
-        const unsigned int t = nn & 0x007F007Fu, u = nn & 0x00800080u;
-        unsigned int v0 = jw_val0(u);                                               // 1 | h << 16 of the low pixel
-        unsigned int v1 = (u >> 7) | 1u;                                            // of the high pixel (bit 0 is set either way)
+    auto count_pair = [&](unsigned int nn_, unsigned int xf, unsigned int xs, unsigned int mul) {
+        unsigned int t, v0, v1;
+        if constexpr (NWIN) {
+            const unsigned int nc = jw_min(jw_sub_sat(nn_, lo_n2), nn1_2);           // n' = clamp(n - lo_n, 0, nn - 1)
+            const unsigned int h = jw_min(jw_sub_sat(nc, halfm1_2), 0x00010001u);   // n' >= half, per pixel
+            t = jw_mad(h, neghalf_2, nc);                                           // n' - h * half (mod 2^16)
+            v0 = (h << 16) | 1u;                                                    // 1 | h << 16 of the low pixel
+            v1 = (h & 0x10000u) | 1u;                                               // of the high pixel
+        } else {
+            t = nn_ & 0x007F007Fu;
+            const unsigned int u = nn_ & 0x00800080u;
+            v0 = jw_val0(u);                                                        // 1 | h << 16 of the low pixel
+            v1 = (u >> 7) | 1u;                                                     // of the high pixel (bit 0 is set either way)
+        }
         if (mul != 1u) { v0 *= mul; v1 = (v1 & 0x10001u) * mul; }
         const unsigned int df = jw_mad(jw_min(jw_sub_sat(xf, lo_f), n1_f), pitch2, t + base_f);
         const unsigned int ds = jw_mad(jw_min(jw_sub_sat(xs, lo_s), n1_s), pitch2, t + base_s);
@@ -281,13 +317,15 @@ __global__ __launch_bounds__(JH_THREADS, 4) void k_joint_count_win(JointCountPar
     // tail pixels of the tile (npix % 4): its last chunk, before the first period
     if (chunk == P.K - 1 && tid < (int)(P.npix & 3)) {
         const uint8_t *p = tile_base + (nquads_tile * 4 + tid) * CH;
-        const unsigned int n = p[2];
+        unsigned int n = p[2] > lo_n ? p[2] - lo_n : 0u;
+        n = n < nn - 1u ? n : nn - 1u;
         unsigned int r = p[0] > lo_r ? p[0] - lo_r : 0u, g = p[1] > lo_g ? p[1] - lo_g : 0u;
         r = r < nr - 1u ? r : nr - 1u;
         g = g < ng - 1u ? g : ng - 1u;
-        const unsigned int v = ((n >> 7) << 16) | 1u;
-        jh_add((r * JW_PITCH + (n & 127u)) << 2, v, tab);
-        jh_add(((nr + g) * JW_PITCH + (n & 127u)) << 2, v, tab);
+        const unsigned int h = n >= half ? 1u : 0u, t = n - h * half;
+        const unsigned int v = (h << 16) | 1u;
+        jh_add((r * pitch + t) << 2, v, tab);
+        jh_add(((nr + g) * pitch + t) << 2, v, tab);
     }
 
     // A scan: every dword whose sum (low half) has reached 4096 moves onto the workgroup's list (in global memory: the LDS is the
@@ -362,12 +400,24 @@ __global__ __launch_bounds__(JH_THREADS, 4) void k_joint_count_win(JointCountPar
     __syncthreads();
 
     // Publish in the full tables' layout (joint.hip): stream s, dword D = x << 7 | (m & 127) with m = (n + 5 x) & 255 holds the cells
-    // (D, 0), (D, 1) = the counts of n0 = (D & 127) - 5 x and of n0 ^ 128 -- the two halves of ONE windowed dword.  Rows outside the
-    // window are zero and, but for those that share a block of 8 rows with the window, not even written: k_joint_finish skips them.
-    auto full_cells = [&](unsigned int wd, unsigned int n0) {       // windowed dword -> (count of n0, count of n0 ^ 128)
-        const unsigned int v = s_tab[wd];
-        const unsigned int hi = v >> 16, lo = (v & 0xFFFFu) - hi;  // cells n & 127 (bit 7 clear) and n | 128
-        return (n0 & 128u) ? make_uint2(hi, lo) : make_uint2(lo, hi);
+    // (D, 0), (D, 1) = the counts of n0 = (D & 127) - 5 x and of n0 ^ 128 -- with NIR whole the two halves of ONE windowed dword, with a
+    // NIR window two cells looked up one by one (zero outside the window).  Rows outside the red / green window are zero and, but for those
+    // that share a block of 8 rows with the window, not even written: k_joint_finish skips them.
+    auto full_cells = [&](unsigned int row, unsigned int n0) {      // (table row, n of the dword's first cell) -> (count of n0, count of n0 ^ 128)
+        if constexpr (NWIN) {
+            auto cell = [&](unsigned int n) {
+                const unsigned int np = n - lo_n;                   // wraps below the window
+                if (np >= nn) return 0u;
+                const unsigned int hh = np >= half ? 1u : 0u;
+                const unsigned int v = s_tab[row * pitch + np - hh * half];
+                return hh ? v >> 16 : (v & 0xFFFFu) - (v >> 16);
+            };
+            return make_uint2(cell(n0), cell(n0 ^ 128u));
+        } else {
+            const unsigned int v = s_tab[row * JW_PITCH + (n0 & 127u)];
+            const unsigned int hi = v >> 16, lo = (v & 0xFFFFu) - hi;  // cells n & 127 (bit 7 clear) and n | 128
+            return (n0 & 128u) ? make_uint2(hi, lo) : make_uint2(lo, hi);
+        }
     };
 #pragma unroll 1
     for (int s = 0; s < 2; ++s) {
@@ -379,10 +429,7 @@ __global__ __launch_bounds__(JH_THREADS, 4) void k_joint_count_win(JointCountPar
         for (int D = d_begin + tid; D < d_end; D += JH_THREADS) {
             const unsigned int x = (unsigned)D >> 7;
             uint2 c = make_uint2(0u, 0u);
-            if (x >= lo && x < lo + nx) {
-                const unsigned int n0 = (((unsigned)D & 127u) - JH_K * x) & 255u;
-                c = full_cells((row0 + x - lo) * JW_PITCH + (n0 & 127u), n0);
-            }
+            if (x >= lo && x < lo + nx) c = full_cells(row0 + x - lo, (((unsigned)D & 127u) - JH_K * x) & 255u);
             *reinterpret_cast<uint2 *>(out + 2 * (long long)D) = c;
         }
     }
@@ -396,13 +443,13 @@ __global__ __launch_bounds__(JH_THREADS, 4) void k_joint_count_win(JointCountPar
         for (unsigned int e = tid; e < nlist; e += JH_THREADS) {
             const unsigned long long mv = __builtin_nontemporal_load(reinterpret_cast<const unsigned long long *>(&list[e]));   // past this CU's L1
             const uint2 m = make_uint2((unsigned int)mv, (unsigned int)(mv >> 32));
-            const unsigned int row = m.x / JW_PITCH, nl = m.x - row * JW_PITCH;     // n & 127
+            const unsigned int row = m.x / pitch, nl = m.x - row * pitch;           // the dword's first cell: n' = nl (NIR whole: n & 127)
             const int s = row >= nr ? 1 : 0;
             const unsigned int x = s ? lo_g + (row - nr) : lo_r + row;
             unsigned int *out = P.part + ((tile * 2 + s) * P.K + chunk) * (long long)(2 * JH_DWORDS);
             const unsigned int hi = m.y >> 16, lo = (m.y & 0xFFFFu) - hi;
-            // cell n = nl (count lo) and n = nl | 128 (count hi), each at (D, h) of the full layout
-            const unsigned int m0 = jh_m(nl, x), m1 = jh_m(nl | 128u, x);
+            // cells n = lo_n + nl (count lo) and n = lo_n + nl + half (count hi), each at (D, h) of the full layout
+            const unsigned int m0 = jh_m(lo_n + nl, x), m1 = jh_m(lo_n + nl + half, x);
             if (lo) jh_publish_add(&out[2 * (long long)((x << 7) | (m0 & 127u)) + (m0 >> 7)], lo);
             if (hi) jh_publish_add(&out[2 * (long long)((x << 7) | (m1 & 127u)) + (m1 >> 7)], hi);
         }
@@ -410,17 +457,17 @@ __global__ __launch_bounds__(JH_THREADS, 4) void k_joint_count_win(JointCountPar
 }
 
 // ---- launchers (called by lars_d_stats_joint, joint.hip) --------------------------------------------------------------------
-void joint_predict_launch(const uint8_t *tiles, long long ntiles, long long npix, int channels, JointWin *win, int test_wrong, hipStream_t s)
+void joint_predict_launch(const uint8_t *tiles, long long ntiles, long long npix, int channels, JointWin *win, int test_mode, hipStream_t s)
 {
     JointPredictParams P;
-    P.tiles = tiles; P.npix = npix; P.ntiles = ntiles; P.win = win; P.test_wrong = test_wrong;
+    P.tiles = tiles; P.npix = npix; P.ntiles = ntiles; P.win = win; P.test_mode = test_mode;
     if (channels == 4) hipLaunchKernelGGL((k_joint_predict<4>), dim3((unsigned)ntiles), dim3(JH_THREADS), 0, s, P);
     else hipLaunchKernelGGL((k_joint_predict<3>), dim3((unsigned)ntiles), dim3(JH_THREADS), 0, s, P);
 }
 void joint_count_win_launch(const JointCountParams &C, int channels, int depth, hipStream_t s)
 {
     const long long units = C.ntiles * C.K;
-#define LARS_JOINT_WIN(DD, CC) hipLaunchKernelGGL((k_joint_count_win<DD, CC>), dim3((unsigned)units), dim3(JH_THREADS), 0, s, C)
+#define LARS_JOINT_WIN(DD, CC) hipLaunchKernelGGL((k_joint_count_win<DD, CC, false>), dim3((unsigned)units), dim3(JH_THREADS), 0, s, C)
     if (channels == 4) LARS_JOINT_WIN(5, 4);
     else if (depth == 4) LARS_JOINT_WIN(4, 3);
     else if (depth == 5) LARS_JOINT_WIN(5, 3);
@@ -428,6 +475,9 @@ void joint_count_win_launch(const JointCountParams &C, int channels, int depth, 
     else if (depth == 12) LARS_JOINT_WIN(12, 3);
     else LARS_JOINT_WIN(15, 3);
 #undef LARS_JOINT_WIN
+    // the tiles with a NIR window as well (the depth of the load ring is noise: one build per pixel format)
+    if (channels == 4) hipLaunchKernelGGL((k_joint_count_win<5, 4, true>), dim3((unsigned)units), dim3(JH_THREADS), 0, s, C);
+    else hipLaunchKernelGGL((k_joint_count_win<15, 3, true>), dim3((unsigned)units), dim3(JH_THREADS), 0, s, C);
 }
 
 }  // namespace lars

@@ -286,7 +286,7 @@ int lars_set_tuning(const char *key, int value)
         t.joint_depth = value;
     }
     else if (!strcmp(key, "joint_window")) {
-        if (value < 0 || value > 3) return fail(LARS_ERR_INVALID, "lars_set_tuning: joint_window is 0, 1, 2 or 3 (got %d)", value);
+        if (value < 0 || value > 5) return fail(LARS_ERR_INVALID, "lars_set_tuning: joint_window is 0 .. 5 (got %d)", value);
         t.joint_window = value;
     }
     else if (!strcmp(key, "joint_win_depth")) {

@@ -69,8 +69,9 @@ def main():
         kind, tiles = content(rng, ntiles, h, w, ch)
         indices = SUBSETS[int(rng.integers(0, len(SUBSETS)))]
         wb, hist, sumsq, med = (bool(rng.integers(0, 2)) for _ in range(4))
-        # the one-read route's tables: 0 full, 3 windowed where they fit (tiles of any size), 2 windows that miss on purpose (recount)
-        window = int(rng.choice([0, 3, 3, 2]))
+        # the one-read route's tables: 0 full, 3 windowed where they fit (tiles of any size), 2 windows that miss on purpose (recount),
+        # 4 three windows (NIR as well) wherever they fit, 5 the same with NIR windows that miss
+        window = int(rng.choice([0, 3, 3, 2, 4, 4, 5]))
         _lars_ffi.set_tuning(joint_window=window)
         b = lars.TileBatch.from_host(tiles)
         what = f"case {case}: {kind} {ntiles}x{h}x{w}x{ch} {indices} wb={wb} hist={hist} sumsq={sumsq} medians={med} window={window}"
@@ -86,7 +87,7 @@ def main():
             windowed[window] = windowed.get(window, 0) + nwin
             recounted[window] = recounted.get(window, 0) + nrec
             assert window != 0 or nwin == 0
-            assert window != 2 or nrec == nwin
+            assert window not in (2, 5) or nrec == nwin
             (rec_c, med_c), (rec_j, med_j) = (rc if med else (rc, None)), (rj if med else (rj, None))
             a, c = rec_c.copy(), rec_j.copy()
             np.testing.assert_allclose(a["sumsq"], c["sumsq"], rtol=1e-12, atol=2.0 ** -26)   # rounded to 2^-32 per workgroup / per tile

@@ -38,14 +38,15 @@ def subsets():
 @pytest.fixture
 def window(request):
     """lars_set_tuning("joint_window", ...) for the test's duration: 0 full tables only, 3 windowed tables for tiles of any size
-    (csrc/joint_win.hip; the default, 1, needs 2^20 pixels per tile), 2 windows that miss on purpose (every tile is recounted)."""
+    (csrc/joint_win.hip; the default, 1, needs 2^20 pixels per tile), 2 windows that miss on purpose (every tile is recounted), 4 three
+    windows (NIR as well) wherever they fit, 5 the same with NIR windows that miss."""
     from lars_image_processing_amd import _ffi
     _ffi.set_tuning(joint_window=request.param)
     yield request.param
     _ffi.set_tuning(joint_window=1)
 
 
-WINDOWS = pytest.mark.parametrize("window", [0, 3, 2], indirect=True)
+WINDOWS = pytest.mark.parametrize("window", [0, 3, 2, 4, 5], indirect=True)
 
 
 @WINDOWS
@@ -67,10 +68,11 @@ def test_joint_route_equals_classic_route(lars, profile, shape, ntiles, window):
             two_streams = "NDVI" in indices and len(indices) > 1
             if window == 0 or not wb or not two_streams:
                 assert (nwin, nrec) == (0, 0)
-            elif window == 2:
+            elif window in (2, 5):
                 assert nwin > 0 and nrec == nwin                 # one-row windows at the median: every windowed tile is counted again
             elif profile == "vegetation":
                 assert (nwin, nrec) == (ntiles, 0)               # 96 + 128 values: both tables fit one workgroup
+                assert b.joint_window_modes() == ((0, ntiles, 0) if window == 3 else (0, 0, ntiles))
             same_records(rec_c, rec_j)
             np.testing.assert_array_equal(med_c, med_j)
             # without the optional parts: sums of squares and bins stay zero
@@ -358,14 +360,16 @@ def test_windowed_and_full_tiles_in_one_batch(lars, channels):
     try:
         want, want_med = b.process(hist=True, medians=True, route="classic")
         want_tab, want_pct = b.host_tables(), b.host_percentiles()
-        for window, expect in ((3, (4, 0)), (2, None), (0, (0, 0))):
+        for window, expect in ((3, (4, 0)), (2, None), (0, (0, 0)), (4, None), (5, None)):
             for blocks in (0, 1, 3):
                 _ffi.set_tuning(joint_window=window, blocks_per_tile=blocks)
                 got, got_med = b.process(hist=True, medians=True, route="joint")
                 report = b.joint_window_report()
                 assert expect is None or report == expect, (window, report)
-                if window == 2:
+                if window in (2, 5):
                     assert report[0] >= 4 and report[1] == report[0]
+                if window == 4:
+                    assert report[0] >= 4 and report[1] == 0
                 assert got.tobytes() == want.tobytes(), (window, blocks)
                 np.testing.assert_array_equal(got_med, want_med)
                 np.testing.assert_array_equal(b.host_tables(), want_tab)
@@ -388,15 +392,54 @@ def test_windowed_ragged_single_tile_and_flavours(lars):
             b.compute_wb_tables(rgn_variant=variant)
             want = b.process(hist=True, sumsq=True, recompute_tables=False, route="classic")
             want_tab = b.host_tables()
-            for window in (3, 0, 2):
+            for window in (3, 0, 2, 4, 5):
                 _ffi.set_tuning(joint_window=window)
                 got = b.process(hist=True, sumsq=True, rgn_variant=variant, route="joint")
-                assert b.joint_window_report() == {3: (1, 0), 0: (0, 0), 2: (1, 1)}[window]
+                assert b.joint_window_report() == {3: (1, 0), 0: (0, 0), 2: (1, 1), 4: (1, 0), 5: (1, 1)}[window]
+                assert b.joint_window_modes() == {3: (0, 1, 0), 0: (1, 0, 0), 2: (0, 1, 0), 4: (0, 0, 1), 5: (0, 0, 1)}[window]
                 same_records(want, got)
                 np.testing.assert_array_equal(b.host_tables(), want_tab)
     finally:
         _ffi.set_tuning(joint_window=1)
         b.free()
+
+
+def test_three_windows_where_two_do_not_fit(lars):
+    """Red and green spanning 170 values each need 344 table rows -- more than one workgroup holds with NIR whole -- but NIR itself spans
+    150: rows of 90 dwords instead of 133 let all three windows share one workgroup (JointWin mode 2).  NIR clamps like the other two;
+    the finish kernel checks its percentiles against its window too.  Tiles with saturated ends, a ragged single tile, RGBA."""
+    from lars_image_processing_amd import _ffi
+    rng = np.random.default_rng(21)
+
+    def tiles_of(n, h, w, ch):
+        t = np.empty((n, h, w, ch), np.uint8)
+        t[..., 0] = rng.integers(20, 190, (n, h, w))
+        t[..., 1] = rng.integers(40, 210, (n, h, w))
+        t[..., 2] = rng.integers(60, 210, (n, h, w))
+        if ch == 4:
+            t[..., 3] = 255
+        t[:, : max(1, h // 128), :, :3] = 255                                             # 0.6-0.8 % of overexposed rows: above every window, and
+                                                                                          # enough to push the safe windows' upper ends to 255
+        t[:, -1, : w // 3, :3] = 0
+        return t
+
+    for shape, ch in (((3, 256, 512), 3), ((1, 333, 335), 3), ((2, 128, 256), 4)):
+        b = lars.TileBatch.from_host(tiles_of(shape[0], shape[1], shape[2], ch))
+        try:
+            want, want_med = b.process(hist=True, medians=True, route="classic")
+            want_tab, want_pct = b.host_tables(), b.host_percentiles()
+            for window, modes, recounted in ((3, (0, 0, shape[0]), 0), (5, (0, 0, shape[0]), shape[0]), (0, (shape[0], 0, 0), 0)):
+                for blocks in (0, 3):
+                    _ffi.set_tuning(joint_window=window, blocks_per_tile=blocks)
+                    got, got_med = b.process(hist=True, medians=True, route="joint")
+                    assert b.joint_window_modes() == modes and b.joint_window_report()[1] == recounted, (shape, window)
+                    assert got.tobytes() == want.tobytes(), (shape, window, blocks)
+                    np.testing.assert_array_equal(got_med, want_med)
+                    np.testing.assert_array_equal(b.host_tables(), want_tab)
+                    assert b.host_percentiles().tobytes() == want_pct.tobytes()
+        finally:
+            _ffi.set_tuning(joint_window=1, blocks_per_tile=0)
+            b.free()
 
 
 def test_window_report_and_channel_histograms(lars):
@@ -465,7 +508,7 @@ def test_plane_writing_calls_that_take_the_one_read_statistics(lars, channels):
 
 def test_tuning_rejects_values_the_kernels_do_not_have(lars):
     from lars_image_processing_amd import _ffi
-    for key, bad in (("joint_depth", 5), ("joint_win_depth", 8), ("joint_window", 4), ("out_stride_planes", 3)):
+    for key, bad in (("joint_depth", 5), ("joint_win_depth", 8), ("joint_window", 6), ("out_stride_planes", 3)):
         with pytest.raises(_ffi.LarsError):
             _ffi.set_tuning(**{key: bad})
     assert _ffi.get_tuning("joint_depth") == 6 and _ffi.get_tuning("joint_win_depth") == 15 and _ffi.get_tuning("joint_window") == 1

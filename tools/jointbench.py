@@ -59,11 +59,13 @@ def handmade(kind, edge):
             own = np.fft.irfft2(amp * np.exp(2j * np.pi * rng.random(amp.shape)), s=(edge, edge))
             f = 0.8 * common + 0.6 * own
             f = (f - f.mean()) / f.std()
-            # natural[_narrow|_soft][_clean|_n<sigma>][_sat|_nirsat]: _soft = as wide as it gets without clipping at 0 / 255; _clean = no
+            # natural[_narrow|_soft|_mid][_clean|_n<sigma>][_sat|_nirsat]: _soft = as wide as it gets without clipping at 0 / 255 (p2 .. p98 spans
+            # 130 values), _mid = p2 .. p98 spans 165 values; _clean = no
             # sensor noise (a denoised JPEG), _n0.7 = noise of sigma 0.7 levels (default 1.5); _sat = the brightest 1 % of the scene
             # overexposed in every channel, _nirsat = NIR alone saturated over the brightest 3.6 % (red and green keep moving)
             parts = kind.split("_")[1:]
-            scale, centre = (14.0, 70.0 + 30 * c) if "narrow" in parts else (32.0, 120.0 + 8 * c) if "soft" in parts else (55.0, 120.0 + 15 * c)
+            scale, centre = ((14.0, 70.0 + 30 * c) if "narrow" in parts else (32.0, 120.0 + 8 * c) if "soft" in parts else
+                             (40.0, 120.0 + 8 * c) if "mid" in parts else (55.0, 120.0 + 15 * c))
             sigma = 0.0 if "clean" in parts else next((float(q[1:]) for q in parts if q[0] == "n" and q[1:2].isdigit()), 1.5)
             noise = rng.normal(0, sigma, (edge, edge)) if sigma else 0.0
             v = np.clip(centre + scale * f + noise, 0, 255)
@@ -181,8 +183,9 @@ def main():
                         ms, mn = timed(lambda: b.run_joint(indices, True, stats, pairs=pairs if med else None), args.rounds)
                         b.check_joint()
                         nw, nrec = b.joint_window_report()
+                        n3 = b.joint_window_modes()[2]
                         report(f"joint   {mname} statistics{' + medians' if med else ''} depth {depth} blocks {blocks} window {window} "
-                               f"[{nw} windowed, {nrec} recounted]", ms, mn)
+                               f"[{nw} windowed{f' ({n3} on three windows)' if n3 else ''}, {nrec} recounted]", ms, mn)
                         rec = stats.download(_ffi.STATS_DTYPE, (b.ntiles, 3))
                         ids = [_ffi.INDEX_IDS[t] for t in indices]
                         assert rec[:, ids].tobytes() == ref[mname][:, ids].tobytes(), "records differ between the routes"

@@ -63,9 +63,16 @@ __device__ inline unsigned int jh_prev_lane(unsigned int w)
 {
     return (unsigned int)__builtin_amdgcn_update_dpp((int)~w, (int)w, 0x111 /* row_shr:1 */, 0xF, 0xF, false);   // first lane of a row: ~w
 }
+// (The gate's own compare lets the first lane of each row of 16 read 0 from beyond the row -- one instruction instead of three; those four
+// lanes may count as repeats when their dword is 0, which moves a threshold of 32 lanes by at most 4.  The run path itself decides heads
+// with jh_prev_lane.)  The count and its compare stay on the scalar unit.
 __device__ inline bool jh_mostly_runs(unsigned int w0)
 {
-    return __builtin_popcountll(__builtin_amdgcn_ballot_w64(jh_prev_lane(w0) == w0)) >= 32;
+    const unsigned int prev = (unsigned int)__builtin_amdgcn_update_dpp(0, (int)w0, 0x111 /* row_shr:1 */, 0xF, 0xF, true);
+    const unsigned long long same = __builtin_amdgcn_ballot_w64(prev == w0);
+    unsigned int n;
+    asm("s_bcnt1_i32_b64 %0, %1" : "=s"(n) : "s"(same) : "scc");
+    return n >= 32u;
 }
 // length of the run a head lane starts: up to the next head, the first inactive lane, or the wave's end
 __device__ inline unsigned int jh_run_length(bool head, int lane)

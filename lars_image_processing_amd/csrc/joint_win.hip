@@ -7,10 +7,13 @@
 // But the white balance itself says which cells matter: process-images.py:438 maps every sample <= p2 to 0 and every sample >= p98
 // to 255, so below a window start lo < p2 and above a window end hi > p98 the samples need not be told apart -- they count as lo
 // resp. hi, and every statistic of the white-balanced quotients comes out the same.  With windows on red and green (NIR keeps its
-// 256 values; no clamp for it) the tables take (nr + ng) rows of 256 cells: both fit one CU when nr + ng <= 306.
+// 256 values; no clamp for it) the tables take (nr + ng) rows of 256 cells: both fit one CU when nr + ng <= 306.  Where they do not,
+// NIR -- white-balanced through its own percentiles like the other two -- gets a window as well and a row shrinks to nn cells: three
+// windows of up to about 196 values each (77 % of the 8-bit range) still fit (k_joint_count_win<.., NWIN = true>, JointWin mode 2).
 //
 //   k_joint_predict     per tile: channel histograms of a subsample (1024 segments of 64 pixels spread over the tile) ->
-//                       [lo, hi] per channel with a margin for the sampling error -> mode 1 (windowed) if the rows fit, else 0
+//                       [lo, hi] per channel with a safe and a tight margin for the sampling error -> mode 1 (red and green windows, NIR
+//                       whole) if the rows fit, else mode 2 (three windows), else 0 (full tables, two readers)
 //   k_joint_count_win   one workgroup per (tile, chunk) of the mode-1 tiles: per pair of pixels 3 v_perm_b32 (n | n' << 16, r | r' << 16,
 //                       g | g' << 16), per window 2 packed clamps (v_pk_sub_u16 clamp, v_pk_min_u16) and 1 v_pk_mad_u16 for both dword
 //                       indices, 4 LDS atomics.  Publishes the counts in the FULL tables' layout (zeros outside the windows), so that

@@ -267,8 +267,12 @@ __global__ __launch_bounds__(JH_THREADS, 4) void k_joint_count_win(JointCountPar
     const unsigned int n1_f = odd ? ng1_2 : nr1_2, n1_s = odd ? nr1_2 : ng1_2;
     const unsigned int base_f = odd ? base_g2 : 0u, base_s = odd ? 0u : base_g2;
     const unsigned int pitch2 = pitch * 0x10001u;
-    const unsigned int lo_n2 = lo_n * 0x10001u, nn1_2 = (nn - 1u) * 0x10001u;          // NWIN: the NIR clamp,
-    const unsigned int halfm1_2 = (half - 1u) * 0x10001u, neghalf_2 = ((0x10000u - half) & 0xFFFFu) * 0x10001u;   // ... and n' -> (dword, half)
+    unsigned int lo_n2 = lo_n * 0x10001u, nn1_2 = (nn - 1u) * 0x10001u;                // NWIN: the NIR clamp,
+    unsigned int halfm1_2 = (half - 1u) * 0x10001u;                                    // ... and n' -> (dword, half)
+    const unsigned int neghalf_2 = ((0x10000u - half) & 0xFFFFu) * 0x10001u;
+    unsigned int one2 = 0x00010001u;
+    // operands of the packed instructions below that take no scalar register: keep them in vector registers, not copied in per use
+    asm volatile("" : "+v"(lo_n2), "+v"(nn1_2), "+v"(halfm1_2), "+v"(one2));
 
     // bytes of a quad r0 g0 n0 r1 | g1 n1 r2 g2 | n2 r3 g3 n3; pixels 0, 1 from perm(w1, w0), pixels 2, 3 from perm(w2, w1)
     const unsigned int seln01 = 0x0c050c02u, selr01 = 0x0c030c00u, selg01 = 0x0c040c01u;
@@ -284,7 +288,7 @@ __global__ __launch_bounds__(JH_THREADS, 4) void k_joint_count_win(JointCountPar
         unsigned int t, v0, v1;
         if constexpr (NWIN) {
             const unsigned int nc = jw_min(jw_sub_sat(nn_, lo_n2), nn1_2);           // n' = clamp(n - lo_n, 0, nn - 1)
-            const unsigned int h = jw_min(jw_sub_sat(nc, halfm1_2), 0x00010001u);   // n' >= half, per pixel
+            const unsigned int h = jw_min(jw_sub_sat(nc, halfm1_2), one2);          // n' >= half, per pixel
             t = jw_mad(h, neghalf_2, nc);                                           // n' - h * half (mod 2^16)
             v0 = (h << 16) | 1u;                                                    // 1 | h << 16 of the low pixel
             v1 = (h & 0x10000u) | 1u;                                               // of the high pixel

@@ -125,7 +125,7 @@ static_assert(sizeof(JointWin) == 24, "JointWin: six dwords");
 // only nn cells: half = ceil(nn / 2) dwords, padded to a pitch whose multiples spread a 5 x 5 neighbourhood of (row, cell) pairs over
 // 25 banks (pitch mod 32 in {5, 6, 26, 27}).  Three windows of up to about 196 values share one workgroup's LDS this way (two of 153 with
 // NIR whole): photographs whose histograms span 60-77 % of the 8-bit range.  The kernel pays three more packed instructions per pixel
-// pair for it (n' -> dword and half by compare instead of by bit 7) and runs 10 % behind the NIR-whole form, 13 % ahead of two readers.
+// pair for it (n' -> dword and half by compare instead of by bit 7) and runs 1-4 % behind the NIR-whole form, 17 % ahead of two readers.
 __host__ __device__ inline unsigned int jw_pitch_for(unsigned int half)
 {
     unsigned int p = half;

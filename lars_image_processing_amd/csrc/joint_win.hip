@@ -152,9 +152,9 @@ __global__ __launch_bounds__(JH_THREADS) void k_joint_predict(JointPredictParams
     }
     __syncthreads();
     if (tid == 0) {
-        // Which tables the tile is counted on: windows on red and green with NIR whole where they fit -- safe margins, then tight ones: that
-        // kernel is 10 % faster than the next, which outweighs the tight windows' misses on all but the smoothest content (and smooth
-        // content has narrow windows) --, else windows on all three channels, else full tables and two readers.
+        // Which tables the tile is counted on: safe margins before tight ones (a miss costs a second count: 2.2 x), and at either margin
+        // windows on red and green with NIR whole before windows on all three channels (that kernel is 1-4 % slower); else full tables
+        // and two readers.
         JointWin w;
         w.flag = 0u;
         w.lo_r = w.lo_g = w.lo_n = 0; w.nr = w.ng = w.nn = 256; w.pitch = (unsigned short)JW_PITCH; w.half = 128; w.mode = 0u;
@@ -175,7 +175,7 @@ __global__ __launch_bounds__(JH_THREADS) void k_joint_predict(JointPredictParams
         };
         if (sampled > 0) {
             if (P.test_mode >= 2) { three(0) || three(1) || two(0) || two(1); }
-            else { two(0) || two(1) || three(0) || three(1); }
+            else { two(0) || three(0) || two(1) || three(1); }
         }
         P.win[tile] = w;
     }

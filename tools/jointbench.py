@@ -40,10 +40,13 @@ def handmade(kind, edge):
     if kind == "steps":
         base = ((xx // 64) * 37 + (yy // 8) * 11) % 200
         return np.stack([(base + 10 * c) % 256 for c in range(3)], axis=-1).astype(np.uint8)
-    if kind == "smooth":
+    if kind in ("smooth", "smooth_mid"):
         out = []
         for c in range(3):
-            g = 60 + 50 * c + 40 * np.sin(xx / 900.0 + c) + 30 * np.cos(yy / 700.0) + rng.integers(-2, 3, (edge, edge))
+            if kind == "smooth":
+                g = 60 + 50 * c + 40 * np.sin(xx / 900.0 + c) + 30 * np.cos(yy / 700.0) + rng.integers(-2, 3, (edge, edge))
+            else:                                     # the same over 160-170 values per channel: safe windows on red and green do not fit
+                g = 100 + 15 * c + 50 * np.sin(xx / 900.0 + c) + 35 * np.cos(yy / 700.0) + rng.integers(-2, 3, (edge, edge))
             out.append(np.clip(g, 0, 255))
         return np.stack(out, axis=-1).astype(np.uint8)
     if kind.startswith("natural"):

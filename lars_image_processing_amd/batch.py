@@ -28,6 +28,8 @@ ARENA_CLASS_GAP = 0.93            # the search ends once its best candidate is 7
 ARENA_WARM_MS = 30.0              # untimed launches before a candidate is timed: after an idle gap a fast arena needs ~22 ms to reach its level
 ARENA_SPAN_BYTES = 20 << 30       # how far from the first planes the last ones may be placed inside an allocation (the memory changes kind every 6-16 GiB)
 ARENA_SPAN_STEP = 4 << 30         # ... in steps of
+ARENA_CROSS_TRIALS = 6            # pairs of allocations tried with the planes split between them when every allocation is of one kind
+ARENA_EXTRA_BLOCKS = 6            # ... and after those, small allocations for the second half of the planes alone
 
 
 # How statistics-only passes over uint8 RGNir batches run (no output planes):
@@ -206,8 +208,10 @@ class TileBatch:
                       placements inside it -- packed, and with the second half of the planes further out in steps of 4 GiB up
                       to 20 GiB from the start -- each timed with the batch's own launches (``_probe_arena``).  If no placement is 7 % faster than another the
                       allocation is of one kind throughout: another one is taken (up to ``placement_trials``, default
-                      ARENA_TRIALS), and the search ends as soon as both classes have been seen.  The fastest (allocation,
-                      placement) is kept, other allocations are freed.  Smaller arenas (they run alike wherever they land)
+                      ARENA_TRIALS), and the search ends as soon as both classes have been seen.  If every allocation was of one
+                      kind (two fresh processes in ten on some boxes), the first half of the planes stays in one allocation and
+                      the rest goes to another (allocations differ in kind among each other): up to ARENA_CROSS_TRIALS pairs;
+                      such outputs keep BOTH allocations.  The fastest (allocation, placement) is kept, other allocations are freed.  Smaller arenas (they run alike wherever they land)
                       are one packed allocation
           "plain"     one packed allocation as it comes, unless ``placement_trials`` asks for a search among packed ones
         ``pick="slowest"`` keeps the slowest candidate instead (a diagnostic: what a process without a fast arena sees).
@@ -280,10 +284,40 @@ class TileBatch:
                 if len(cands) >= 2 and min(times) <= ARENA_CLASS_GAP * max(times):
                     stopped = "both classes seen"
                     break
+            # Every allocation of ONE kind throughout (no placement 7 % under another; seen for all four 24 GiB allocations of some
+            # processes: profiles/r05_arena_first_process.txt): allocations differ in kind among each other -- their slow levels do,
+            # 3.01 against 3.09 ms -- so the first cluster of planes stays in one and the rest goes to another, tried from the pair
+            # whose levels lie furthest apart.  Both allocations are then kept.
+            times = [c[0] for c in cands]
+            if (spread and pick == "fastest" and stopped != "both classes seen" and len(arenas) >= 2
+                    and min(times) > ARENA_CLASS_GAP * max(times)):
+                level = [float(np.mean([t for t, a, _ in cands if a == j])) for j in range(len(arenas))]
+                pairs = sorted(((abs(level[i] - level[j]), i, j) for i in range(len(arenas)) for j in range(len(arenas)) if i != j), reverse=True)
+                first = tuple(j * outs.plane_bytes for j in range(n_first))
+                second = tuple(j * outs.plane_bytes for j in range(nplanes - n_first))
+                for _, i, j in pairs[:ARENA_CROSS_TRIALS]:
+                    outs.adopt_two_arenas(arenas[i], first, arenas[j], second)
+                    cands.append((self._probe_arena(outs, indices, stats, warm_ms=5.0), (i, j), first + second))
+                    if cands[-1][0] <= ARENA_CLASS_GAP * max(times):
+                        stopped = "both classes seen: planes split between two allocations"
+                        break
+                # ... and if all of them are of the SAME kind: small allocations for the second cluster alone (while the large ones are
+                # held they come from other memory), next to the first cluster in the first allocation
+                while stopped == "placement_trials" and len(arenas) < int(placement_trials) + ARENA_EXTRA_BLOCKS:
+                    _ffi.call("lars_mem_info", C.byref(free_b), C.byref(total_b))
+                    if free_b.value < second_bytes + (8 << 30):
+                        break
+                    t0 = time.perf_counter()
+                    arenas.append(DeviceBuffer(second_bytes))
+                    malloc_ms.append((time.perf_counter() - t0) * 1e3)
+                    outs.adopt_two_arenas(arenas[0], first, arenas[-1], second)
+                    cands.append((self._probe_arena(outs, indices, stats, warm_ms=5.0), (0, len(arenas) - 1), first + second))
+                    if cands[-1][0] <= ARENA_CLASS_GAP * max(times):
+                        stopped = "both classes seen: second half of the planes in an allocation of its own"
         except BaseException:
             # a failed probe launch or allocation: nothing of the search may stay behind, and `outs` must not point into a freed arena
             _ffi.call("lars_synchronize", None)
-            outs.arena = None
+            outs.arena = outs.arena2 = None
             for buf in arenas:
                 buf.free()
             stats.free()
@@ -291,24 +325,30 @@ class TileBatch:
         times = [c[0] for c in cands]
         best = int(np.argmin(times) if pick == "fastest" else np.argmax(times))
         chosen_ms, chosen_alloc, chosen_offsets = cands[best]
-        outs.adopt_arena(arenas[chosen_alloc], chosen_offsets)
+        keep = set(chosen_alloc) if isinstance(chosen_alloc, tuple) else {chosen_alloc}
+        if isinstance(chosen_alloc, tuple):
+            outs.adopt_two_arenas(arenas[chosen_alloc[0]], chosen_offsets[:n_first], arenas[chosen_alloc[1]], chosen_offsets[n_first:])
+        else:
+            outs.adopt_arena(arenas[chosen_alloc], chosen_offsets)
         for j, buf in enumerate(arenas):
-            if j != chosen_alloc:
+            if j not in keep:
                 buf.free()
         _ffi.call("lars_synchronize", None)
         # the survivor once more, now that the rejected allocations are gone: the figure the steps should reproduce
         post_free = self._probe_arena(outs, indices, stats) if len(arenas) > 1 else float(chosen_ms)
         stats.free()
         gib = float(1 << 30)
+        kept_bytes = sum(arenas[j].nbytes for j in keep)
         outs.placement_ms = {"arenas": [float(x) for x in times], "chosen": float(chosen_ms)}
         outs.arena_report = {
-            "kind": f"plain hipMalloc of {arenas[chosen_alloc].nbytes / gib:.1f} GiB, the {pick} of {len(cands)} placements of the planes in "
-                    f"{len(arenas)} allocation(s), timed with the batch's own launches (search ended by: {stopped})",
+            "kind": f"plain hipMalloc of {kept_bytes / gib:.1f} GiB{' in two allocations' if len(keep) > 1 else ''}, the {pick} of {len(cands)} "
+                    f"placements of the planes in {len(arenas)} allocation(s), timed with the batch's own launches (search ended by: {stopped})",
             "search_ms": (time.perf_counter() - t_search) * 1e3, "chosen_ms": float(chosen_ms), "post_free_ms": float(post_free),
-            "rejected": len(arenas) - 1, "candidate_ms": [float(x) for x in times], "malloc_ms": [float(x) for x in malloc_ms],
-            "placements": [{"allocation": int(a), "offsets_gib": [round(o / gib, 3) for o in offs], "ms": float(t)} for t, a, offs in cands],
+            "rejected": len(arenas) - len(keep), "candidate_ms": [float(x) for x in times], "malloc_ms": [float(x) for x in malloc_ms],
+            "placements": [{"allocation": list(a) if isinstance(a, tuple) else int(a), "offsets_gib": [round(o / gib, 3) for o in offs], "ms": float(t)}
+                           for t, a, offs in cands],
             "chosen_offsets_gib": [round(o / gib, 3) for o in chosen_offsets],
-            "arena_bytes": int(arenas[chosen_alloc].nbytes), "packed_bytes": int(packed_bytes), "allocations": len(arenas),
+            "arena_bytes": int(kept_bytes), "packed_bytes": int(packed_bytes), "allocations": len(arenas),
             "transient_bytes": int(sum(b.nbytes for b in arenas)),
             "probe": f">= {ARENA_WARM_MS:.0f} ms of untimed launches per allocation, then per placement one timed pass of launches over the batch's chunks"}
         return outs
@@ -798,6 +838,7 @@ class BatchOutputs:
         self._index_ids = sorted(INDEX_IDS[t] for t in indices) if index else []
         self._rgba_ids = sorted(INDEX_IDS[t] for t in indices) if rgba else []      # RGBA8 planes: 4 bytes per pixel too
         self.arena = None
+        self.arena2 = None                     # a second allocation holding the last planes (make_outputs' cross-allocation fall-back)
         self.arena_report = None
         if allocate and (self._index_ids or self._rgba_ids):
             self.adopt_arena(DeviceBuffer((len(self._index_ids) + len(self._rgba_ids)) * self.plane_bytes))
@@ -820,11 +861,30 @@ class BatchOutputs:
         order = sorted(offsets)
         assert all(b - a >= self.plane_bytes for a, b in zip(order, order[1:])), "planes overlap"
         self.arena = arena
+        self.arena2 = None
         self.plane_offsets = offsets
         for j, k in enumerate(self._index_ids):
             self.index[k] = DeviceSlice(arena, offsets[j], self.plane_bytes)
         for j, k in enumerate(self._rgba_ids):
             self.rgba[k] = DeviceSlice(arena, offsets[len(self._index_ids) + j], self.plane_bytes)
+
+    def adopt_two_arenas(self, arena, offsets, arena2, offsets2):
+        """The first ``len(offsets)`` planes inside ``arena``, the rest inside ``arena2`` (both stay owned by these outputs):
+        what ``TileBatch.make_outputs`` falls back to when every allocation it took is of ONE kind of memory throughout."""
+        offsets, offsets2 = tuple(int(o) for o in offsets), tuple(int(o) for o in offsets2)
+        nplanes = len(self._index_ids) + len(self._rgba_ids)
+        assert len(offsets) + len(offsets2) == nplanes
+        for buf, offs in ((arena, offsets), (arena2, offsets2)):
+            assert all(o % 256 == 0 and o + self.plane_bytes <= buf.nbytes for o in offs)
+            order = sorted(offs)
+            assert all(b - a >= self.plane_bytes for a, b in zip(order, order[1:])), "planes overlap"
+        self.arena, self.arena2 = arena, arena2
+        self.plane_offsets = offsets + offsets2
+        where = [(arena, o) for o in offsets] + [(arena2, o) for o in offsets2]
+        for j, k in enumerate(self._index_ids):
+            self.index[k] = DeviceSlice(where[j][0], where[j][1], self.plane_bytes)
+        for j, k in enumerate(self._rgba_ids):
+            self.rgba[k] = DeviceSlice(*where[len(self._index_ids) + j], self.plane_bytes)
 
     def host_index(self, index_type, slot=0, count=1):
         k = INDEX_IDS[index_type]
@@ -841,10 +901,10 @@ class BatchOutputs:
         return self.wb.download(np.uint8, (count, b.h, b.w, b.channels), slot * b.npix * b.channels)
 
     def free(self):
-        for b in self.index + self.rgba + self.luts + [self.wb, self.arena]:
+        for b in self.index + self.rgba + self.luts + [self.wb, self.arena, getattr(self, "arena2", None)]:
             if b is not None:
                 b.free()
-        self.index, self.rgba, self.arena = [None] * 3, [None] * 3, None
+        self.index, self.rgba, self.arena, self.arena2 = [None] * 3, [None] * 3, None, None
 
 
 # ---------------------------------------------------------------------------

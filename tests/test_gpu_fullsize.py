@@ -102,4 +102,36 @@ def test_placement_search_of_a_multi_gib_arena():
     # one plane: nothing to split, one packed allocation
     single = b.make_outputs(indices=("NDVI",), index=True, ring=ring)
     assert single.arena_report["kind"] == "plain hipMalloc"
-    single.free(); plain.free(); auto.free(); b.free()
+    single.free(); auto.free()
+    # Every allocation of one kind throughout (forced here: no gap between candidates counts as a class): the planes are split between two
+    # allocations, tried pair by pair; whatever wins, the planes written there are the same bits, and both allocations belong to the outputs.
+    gap, trials = lars.batch.ARENA_CLASS_GAP, lars.batch.ARENA_TRIALS
+    lars.batch.ARENA_CLASS_GAP, lars.batch.ARENA_TRIALS = 0.0, 2
+    try:
+        cross = b.make_outputs(index=True, ring=ring)
+    finally:
+        lars.batch.ARENA_CLASS_GAP, lars.batch.ARENA_TRIALS = gap, trials
+    rep = cross.arena_report
+    split = [p for p in rep["placements"] if isinstance(p["allocation"], list)]
+    extra = lars.batch.ARENA_EXTRA_BLOCKS                           # then small allocations for the third plane alone, next to allocation 0's first two
+    assert rep["allocations"] == 2 + extra and len(split) == 2 + extra
+    assert {tuple(p["allocation"]) for p in split} == {(0, 1), (1, 0)} | {(0, 2 + k) for k in range(extra)}
+    assert rep["rejected"] == rep["allocations"] - (2 if cross.arena2 is not None else 1)
+    assert rep["chosen_ms"] == min(rep["candidate_ms"])
+    assert rep["arena_bytes"] == cross.arena.nbytes + (cross.arena2.nbytes if cross.arena2 is not None else 0)
+    rec_c = b.process(outputs=cross)
+    assert rec_c.tobytes() == rec_p.tobytes()
+    for name in TYPES:
+        assert plain.host_index(name, 0, ring).tobytes() == cross.host_index(name, 0, ring).tobytes(), name
+    # ... and explicitly: two planes in one buffer, the third in another
+    two = lars.batch.BatchOutputs(b, TYPES, True, False, False, ring, allocate=False)
+    a1, a2 = _ffi.DeviceBuffer(2 * two.plane_bytes), _ffi.DeviceBuffer(two.plane_bytes)
+    two.adopt_two_arenas(a1, (0, two.plane_bytes), a2, (0,))
+    assert two.index[2].ptr == a2.ptr and two.index[1].ptr == a1.ptr + two.plane_bytes
+    rec_t = b.process(outputs=two)
+    assert rec_t.tobytes() == rec_p.tobytes()
+    for name in TYPES:
+        assert plain.host_index(name, 0, ring).tobytes() == two.host_index(name, 0, ring).tobytes(), name
+    two.free()
+    assert two.arena is None and two.arena2 is None
+    cross.free(); plain.free(); b.free()

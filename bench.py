@@ -488,7 +488,7 @@ def smooth_tile(edge, seed=7):
     return out
 
 
-def natural_tile(edge, seed=7):
+def natural_tile(edge, seed=7, scale=55.0, centre=(120.0, 135.0, 150.0)):
     """One photograph-like tile (tools/jointbench.py's `natural`): 1 / f noise -- structure at every scale --, channels that share most
     of it, sensor noise on top, stretched over the whole 8-bit range so that both ends clip (0.3-0.7 % of the pixels sit on the
     (255, 255) byte pairs): broad histograms with piled-up ends, what a processed JPEG looks like to the counting kernels."""
@@ -501,7 +501,7 @@ def natural_tile(edge, seed=7):
         own = np.fft.irfft2(amp * np.exp(2j * np.pi * rng.random(amp.shape)), s=(edge, edge))
         f = 0.8 * common + 0.6 * own
         f = (f - f.mean()) / f.std()
-        out[:, :, c] = np.clip(120.0 + 15 * c + 55.0 * f + rng.normal(0, 1.5, (edge, edge)), 0, 255).astype(np.uint8)
+        out[:, :, c] = np.clip(centre[c] + scale * f + rng.normal(0, 1.5, (edge, edge)), 0, 255).astype(np.uint8)
     return out
 
 
@@ -513,7 +513,11 @@ def smooth_leg(tiles=256, edge=4096, rounds=4, kind="smooth"):
     import lars_image_processing_amd as lars
     from lars_image_processing_amd import _ffi
     b = lars.TileBatch(tiles, edge, edge, 3, np.uint8)
-    b.tiles.upload((smooth_tile(edge) if kind == "smooth" else natural_tile(edge))[None])
+    # "natural": histograms over the whole range, clipped at both ends (two readers); "natural_mid": p2 .. p98 over 165 values per channel, the
+    # range in which three windows (NIR as well) still share one workgroup's LDS
+    tile = (smooth_tile(edge) if kind == "smooth" else natural_tile(edge) if kind == "natural" else
+            natural_tile(edge, scale=40.0, centre=(120.0, 128.0, 136.0)))
+    b.tiles.upload(tile[None])
     row = edge * 3
     for i in range(1, tiles):
         r = (i * 997) % edge
@@ -542,7 +546,8 @@ def smooth_leg(tiles=256, edge=4096, rounds=4, kind="smooth"):
 
     npix = tiles * edge * edge
     what = ("gradients + two levels of noise per channel" if kind == "smooth" else
-            "1/f noise with correlated channels + sensor noise over the whole 8-bit range, clipped at both ends")
+            "1/f noise with correlated channels + sensor noise over the whole 8-bit range, clipped at both ends" if kind == "natural" else
+            "1/f noise with correlated channels + sensor noise, p2 .. p98 over 165 values per channel")
     out = {"workload": f"{tiles} row-rolled copies of one {edge}x{edge} uint8 tile: {what} (image-like; the headline's tiles are iid)",
            "algorithmic_bytes_per_pixel": 3}
     for name, indices, med in (("wb_ndvi_stats_only", ("NDVI",), False), ("wb3idx_stats_only", ("NDVI", "GNDVI", "NDWI"), False),
@@ -561,6 +566,7 @@ def smooth_leg(tiles=256, edge=4096, rounds=4, kind="smooth"):
         j_ms = timed(lambda: b.run_joint(indices, True, stats, pairs=pairs if med else None))
         b.check_joint()
         windowed, recounted = b.joint_window_report()
+        three = b.joint_window_modes()[2]
         same = stats.download(_ffi.STATS_DTYPE, (tiles, 3)).tobytes() == want
         if med:
             same = same and pairs.download(np.float32, (tiles, 2, 2)).tobytes() == want_med
@@ -570,7 +576,8 @@ def smooth_leg(tiles=256, edge=4096, rounds=4, kind="smooth"):
         out[name] = {"one_read_ms": j_ms, "per_pixel_ms": c_ms, "auto_route": "one read" if auto == "joint" else "per pixel",
                      "ms_per_step": chosen, "whole_step_frac": npix * 3 / (chosen * 1e-3) / 1e9 / HBM_PEAK_GBS,
                      "one_read_frac": npix * 3 / (j_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, "per_pixel_frac": npix * 3 / (c_ms * 1e-3) / 1e9 / HBM_PEAK_GBS,
-                     "records_identical": bool(same), "tiles_on_windowed_tables": windowed, "tiles_recounted": recounted}
+                     "records_identical": bool(same), "tiles_on_windowed_tables": windowed, "tiles_recounted": recounted,
+                     "tiles_on_three_windows": three}
     for e in ev:
         _ffi.call("lars_event_destroy", e)
     stats.free(); pairs.free(); scratch.free(); b.free()
@@ -812,6 +819,7 @@ def main():
     if args.all_modes and world == 1 and args.smooth_leg:
         extra["smooth_content"] = smooth_leg(tiles=min(256, args.tiles), edge=args.tile)
         extra["natural_content"] = smooth_leg(tiles=min(256, args.tiles), edge=args.tile, kind="natural")
+        extra["natural_mid_content"] = smooth_leg(tiles=min(256, args.tiles), edge=args.tile, kind="natural_mid")
     if rank == 0:
         cpu = None if args.no_cpu_baseline or world > 1 else cpu_baseline(args)
         g = {t: runner.lb.summarize(glob[_ffi.INDEX_IDS[t]]) for t in indices}

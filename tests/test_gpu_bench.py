@@ -108,7 +108,7 @@ def test_bench_all_modes_and_their_self_check():
         assert line["verified"][name] == {"records": True, "planes": (True if name == "wb3idx_out_stats_medians" else None), "medians": True, "ok": True}
     assert len(line["verified"]["modes_compared"]) == 10
     # the statistics-only jobs once more on image-like content: both routes timed, their records identical, auto's choice named
-    for content in ("smooth_content", "natural_content"):
+    for content in ("smooth_content", "natural_content", "natural_mid_content"):
         for name in ("wb_ndvi_stats_only", "wb3idx_stats_only", "wb3idx_stats_medians"):
             leg = modes[content][name]
             assert leg["records_identical"] is True and leg["auto_route"] in ("one read", "per pixel"), (content, name)

@@ -392,12 +392,15 @@ def device_probe(runner):
     outs = runner.outputs.get(("NDVI", "GNDVI", "NDWI"))
     if outs is not None and getattr(outs, "plane_offsets", None) is not None and hasattr(lablib, "probe_mix3"):
         nquads = min(outs.slots, runner.batch.ntiles) * runner.batch.npix // 4
-        for name, offs in (("mix_12B_read_48B_write_planes_as_placed", outs.plane_offsets),
-                           ("mix_12B_read_48B_write_planes_packed", tuple(j * outs.plane_bytes for j in range(3)))):
+        # (the planes' own pointers: outputs whose search ended with the planes split between two allocations have no common base)
+        for name, ptrs in (("mix_12B_read_48B_write_planes_as_placed", tuple(outs.index[k].ptr for k in range(3))),
+                           ("mix_12B_read_48B_write_planes_packed", tuple(outs.arena.ptr + j * outs.plane_bytes for j in range(3)))):
+            if name.endswith("packed") and outs.arena.nbytes < 3 * outs.plane_bytes:
+                continue
             ts = []
             for _ in range(5):
                 ffi.call("lars_event_record", runner.ev[0], None)
-                lablib.probe_mix3(src, *(outs.arena.ptr + o for o in offs), nquads)
+                lablib.probe_mix3(src, *ptrs, nquads)
                 ffi.call("lars_event_record", runner.ev[1], None)
                 ms = C.c_float(0)
                 ffi.call("lars_event_elapsed_ms", runner.ev[0], runner.ev[1], C.byref(ms))

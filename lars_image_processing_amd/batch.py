@@ -29,7 +29,8 @@ ARENA_WARM_MS = 30.0              # untimed launches before a candidate is timed
 ARENA_SPAN_BYTES = 20 << 30       # how far from the first planes the last ones may be placed inside an allocation (the memory changes kind every 6-16 GiB)
 ARENA_SPAN_STEP = 4 << 30         # ... in steps of
 ARENA_CROSS_TRIALS = 6            # pairs of allocations tried with the planes split between them when every allocation is of one kind
-ARENA_EXTRA_BLOCKS = 6            # ... and after those, small allocations for the second half of the planes alone
+ARENA_EXTRA_BLOCKS = 24           # ... and after those, small allocations for the second half of the planes alone: stretches of one kind
+                                  # reach 72 GiB in some processes (tools/lab/kindmap.py), and the allocations held so far have used most of one
 
 
 # How statistics-only passes over uint8 RGNir batches run (no output planes):

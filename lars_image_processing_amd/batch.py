@@ -309,7 +309,10 @@ class TileBatch:
                     if free_b.value < second_bytes + (8 << 30):
                         break
                     t0 = time.perf_counter()
-                    arenas.append(DeviceBuffer(second_bytes))
+                    try:
+                        arenas.append(DeviceBuffer(second_bytes))
+                    except _ffi.LarsError:
+                        break
                     malloc_ms.append((time.perf_counter() - t0) * 1e3)
                     outs.adopt_two_arenas(arenas[0], first, arenas[-1], second)
                     cands.append((self._probe_arena(outs, indices, stats, warm_ms=5.0), (0, len(arenas) - 1), first + second))

@@ -30,6 +30,7 @@ def main():
     ap.add_argument("--tile", type=int, default=4096)
     ap.add_argument("--rounds", type=int, default=7)
     ap.add_argument("--content", default="vegetation,uniform")
+    ap.add_argument("--window", type=int, default=1, help="lars_set_tuning(\"joint_window\", ..) in every library (0: full tables, two readers)")
     ap.add_argument("--no-roll", action="store_true", help="hand-made contents: plain replicas of one tile (jointbench.make_batch)")
     args = ap.parse_args()
     libs = [("product", _ffi.load())]
@@ -42,6 +43,10 @@ def main():
         lib.lars_synchronize.argtypes = [C.c_void_p]
         lib.lars_joint_scratch_bytes.restype = C.c_size_t
         lib.lars_joint_scratch_bytes.argtypes = [C.c_int64, C.c_int64, C.c_uint32]
+    for _, lib in libs:
+        lib.lars_set_tuning.restype = C.c_int
+        lib.lars_set_tuning.argtypes = [C.c_char_p, C.c_int]
+        assert lib.lars_set_tuning(b"joint_window", args.window) == 0
     for content in args.content.split(","):
         b = jointbench.make_batch(content, args.tiles, args.tile, roll=not args.no_roll)
         npix = args.tiles * args.tile * args.tile

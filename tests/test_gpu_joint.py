@@ -162,11 +162,13 @@ def test_joint_full_size_tiles(lars):
     rec_c, med_c = b.process(hist=True, medians=True, route="classic")
     try:
         for blocks in (1, 0, 5):
-            for window in (1, 0, 2):
+            for window in (1, 0, 2, 4, 5):
                 _ffi.set_tuning(blocks_per_tile=blocks, joint_window=window)
                 rec_j, med_j = b.process(hist=True, medians=True, route="joint")
-                # the default: all six tiles on windowed tables (96 + 128 values; the one-colour tile: 3 + 3), nothing recounted
-                assert b.joint_window_report() == {1: (6, 0), 0: (0, 0), 2: (6, 6)}[window]
+                # the default: all six tiles on windowed tables (96 + 128 values; the one-colour tile: 3 + 3), nothing recounted;
+                # 4 / 5: on three windows (NIR as well: sweeps and hand-over lists of that kernel at full size), none / all recounted
+                assert b.joint_window_report() == {1: (6, 0), 0: (0, 0), 2: (6, 6), 4: (6, 0), 5: (6, 6)}[window]
+                assert b.joint_window_modes() == {1: (0, 6, 0), 0: (6, 0, 0), 2: (0, 6, 0), 4: (0, 0, 6), 5: (0, 0, 6)}[window]
                 assert rec_j.tobytes() == rec_c.tobytes(), (blocks, window)
                 np.testing.assert_array_equal(med_j, med_c)
     finally:

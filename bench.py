@@ -136,6 +136,14 @@ class Runner:
                                                         placement_trials=None if self.args.placement_trials < 0 else self.args.placement_trials)
         return self.outputs[key]
 
+    def joint_then_planes(self, base_mode):
+        """Modes that take the one-read statistics pass and then the plane-writing kernel WITHOUT statistics (TileBatch.process does the
+        same): medians and the 50-bin histograms come out of the counted cells for any set of indices; for one value stream the read
+        costs what the channel-histogram pass costs."""
+        if not (self.args.stats_route == "joint" and self.batch.can_joint()):
+            return base_mode == "wb3idx_out_stats_medians"
+        return base_mode in ("wb3idx_out_stats_medians", "wb3idx_out_stats_hist", "wb_ndvi_out_stats")
+
     def step(self, mode, timed=None, launch_events=None):
         """One pass over the batch.  ``timed`` collects (pre_ms, main_ms, launches of the main kernel): pre = the channel-
         histogram pass + tables (or, in the like-for-like mode, the one-read statistics pass), main = the fused kernel(s)
@@ -153,7 +161,7 @@ class Runner:
             ffi.call("lars_event_record", self.ev[1], None)
             b.run_joint(indices, True, self.stats, hist, False, self.pairs if base_mode in MEDIAN_MODES else None)
             launches = 1
-        elif base_mode == "wb3idx_out_stats_medians" or (base_mode == "wb_ndvi_out_stats" and self.args.stats_route == "joint" and b.can_joint()):
+        elif self.joint_then_planes(base_mode):
             # one read for statistics, (medians,) and the tables the planes need; then the plane-writing kernel without statistics.
             # For ONE value stream (the NDVI plane) this read costs what the channel-histogram pass costs and the planes-only kernel
             # is 8 % faster than with statistics: TileBatch.process takes the same route (profiles/r04_ndvi_plane_step_ways.txt)
@@ -773,7 +781,7 @@ def main():
                           "k_joint_count_win + k_joint_finish; full tables, two readers, where the windows do not fit or one value "
                           "stream is counted: k_joint_count)" if one_read else
                           "one-read statistics pass (k_joint_count_win / k_joint_count + k_joint_finish), then k_fused_u8c3 planes only"
-                          if (base == "wb3idx_out_stats_medians" or (base == "wb_ndvi_out_stats" and args.stats_route == "joint" and runner.batch.can_joint())) else
+                          if runner.joint_then_planes(base) else
                           "channel-histogram pass + tables, then the fused kernel"),
                 "fused_ms": f_ms, "hist_pass_ms": float(np.mean([t[0] for t in tm])),
                 "fused_GBs_algorithmic": npix_rank * MODES[base][3] / (f_ms * 1e-3) / 1e9,

@@ -678,12 +678,14 @@ class TileBatch:
         if route == "joint" and outputs is None:
             raise ValueError("route='joint' serves uint8 tiles with 3 channels (4-byte aligned) only")
         if (outputs is not None and outputs.wb is None and route != "classic" and not reuse and self.can_joint() and bool(indices)
-                and (medians or select_streams(indices) in (1, 2))):
+                and (medians or hist or select_streams(indices) in (1, 2))):
             # Planes wanted (no white-balanced image: that needs all three tables).  Where the one-read pass costs no more than
             # the channel-histogram pass it replaces -- one value stream: 8.5 ms per 1024 tiles of 4096 x 4096 either way -- it
             # delivers the tables AND the statistics, and the plane-writing kernel runs without its statistics registers and
             # flush: 28.7 instead of 30.5 ms for the NDVI plane (profiles/r04_ndvi_plane_step_ways.txt).  With medians it wins
-            # for any set of indices (the medians come with the same read instead of two more passes).
+            # for any set of indices (the medians come with the same read instead of two more passes), and so it does with the 50-bin
+            # histograms: they fall out of the counted cells, where the plane-writing kernel pays LDS atomics for them (0.76 against
+            # 0.82 of the roofline): 48.9 instead of 51.7 ms per 1024 tiles on windowed tables, the same on full ones.
             stats = self.new_stats()
             stats.zero(stream)
             pairs_dev = DeviceBuffer(self.ntiles * 4 * 4) if medians else None

@@ -472,8 +472,9 @@ def test_window_report_and_channel_histograms(lars):
 
 @pytest.mark.parametrize("channels", [3, 4])
 def test_plane_writing_calls_that_take_the_one_read_statistics(lars, channels):
-    """process(outputs=...) sends two kinds of plane-writing calls through the one-read statistics pass followed by a fused launch
-    WITHOUT statistics (batch.py): planes of one value stream, and any planes with medians.  Records, planes and medians against
+    """process(outputs=...) sends three kinds of plane-writing calls through the one-read statistics pass followed by a fused launch
+    WITHOUT statistics (batch.py): planes of one value stream, any planes with medians, any planes with the 50-bin histograms (they
+    fall out of the counted cells).  Records, planes and medians against
     route="classic" -- packed outputs and a ring, RGB and RGBA; the optional sum of squares within its documented few units of
     2^-32; and the tables the batch holds afterwards cover only the channels the indices read."""
     rng = np.random.default_rng(21)
@@ -481,7 +482,8 @@ def test_plane_writing_calls_that_take_the_one_read_statistics(lars, channels):
     b = lars.TileBatch.from_host(tiles)
     try:
         for ring in (None, 2):
-            for indices, kw in ((("NDVI",), dict(hist=True, sumsq=True)), (TYPES, dict(medians=True)), (("GNDVI", "NDWI"), dict(hist=True))):
+            for indices, kw in ((("NDVI",), dict(hist=True, sumsq=True)), (TYPES, dict(medians=True)), (("GNDVI", "NDWI"), dict(hist=True)),
+                                (TYPES, dict(hist=True)), (TYPES, dict(hist=True, medians=True, sumsq=True))):
                 oc = b.make_outputs(indices=indices, index=True, ring=ring, arena="plain")
                 oj = b.make_outputs(indices=indices, index=True, ring=ring, arena="plain")
                 got_c = b.process(indices=indices, outputs=oc, route="classic", **kw)
